@@ -1,0 +1,193 @@
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference); nothing here travels to the GPU
+box except the .npz files it writes.  Usage:  python tests/golden/make_goldens.py
+
+What is frozen:
+  g1_attention.npz      HeteroAttention.forward, L=3 mixed types, C=64, 2x3 windows of 4x4,
+                        random key mask with the ego column forced to 1; stores sim (pre
+                        softmax), attn and the output.
+  g2_warp.npz           warp_affine (bilinear) + get_roi_and_cav_mask for several yaw /
+                        translation pairs on 32x48 maps.
+  g3_block_seq.npz /    HeteroFusionBlock sequential / parallel, L=3, record_len=2 (one
+  g3_block_par.npz      padded agent), C=64, 16x24, window 4.
+  g4_fusion_c256.npz    HeteroFusion, 2 iters, L=5 modes 10110, C=256, 16x16, window 8.
+  g5_fusion_ragged.npz  HeteroFusion, B=2, record_len=[3,2], C=64, 16x16, window 4.
+  g6_fusion_cfg1.npz    HeteroFusion at BASELINE configs[0]: 2 LiDAR agents, 100x352, C=64,
+                        window 4 -- output sub-sampled (every 5th row / 11th col) + moments.
+
+Weights and inputs are NOT stored where they can be regenerated bit-exactly from a numpy
+legacy RandomState seed (oracle.hmvit_oracle.random_state_dict / synthetic_scene); the
+files then hold the seeds, the config and the reference's outputs.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+
+
+_stub("shapely")
+_stub("shapely.geometry", Polygon=object)                       # common_utils.py:8 (NMS only)
+_stub("opencood.models.bevformer_wrapper", BEVFormerWrapper=object)  # mmdet3d, out of scope
+
+from opencood.models.bevformer_point_pillar_hetero import HeteroFusion  # noqa: E402
+from opencood.models.sub_modules.hetero_fusion import HeteroAttention, HeteroFusionBlock  # noqa: E402
+from opencood.models.sub_modules.torch_transformation_utils import (  # noqa: E402
+    get_discretized_transformation_matrix, get_roi_and_cav_mask, get_transformation_matrix,
+    warp_affine)
+
+from oracle import hmvit_oracle as O  # noqa: E402  (only for the seeded input generators)
+
+torch.set_grad_enabled(False)
+
+
+def load_into(module, sd, prefix=""):
+    own = module.state_dict()
+    sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    missing = [k for k in own if k not in sub]
+    assert not missing, missing
+    module.load_state_dict({k: sub[k] for k in own}, strict=True)
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.numpy()
+        if isinstance(v, (dict, list)):
+            v = np.frombuffer(json.dumps(v).encode(), dtype=np.uint8)
+        out[k] = v
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def g1_attention():
+    C, w, L, X, Y, dh = 64, 4, 3, 2, 3, 32
+    cfg = O.make_config(C, w, L)
+    sd = O.random_state_dict(cfg, seed=11)
+    att = HeteroAttention(C, dh, 0.1, L, w).eval()
+    load_into(att, sd, "hetero_fusion_block.window_attention.")
+    rs = np.random.RandomState(12)
+    xw = torch.from_numpy(rs.standard_normal((1, L, X, Y, w, w, C)).astype(np.float32))
+    mask = torch.from_numpy((rs.uniform(size=(1, X, Y, w, w, 1, L)) > 0.35).astype(np.float32))
+    mask[..., 0] = 1.0
+    mode = torch.tensor([[1, 0, 1]], dtype=torch.int32)
+    captured = {}
+    orig = att.attend
+
+    class Tap(torch.nn.Module):
+        def forward(self, s):
+            captured["sim"] = s.clone()
+            a = orig(s)
+            captured["attn"] = a.clone()
+            return a
+
+    att.attend = Tap()
+    out = att(xw, mode, mask=mask)
+    save("g1_attention.npz", cfg=cfg, seed_weights=11, xw=xw, mask=mask, mode=mode,
+         sim=captured["sim"], attn=captured["attn"], out=out)
+
+
+def g2_warp():
+    H, W, C = 32, 48, 3
+    rs = np.random.RandomState(21)
+    src = torch.from_numpy(rs.standard_normal((1, C, H, W)).astype(np.float32))
+    cases = [(0.0, 0.0, 0.0), (0.0, 3.2, -1.6), (0.0, 1.3, 0.7), (0.3, 4.0, -2.5),
+             (np.pi / 2, 2.0, 1.0), (-1.1, -6.3, 3.9), (3.0, 0.4, 0.4), (0.05, 40.0, 0.0)]
+    bil, near, mats = [], [], []
+    for yaw, tx, ty in cases:
+        T = O.rigid(yaw, tx, ty).to(torch.float32)[None, None]
+        disc = get_discretized_transformation_matrix(T, 0.4, 4)
+        A = get_transformation_matrix(disc.reshape(-1, 2, 3), (H, W))
+        mats.append(A[0].clone())
+        bil.append(warp_affine(src, A, (H, W))[0])
+        m = get_roi_and_cav_mask((1, 1, H, W, C), torch.ones(1, 1), T, 0.4, 4)
+        near.append(m[0, :, :, 0, 0])
+    save("g2_warp.npz", src=src, cases=np.array(cases, dtype=np.float64),
+         A=torch.stack(mats), bilinear=torch.stack(bil), roi=torch.stack(near))
+
+
+def g3_block(arch):
+    C, w, L, H, W = 64, 4, 3, 16, 24
+    cfg = O.make_config(C, w, L, arch=arch)
+    sd = O.random_state_dict(cfg, seed=31)
+    blk = HeteroFusionBlock(cfg["hetero_fusion_block"]).eval()
+    load_into(blk, sd, "hetero_fusion_block.")
+    x, pw, mode, rl, mask = O.synthetic_scene(L, C, H, W, [0, 1, 0], n_valid=2, seed=32,
+                                              tx_step=6.0, ty_step=-4.0)
+    y = blk(x, pw, mode, rl, mask)
+    save(f"g3_block_{'seq' if arch == 'sequential' else 'par'}.npz", cfg=cfg, seed_weights=31,
+         scene=dict(L=L, C=C, H=H, W=W, modes=[0, 1, 0], n_valid=2, seed=32, tx_step=6.0,
+                    ty_step=-4.0), out=y)
+
+
+def _run_fusion(cfg, sd, scene_kw, B=1):
+    net = HeteroFusion(cfg).eval()
+    load_into(net, sd)
+    x, pw, mode, rl, mask = O.synthetic_scene(B=B, **scene_kw)
+    return net, (x, pw, mode, rl, mask)
+
+
+def g4_fusion_c256():
+    cfg = O.make_config(256, 8, 5)
+    sd = O.random_state_dict(cfg, seed=41)
+    kw = dict(L=5, C=256, H=16, W=16, modes=[1, 0, 1, 1, 0], seed=42, tx_step=4.0, ty_step=-2.4)
+    net, (x, pw, mode, rl, mask) = _run_fusion(cfg, sd, kw)
+    y = net(x, pw, mode, rl, mask)
+    save("g4_fusion_c256.npz", cfg=cfg, seed_weights=41, scene=kw, out=y)
+
+
+def g5_fusion_ragged():
+    cfg = O.make_config(64, 4, 3)
+    sd = O.random_state_dict(cfg, seed=51)
+    kw = dict(L=3, C=64, H=16, W=16, modes=[1, 0, 0], seed=52, tx_step=5.0, ty_step=3.0)
+    net, (x, pw, mode, rl, mask) = _run_fusion(cfg, sd, kw, B=2)
+    # sample 1 has only 2 agents: zero its third map, identity transforms, mode/mask 0
+    x[1, 2] = 0
+    eye = torch.eye(4)
+    pw[1, 2, :] = eye
+    pw[1, :, 2] = eye
+    mode[1, 2] = 0
+    mask[1, 2] = 0
+    rl = torch.tensor([3, 2])
+    y = net(x, pw, mode, rl, mask)
+    save("g5_fusion_ragged.npz", cfg=cfg, seed_weights=51, scene=kw, x=x, pairwise=pw,
+         mode=mode, record_len=rl, mask=mask, out=y)
+
+
+def g6_fusion_cfg1():
+    cfg = O.make_config(64, 4, 2, voxel=0.4, downsample=2)
+    sd = O.random_state_dict(cfg, seed=61)
+    kw = dict(L=2, C=64, H=100, W=352, modes=[1, 1], seed=1)
+    net, (x, pw, mode, rl, mask) = _run_fusion(cfg, sd, kw)
+    y = net(x, pw, mode, rl, mask)
+    y64 = y.double()
+    save("g6_fusion_cfg1.npz", cfg=cfg, seed_weights=61, scene=kw,
+         out_sub=y[:, :, ::5, ::11].contiguous(),
+         chan_mean=y64.mean((0, 2, 3)), chan_absmean=y64.abs().mean((0, 2, 3)),
+         abs_max=y64.abs().max())
+
+
+if __name__ == "__main__":
+    g1_attention()
+    g2_warp()
+    g3_block("sequential")
+    g3_block("parallel")
+    g4_fusion_c256()
+    g5_fusion_ragged()
+    g6_fusion_cfg1()
