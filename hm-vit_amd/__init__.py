@@ -1,0 +1,7 @@
+"""hm-vit_amd: MI355X-native HM-ViT fusion hot path (HIP kernels behind the reference's
+fuse-module API).  Import as ``hmvit_amd`` (see hmvit_amd.py at the repository root: the
+directory name carries a hyphen)."""
+from . import _lib  # noqa: F401  (raises ImportError when libhmvit.so is not built)
+from .fusion import HeteroFusion, HeteroFusionBlock  # noqa: F401
+
+__all__ = ["HeteroFusion", "HeteroFusionBlock"]

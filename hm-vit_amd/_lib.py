@@ -1,0 +1,99 @@
+"""ctypes binding of libhmvit.so (include/hmvit.h).  There is no CPU fallback: importing the
+package without the built library raises, so a GPU box can never silently run something else."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhmvit.so")
+
+ABI_VERSION = 1
+PREC_F32, PREC_F16 = 0, 1
+PART_WINDOW, PART_GRID = 0, 1
+NUM_TYPES = 2
+MAX_AGENTS = 8
+
+c_f32p = C.POINTER(C.c_float)
+c_i32p = C.POINTER(C.c_int32)
+
+
+class StageWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "ln_gamma", "ln_beta", "w_q", "b_q", "w_kv", "b_kv", "bias_frag", "w_o", "b_o",
+        "ffn_ln_gamma", "ffn_ln_beta", "w_1", "b_1", "w_2", "b_2")]
+
+
+class FusionDesc(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("L", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("heads", C.c_int32), ("dim_head", C.c_int32), ("window", C.c_int32),
+        ("mlp_dim", C.c_int32), ("num_iters", C.c_int32), ("precision", C.c_int32),
+        ("apply_head", C.c_int32), ("skip_masked", C.c_int32),
+        ("discrete_ratio", C.c_float), ("downsample_rate", C.c_float),
+        ("mode", c_i32p), ("record_len", c_i32p), ("cav_mask", c_i32p),
+        ("x", C.c_void_p), ("pairwise_t", C.c_void_p), ("out", C.c_void_p),
+        ("stage", StageWeights * 2),
+        ("head_w1", C.c_void_p), ("head_b1", C.c_void_p), ("head_w2", C.c_void_p),
+        ("head_b2", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class HmvitError(RuntimeError):
+    pass
+
+
+_SIGNATURES = {
+    "hmvit_abi_version": (C.c_int, []),
+    "hmvit_last_error": (C.c_char_p, []),
+    "hmvit_fusion_workspace_bytes": (C.c_size_t, [C.POINTER(FusionDesc)]),
+    "hmvit_fusion_forward": (C.c_int, [C.POINTER(FusionDesc), C.c_void_p]),
+    "hmvit_nchw_to_tokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "hmvit_tokens_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "hmvit_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p, C.c_void_p, C.c_void_p, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "hmvit_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "hmvit_pair_affines": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                     C.c_float, C.c_void_p]),
+    "hmvit_warp_affine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_void_p]),
+    "hmvit_window_attention": (C.c_int, [C.c_void_p] * 6 + [c_i32p, c_i32p, c_i32p, C.c_void_p] +
+                               [C.c_int] * 12 + [C.c_void_p]),
+    "hmvit_debug_tr16": (C.c_int, [C.c_void_p, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C hm-vit_amd/csrc`).  hm-vit_amd has no CPU / PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.hmvit_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"libhmvit.so ABI {got} != binding ABI {ABI_VERSION}: rebuild")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib.hmvit_last_error().decode(errors="replace")
+        if rc == -22:
+            raise ValueError(f"{what}: {msg}")
+        raise HmvitError(f"{what} failed ({rc}): {msg}")
+
+
+def i32_array(values):
+    arr = (C.c_int32 * len(values))(*[int(v) for v in values])
+    return arr

@@ -1,0 +1,412 @@
+// Fused H3GAT window / grid attention for one (sample, ego, window, head group) per workgroup.
+//
+// Replaces, for every ego i of HeteroFusionBlock.{local,global}_spatial_multi_agent_attention
+// (hetero_fusion.py:363-444): warp_features (:338-361, L^2 bilinear BEV warps + nearest ROI
+// masks), the window / dilated-grid rearranges (:384-394, :427-434) and HeteroAttention.forward
+// (:187-277) up to, not including, the output projection.  Nothing is materialised: the K / V
+// tiles of a window are bilinear-gathered straight from the per-source projected maps
+// (Linear(warp(x)) == warp(x W^T) + b, SURVEY.md 8a identity (i)) into LDS.
+//
+// Work decomposition: one wavefront per head (dim_head = 32), HG heads per workgroup.
+// Keys are consumed in chunks of 64 (one source agent for window 8, four for window 4) with an
+// online softmax across chunks.  Per chunk and 16-query tile the wave computes the transposed
+// logits S^T = K Q^T (rows = keys, cols = queries) so that every lane owns ONE query column:
+// the softmax reductions are in-register plus two cross-lane shuffles, and exp(S^T) is already
+// in the B-operand layout of the second product O^T = V^T P^T.
+//   f16 mode: v_mfma_f32_16x16x32_f16; V^T fragments come from ds_read_b64_tr_b16.
+//   f32 mode: v_mfma_f32_16x16x4_f32 (exact f32), element-granular operands, no transposes.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace hmvit {
+
+template <typename T, int HG>
+struct AttnCfg;
+template <int HG>
+struct AttnCfg<half_t, HG> {
+    static constexpr int CH = HG * 32;       // channels of this head group
+    static constexpr int QS = CH + 8;        // LDS row strides in elements
+    static constexpr int KS = CH + 8;
+    static constexpr int VS = CH + 16;
+};
+template <int HG>
+struct AttnCfg<float, HG> {
+    static constexpr int CH = HG * 32;
+    static constexpr int QS = CH + 2;
+    static constexpr int KS = CH + 2;
+    static constexpr int VS = CH + 4;
+};
+
+// 8 consecutive channels of one token
+template <typename T>
+__device__ __forceinline__ void load8(const T* __restrict__ p, float (&v)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        const half8 h = *reinterpret_cast<const half8*>(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+    } else {
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        const float4 b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store8_lds(T* p, const float (&v)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        half8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (half_t)v[e];
+        *reinterpret_cast<half8*>(p) = h;
+    } else {
+        // f32 tiles use odd-ish strides (2 / 4 mod 32): 8-byte aligned only
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) *reinterpret_cast<float2*>(p + e) = make_float2(v[e], v[e + 1]);
+    }
+}
+
+// bilinear sample (or direct read) of 8 channels of a projected map + bias
+template <typename T>
+__device__ __forceinline__ void sample8(const T* __restrict__ plane, int C, int ch, const Taps& t,
+                                        bool ident, int self_idx, const float* __restrict__ bias,
+                                        float (&out)[8]) {
+    float b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b[e] = bias[ch + e];
+    if (ident) {
+        float v[8];
+        load8(plane + (size_t)self_idx * C + ch, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[e] = v[e] + b[e];
+    } else {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (t.w[k] != 0.f) {
+                float v[8];
+                load8(plane + (size_t)t.idx[k] * C + ch, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(t.w[k], v[e], acc[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[e] = acc[e] + b[e];
+    }
+}
+
+template <typename T, int WIN, int HG>
+__global__ __launch_bounds__(HG * 64) void k_attention(AttnParams p) {
+    using Cfg = AttnCfg<T, HG>;
+    constexpr int N = WIN * WIN;          // tokens per window
+    constexpr int NQT = N / 16;           // 16-query tiles
+    constexpr int SPC = 64 / N;           // source agents per 64-key chunk
+    constexpr int NB = (WIN == 8) ? 7 : 1;
+    constexpr int CH = Cfg::CH, QS = Cfg::QS, KS = Cfg::KS, VS = Cfg::VS;
+    constexpr int TPK = CH / 8;           // lanes cooperating on one key row
+    constexpr int KPP = HG * 64 / TPK;    // key rows gathered per pass (= 16)
+    constexpr bool F16 = sizeof(T) == 2;
+
+    __shared__ __attribute__((aligned(16))) T Qs[N * QS];
+    __shared__ __attribute__((aligned(16))) T Ks[64 * KS];
+    __shared__ __attribute__((aligned(16))) T Vs[64 * VS];
+    __shared__ __attribute__((aligned(16))) float maskadd[64];
+
+    const int C = p.C, H = p.H, W = p.W, L = p.L, P = H * W;
+    const int X = H / WIN, Y = W / WIN;
+    const int NG = C / CH;
+    const int win = blockIdx.x / NG, hg = blockIdx.x - win * NG;
+    const int ego = blockIdx.y, b = blockIdx.z;
+    const int wx = win / Y, wy = win - wx * Y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lq = lane & 15, g = lane >> 4;
+    const int head = hg * HG + wave;
+    const int te = p.mode[b * L + ego];
+    const int ev = p.ego_e[b * L + ego];
+    const int ch0 = hg * CH;               // first channel of this head group
+
+    const T* qplanes = reinterpret_cast<const T*>(p.q);
+    const T* kvplanes = reinterpret_cast<const T*>(p.kv);
+
+    // ---- gather the query tile (ego's own map through T[i,i], normally the identity) ----
+    {
+        const float* a = p.ainv + ((size_t)(b * L + ego) * L + ego) * 8;
+        const bool ident = a[6] != 0.f;
+        const T* plane = qplanes + (size_t)(b * L + ego) * P * C;
+        const float* bq = p.b_q + te * C + ch0;
+        const int cl = (tid % TPK) * 8;
+        for (int n = tid / TPK; n < N; n += KPP) {
+            int row, col;
+            token_pixel(p.partition, WIN, X, Y, wx, wy, n, row, col);
+            Taps t;
+            if (!ident) t = make_taps(a, col, row, H, W);
+            float v[8];
+            sample8<T>(plane + ch0, C, cl, t, ident, row * W + col, bq, v);
+            store8_lds<T>(Qs + n * QS + cl, v);
+        }
+    }
+
+    // relative-position bias fragments of this head (accumulator layout)
+    float4v biasf[NB];
+#pragma unroll
+    for (int v = 0; v < NB; ++v)
+        biasf[v] = *reinterpret_cast<const float4v*>(p.bias_frag + ((size_t)(head * NB + v) * 64 + lane) * 4);
+
+    __syncthreads();
+
+    // query fragments (B operand: k = channel, col = query)
+    half8 qh[NQT];
+    float qf[NQT][8];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        if constexpr (F16) {
+            qh[qt] = *reinterpret_cast<const half8*>(Qs + (qt * 16 + lq) * QS + wave * 32 + g * 8);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                qf[qt][ks] = reinterpret_cast<const float*>(Qs)[(qt * 16 + lq) * QS + wave * 32 + ks * 4 + g];
+        }
+    }
+
+    float m_run[NQT], l_run[NQT];
+    float4v o_acc[NQT][2];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        m_run[qt] = -INFINITY;
+        l_run[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) o_acc[qt][dt] = (float4v)(0.f);
+    }
+
+    const int n_chunks = (p.n_src + SPC - 1) / SPC;
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        // ---------------- gather 64 keys x CH channels of K and V ----------------
+        int any_visible = 0;
+        {
+            const int cl = (tid % TPK) * 8;
+#pragma unroll
+            for (int pass = 0; pass < 64 / KPP; ++pass) {
+                const int kk = pass * KPP + tid / TPK;
+                const int src = chunk * SPC + kk / N;
+                const int n = kk % N;
+                float kvv[2][8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) kvv[0][e] = kvv[1][e] = 0.f;
+                bool visible = false;
+                if (src < p.n_src) {
+                    int row, col;
+                    token_pixel(p.partition, WIN, X, Y, wx, wy, n, row, col);
+                    const float* a = p.ainv + ((size_t)(b * L + src) * L + ego) * 8;
+                    const bool ident = a[6] != 0.f;
+                    Taps t;
+                    if (ident) {
+                        t.roi = 1.f;
+                    } else {
+                        t = make_taps(a, col, row, H, W);
+                    }
+                    visible = (t.roi != 0.f) && (p.cav[b * L + src] != 0);
+                    if (visible) {
+                        const int ts = p.mode[b * L + src];
+                        const T* kpl = kvplanes + ((size_t)((b * L + src) * p.E + ev) * 2) * P * C + ch0;
+                        const float* bk = p.b_kv + (size_t)(te * HMVIT_NUM_TYPES + ts) * 2 * C + ch0;
+                        sample8<T>(kpl, C, cl, t, ident, row * W + col, bk, kvv[0]);
+                        sample8<T>(kpl + (size_t)P * C, C, cl, t, ident, row * W + col, bk + C, kvv[1]);
+                    }
+                }
+                store8_lds<T>(Ks + kk * KS + cl, kvv[0]);
+                store8_lds<T>(Vs + kk * VS + cl, kvv[1]);
+                if (cl == 0) maskadd[kk] = visible ? 0.f : -INFINITY;
+                any_visible |= visible ? 1 : 0;
+            }
+        }
+        any_visible = __syncthreads_or(any_visible);
+
+        if (any_visible || !p.skip_masked) {
+            float4v madd[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) madd[kt] = *reinterpret_cast<const float4v*>(maskadd + kt * 16 + 4 * g);
+
+            // operand fragments shared by all query tiles of this chunk
+            half8 kh[4], vh[2][2];
+            float kf[4][8], vf[4][4][2];
+            if constexpr (F16) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+                    kh[kt] = *reinterpret_cast<const half8*>(Ks + (kt * 16 + lq) * KS + wave * 32 + g * 8);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        // 4 keys x 16 channels block per 16-lane group, transposed on read
+                        const T* base = Vs + (ks * 32 + 4 * g + (lq >> 2)) * VS + wave * 32 + dt * 16 + (lq & 3) * 4;
+                        const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                            (__attribute__((address_space(3))) fp16x4_t*)(base));
+                        const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                            (__attribute__((address_space(3))) fp16x4_t*)(base + 16 * VS));
+                        half8 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = (half_t)lo[e];
+                            v[4 + e] = (half_t)hi[e];
+                        }
+                        vh[dt][ks] = v;
+                    }
+            } else {
+                const float* Kf = reinterpret_cast<const float*>(Ks);
+                const float* Vf = reinterpret_cast<const float*>(Vs);
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) kf[kt][ks] = Kf[(kt * 16 + lq) * KS + wave * 32 + ks * 4 + g];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt)
+                            vf[kt][r][dt] = Vf[(kt * 16 + 4 * g + r) * VS + wave * 32 + dt * 16 + lq];
+            }
+
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt) {
+                // S^T tiles: rows = keys kt*16 + 4g + r, col = query qt*16 + lq
+                float4v s[4];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const int bv = (WIN == 8) ? (qt - kt + 3) : 0;
+                    float4v acc = biasf[bv];
+                    if constexpr (F16) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[kt], qh[qt], acc, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int ks = 0; ks < 8; ++ks)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][ks], qf[qt][ks], acc, 0, 0, 0);
+                    }
+                    s[kt] = acc + madd[kt];
+                }
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run[qt], mx);
+                const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+                float alpha, rs = 0.f;
+                if constexpr (F16) alpha = __expf(m_run[qt] - m_safe); else alpha = expf(m_run[qt] - m_safe);
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float e;
+                        if constexpr (F16) e = __expf(s[kt][r] - m_safe); else e = expf(s[kt][r] - m_safe);
+                        s[kt][r] = e;
+                        rs += e;
+                    }
+                rs += __shfl_xor(rs, 16, 64);
+                rs += __shfl_xor(rs, 32, 64);
+                l_run[qt] = l_run[qt] * alpha + rs;
+                m_run[qt] = m_new;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) o_acc[qt][dt] *= alpha;
+
+                // O^T += V^T P^T
+                if constexpr (F16) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        half8 ph;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            ph[e] = (half_t)s[2 * ks][e];
+                            ph[4 + e] = (half_t)s[2 * ks + 1][e];
+                        }
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt)
+                            o_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dt][ks], ph, o_acc[qt][dt], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int dt = 0; dt < 2; ++dt)
+                                o_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][r][dt], s[kt][r], o_acc[qt][dt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane holds channels dt*16 + 4g + (0..3) of query qt*16 + lq ----
+    T* outp = reinterpret_cast<T*>(p.out) + (size_t)(b * L + ego) * P * C;
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        int row, col;
+        token_pixel(p.partition, WIN, X, Y, wx, wy, qt * 16 + lq, row, col);
+        const float inv = 1.f / l_run[qt];
+        T* o = outp + (size_t)(row * W + col) * C + head * 32 + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            if constexpr (F16) {
+                half4 h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = (half_t)(o_acc[qt][dt][r] * inv);
+                *reinterpret_cast<half4*>(o + dt * 16) = h;
+            } else {
+                *reinterpret_cast<float4*>(o + dt * 16) =
+                    make_float4(o_acc[qt][dt][0] * inv, o_acc[qt][dt][1] * inv, o_acc[qt][dt][2] * inv,
+                                o_acc[qt][dt][3] * inv);
+            }
+        }
+    }
+}
+
+template <typename T, int WIN, int HG>
+static int launch_attn_t(const AttnParams& p, hipStream_t st) {
+    const int NG = p.C / (HG * 32);
+    dim3 grid((p.H / WIN) * (p.W / WIN) * NG, p.n_ego, p.B);
+    hipLaunchKernelGGL((k_attention<T, WIN, HG>), grid, dim3(HG * 64), 0, st, p);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+int launch_attention(const AttnParams& p, int precision, hipStream_t st) {
+    HMVIT_CHECK_ARG(p.window == 4 || p.window == 8, "attention: window=%d unsupported (4 or 8)", p.window);
+    HMVIT_CHECK_ARG(p.C == 64 || p.C == 128 || p.C == 256, "attention: C=%d unsupported (64, 128, 256)", p.C);
+    HMVIT_CHECK_ARG(p.H % p.window == 0 && p.W % p.window == 0, "attention: %dx%d not divisible by window %d",
+                    p.H, p.W, p.window);
+    HMVIT_CHECK_ARG(p.B * p.L <= kMaxSlots, "attention: B*L=%d exceeds %d per launch", p.B * p.L, kMaxSlots);
+    if (p.n_ego <= 0 || p.B <= 0) return HMVIT_OK;
+    const bool w8 = p.window == 8;
+    if (precision == HMVIT_PREC_F32) {
+        return w8 ? launch_attn_t<float, 8, 2>(p, st) : launch_attn_t<float, 4, 2>(p, st);
+    }
+    if (p.C == 64) return w8 ? launch_attn_t<half_t, 8, 2>(p, st) : launch_attn_t<half_t, 4, 2>(p, st);
+    return w8 ? launch_attn_t<half_t, 8, 4>(p, st) : launch_attn_t<half_t, 4, 4>(p, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// debug: dump what ds_read_b64_tr_b16 returns when LDS holds lds[i] = i (u16) and lane l
+// passes the address of element 4*l.
+// ------------------------------------------------------------------------------------------
+__global__ void k_debug_tr16(uint16_t* out) {
+    __shared__ __attribute__((aligned(16))) uint16_t lds[256];
+    for (int i = threadIdx.x; i < 256; i += 64) lds[i] = (uint16_t)i;
+    __syncthreads();
+    typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
+    const short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) short4v*)(lds + threadIdx.x * 4));
+    for (int e = 0; e < 4; ++e) out[threadIdx.x * 4 + e] = (uint16_t)v[e];
+}
+
+int launch_debug_tr16(uint16_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_debug_tr16, dim3(1), dim3(64), 0, st, out);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+}  // namespace hmvit

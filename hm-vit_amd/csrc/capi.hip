@@ -1,0 +1,405 @@
+// C ABI of libhmvit: argument checking, workspace carving and the launch sequence of one
+// HeteroFusion forward (bevformer_point_pillar_hetero.py:39-49, hetero_fusion.py:363-474).
+#include <string.h>
+
+#include <vector>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace hmvit {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static size_t elem_size(int precision) { return precision == HMVIT_PREC_F32 ? 4 : 2; }
+
+struct Plan {
+    int B, L, C, H, W, P, mlp, n_slots, max_cav, E_max;
+    size_t es;
+    // byte offsets into the workspace
+    size_t off_xs, off_xn, off_q, off_kv, off_o, off_hid, off_ainv, off_ytok, total;
+};
+
+static int check_desc(const HmvitFusionDesc* d) {
+    HMVIT_CHECK_ARG(d != nullptr, "desc is null");
+    HMVIT_CHECK_ARG(d->B > 0 && d->L > 0 && d->L <= HMVIT_MAX_AGENTS, "B=%d L=%d out of range (L <= %d)", d->B,
+                    d->L, HMVIT_MAX_AGENTS);
+    HMVIT_CHECK_ARG(d->dim_head == 32, "dim_head=%d unsupported (32)", d->dim_head);
+    HMVIT_CHECK_ARG(d->C == d->heads * d->dim_head, "C=%d != heads*dim_head=%d", d->C, d->heads * d->dim_head);
+    HMVIT_CHECK_ARG(d->C == 64 || d->C == 128 || d->C == 256, "C=%d unsupported (64, 128, 256)", d->C);
+    HMVIT_CHECK_ARG(d->window == 4 || d->window == 8, "window_size=%d unsupported (4 or 8)", d->window);
+    HMVIT_CHECK_ARG(d->H > 0 && d->W > 0 && d->H % d->window == 0 && d->W % d->window == 0,
+                    "BEV %dx%d must be divisible by window_size %d", d->H, d->W, d->window);
+    HMVIT_CHECK_ARG(d->mlp_dim > 0 && d->mlp_dim % 64 == 0, "mlp_dim=%d must be a multiple of 64", d->mlp_dim);
+    HMVIT_CHECK_ARG(d->num_iters >= 1, "num_iters=%d", d->num_iters);
+    HMVIT_CHECK_ARG(d->precision == HMVIT_PREC_F32 || d->precision == HMVIT_PREC_F16, "precision=%d", d->precision);
+    HMVIT_CHECK_ARG(d->mode && d->record_len && d->cav_mask, "mode / record_len / cav_mask must be host arrays");
+    HMVIT_CHECK_ARG(d->discrete_ratio * d->downsample_rate != 0.f, "discrete_ratio * downsample_rate is 0");
+    for (int i = 0; i < d->B * d->L; ++i)
+        HMVIT_CHECK_ARG(d->mode[i] >= 0 && d->mode[i] < HMVIT_NUM_TYPES, "mode[%d]=%d is not an agent type", i,
+                        d->mode[i]);
+    for (int b = 0; b < d->B; ++b)
+        HMVIT_CHECK_ARG(d->record_len[b] >= 1 && d->record_len[b] <= d->L, "record_len[%d]=%d out of [1, %d]", b,
+                        d->record_len[b], d->L);
+    return HMVIT_OK;
+}
+
+static void make_plan(const HmvitFusionDesc* d, Plan& pl) {
+    pl.B = d->B; pl.L = d->L; pl.C = d->C; pl.H = d->H; pl.W = d->W;
+    pl.P = d->H * d->W; pl.mlp = d->mlp_dim; pl.n_slots = d->B * d->L;
+    pl.es = elem_size(d->precision);
+    pl.max_cav = 0;
+    for (int b = 0; b < d->B; ++b) pl.max_cav = d->record_len[b] > pl.max_cav ? d->record_len[b] : pl.max_cav;
+    bool seen[HMVIT_NUM_TYPES] = {false, false};
+    for (int b = 0; b < d->B; ++b)
+        for (int i = 0; i < pl.max_cav; ++i) seen[d->mode[b * d->L + i]] = true;
+    pl.E_max = (int)seen[0] + (int)seen[1];
+    const size_t tok = (size_t)pl.n_slots * pl.P;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    pl.off_xs = carve(tok * pl.C * 4);
+    pl.off_xn = carve(tok * pl.C * pl.es);
+    pl.off_q = carve(tok * pl.C * pl.es);
+    const size_t kv_bytes = tok * pl.E_max * 2 * pl.C * pl.es;
+    const size_t hid_bytes = tok * pl.mlp * pl.es;
+    pl.off_kv = carve(kv_bytes > hid_bytes ? kv_bytes : hid_bytes);
+    pl.off_hid = pl.off_kv;  // the FFN hidden activations reuse the K/V planes (dead after attention)
+    pl.off_o = carve(tok * pl.C * pl.es);
+    pl.off_ainv = carve((size_t)pl.n_slots * pl.L * 8 * 4);
+    pl.off_ytok = carve((size_t)pl.B * pl.P * pl.C * 4);
+    pl.total = off;
+}
+
+struct JobBatcher {
+    GemmJobs jobs;
+    bool a_f32, gelu, out_f32;
+    int precision;
+    hipStream_t st;
+    JobBatcher(bool af, bool ge, bool of, int prec, hipStream_t s) : a_f32(af), gelu(ge), out_f32(of), precision(prec), st(s) {
+        jobs.n = 0;
+    }
+    int flush() {
+        if (jobs.n == 0) return HMVIT_OK;
+        int rc = launch_gemm(jobs, a_f32, gelu, out_f32, precision, st);
+        jobs.n = 0;
+        return rc;
+    }
+    int add(const GemmJob& j) {
+        jobs.j[jobs.n++] = j;
+        if (jobs.n == kMaxJobs) return flush();
+        return HMVIT_OK;
+    }
+};
+
+#define HMVIT_TRY(expr)             \
+    do {                            \
+        int _rc = (expr);           \
+        if (_rc != HMVIT_OK) return _rc; \
+    } while (0)
+
+static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st) {
+    HMVIT_TRY(check_desc(d));
+    Plan pl;
+    make_plan(d, pl);
+    HMVIT_CHECK_ARG(d->x && d->pairwise_t && d->out && d->workspace, "x / pairwise_t / out / workspace is null");
+    if (d->workspace_bytes < pl.total) {
+        set_error("workspace too small: %zu < %zu bytes", d->workspace_bytes, pl.total);
+        return HMVIT_ENOMEM;
+    }
+    HMVIT_CHECK_ARG(pl.n_slots <= kMaxSlots, "B*L=%d exceeds %d agent slots per call", pl.n_slots, kMaxSlots);
+
+    const int B = pl.B, L = pl.L, C = pl.C, P = pl.P, mlp = pl.mlp, prec = d->precision;
+    const size_t es = pl.es;
+    char* ws = reinterpret_cast<char*>(d->workspace);
+    float* xs = reinterpret_cast<float*>(ws + pl.off_xs);
+    char* xn = ws + pl.off_xn;
+    char* qb = ws + pl.off_q;
+    char* kvb = ws + pl.off_kv;
+    char* ob = ws + pl.off_o;
+    char* hid = ws + pl.off_hid;
+    float* ainv = reinterpret_cast<float*>(ws + pl.off_ainv);
+    float* ytok = reinterpret_cast<float*>(ws + pl.off_ytok);
+    const size_t map_elems = (size_t)P * C;
+
+    AgentTypes all_types;
+    memset(&all_types, 0, sizeof(all_types));
+    for (int i = 0; i < pl.n_slots; ++i) all_types.t[i] = (int8_t)d->mode[i];
+
+    // NCHW -> token-major residual stream; sampling maps of every (source, ego) pair
+    HMVIT_TRY(launch_transpose(d->x, xs, pl.n_slots, C, P, st));
+    HMVIT_TRY(launch_pair_affines(d->pairwise_t, ainv, pl.n_slots * L, d->H, d->W, d->discrete_ratio,
+                                  d->downsample_rate, st));
+
+    for (int it = 0; it < d->num_iters; ++it) {
+        for (int s = 0; s < 2; ++s) {
+            const HmvitStageWeights& wt = d->stage[s];
+            // In the last stage of HeteroFusion only ego 0 is consumed (x[:, 0],
+            // bevformer_point_pillar_hetero.py:47): the other egos' rows are dead code.
+            const bool last = d->apply_head && it == d->num_iters - 1 && s == 1;
+            const int n_ego = last ? 1 : pl.max_cav;
+            const int n_src = pl.max_cav;
+
+            // K/V variants needed = ego types taking part in this stage
+            int e_of_type[HMVIT_NUM_TYPES] = {-1, -1};
+            int e_type[HMVIT_NUM_TYPES] = {0, 0};
+            int E = 0;
+            for (int b = 0; b < B; ++b)
+                for (int i = 0; i < n_ego; ++i) {
+                    const int t = d->mode[b * L + i];
+                    if (e_of_type[t] < 0) { e_of_type[t] = E; e_type[E] = t; ++E; }
+                }
+
+            // 1. typed LayerNorm of every agent map (sources j < max_cav are all that is read)
+            HMVIT_TRY(launch_layernorm(xs, xn, wt.ln_gamma, wt.ln_beta, all_types, pl.n_slots, P, C, prec, st));
+
+            // 2. Q and relation-folded K/V projections (no bias: added after the gather)
+            {
+                JobBatcher jb(false, false, false, prec, st);
+                for (int b = 0; b < B; ++b)
+                    for (int l = 0; l < pl.max_cav; ++l) {
+                        const int slot = b * L + l, t = d->mode[slot];
+                        GemmJob j;
+                        j.a = xn + (size_t)slot * map_elems * es;
+                        j.bias = nullptr; j.residual = nullptr;
+                        j.M = P; j.K = C; j.n_per_plane = C; j.plane_stride = (long long)map_elems;
+                        if (l < n_ego) {
+                            j.w = reinterpret_cast<const char*>(wt.w_q) + (size_t)t * C * C * es;
+                            j.y = qb + (size_t)slot * map_elems * es;
+                            j.N = C;
+                            HMVIT_TRY(jb.add(j));
+                        }
+                        for (int e = 0; e < E; ++e) {
+                            j.w = reinterpret_cast<const char*>(wt.w_kv) +
+                                  (size_t)(e_type[e] * HMVIT_NUM_TYPES + t) * 2 * C * C * es;
+                            j.y = kvb + (size_t)(slot * E + e) * 2 * map_elems * es;
+                            j.N = 2 * C;
+                            HMVIT_TRY(jb.add(j));
+                        }
+                    }
+                HMVIT_TRY(jb.flush());
+            }
+
+            // 3. fused warp + partition + attention for every ego
+            {
+                AttnParams ap;
+                memset(&ap, 0, sizeof(ap));
+                ap.q = qb; ap.kv = kvb; ap.b_q = wt.b_q; ap.b_kv = wt.b_kv; ap.bias_frag = wt.bias_frag;
+                ap.ainv = ainv; ap.out = ob;
+                ap.B = B; ap.L = L; ap.n_ego = n_ego; ap.n_src = n_src; ap.E = E; ap.C = C; ap.H = d->H; ap.W = d->W;
+                ap.window = d->window; ap.partition = s == 0 ? HMVIT_PART_WINDOW : HMVIT_PART_GRID;
+                ap.skip_masked = d->skip_masked;
+                for (int i = 0; i < pl.n_slots; ++i) {
+                    ap.mode[i] = (int8_t)d->mode[i];
+                    ap.cav[i] = (int8_t)(d->cav_mask[i] != 0);
+                    ap.ego_e[i] = (int8_t)(e_of_type[d->mode[i]] < 0 ? 0 : e_of_type[d->mode[i]]);
+                }
+                HMVIT_TRY(launch_attention(ap, prec, st));
+            }
+
+            // 4. typed output projection + residual (in place on the f32 stream)
+            {
+                JobBatcher jb(false, false, true, prec, st);
+                for (int b = 0; b < B; ++b)
+                    for (int i = 0; i < n_ego; ++i) {
+                        const int slot = b * L + i, t = d->mode[slot];
+                        GemmJob j;
+                        j.a = ob + (size_t)slot * map_elems * es;
+                        j.w = reinterpret_cast<const char*>(wt.w_o) + (size_t)t * C * C * es;
+                        j.bias = wt.b_o + t * C;
+                        j.residual = xs + (size_t)slot * map_elems;
+                        j.y = xs + (size_t)slot * map_elems;
+                        j.M = P; j.N = C; j.K = C; j.n_per_plane = C; j.plane_stride = 0;
+                        HMVIT_TRY(jb.add(j));
+                    }
+                HMVIT_TRY(jb.flush());
+            }
+
+            // 5. pre-norm typed FFN + residual for every agent (only the egos in the last stage)
+            {
+                const int n_ffn = last ? 1 : L;
+                if (n_ffn == L) {
+                    HMVIT_TRY(launch_layernorm(xs, xn, wt.ffn_ln_gamma, wt.ffn_ln_beta, all_types, pl.n_slots, P, C,
+                                               prec, st));
+                } else {
+                    for (int b = 0; b < B; ++b) {
+                        AgentTypes one;
+                        memset(&one, 0, sizeof(one));
+                        one.t[0] = (int8_t)d->mode[b * L];
+                        HMVIT_TRY(launch_layernorm(xs + (size_t)b * L * map_elems, xn + (size_t)b * L * map_elems * es,
+                                                   wt.ffn_ln_gamma, wt.ffn_ln_beta, one, 1, P, C, prec, st));
+                    }
+                }
+                JobBatcher j1(false, true, false, prec, st);
+                for (int b = 0; b < B; ++b)
+                    for (int l = 0; l < n_ffn; ++l) {
+                        const int slot = b * L + l, t = d->mode[slot];
+                        GemmJob j;
+                        j.a = xn + (size_t)slot * map_elems * es;
+                        j.w = reinterpret_cast<const char*>(wt.w_1) + (size_t)t * mlp * C * es;
+                        j.bias = wt.b_1 + t * mlp;
+                        j.residual = nullptr;
+                        j.y = hid + (size_t)slot * P * mlp * es;
+                        j.M = P; j.N = mlp; j.K = C; j.n_per_plane = mlp; j.plane_stride = 0;
+                        HMVIT_TRY(j1.add(j));
+                    }
+                HMVIT_TRY(j1.flush());
+                JobBatcher j2(false, false, true, prec, st);
+                for (int b = 0; b < B; ++b)
+                    for (int l = 0; l < n_ffn; ++l) {
+                        const int slot = b * L + l, t = d->mode[slot];
+                        GemmJob j;
+                        j.a = hid + (size_t)slot * P * mlp * es;
+                        j.w = reinterpret_cast<const char*>(wt.w_2) + (size_t)t * C * mlp * es;
+                        j.bias = wt.b_2 + t * C;
+                        j.residual = xs + (size_t)slot * map_elems;
+                        j.y = xs + (size_t)slot * map_elems;
+                        j.M = P; j.N = C; j.K = mlp; j.n_per_plane = C; j.plane_stride = 0;
+                        HMVIT_TRY(j2.add(j));
+                    }
+                HMVIT_TRY(j2.flush());
+            }
+        }
+    }
+
+    if (!d->apply_head) {
+        return launch_transpose(xs, d->out, pl.n_slots, P, C, st);
+    }
+
+    // mlp_head on the ego map: Linear -> GELU -> Linear, no norm, no residual
+    // (bevformer_point_pillar_hetero.py:37,47-48)
+    HMVIT_CHECK_ARG(d->head_w1 && d->head_b1 && d->head_w2 && d->head_b2, "mlp_head weights are null");
+    {
+        JobBatcher j1(true, true, false, prec, st);
+        for (int b = 0; b < B; ++b) {
+            const int slot = b * L, t = d->mode[slot];
+            GemmJob j;
+            j.a = xs + (size_t)slot * map_elems;
+            j.w = reinterpret_cast<const char*>(d->head_w1) + (size_t)t * C * C * es;
+            j.bias = d->head_b1 + t * C;
+            j.residual = nullptr;
+            j.y = hid + (size_t)slot * map_elems * es;
+            j.M = P; j.N = C; j.K = C; j.n_per_plane = C; j.plane_stride = 0;
+            HMVIT_TRY(j1.add(j));
+        }
+        HMVIT_TRY(j1.flush());
+        JobBatcher j2(false, false, true, prec, st);
+        for (int b = 0; b < B; ++b) {
+            const int slot = b * L, t = d->mode[slot];
+            GemmJob j;
+            j.a = hid + (size_t)slot * map_elems * es;
+            j.w = reinterpret_cast<const char*>(d->head_w2) + (size_t)t * C * C * es;
+            j.bias = d->head_b2 + t * C;
+            j.residual = nullptr;
+            j.y = ytok + (size_t)b * map_elems;
+            j.M = P; j.N = C; j.K = C; j.n_per_plane = C; j.plane_stride = 0;
+            HMVIT_TRY(j2.add(j));
+        }
+        HMVIT_TRY(j2.flush());
+    }
+    return launch_transpose(ytok, d->out, B, P, C, st);
+}
+
+}  // namespace hmvit
+
+using namespace hmvit;
+
+extern "C" {
+
+int hmvit_abi_version(void) { return HMVIT_ABI_VERSION; }
+
+const char* hmvit_last_error(void) { return hmvit::g_err; }
+
+size_t hmvit_fusion_workspace_bytes(const HmvitFusionDesc* desc) {
+    if (check_desc(desc) != HMVIT_OK) return 0;
+    Plan pl;
+    make_plan(desc, pl);
+    return pl.total;
+}
+
+int hmvit_fusion_forward(const HmvitFusionDesc* desc, void* stream) {
+    return fusion_forward(desc, reinterpret_cast<hipStream_t>(stream));
+}
+
+int hmvit_nchw_to_tokens(const float* x, float* y, int n_agents, int C, int P, void* stream) {
+    HMVIT_CHECK_ARG(x && y && n_agents > 0 && C > 0 && P > 0, "nchw_to_tokens: bad argument");
+    return launch_transpose(x, y, n_agents, C, P, reinterpret_cast<hipStream_t>(stream));
+}
+
+int hmvit_tokens_to_nchw(const float* x, float* y, int n_agents, int C, int P, void* stream) {
+    HMVIT_CHECK_ARG(x && y && n_agents > 0 && C > 0 && P > 0, "tokens_to_nchw: bad argument");
+    return launch_transpose(x, y, n_agents, P, C, reinterpret_cast<hipStream_t>(stream));
+}
+
+int hmvit_layernorm(const float* x, void* y, const int32_t* types, const float* gamma, const float* beta,
+                    int n_agents, int P, int C, int precision, void* stream) {
+    HMVIT_CHECK_ARG(x && y && types && gamma && beta, "layernorm: null pointer");
+    HMVIT_CHECK_ARG(n_agents > 0 && n_agents <= kMaxSlots, "layernorm: n_agents=%d out of (0, %d]", n_agents, kMaxSlots);
+    AgentTypes t;
+    memset(&t, 0, sizeof(t));
+    for (int i = 0; i < n_agents; ++i) {
+        HMVIT_CHECK_ARG(types[i] >= 0 && types[i] < HMVIT_NUM_TYPES, "layernorm: types[%d]=%d", i, types[i]);
+        t.t[i] = (int8_t)types[i];
+    }
+    return launch_layernorm(x, y, gamma, beta, t, n_agents, P, C, precision, reinterpret_cast<hipStream_t>(stream));
+}
+
+int hmvit_linear(const void* a, const void* w, const float* bias, const float* residual, void* y, int M, int N,
+                 int K, int gelu, int out_f32, int precision, void* stream) {
+    HMVIT_CHECK_ARG(a && w && y && M > 0 && N > 0 && K > 0, "linear: bad argument");
+    GemmJobs jobs;
+    jobs.n = 1;
+    GemmJob& j = jobs.j[0];
+    j.a = a; j.w = w; j.bias = bias; j.residual = residual; j.y = y;
+    j.M = M; j.N = N; j.K = K; j.n_per_plane = N; j.plane_stride = 0;
+    return launch_gemm(jobs, false, gelu != 0, out_f32 != 0, precision, reinterpret_cast<hipStream_t>(stream));
+}
+
+int hmvit_pair_affines(const float* pairwise_t, float* ainv, int n, int H, int W, float discrete_ratio,
+                       float downsample_rate, void* stream) {
+    HMVIT_CHECK_ARG(pairwise_t && ainv && n > 0 && H > 0 && W > 0, "pair_affines: bad argument");
+    HMVIT_CHECK_ARG(discrete_ratio * downsample_rate != 0.f, "pair_affines: zero scale");
+    return launch_pair_affines(pairwise_t, ainv, n, H, W, discrete_ratio, downsample_rate,
+                               reinterpret_cast<hipStream_t>(stream));
+}
+
+int hmvit_warp_affine(const float* src, const float* ainv, float* dst, float* roi, int n, int H, int W, int C,
+                      void* stream) {
+    HMVIT_CHECK_ARG(src && ainv && dst && roi && n > 0 && H > 0 && W > 0 && C > 0, "warp_affine: bad argument");
+    return launch_warp(src, ainv, dst, roi, n, H, W, C, reinterpret_cast<hipStream_t>(stream));
+}
+
+int hmvit_window_attention(const void* q, const void* kv, const float* b_q, const float* b_kv,
+                           const float* bias_frag, const float* ainv, const int32_t* mode,
+                           const int32_t* cav_mask, const int32_t* ego_e, void* out, int B, int L, int n_ego,
+                           int n_src, int E, int C, int H, int W, int window, int partition, int precision,
+                           int skip_masked, void* stream) {
+    HMVIT_CHECK_ARG(q && kv && b_q && b_kv && bias_frag && ainv && mode && cav_mask && ego_e && out,
+                    "window_attention: null pointer");
+    HMVIT_CHECK_ARG(B > 0 && L > 0 && B * L <= kMaxSlots && n_ego <= L && n_src <= L && E >= 1 && E <= 2,
+                    "window_attention: bad sizes");
+    AttnParams ap;
+    memset(&ap, 0, sizeof(ap));
+    ap.q = q; ap.kv = kv; ap.b_q = b_q; ap.b_kv = b_kv; ap.bias_frag = bias_frag; ap.ainv = ainv; ap.out = out;
+    ap.B = B; ap.L = L; ap.n_ego = n_ego; ap.n_src = n_src; ap.E = E; ap.C = C; ap.H = H; ap.W = W;
+    ap.window = window; ap.partition = partition; ap.skip_masked = skip_masked;
+    for (int i = 0; i < B * L; ++i) {
+        ap.mode[i] = (int8_t)mode[i];
+        ap.cav[i] = (int8_t)(cav_mask[i] != 0);
+        ap.ego_e[i] = (int8_t)ego_e[i];
+    }
+    return launch_attention(ap, precision, reinterpret_cast<hipStream_t>(stream));
+}
+
+int hmvit_debug_tr16(uint16_t* out, void* stream) {
+    HMVIT_CHECK_ARG(out != nullptr, "debug_tr16: null pointer");
+    return launch_debug_tr16(out, reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// Shared device/host helpers for libhmvit (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/hmvit.h"
+
+namespace hmvit {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+// ---- thread-local error string (hmvit_last_error) ----
+void set_error(const char* fmt, ...);
+#define HMVIT_CHECK_ARG(cond, ...)            \
+    do {                                      \
+        if (!(cond)) {                        \
+            ::hmvit::set_error(__VA_ARGS__);  \
+            return HMVIT_EINVAL;              \
+        }                                     \
+    } while (0)
+#define HMVIT_CHECK_HIP(expr)                                                         \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            ::hmvit::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                               __FILE__, __LINE__);                                   \
+            return HMVIT_EHIP;                                                        \
+        }                                                                             \
+    } while (0)
+#define HMVIT_CHECK_LAUNCH() HMVIT_CHECK_HIP(hipGetLastError())
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+template <typename T>
+struct ElemOf;
+template <>
+struct ElemOf<float> {
+    static constexpr int prec = HMVIT_PREC_F32;
+};
+template <>
+struct ElemOf<half_t> {
+    static constexpr int prec = HMVIT_PREC_F16;
+};
+
+// ---- sampling geometry shared by the warp operator and the attention gather ----
+// ainv record: [a00 a01 a02 a10 a11 a12 is_identity pad]; src = Ainv [u, v, 1] in pixels,
+// u = column (x, width axis), v = row (y, height axis).
+struct Taps {
+    int idx[4];    // token index y * W + x of the 4 bilinear taps (clamped when weight is 0)
+    float w[4];    // bilinear weights, 0 for out-of-range taps (zeros padding)
+    float roi;     // 1 when the nearest source pixel is inside the map
+};
+
+__device__ __forceinline__ Taps make_taps(const float* __restrict__ a, int u, int v, int H, int W) {
+    Taps t;
+    const float fu = (float)u, fv = (float)v;
+    const float sx = fmaf(a[0], fu, fmaf(a[1], fv, a[2]));
+    const float sy = fmaf(a[3], fu, fmaf(a[4], fv, a[5]));
+    const float x0f = floorf(sx), y0f = floorf(sy);
+    const float wx1 = sx - x0f, wy1 = sy - y0f;
+    const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    // keep the integer conversion defined for far-away samples
+    const float lim = 1.0e6f;
+    const int x0 = (int)fminf(fmaxf(x0f, -lim), lim), y0 = (int)fminf(fmaxf(y0f, -lim), lim);
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = (x0 >= 0) & (x0 < W), vx1 = (x1 >= 0) & (x1 < W);
+    const bool vy0 = (y0 >= 0) & (y0 < H), vy1 = (y1 >= 0) & (y1 < H);
+    const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+    const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+    t.idx[0] = cy0 * W + cx0; t.w[0] = (vx0 & vy0) ? wx0 * wy0 : 0.f;
+    t.idx[1] = cy0 * W + cx1; t.w[1] = (vx1 & vy0) ? wx1 * wy0 : 0.f;
+    t.idx[2] = cy1 * W + cx0; t.w[2] = (vx0 & vy1) ? wx0 * wy1 : 0.f;
+    t.idx[3] = cy1 * W + cx1; t.w[3] = (vx1 & vy1) ? wx1 * wy1 : 0.f;
+    // nearest (round-half-even, as std::nearbyint in grid_sample)
+    const float nx = rintf(sx), ny = rintf(sy);
+    t.roi = (nx >= 0.f && nx <= (float)(W - 1) && ny >= 0.f && ny <= (float)(H - 1)) ? 1.f : 0.f;
+    return t;
+}
+
+// pixel (row, col) of token `n` (row-major inside the w x w window) of window (wx, wy)
+// for the two partitions (hetero_fusion.py:387-389 / :430-431)
+__device__ __forceinline__ void token_pixel(int partition, int window, int X, int Y, int wx, int wy,
+                                            int n, int& row, int& col) {
+    const int w1 = n / window, w2 = n - w1 * window;
+    if (partition == HMVIT_PART_WINDOW) {
+        row = wx * window + w1;
+        col = wy * window + w2;
+    } else {
+        row = w1 * X + wx;
+        col = w2 * Y + wy;
+    }
+}
+
+}  // namespace hmvit

@@ -1,0 +1,61 @@
+// Internal launch interfaces between the translation units of libhmvit.
+#pragma once
+#include "common.hpp"
+
+namespace hmvit {
+
+constexpr int kMaxSlots = 64;  // agent slots (B * L) handled by one launch
+
+struct AgentTypes {
+    int8_t t[kMaxSlots];
+};
+
+// ---- tok.hip ----
+int launch_transpose(const float* x, float* y, int n, int R, int S, hipStream_t st);
+int launch_layernorm(const float* x, void* y, const float* gamma, const float* beta,
+                     const AgentTypes& types, int n_agents, int P, int C, int precision,
+                     hipStream_t st);
+int launch_pair_affines(const float* t, float* ainv, int n, int H, int W, float discrete_ratio,
+                        float downsample_rate, hipStream_t st);
+int launch_warp(const float* src, const float* ainv, float* dst, float* roi, int n, int H, int W,
+                int C, hipStream_t st);
+
+// ---- gemm.hip ----
+// y[plane(n)][m][n % n_per_plane] = act(sum_k a[m][k] w[n][k] + bias[n]) + residual[m][n]
+struct GemmJob {
+    const void* a;          // (M, K) element type T, or f32 when a_f32
+    const void* w;          // (N, K) element type T
+    const float* bias;      // (N) or null
+    const float* residual;  // (M, N) f32 or null (may alias y when out_f32)
+    void* y;
+    long long plane_stride;  // elements between output planes
+    int M, N, K;
+    int n_per_plane;        // columns per output plane (N when there is a single plane)
+};
+constexpr int kMaxJobs = 24;
+struct GemmJobs {
+    GemmJob j[kMaxJobs];
+    int n;
+};
+// all jobs of one launch share a_f32 / gelu / out_f32
+int launch_gemm(const GemmJobs& jobs, bool a_f32, bool gelu, bool out_f32, int precision,
+                hipStream_t st);
+
+// ---- attn.hip ----
+struct AttnParams {
+    const void* q;            // (B, L, P, C)
+    const void* kv;           // (B, L, E, 2, P, C)
+    const float* b_q;         // (T, C)
+    const float* b_kv;        // (T_ego, T_src, 2C)
+    const float* bias_frag;   // (heads, NB, 64, 4)
+    const float* ainv;        // (B, L_src, L_ego, 8): sampling map of pairwise_t[b, src, ego]
+    void* out;                // (B, L, P, C)
+    int B, L, n_ego, n_src, E, C, H, W, window, partition, skip_masked;
+    int8_t mode[kMaxSlots];   // (B, L)
+    int8_t cav[kMaxSlots];    // (B, L)
+    int8_t ego_e[kMaxSlots];  // (B, L): K/V variant used by ego (b, i)
+};
+int launch_attention(const AttnParams& p, int precision, hipStream_t st);
+int launch_debug_tr16(uint16_t* out, hipStream_t st);
+
+}  // namespace hmvit

@@ -1,0 +1,178 @@
+// Token-wise, HBM-bound kernels: layout changes, typed LayerNorm, pair affines, warp operator.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace hmvit {
+
+// ------------------------------------------------------------------------------------------
+// (n, C, P) <-> (n, P, C) through a 64x64 LDS tile; both sides move 256-byte row segments.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ x, float* __restrict__ y,
+                                                    int R, int S) {
+    // x: (n, R, S) -> y: (n, S, R)
+    __shared__ float tile[64][65];
+    const int n = blockIdx.z;
+    const int r0 = blockIdx.y * 64, s0 = blockIdx.x * 64;
+    const float* xb = x + (size_t)n * R * S;
+    float* yb = y + (size_t)n * R * S;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, s = s0 + tx;
+        tile[i][tx] = (r < R && s < S) ? xb[(size_t)r * S + s] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int s = s0 + i, r = r0 + tx;
+        if (r < R && s < S) yb[(size_t)s * R + r] = tile[tx][i];
+    }
+}
+
+int launch_transpose(const float* x, float* y, int n, int R, int S, hipStream_t st) {
+    dim3 grid(cdiv(S, 64), cdiv(R, 64), n);
+    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, st, x, y, R, S);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// HeteroLayerNorm: one wavefront per token, C/64 channels per lane, two-pass variance.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int VPL, typename TO>
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, TO* __restrict__ y,
+                                                    const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, AgentTypes types,
+                                                    int P) {
+    constexpr int C = VPL * 64;
+    const int agent = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= P) return;
+    const int t = types.t[agent];
+    const size_t base = ((size_t)agent * P + tok) * C + lane * VPL;
+    float v[VPL];
+    if constexpr (VPL == 4) {
+        const float4 f = *reinterpret_cast<const float4*>(x + base);
+        v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+    } else if constexpr (VPL == 2) {
+        const float2 f = *reinterpret_cast<const float2*>(x + base);
+        v[0] = f.x; v[1] = f.y;
+    } else {
+        v[0] = x[base];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) s += v[i];
+    const float mean = wave_sum(s) * (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        v[i] -= mean;
+        q += v[i] * v[i];
+    }
+    const float rstd = rsqrtf(wave_sum(q) * (1.f / C) + 1e-5f);
+    const float* g = gamma + t * C + lane * VPL;
+    const float* b = beta + t * C + lane * VPL;
+    TO o[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) o[i] = (TO)(v[i] * rstd * g[i] + b[i]);
+    TO* yp = y + base;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) yp[i] = o[i];
+}
+
+template <typename TO>
+static int launch_ln_t(const float* x, TO* y, const float* gamma, const float* beta,
+                       const AgentTypes& types, int n_agents, int P, int C, hipStream_t st) {
+    dim3 grid(cdiv(P, 4), n_agents);
+    switch (C) {
+        case 64: hipLaunchKernelGGL((k_layernorm<1, TO>), grid, dim3(256), 0, st, x, y, gamma, beta, types, P); break;
+        case 128: hipLaunchKernelGGL((k_layernorm<2, TO>), grid, dim3(256), 0, st, x, y, gamma, beta, types, P); break;
+        case 256: hipLaunchKernelGGL((k_layernorm<4, TO>), grid, dim3(256), 0, st, x, y, gamma, beta, types, P); break;
+        default: set_error("layernorm: C=%d unsupported (64, 128, 256)", C); return HMVIT_EINVAL;
+    }
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+int launch_layernorm(const float* x, void* y, const float* gamma, const float* beta,
+                     const AgentTypes& types, int n_agents, int P, int C, int precision,
+                     hipStream_t st) {
+    if (precision == HMVIT_PREC_F32)
+        return launch_ln_t<float>(x, (float*)y, gamma, beta, types, n_agents, P, C, st);
+    return launch_ln_t<half_t>(x, (half_t*)y, gamma, beta, types, n_agents, P, C, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// pairwise_t (n, 4, 4) -> inverse pixel affine (n, 8)
+// ------------------------------------------------------------------------------------------
+__global__ void k_pair_affines(const float* __restrict__ t, float* __restrict__ ainv, int n, int H,
+                               int W, float inv_scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* m = t + (size_t)i * 16;
+    const float r00 = m[0], r01 = m[1], r10 = m[4], r11 = m[5];
+    const float tx = m[3] * inv_scale, ty = m[7] * inv_scale;
+    const float cx = 0.5f * W, cy = 0.5f * H;
+    // A = S(c) R S(-c) + t   (get_transformation_matrix)
+    const float a02 = cx - (r00 * cx + r01 * cy) + tx;
+    const float a12 = cy - (r10 * cx + r11 * cy) + ty;
+    const float det = r00 * r11 - r01 * r10;
+    const float id = 1.f / det;
+    const float i00 = r11 * id, i01 = -r01 * id, i10 = -r10 * id, i11 = r00 * id;
+    const float i02 = -(i00 * a02 + i01 * a12);
+    const float i12 = -(i10 * a02 + i11 * a12);
+    float* o = ainv + (size_t)i * 8;
+    o[0] = i00; o[1] = i01; o[2] = i02; o[3] = i10; o[4] = i11; o[5] = i12;
+    const bool ident = (i00 == 1.f) && (i01 == 0.f) && (i02 == 0.f) && (i10 == 0.f) && (i11 == 1.f) &&
+                       (i12 == 0.f);
+    o[6] = ident ? 1.f : 0.f;
+    o[7] = 0.f;
+}
+
+int launch_pair_affines(const float* t, float* ainv, int n, int H, int W, float discrete_ratio,
+                        float downsample_rate, hipStream_t st) {
+    hipLaunchKernelGGL(k_pair_affines, dim3(cdiv(n, 64)), dim3(64), 0, st, t, ainv, n, H, W,
+                       1.f / (discrete_ratio * downsample_rate));
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// stand-alone warp operator (parity tests of the sampling code)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_warp(const float* __restrict__ src, const float* __restrict__ ainv,
+                                               float* __restrict__ dst, float* __restrict__ roi, int H,
+                                               int W, int C) {
+    const int n = blockIdx.y;
+    const int P = H * W;
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= P) return;
+    const int v = tok / W, u = tok - v * W;
+    const Taps t = make_taps(ainv + (size_t)n * 8, u, v, H, W);
+    const float* s = src + (size_t)n * P * C;
+    float* d = dst + ((size_t)n * P + tok) * C;
+    for (int c = lane; c < C; c += 64) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc += t.w[k] * s[(size_t)t.idx[k] * C + c];
+        d[c] = acc;
+    }
+    if (lane == 0) roi[(size_t)n * P + tok] = t.roi;
+}
+
+int launch_warp(const float* src, const float* ainv, float* dst, float* roi, int n, int H, int W,
+                int C, hipStream_t st) {
+    dim3 grid(cdiv(H * W, 4), n);
+    hipLaunchKernelGGL(k_warp, grid, dim3(256), 0, st, src, ainv, dst, roi, H, W, C);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+}  // namespace hmvit

@@ -1,0 +1,239 @@
+"""Drop-in ``HeteroFusion`` / ``HeteroFusionBlock`` modules backed by libhmvit (HIP, gfx950).
+
+Mirror of the reference's fuse-module surface:
+
+* ``HeteroFusion(config)`` -- same config dict keys, same ``forward(x, pairwise_t_matrix, mode,
+  record_len, mask)`` signature and return shape, same ``state_dict`` key names as
+  ``opencood/models/bevformer_point_pillar_hetero.py:22-49`` so a reference checkpoint loads with
+  ``load_state_dict`` and the model file can do ``self.fusion_net = HeteroFusion(cfg)`` unchanged.
+* ``HeteroFusionBlock(config)`` -- ``opencood/models/sub_modules/hetero_fusion.py:279-474``
+  (sequential mode).
+
+The parameter containers below only hold parameters under the reference's names; the arithmetic
+is one call into ``hmvit_fusion_forward`` (include/hmvit.h).  Inference only in this round: the
+output does not carry autograd history.  No CPU path: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from . import _lib, weights
+
+NUM_TYPES = _lib.NUM_TYPES
+_PRECISIONS = {"f32": _lib.PREC_F32, "fp32": _lib.PREC_F32, "strict": _lib.PREC_F32,
+               "f16": _lib.PREC_F16, "fp16": _lib.PREC_F16, "fast": _lib.PREC_F16}
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter containers with the reference's names
+# ---------------------------------------------------------------------------------------------
+class _Typed(nn.Module):
+    """``net``: one sub-module per agent type (BaseSimpleHetero, base_transformer.py:138-145)."""
+
+    def __init__(self, make, num_types: int = NUM_TYPES):
+        super().__init__()
+        self.net = nn.ModuleList([make() for _ in range(num_types)])
+
+
+class HeteroLayerNorm(_Typed):
+    def __init__(self, dim: int):
+        super().__init__(lambda: nn.LayerNorm(dim))
+
+
+class HeteroFeedForward(_Typed):
+    def __init__(self, dim: int, hidden_dim: int, dropout: float = 0., out_dim: Optional[int] = None):
+        out_dim = dim if out_dim is None else out_dim
+        super().__init__(lambda: nn.Sequential(nn.Linear(dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
+                                               nn.Linear(hidden_dim, out_dim), nn.Dropout(dropout)))
+
+
+class HeteroPreNormResidual(nn.Module):
+    def __init__(self, dim: int, fn: nn.Module):
+        super().__init__()
+        self.norm = HeteroLayerNorm(dim)
+        self.fn = fn
+
+
+class HeteroAttention(nn.Module):
+    """Parameters of hetero_fusion.py:32-109 (typed q/k/v/out linears, relation matrices,
+    relative-position bias table + index buffer)."""
+
+    def __init__(self, dim: int, dim_head: int, dropout: float, agent_size: int, window_size: int):
+        super().__init__()
+        if dim % dim_head:
+            raise ValueError("dimension should be divisible by dimension per head")
+        self.heads = dim // dim_head
+        self.k_linears = nn.ModuleList([nn.Linear(dim, dim) for _ in range(NUM_TYPES)])
+        self.q_linears = nn.ModuleList([nn.Linear(dim, dim) for _ in range(NUM_TYPES)])
+        self.v_linears = nn.ModuleList([nn.Linear(dim, dim) for _ in range(NUM_TYPES)])
+        self.a_linears = nn.ModuleList([nn.Sequential(nn.Linear(dim, dim), nn.Dropout(dropout))
+                                        for _ in range(NUM_TYPES)])
+        self.norms = nn.ModuleList()
+        self.relation_att = nn.Parameter(torch.empty(NUM_TYPES ** 2, self.heads, dim_head, dim_head))
+        self.relation_msg = nn.Parameter(torch.empty(NUM_TYPES ** 2, self.heads, dim_head, dim_head))
+        nn.init.xavier_uniform_(self.relation_att)
+        nn.init.xavier_uniform_(self.relation_msg)
+        w = window_size
+        self.relative_position_bias_table = nn.Embedding((2 * w - 1) ** 2, self.heads)
+        r = torch.arange(w)
+        rr, cc = torch.meshgrid(r, r, indexing="ij")
+        rr, cc = rr.reshape(-1), cc.reshape(-1)
+        index = (rr[:, None] - rr[None, :] + w - 1) * (2 * w - 1) + (cc[:, None] - cc[None, :] + w - 1)
+        self.register_buffer("relative_position_index", index)
+
+
+class _FusionBase(nn.Module):
+    """Shared launch logic.  Subclasses provide ``_block_prefix`` / ``_head_prefix`` and
+    ``_block_cfg``."""
+
+    precision = "f16"
+    skip_masked = True
+
+    def _init_runtime(self):
+        self._folded = None
+        self._folded_key = None
+        self._workspace = None
+        self._host_cache: Dict[str, tuple] = {}
+
+    # -- host copies of the small integer inputs (one sync unless cached / already on CPU) --
+    def _host_ints(self, name: str, t: torch.Tensor):
+        if t.device.type == "cpu":
+            return [int(v) for v in t.reshape(-1).tolist()]
+        key = (t.data_ptr(), t._version, tuple(t.shape))
+        hit = self._host_cache.get(name)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        vals = [int(v) for v in t.reshape(-1).tolist()]
+        self._host_cache[name] = (key, vals)
+        return vals
+
+    def _weights(self, device, prec: int):
+        params = list(self.parameters()) + list(self.buffers())
+        key = (prec, str(device)) + tuple((p.data_ptr(), p._version) for p in params)
+        if self._folded_key != key:
+            dtype = torch.float32 if prec == _lib.PREC_F32 else torch.float16
+            sd = {k: v.to(device) for k, v in self.state_dict().items()}
+            blk = self._block_cfg
+            folded = {}
+            for s, which in enumerate(("window", "grid")):
+                folded[s] = weights.fold_stage(sd, self._block_prefix, which, blk["dim_head"],
+                                               blk["window_size"], dtype)
+            if self._head_prefix is not None:
+                folded["head"] = weights.fold_head(sd, self._head_prefix, dtype)
+            self._folded, self._folded_key = folded, key
+        return self._folded
+
+    def _run(self, x, pairwise_t_matrix, mode, record_len, mask, apply_head: bool, num_iters: int):
+        blk = self._block_cfg
+        if blk["architect_mode"] != "sequential":
+            if blk["architect_mode"] == "parallel":
+                raise NotImplementedError("architect_mode='parallel' (SplitAttn) is not built yet")
+            raise ValueError(f"{blk['architect_mode']} not implemented")
+        if x.device.type != "cuda":
+            raise RuntimeError("hm-vit_amd runs on the GPU only (HIP kernels, no CPU fallback)")
+        if x.dim() != 5:
+            raise ValueError("x must be (B, L, C, H, W)")
+        B, L, Cc, H, W = x.shape
+        prec = _PRECISIONS[self.precision]
+        x = x.detach().to(torch.float32).contiguous()
+        pw = pairwise_t_matrix.detach().to(device=x.device, dtype=torch.float32).contiguous()
+        if tuple(pw.shape) != (B, L, L, 4, 4):
+            raise ValueError(f"pairwise_t_matrix must be {(B, L, L, 4, 4)}, got {tuple(pw.shape)}")
+        mode_h = self._host_ints("mode", mode)
+        rl_h = self._host_ints("record_len", record_len)
+        mask_h = self._host_ints("mask", mask)
+        if len(mode_h) != B * L or len(mask_h) != B * L or len(rl_h) != B:
+            raise ValueError("mode / mask must be (B, L) and record_len (B,)")
+
+        w = self._weights(x.device, prec)
+        d = _lib.FusionDesc()
+        d.B, d.L, d.C, d.H, d.W = B, L, Cc, H, W
+        d.heads, d.dim_head = Cc // blk["dim_head"], blk["dim_head"]
+        d.window, d.mlp_dim, d.num_iters = blk["window_size"], blk["mlp_dim"], num_iters
+        d.precision, d.apply_head, d.skip_masked = prec, int(apply_head), int(self.skip_masked)
+        d.discrete_ratio = float(self.discrete_ratio)
+        d.downsample_rate = float(self.downsample_rate)
+        keep = (_lib.i32_array(mode_h), _lib.i32_array(rl_h), _lib.i32_array(mask_h))
+        d.mode, d.record_len, d.cav_mask = keep
+        out = torch.empty((B, Cc, H, W) if apply_head else (B, L, Cc, H, W), device=x.device,
+                          dtype=torch.float32)
+        d.x, d.pairwise_t, d.out = x.data_ptr(), pw.data_ptr(), out.data_ptr()
+        for s in range(2):
+            for name, _ in _lib.StageWeights._fields_:
+                setattr(d.stage[s], name, w[s][name].data_ptr())
+        if apply_head:
+            for name in ("head_w1", "head_b1", "head_w2", "head_b2"):
+                setattr(d, name, w["head"][name].data_ptr())
+        need = _lib.lib.hmvit_fusion_workspace_bytes(ctypes.byref(d))
+        if need == 0:
+            _lib.check(-22, "hmvit_fusion_workspace_bytes")
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != x.device:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+        d.workspace, d.workspace_bytes = self._workspace.data_ptr(), self._workspace.numel()
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib.hmvit_fusion_forward(ctypes.byref(d), ctypes.c_void_p(stream)),
+                       "hmvit_fusion_forward")
+        return out
+
+
+class HeteroFusionBlock(_FusionBase):
+    """hetero_fusion.py:279-474; ``forward`` returns (B, L, C, H, W)."""
+
+    _block_prefix = ""
+    _head_prefix = None
+
+    def __init__(self, config: dict):
+        super().__init__()
+        dim, mlp_dim = config["input_dim"], config["mlp_dim"]
+        self._block_cfg = dict(config)
+        self.architect_mode = config["architect_mode"]
+        self.window_size = config["window_size"]
+        self.downsample_rate = config["spatial_transform"]["downsample_rate"]
+        self.discrete_ratio = config["spatial_transform"]["voxel_size"][0]
+        args = (dim, config["dim_head"], config["drop_out"], config["agent_size"], config["window_size"])
+        self.window_norm = HeteroLayerNorm(dim)
+        self.window_attention = HeteroAttention(*args)
+        self.window_ffd = HeteroPreNormResidual(dim, HeteroFeedForward(dim, mlp_dim, config["drop_out"]))
+        self.grid_norm = HeteroLayerNorm(dim)
+        self.grid_attention = HeteroAttention(*args)
+        self.grid_ffd = HeteroPreNormResidual(dim, HeteroFeedForward(dim, mlp_dim, config["drop_out"]))
+        # constructed but unused by the reference forward (hetero_fusion.py:326-327); kept so
+        # that state_dict keys match
+        self.aggregate_fc = HeteroFeedForward(mlp_dim * 3, mlp_dim, config["drop_out"], out_dim=mlp_dim)
+        self._init_runtime()
+
+    def forward(self, x, pairwise_t_matrix, mode, record_len, mask):
+        return self._run(x, pairwise_t_matrix, mode, record_len, mask, apply_head=False, num_iters=1)
+
+
+class HeteroFusion(_FusionBase):
+    """bevformer_point_pillar_hetero.py:22-49; ``forward`` returns (B, C, H, W)."""
+
+    _block_prefix = "hetero_fusion_block"
+    _head_prefix = "mlp_head"
+
+    def __init__(self, config: dict, precision: str = "f16"):
+        super().__init__()
+        self.downsample_rate = config["spatial_transform"]["downsample_rate"]
+        self.discrete_ratio = config["spatial_transform"]["voxel_size"][0]
+        self.hetero_fusion_block = HeteroFusionBlock(config["hetero_fusion_block"])
+        self._block_cfg = dict(config["hetero_fusion_block"])
+        dim = config["hetero_fusion_block"]["input_dim"]
+        self.num_iters = config["num_iters"]
+        self.mlp_head = HeteroFeedForward(dim, dim, 0)
+        if precision not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+        self.precision = precision
+        self._init_runtime()
+        # the block's own spatial_transform config drives the warp, as in the reference
+        self.downsample_rate = self.hetero_fusion_block.downsample_rate
+        self.discrete_ratio = self.hetero_fusion_block.discrete_ratio
+
+    def forward(self, x, pairwise_t_matrix, mode, record_len, mask):
+        return self._run(x, pairwise_t_matrix, mode, record_len, mask, apply_head=True,
+                         num_iters=self.num_iters)

@@ -1,0 +1,101 @@
+"""Host-side weight preparation for libhmvit: the exact algebraic folds of SURVEY.md 8(a).
+
+Runs once per parameter version (cached by the module), on whatever device the parameters
+live on, with plain torch tensor algebra; nothing here is on the per-scene hot path.
+
+Folds (all exact in real arithmetic, reference hetero_fusion.py line numbers):
+  * q scale ``dim_head**-0.5`` (:217) goes into the q weights and bias;
+  * ``relation_att[e]`` (:221-223) is applied to the K projection of source type ``ts`` for
+    ego type ``te`` (e = te*2 + ts, :154-155): k' = blockdiag_h(W_att[e,h]) k;
+  * ``relation_msg[e]`` (:263-264) is applied to the V projection: v' = blockdiag_h(W_msg[e,h]^T) v;
+  * the relative-position bias table (:82-109, 227-233) is expanded into the accumulator
+    fragment order of the 16x16 MFMA tile (row = key 4*(lane>>4)+r, col = query lane&15).
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from . import _lib
+
+NUM_TYPES = _lib.NUM_TYPES
+
+
+def bias_fragments(table: torch.Tensor, window: int) -> torch.Tensor:
+    """table ((2w-1)^2, heads) -> (heads, NB, 64, 4) f32; NB = 7 for window 8 (one fragment per
+    query-tile minus key-tile offset -3..3), 1 for window 4."""
+    w = window
+    lane = torch.arange(64)
+    ql = (lane & 15)[:, None].expand(64, 4)
+    kl = (4 * (lane >> 4))[:, None] + torch.arange(4)[None, :]
+    if w == 8:
+        dq = torch.arange(-3, 4)[:, None, None]                 # qt - kt
+        drow = 2 * dq + (ql >> 3)[None] - (kl >> 3)[None]
+        dcol = ((ql & 7) - (kl & 7))[None].expand(7, 64, 4)
+    elif w == 4:
+        drow = ((ql >> 2) - (kl >> 2))[None]
+        dcol = ((ql & 3) - (kl & 3))[None]
+    else:
+        raise ValueError(f"window_size={w} unsupported (4 or 8)")
+    idx = (drow + w - 1) * (2 * w - 1) + (dcol + w - 1)          # (NB, 64, 4)
+    frag = table.detach().float()[idx.to(table.device)]           # (NB, 64, 4, heads)
+    return frag.permute(3, 0, 1, 2).contiguous()
+
+
+def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: int, window: int,
+               dtype: torch.dtype) -> Dict[str, torch.Tensor]:
+    """Folded tensors of one stage (which = 'window' | 'grid') in the layout of
+    HmvitStageWeights (include/hmvit.h).  Matrices in `dtype`, vectors in f32."""
+    prefix = f"{prefix}." if prefix else ""
+    att = f"{prefix}{which}_attention"
+    f = lambda k: sd[k].detach().float()
+    C = f(f"{att}.q_linears.0.weight").shape[0]
+    M = C // dim_head
+    scale = dim_head ** -0.5
+    rel_att = f(f"{att}.relation_att")     # (4, M, d, d) [e, h, p, q]
+    rel_msg = f(f"{att}.relation_msg")
+
+    out: Dict[str, torch.Tensor] = {}
+    stack = lambda fmt: torch.stack([f(fmt.format(t=t)) for t in range(NUM_TYPES)])
+    out["ln_gamma"] = stack(f"{prefix}{which}_norm.net.{{t}}.weight")
+    out["ln_beta"] = stack(f"{prefix}{which}_norm.net.{{t}}.bias")
+    out["w_q"] = (stack(f"{att}.q_linears.{{t}}.weight") * scale).to(dtype)
+    out["b_q"] = stack(f"{att}.q_linears.{{t}}.bias") * scale
+
+    w_kv = torch.empty(NUM_TYPES, NUM_TYPES, 2 * C, C, device=rel_att.device)
+    b_kv = torch.empty(NUM_TYPES, NUM_TYPES, 2 * C, device=rel_att.device)
+    for te in range(NUM_TYPES):
+        for ts in range(NUM_TYPES):
+            e = te * NUM_TYPES + ts
+            wk = f(f"{att}.k_linears.{ts}.weight").reshape(M, dim_head, C)
+            bk = f(f"{att}.k_linears.{ts}.bias").reshape(M, dim_head)
+            wv = f(f"{att}.v_linears.{ts}.weight").reshape(M, dim_head, C)
+            bv = f(f"{att}.v_linears.{ts}.bias").reshape(M, dim_head)
+            w_kv[te, ts, :C] = torch.einsum("hpq,hqc->hpc", rel_att[e], wk).reshape(C, C)
+            b_kv[te, ts, :C] = torch.einsum("hpq,hq->hp", rel_att[e], bk).reshape(C)
+            w_kv[te, ts, C:] = torch.einsum("hpq,hpc->hqc", rel_msg[e], wv).reshape(C, C)
+            b_kv[te, ts, C:] = torch.einsum("hpq,hp->hq", rel_msg[e], bv).reshape(C)
+    out["w_kv"] = w_kv.to(dtype)
+    out["b_kv"] = b_kv
+    out["bias_frag"] = bias_fragments(sd[f"{att}.relative_position_bias_table.weight"], window)
+    out["w_o"] = stack(f"{att}.a_linears.{{t}}.0.weight").to(dtype)
+    out["b_o"] = stack(f"{att}.a_linears.{{t}}.0.bias")
+    out["ffn_ln_gamma"] = stack(f"{prefix}{which}_ffd.norm.net.{{t}}.weight")
+    out["ffn_ln_beta"] = stack(f"{prefix}{which}_ffd.norm.net.{{t}}.bias")
+    out["w_1"] = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.0.weight").to(dtype)
+    out["b_1"] = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.0.bias")
+    out["w_2"] = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.3.weight").to(dtype)
+    out["b_2"] = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.3.bias")
+    return {k: v.contiguous() for k, v in out.items()}
+
+
+def fold_head(sd: Dict[str, torch.Tensor], prefix: str, dtype: torch.dtype) -> Dict[str, torch.Tensor]:
+    f = lambda k: sd[k].detach().float()
+    stack = lambda fmt: torch.stack([f(fmt.format(t=t)) for t in range(NUM_TYPES)])
+    return {
+        "head_w1": stack(f"{prefix}.net.{{t}}.0.weight").to(dtype).contiguous(),
+        "head_b1": stack(f"{prefix}.net.{{t}}.0.bias").contiguous(),
+        "head_w2": stack(f"{prefix}.net.{{t}}.3.weight").to(dtype).contiguous(),
+        "head_b2": stack(f"{prefix}.net.{{t}}.3.bias").contiguous(),
+    }

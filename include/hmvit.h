@@ -1,0 +1,180 @@
+/* hmvit.h -- C ABI of the MI355X-native HM-ViT fusion hot path (libhmvit.so).
+ *
+ * The reference has no FFI for this path: it is pure Python/PyTorch, and its GPU arithmetic
+ * comes from torch (cuBLAS/cuDNN).  The entry points below are what a binding for the path
+ * would call; each one names the reference code it replaces (paths relative to the reference
+ * repository root).  Conventions:
+ *   - plain pointers and sizes only, no torch / C++ types;
+ *   - every pointer marked "device" is HBM memory of the current HIP device;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*) and is stream-ordered;
+ *     nothing here synchronises or allocates device memory: scratch comes from the caller
+ *     (`workspace`, size from hmvit_fusion_workspace_bytes);
+ *   - return 0 on success, a negative HMVIT_E* code otherwise; hmvit_last_error() gives the
+ *     message of the last failure on the calling thread;
+ *   - re-entrant: no global mutable state besides the thread-local error string.
+ */
+#ifndef HMVIT_H
+#define HMVIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMVIT_ABI_VERSION 1
+
+#define HMVIT_OK 0
+#define HMVIT_EINVAL (-22)   /* bad argument / unsupported shape */
+#define HMVIT_ENOMEM (-12)   /* workspace too small */
+#define HMVIT_EHIP (-5)      /* a HIP call failed */
+
+#define HMVIT_MAX_AGENTS 8   /* L (max_cav) upper bound */
+#define HMVIT_NUM_TYPES 2    /* 0 = camera, 1 = lidar (base_camera_lidar_dataset.py:136,178) */
+
+/* arithmetic modes */
+#define HMVIT_PREC_F32 0     /* f32 MFMA everywhere: strict parity mode */
+#define HMVIT_PREC_F16 1     /* f16 operands, f32 accumulate, f32 LN/softmax/residual */
+
+/* partition of one attention stage (hetero_fusion.py:387-389 vs :430-431) */
+#define HMVIT_PART_WINDOW 0  /* 'b m d (x w1) (y w2)': contiguous w x w windows */
+#define HMVIT_PART_GRID 1    /* 'b m d (w1 x) (w2 y)': dilated grid */
+
+/* Weights of one attention stage, already folded by the host
+ * (hm-vit_amd/weights.py; identities (i)-(ii) of SURVEY.md 8a).  Element type is f32 or
+ * f16 according to the precision mode, except where noted.  All device pointers.
+ *   ln_*      (T, C)            f32   HeteroLayerNorm affine, base_transformer.py:172-177
+ *   w_q       (T, C, C)               q_linears[t].weight * dim_head^-0.5, hetero_fusion.py:111-140,217
+ *   b_q       (T, C)            f32   q_linears[t].bias   * dim_head^-0.5
+ *   w_kv      (T_ego, T_src, 2C, C)   rows [0,C): blockdiag_h(relation_att[e,h]) k_linears[ts].weight
+ *                                     rows [C,2C): blockdiag_h(relation_msg[e,h]^T) v_linears[ts].weight,
+ *                                     e = t_ego*2 + t_src  (hetero_fusion.py:154-185,221-223,263-264)
+ *   b_kv      (T_ego, T_src, 2C) f32  the same maps applied to the k / v biases
+ *   bias_frag (heads, NB, 64, 4) f32  relative-position bias in MFMA accumulator order,
+ *                                     NB = 7 (window 8) or 1 (window 4), hetero_fusion.py:82-109,227-233
+ *   w_o, b_o  (T, C, C), (T, C)       a_linears[t][0], hetero_fusion.py:142-152
+ *   ffn_ln_*  (T, C)            f32   {window,grid}_ffd.norm, base_transformer.py:129-136
+ *   w_1,b_1   (T, mlp, C),(T, mlp)    {window,grid}_ffd.fn.net[t][0], base_transformer.py:180-192
+ *   w_2,b_2   (T, C, mlp),(T, C)      {window,grid}_ffd.fn.net[t][3]
+ * Biases are always f32. */
+typedef struct HmvitStageWeights {
+    const float* ln_gamma;
+    const float* ln_beta;
+    const void* w_q;
+    const float* b_q;
+    const void* w_kv;
+    const float* b_kv;
+    const float* bias_frag;
+    const void* w_o;
+    const float* b_o;
+    const float* ffn_ln_gamma;
+    const float* ffn_ln_beta;
+    const void* w_1;
+    const float* b_1;
+    const void* w_2;
+    const float* b_2;
+} HmvitStageWeights;
+
+/* One HeteroFusion / HeteroFusionBlock forward.
+ * Replaces HeteroFusion.forward (opencood/models/bevformer_point_pillar_hetero.py:39-49) when
+ * apply_head = 1 and HeteroFusionBlock.forward, sequential mode
+ * (opencood/models/sub_modules/hetero_fusion.py:446-458) iterated num_iters times when
+ * apply_head = 0. */
+typedef struct HmvitFusionDesc {
+    int32_t B, L, C, H, W;        /* x is (B, L, C, H, W) f32, NCHW per agent            */
+    int32_t heads, dim_head;      /* C = heads * dim_head; dim_head must be 32            */
+    int32_t window;               /* 4 or 8; H and W must be divisible by it              */
+    int32_t mlp_dim;              /* FFN hidden width                                     */
+    int32_t num_iters;            /* the same block weights are applied num_iters times   */
+    int32_t precision;            /* HMVIT_PREC_*                                         */
+    int32_t apply_head;           /* 1: ego slice + mlp_head -> out (B, C, H, W)
+                                     0: out (B, L, C, H, W), all agents                   */
+    int32_t skip_masked;          /* 1: skip key tiles whose 64 keys are all masked (exact) */
+    float discrete_ratio;         /* spatial_transform.voxel_size[0]                      */
+    float downsample_rate;        /* spatial_transform.downsample_rate                    */
+    /* host arrays (read during the call, not retained) */
+    const int32_t* mode;          /* (B, L) agent types; padding = 0                      */
+    const int32_t* record_len;    /* (B)                                                  */
+    const int32_t* cav_mask;      /* (B, L) 1 = real agent                                */
+    /* device arrays */
+    const float* x;               /* (B, L, C, H, W)                                      */
+    const float* pairwise_t;      /* (B, L, L, 4, 4), [b,i,j] maps agent i into agent j   */
+    float* out;
+    HmvitStageWeights stage[2];   /* [0] window (local), [1] grid (global)                */
+    const void* head_w1;          /* mlp_head.net[t][0]: (T, C, C)                        */
+    const float* head_b1;         /* (T, C)                                               */
+    const void* head_w2;          /* mlp_head.net[t][3]: (T, C, C)                        */
+    const float* head_b2;
+    void* workspace;              /* device scratch                                       */
+    size_t workspace_bytes;
+} HmvitFusionDesc;
+
+int hmvit_abi_version(void);
+const char* hmvit_last_error(void);
+
+/* bytes of device scratch hmvit_fusion_forward needs for this descriptor (0 on bad input) */
+size_t hmvit_fusion_workspace_bytes(const HmvitFusionDesc* desc);
+
+/* bevformer_point_pillar_hetero.py:39-49 / hetero_fusion.py:446-458 (see HmvitFusionDesc) */
+int hmvit_fusion_forward(const HmvitFusionDesc* desc, void* stream);
+
+/* ---- single operators (used by the parity tests; same kernels as the fused forward) ---- */
+
+/* (n_agents, C, P) f32 -> (n_agents, P, C) f32 and back: the layout change between the
+ * reference's NCHW maps and the token-major residual stream used internally. */
+int hmvit_nchw_to_tokens(const float* x, float* y, int n_agents, int C, int P, void* stream);
+int hmvit_tokens_to_nchw(const float* x, float* y, int n_agents, int C, int P, void* stream);
+
+/* HeteroLayerNorm (base_transformer.py:138-177) on token-major maps.
+ * x (n_agents, P, C) f32; types: host array (n_agents); gamma/beta (T, C) f32 device;
+ * y (n_agents, P, C) f32 or f16 by `precision`. */
+int hmvit_layernorm(const float* x, void* y, const int32_t* types, const float* gamma,
+                    const float* beta, int n_agents, int P, int C, int precision, void* stream);
+
+/* y = act(a @ w^T + bias) (+ residual): nn.Linear as used by to_qkv / to_out /
+ * HeteroFeedForward (hetero_fusion.py:111-152, base_transformer.py:180-192).
+ * a (M, K), w (N, K) in the precision's element type; bias (N) f32 or NULL;
+ * residual (M, N) f32 or NULL; gelu: 0/1 (exact erf form);
+ * out_f32: 1 -> y is f32, 0 -> y has the precision's element type. */
+int hmvit_linear(const void* a, const void* w, const float* bias, const float* residual,
+                 void* y, int M, int N, int K, int gelu, int out_f32, int precision,
+                 void* stream);
+
+/* get_discretized_transformation_matrix + get_transformation_matrix + inverse
+ * (torch_transformation_utils.py:108-134, 254-297, 349): pairwise_t (n, 4, 4) f32 device ->
+ * ainv (n, 8) f32 device: [a00 a01 a02 a10 a11 a12 is_identity 0], the pixel-space map
+ * src = Ainv [u, v, 1] used for sampling. */
+int hmvit_pair_affines(const float* pairwise_t, float* ainv, int n, int H, int W,
+                       float discrete_ratio, float downsample_rate, void* stream);
+
+/* warp_affine (bilinear, zeros, align_corners=True) + get_roi_and_cav_mask (nearest)
+ * (torch_transformation_utils.py:11-105, 317-355) of token-major maps, with the sampling code
+ * the attention kernel uses.  src (n, P, C) f32, ainv (n, 8) -> dst (n, P, C) f32,
+ * roi (n, P) f32. */
+int hmvit_warp_affine(const float* src, const float* ainv, float* dst, float* roi, int n,
+                      int H, int W, int C, void* stream);
+
+/* One call of HeteroAttention.forward for every ego (hetero_fusion.py:187-277) minus the
+ * output projection, fused with the L^2 warps of warp_features (:338-361) and the window /
+ * grid partition (:384-394, 427-434).
+ *   q      (B, L, P, C)          projected queries (scale folded), no bias
+ *   kv     (B, L, E, 2, P, C)    projected, relation-folded keys / values, no bias
+ *   ego_e  host (B, L)           which of the E variants ego (b, i) uses
+ *   b_q    (T, C) f32, b_kv (T_ego, T_src, 2C) f32, mode host (B, L)
+ *   ainv   (B, L_src, L_ego, 8)  hmvit_pair_affines(pairwise_t): record [b, j, i] samples source j
+ *                                 in ego i's frame (pairwise_t[:, :, i] of hetero_fusion.py:345)
+ *   out    (B, L, P, C)          attention output of ego i (rows >= n_ego untouched) */
+int hmvit_window_attention(const void* q, const void* kv, const float* b_q, const float* b_kv,
+                           const float* bias_frag, const float* ainv, const int32_t* mode,
+                           const int32_t* cav_mask, const int32_t* ego_e, void* out, int B, int L,
+                           int n_ego, int n_src, int E, int C, int H, int W, int window,
+                           int partition, int precision, int skip_masked, void* stream);
+
+/* debug: lane mapping of ds_read_b64_tr_b16 (used once to pin the V-operand layout) */
+int hmvit_debug_tr16(uint16_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HMVIT_H */

@@ -1,0 +1,126 @@
+"""GPU parity tests of the drop-in modules (hm-vit_amd/fusion.py -> hmvit_fusion_forward) against
+the golden vectors frozen from the reference and against the CPU oracle on the same seeded
+inputs.  Tolerance (north_star): max |y - ref| / max |ref| <= 1e-3 in the f16-operand mode;
+the f32 mode is held to 1e-4 (fp32 re-association + the fp32 round-off of the reference's own
+normalised sampling coordinates)."""
+import pytest
+import torch
+
+from conftest import load_golden, rel_max_err
+from oracle import hmvit_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f32": 1e-4, "f16": 1e-3}
+
+
+def _cuda(*ts):
+    return [t.cuda() for t in ts]
+
+
+def _fusion(cfg, sd, precision):
+    import hmvit_amd
+    net = hmvit_amd.HeteroFusion(cfg, precision=precision)
+    net.load_state_dict(sd, strict=True)
+    return net.cuda().eval()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_block_g3(precision):
+    import hmvit_amd
+    g = load_golden("g3_block_seq.npz")
+    sd = O.random_state_dict(g["cfg"], g["seed_weights"])
+    blk = hmvit_amd.HeteroFusionBlock(g["cfg"]["hetero_fusion_block"])
+    blk.precision = precision
+    blk.load_state_dict({k[len("hetero_fusion_block."):]: v for k, v in sd.items()
+                         if k.startswith("hetero_fusion_block.")}, strict=True)
+    blk = blk.cuda().eval()
+    x, pw, mode, rl, mask = O.synthetic_scene(**g["scene"])
+    y = blk(*_cuda(x, pw, mode, rl, mask)).cpu()
+    assert y.shape == g["out"].shape
+    assert rel_max_err(y, g["out"]) < TOL[precision]
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_fusion_g4_c256_mixed(precision):
+    g = load_golden("g4_fusion_c256.npz")
+    sd = O.random_state_dict(g["cfg"], g["seed_weights"])
+    net = _fusion(g["cfg"], sd, precision)
+    y = net(*_cuda(*O.synthetic_scene(**g["scene"]))).cpu()
+    assert rel_max_err(y, g["out"]) < TOL[precision]
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_fusion_g5_ragged_batch(precision):
+    g = load_golden("g5_fusion_ragged.npz")
+    sd = O.random_state_dict(g["cfg"], g["seed_weights"])
+    net = _fusion(g["cfg"], sd, precision)
+    y = net(*_cuda(g["x"], g["pairwise"], g["mode"], g["record_len"], g["mask"])).cpu()
+    assert torch.isfinite(y).all()
+    assert rel_max_err(y, g["out"]) < TOL[precision]
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_fusion_g6_cfg1_full_size(precision):
+    """BASELINE configs[0]: 2 LiDAR agents, 100x352, C=64, window 4."""
+    g = load_golden("g6_fusion_cfg1.npz")
+    sd = O.random_state_dict(g["cfg"], g["seed_weights"])
+    net = _fusion(g["cfg"], sd, precision)
+    y = net(*_cuda(*O.synthetic_scene(**g["scene"]))).cpu()
+    scale = float(g["abs_max"])
+    assert float((y[:, :, ::5, ::11] - g["out_sub"]).abs().max()) / scale < TOL[precision]
+    assert float((y.double().mean((0, 2, 3)) - g["chan_mean"]).abs().max()) / scale < TOL[precision]
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+@pytest.mark.parametrize("modes,n_valid", [([1, 1, 1, 1, 1], 5), ([0, 0, 0, 0, 0], 5), ([0, 1, 1, 0, 1], 4),
+                                           ([1, 0, 0, 0, 0], 1)])
+def test_fusion_vs_oracle_native_window8(precision, modes, n_valid):
+    """5 agents, C=256, window 8 on a 32x48 map (cfg2 / cfg3 / cfg4 type patterns), oracle run live."""
+    cfg = O.make_config(256, 8, 5, voxel=0.4, downsample=4)
+    sd = O.random_state_dict(cfg, seed=7)
+    scene = O.synthetic_scene(5, 256, 32, 48, modes, n_valid=n_valid, seed=3, tx_step=6.0, ty_step=-4.0)
+    ref = O.hetero_fusion(*scene, sd, cfg)
+    y = _fusion(cfg, sd, precision)(*_cuda(*scene)).cpu()
+    assert rel_max_err(y, ref) < TOL[precision]
+
+
+def test_skip_masked_is_exact():
+    cfg = O.make_config(64, 8, 3)
+    sd = O.random_state_dict(cfg, seed=9)
+    scene = _cuda(*O.synthetic_scene(3, 64, 32, 32, [1, 0, 1], seed=5, tx_step=25.0, ty_step=-20.0))
+    net = _fusion(cfg, sd, "f32")
+    net.skip_masked = True
+    a = net(*scene)
+    net.skip_masked = False
+    b = net(*scene)
+    assert torch.equal(a, b)
+
+
+def test_inputs_not_mutated_and_repeatable():
+    cfg = O.make_config(64, 4, 2)
+    sd = O.random_state_dict(cfg, seed=2)
+    scene = _cuda(*O.synthetic_scene(2, 64, 16, 16, [1, 0], seed=4))
+    keep = [t.clone() for t in scene]
+    net = _fusion(cfg, sd, "f16")
+    a = net(*scene)
+    b = net(*scene)
+    assert torch.equal(a, b)
+    for t, k in zip(scene, keep):
+        assert torch.equal(t, k)
+
+
+def test_errors():
+    import hmvit_amd
+    cfg = O.make_config(64, 4, 2)
+    sd = O.random_state_dict(cfg, seed=2)
+    scene = O.synthetic_scene(2, 64, 16, 16, [1, 0], seed=4)
+    net = _fusion(cfg, sd, "f16")
+    with pytest.raises(RuntimeError):
+        net(*scene)                                     # CPU tensors: no fallback
+    bad = O.make_config(64, 4, 2, arch="bogus")
+    with pytest.raises(ValueError):
+        hmvit_amd.HeteroFusion(bad).cuda()(*_cuda(*scene))
+    x, pw, mode, rl, mask = _cuda(*O.synthetic_scene(2, 64, 18, 16, [1, 0], seed=4))
+    with pytest.raises(ValueError):
+        net(x, pw, mode, rl, mask)                      # 18 not divisible by window 4

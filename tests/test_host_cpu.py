@@ -1,0 +1,120 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/hmvit.h
+declares, argument validation works without touching a device, the host-side weight folds are
+the algebra the oracle performs, and the drop-in module mirrors the reference's state_dict."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from oracle import hmvit_oracle as O
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import hmvit_amd
+    return hmvit_amd
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    from hmvit_amd import _lib
+    header = open(os.path.join(ROOT, "include", "hmvit.h")).read()
+    declared = set(re.findall(r"\b(hmvit_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert raw.hmvit_abi_version() == _lib.ABI_VERSION
+
+
+def test_descriptor_validation_without_gpu(pkg):
+    from hmvit_amd import _lib
+    d = _lib.FusionDesc()
+    d.B, d.L, d.C, d.H, d.W = 1, 2, 64, 16, 16
+    d.heads, d.dim_head, d.window, d.mlp_dim, d.num_iters = 2, 32, 4, 64, 2
+    d.precision, d.apply_head = _lib.PREC_F16, 1
+    d.discrete_ratio, d.downsample_rate = 0.4, 4.0
+    keep = (_lib.i32_array([1, 0]), _lib.i32_array([2]), _lib.i32_array([1, 1]))
+    d.mode, d.record_len, d.cav_mask = keep
+    assert _lib.lib.hmvit_fusion_workspace_bytes(ctypes.byref(d)) > 0
+    d.window = 7
+    assert _lib.lib.hmvit_fusion_workspace_bytes(ctypes.byref(d)) == 0
+    assert b"window_size" in _lib.lib.hmvit_last_error()
+    d.window, d.H = 4, 18
+    assert _lib.lib.hmvit_fusion_workspace_bytes(ctypes.byref(d)) == 0
+    assert b"divisible" in _lib.lib.hmvit_last_error()
+
+
+def test_state_dict_names_match_reference(pkg):
+    g = load_golden("g4_fusion_c256.npz")
+    sd = O.random_state_dict(g["cfg"], 0)          # keys enumerated from the reference
+    net = pkg.HeteroFusion(g["cfg"])
+    assert set(net.state_dict().keys()) == set(sd.keys())
+    for k, v in net.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    net.load_state_dict(sd, strict=True)
+
+
+def test_cpu_tensors_raise(pkg):
+    cfg = O.make_config(64, 4, 2)
+    net = pkg.HeteroFusion(cfg)
+    with pytest.raises(RuntimeError):
+        net(*O.synthetic_scene(2, 64, 8, 8, [1, 1]))
+
+
+def test_relation_fold_equals_unfolded_attention(pkg):
+    """weights.fold_stage: q.(W_att k) and attn.(W_msg^T v) with folded projection weights equal the
+    oracle's unfolded computation (identity (ii) of SURVEY 8a)."""
+    from hmvit_amd import weights
+    g = load_golden("g1_attention.npz")
+    cfg = g["cfg"]["hetero_fusion_block"]
+    sd = O.random_state_dict(g["cfg"], g["seed_weights"])
+    C, dh, w = cfg["input_dim"], cfg["dim_head"], cfg["window_size"]
+    f = weights.fold_stage(sd, "hetero_fusion_block", "window", dh, w, torch.float32)
+    xw, mode, mask = g["xw"], g["mode"], g["mask"]
+    B, L, X, Y, _, _, _ = xw.shape
+    n, M = w * w, C // dh
+    te = int(mode[0, 0])
+    q = xw[:, 0].reshape(B, X, Y, n, C) @ f["w_q"][te].t() + f["b_q"][te]
+    ks, vs = [], []
+    for j in range(L):
+        ts = int(mode[0, j])
+        kv = xw[:, j].reshape(B, X, Y, n, C) @ f["w_kv"][te, ts].t() + f["b_kv"][te, ts]
+        ks.append(kv[..., :C])
+        vs.append(kv[..., C:])
+    k, v = torch.stack(ks, 3), torch.stack(vs, 3)                    # (B, X, Y, L, n, C)
+    qh = q.reshape(B, X, Y, n, M, dh).permute(0, 1, 2, 4, 3, 5)
+    kh = k.reshape(B, X, Y, L * n, M, dh).permute(0, 1, 2, 4, 3, 5)
+    vh = v.reshape(B, X, Y, L * n, M, dh).permute(0, 1, 2, 4, 3, 5)
+    sim = qh @ kh.transpose(-1, -2)
+    table = sd["hetero_fusion_block.window_attention.relative_position_bias_table.weight"]
+    bias = table[O.relative_position_index(w)].permute(2, 0, 1)      # (M, n, n)
+    sim = sim + bias.repeat(1, 1, L)[None, None, None]
+    km = mask.reshape(B, X, Y, n, L).permute(0, 1, 2, 4, 3).reshape(B, X, Y, 1, 1, L * n)
+    sim = sim.masked_fill(km == 0, -float("inf"))
+    finite = torch.isfinite(g["sim"])
+    assert float((sim.reshape(g["sim"].shape)[finite] - g["sim"][finite]).abs().max()) < 2e-5
+    out = torch.softmax(sim, -1) @ vh
+    out = out.permute(0, 1, 2, 4, 3, 5).reshape(B, X, Y, n, C)
+    out = out @ f["w_o"][te].t() + f["b_o"][te]
+    assert float((out.reshape(g["out"].shape) - g["out"]).abs().max()) < 2e-5
+
+
+def test_bias_fragments_layout(pkg):
+    from hmvit_amd import weights
+    for w, nb in ((8, 7), (4, 1)):
+        M = 3
+        table = torch.randn((2 * w - 1) ** 2, M)
+        frag = weights.bias_fragments(table, w)
+        assert frag.shape == (M, nb, 64, 4)
+        full = table[O.relative_position_index(w)].permute(2, 0, 1)   # (M, n_q, n_k)
+        n = w * w
+        for qt in range(n // 16):
+            for kt in range(n // 16):
+                v = qt - kt + 3 if w == 8 else 0
+                for lane in (0, 5, 17, 42, 63):
+                    for r in range(4):
+                        q, k = qt * 16 + (lane & 15), kt * 16 + 4 * (lane >> 4) + r
+                        assert torch.equal(frag[:, v, lane, r], full[:, q, k])
