@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fused 5-agent BEV scenes/s of the HM-ViT fusion hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one HeteroFusion forward (bevformer_point_pillar_hetero.py:39-49) on one synthetic
+scene of BASELINE.json configs[1]: 5 LiDAR agents, 200x704 BEV, C=256, window 8, 2 iterations,
+poses / metres-per-pixel of SURVEY.md 8(d).  Inputs are resident in HBM before the timed region.
+Scenes shard one-per-GPU with no data-path collective (inference): every rank runs its own
+scene, `value` = scenes processed by all ranks / max-over-ranks wall time ("weak" scaling).
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      the dominant kernel (by HIP-event time inside this process) against its roof,
+  cpu_baseline  the CPU oracle (oracle/hmvit_oracle.py, PyTorch-CPU fp32 restatement of the
+                reference) timed on the host cores on a bounded crop of the same workload,
+  phases        per-phase milliseconds of one forward (HIP events on the launch stream),
+  strict_f32    scenes/s of the exact-f32 MFMA mode, for reference.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (L, C, H, W, window, modes, voxel, downsample)
+    "cfg1": dict(L=2, C=64, H=100, W=352, window=4, modes=[1, 1], voxel=0.4, downsample=2),
+    "cfg2": dict(L=5, C=256, H=200, W=704, window=8, modes=[1, 1, 1, 1, 1], voxel=0.4, downsample=1),
+    "cfg3": dict(L=5, C=256, H=200, W=704, window=8, modes=[1, 0, 1, 1, 0], voxel=0.4, downsample=1),
+    "cfg4": dict(L=5, C=256, H=200, W=704, window=8, modes=[0, 0, 0, 0, 0], voxel=0.4, downsample=1),
+    "native": dict(L=5, C=256, H=128, W=128, window=8, modes=[1, 0, 1, 1, 0], voxel=0.4, downsample=4),
+}
+PEAK = {"f16": 2500.0, "f32": 157.3}      # dense MFMA TFLOP/s (MI355X_MICROARCH.md)
+PEAK_HBM = 8000.0                          # GB/s
+
+
+def phase_work(c, num_iters, es):
+    """Algorithmic FLOPs (MFMA phases) or bytes (HBM phases) of ONE launch of each phase for a
+    full (un-pruned) stage, and of the pruned last stage; SURVEY.md 8(d) formulas."""
+    L, C, P = c["L"], c["C"], c["H"] * c["W"]
+    n = c["window"] ** 2
+    mlp = C
+    E = len(set(c["modes"]))
+
+    def stage(n_ego, n_ffn, e):
+        return {
+            "ln_attn": ("hbm", L * P * C * (4 + es)),
+            "qkv_gemm": ("mfma", 2 * P * C * C * n_ego + 2 * P * 2 * C * C * L * e),
+            "attention": ("mfma", 2 * 2 * n_ego * P * (L * n) * C),
+            "out_proj": ("mfma", 2 * P * C * C * n_ego),
+            "ln_ffn": ("hbm", n_ffn * P * C * (4 + es)),
+            "ffn1": ("mfma", 2 * P * C * mlp * n_ffn),
+            "ffn2": ("mfma", 2 * P * C * mlp * n_ffn),
+        }
+    full, last = stage(L, L, E), stage(1, 1, 1)
+    n_stages = 2 * num_iters
+    out = {}
+    for k in full:
+        kind, w_full = full[k]
+        out[k] = (kind, (w_full * (n_stages - 1) + last[k][1]) / n_stages)   # mean per launch
+    out["head"] = ("mfma", 2 * 2 * P * C * C)
+    out["layout_in"] = ("hbm", L * P * C * 8)
+    out["layout_out"] = ("hbm", P * C * 8)
+    return out
+
+
+def cpu_baseline(cfgd, num_iters, seed):
+    """The oracle timed on the host cores on a crop of the workload (same agents, channels,
+    window and poses; 40x176 pixels instead of 200x704), scaled to full scenes by pixel count --
+    the reference's cost is linear in the number of windows."""
+    from oracle import hmvit_oracle as O
+    Hs, Ws = (40, 176) if cfgd["H"] * cfgd["W"] > 40 * 176 else (cfgd["H"], cfgd["W"])
+    cfg = O.make_config(cfgd["C"], cfgd["window"], cfgd["L"], voxel=cfgd["voxel"],
+                        downsample=cfgd["downsample"], num_iters=num_iters)
+    sd = O.random_state_dict(cfg, seed=0)
+    scene = O.synthetic_scene(cfgd["L"], cfgd["C"], Hs, Ws, cfgd["modes"], seed=seed)
+    O.hetero_fusion(*scene, sd, cfg)                     # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        O.hetero_fusion(*scene, sd, cfg)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > 12.0 or reps >= 5:
+            break
+    frac = (Hs * Ws) / float(cfgd["H"] * cfgd["W"])
+    return {"value": reps / dt * frac, "unit": "scenes/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{reps} forward(s) of the CPU oracle on a {Hs}x{Ws} crop ({frac * 100:.1f}% of the "
+                      f"{cfgd['H']}x{cfgd['W']} scene's windows), {dt / reps:.2f} s each, scaled by pixel count"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--num-iters", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strict", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+
+    import hmvit_amd
+    from oracle import hmvit_oracle as O      # only the seeded input generators + cpu_baseline
+
+    c = CONFIGS[args.config]
+    cfg = O.make_config(c["C"], c["window"], c["L"], voxel=c["voxel"], downsample=c["downsample"],
+                        num_iters=args.num_iters)
+    sd = O.random_state_dict(cfg, seed=0)
+    # every rank gets its own scene (different features, same geometry)
+    scene = [t.to(dev) for t in O.synthetic_scene(c["L"], c["C"], c["H"], c["W"], c["modes"], seed=1 + rank)]
+
+    def make(precision):
+        net = hmvit_amd.HeteroFusion(cfg, precision=precision)
+        net.load_state_dict(sd, strict=True)
+        return net.to(dev).eval()
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def timed(net, steps, warmup):
+        for _ in range(warmup):
+            net(*scene)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            net(*scene)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    net = make(args.precision)
+    dt = timed(net, args.steps, args.warmup)
+    value = world * args.steps / dt
+
+    result = {
+        "metric": "fused BEV scenes/sec (5 agents, 200x704 BEV, C=256)" if args.config == "cfg2"
+                  else f"fused BEV scenes/sec ({args.config})",
+        "value": value, "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f16 operands, f32 accumulate/softmax/LayerNorm/residual" if args.precision == "f16" else "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.config}: {c['L']} agents modes {''.join(map(str, c['modes']))}, "
+                               f"{c['H']}x{c['W']} BEV, C={c['C']}, window {c['window']}, "
+                               f"{args.num_iters} iters, {c['voxel'] * c['downsample']:.1f} m/px; "
+                               "HeteroFusion.forward, inputs resident in HBM",
+                   "parallelism": f"{world} independent scene replica(s), no data-path collective",
+                   "tolerance": "1e-3 rel-max vs the CPU oracle (tests/test_hip_fusion.py)"},
+    }
+
+    if rank == 0:
+        # per-phase HIP-event times of one forward on the launch stream (median of 5 forwards)
+        runs = [net.profile_phases(*scene) for _ in range(5)]
+        es = 2 if args.precision == "f16" else 4
+        work = phase_work(c, args.num_iters, es)
+        phases = {}
+        for name in runs[0]:
+            ms = sorted(r[name][0] for r in runs)[2]
+            cnt = runs[0][name][1]
+            if cnt:
+                phases[name] = {"ms_total": round(ms, 4), "launches": cnt}
+        dom = max(phases, key=lambda k: phases[k]["ms_total"])
+        kind, per_launch = work[dom]
+        avg_s = phases[dom]["ms_total"] / phases[dom]["launches"] * 1e-3
+        if kind == "mfma":
+            achieved, peak, unit = per_launch / avg_s / 1e12, PEAK[args.precision], "TFLOP/s"
+        else:
+            achieved, peak, unit = per_launch / avg_s / 1e9, PEAK_HBM, "GB/s"
+        result["roofline"] = {"kernel": dom, "bound": kind, "achieved": achieved, "peak": peak, "unit": unit,
+                              "frac": achieved / peak, "traffic": None,
+                              "avg_launch_ms": avg_s * 1e3,
+                              "algorithmic_per_launch": per_launch}
+        result["phases"] = phases
+        if not args.no_strict and world == 1 and args.precision == "f16":
+            del net
+            torch.cuda.empty_cache()
+            strict = make("f32")
+            sdt = timed(strict, max(2, args.steps // 5), 1)
+            result["strict_f32"] = {"value": max(2, args.steps // 5) / sdt, "unit": "scenes/s"}
+            del strict
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(c, args.num_iters, seed=1)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,8 @@ PREC_F32, PREC_F16 = 0, 1
 PART_WINDOW, PART_GRID = 0, 1
 NUM_TYPES = 2
 MAX_AGENTS = 8
+PHASES = ("layout_in", "ln_attn", "qkv_gemm", "attention", "out_proj", "ln_ffn", "ffn1", "ffn2", "head",
+          "layout_out")
 
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
@@ -49,6 +51,7 @@ _SIGNATURES = {
     "hmvit_last_error": (C.c_char_p, []),
     "hmvit_fusion_workspace_bytes": (C.c_size_t, [C.POINTER(FusionDesc)]),
     "hmvit_fusion_forward": (C.c_int, [C.POINTER(FusionDesc), C.c_void_p]),
+    "hmvit_fusion_profile": (C.c_int, [C.POINTER(FusionDesc), C.c_void_p, c_f32p, c_i32p]),
     "hmvit_nchw_to_tokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hmvit_tokens_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hmvit_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p, C.c_void_p, C.c_void_p, C.c_int,

@@ -66,39 +66,65 @@ __device__ __forceinline__ void store8_lds(T* p, const float (&v)[8]) {
     }
 }
 
-// bilinear sample (or direct read) of 8 channels of a projected map + bias
+// 8 channels of one token, kept in the storage type until all loads of a batch are issued
 template <typename T>
-__device__ __forceinline__ void sample8(const T* __restrict__ plane, int C, int ch, const Taps& t,
-                                        bool ident, int self_idx, const float* __restrict__ bias,
-                                        float (&out)[8]) {
-    float b[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) b[e] = bias[ch + e];
-    if (ident) {
-        float v[8];
-        load8(plane + (size_t)self_idx * C + ch, v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) out[e] = v[e] + b[e];
-    } else {
-        float acc[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (t.w[k] != 0.f) {
-                float v[8];
-                load8(plane + (size_t)t.idx[k] * C + ch, v);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = fmaf(t.w[k], v[e], acc[e]);
-            }
+struct Raw8;
+template <>
+struct Raw8<half_t> {
+    half8 h;
+    __device__ __forceinline__ void load(const half_t* __restrict__ p) { h = *reinterpret_cast<const half8*>(p); }
+    __device__ __forceinline__ float get(int e) const { return (float)h[e]; }
+};
+template <>
+struct Raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* __restrict__ p) {
+        a = *reinterpret_cast<const float4*>(p);
+        b = *reinterpret_cast<const float4*>(p + 4);
+    }
+    __device__ __forceinline__ float get(int e) const {
+        switch (e) {
+            case 0: return a.x; case 1: return a.y; case 2: return a.z; case 3: return a.w;
+            case 4: return b.x; case 5: return b.y; case 6: return b.z; default: return b.w;
         }
+    }
+};
+
+// Bilinear sample (or direct read) of 8 channels of NP projected maps (planes `pstride` elements
+// apart) + bias.  All tap loads are issued before the first use (no per-tap branches): taps with
+// zero weight read a clamped, valid address.
+template <typename T, int NP>
+__device__ __forceinline__ void sample8(const T* __restrict__ plane, size_t pstride, int C, int ch, const Taps& t,
+                                        bool ident, int self_idx, const float* __restrict__ bias, int bstride,
+                                        float (&out)[NP][8]) {
+    if (ident) {
+        Raw8<T> raw[NP];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) out[e] = acc[e] + b[e];
+        for (int pl = 0; pl < NP; ++pl) raw[pl].load(plane + pl * pstride + (size_t)self_idx * C + ch);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) out[pl][e] = raw[pl].get(e) + bias[pl * bstride + ch + e];
+    } else {
+        Raw8<T> raw[NP][4];
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) raw[pl][k].load(plane + pl * pstride + (size_t)t.idx[k] * C + ch);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float acc = t.w[0] * raw[pl][0].get(e);
+#pragma unroll
+                for (int k = 1; k < 4; ++k) acc = fmaf(t.w[k], raw[pl][k].get(e), acc);
+                out[pl][e] = acc + bias[pl * bstride + ch + e];
+            }
     }
 }
 
 template <typename T, int WIN, int HG>
-__global__ __launch_bounds__(HG * 64) void k_attention(AttnParams p) {
+__global__ __launch_bounds__(HG * 64, (sizeof(T) == 2 ? 2 : 1)) void k_attention(AttnParams p) {
     using Cfg = AttnCfg<T, HG>;
     constexpr int N = WIN * WIN;          // tokens per window
     constexpr int NQT = N / 16;           // 16-query tiles
@@ -142,9 +168,9 @@ __global__ __launch_bounds__(HG * 64) void k_attention(AttnParams p) {
             token_pixel(p.partition, WIN, X, Y, wx, wy, n, row, col);
             Taps t;
             if (!ident) t = make_taps(a, col, row, H, W);
-            float v[8];
-            sample8<T>(plane + ch0, C, cl, t, ident, row * W + col, bq, v);
-            store8_lds<T>(Qs + n * QS + cl, v);
+            float v[1][8];
+            sample8<T, 1>(plane + ch0, 0, C, cl, t, ident, row * W + col, bq, 0, v);
+            store8_lds<T>(Qs + n * QS + cl, v[0]);
         }
     }
 
@@ -211,8 +237,7 @@ __global__ __launch_bounds__(HG * 64) void k_attention(AttnParams p) {
                         const int ts = p.mode[b * L + src];
                         const T* kpl = kvplanes + ((size_t)((b * L + src) * p.E + ev) * 2) * P * C + ch0;
                         const float* bk = p.b_kv + (size_t)(te * HMVIT_NUM_TYPES + ts) * 2 * C + ch0;
-                        sample8<T>(kpl, C, cl, t, ident, row * W + col, bk, kvv[0]);
-                        sample8<T>(kpl + (size_t)P * C, C, cl, t, ident, row * W + col, bk + C, kvv[1]);
+                        sample8<T, 2>(kpl, (size_t)P * C, C, cl, t, ident, row * W + col, bk, C, kvv);
                     }
                 }
                 store8_lds<T>(Ks + kk * KS + cl, kvv[0]);

@@ -98,13 +98,39 @@ struct JobBatcher {
     }
 };
 
+// Optional phase timer (hmvit_fusion_profile): one HIP event after every phase's launches, on the
+// stream the kernels run on.
+struct PhaseTimer {
+    hipStream_t st;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> phase;
+    int mark(int ph) {
+        hipEvent_t e;
+        HMVIT_CHECK_HIP(hipEventCreate(&e));
+        HMVIT_CHECK_HIP(hipEventRecord(e, st));
+        ev.push_back(e);
+        phase.push_back(ph);
+        return HMVIT_OK;
+    }
+    ~PhaseTimer() {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    }
+};
+#define HMVIT_MARK(ph)                                   \
+    do {                                                 \
+        if (timer) {                                     \
+            int _rc = timer->mark(ph);                   \
+            if (_rc != HMVIT_OK) return _rc;             \
+        }                                                \
+    } while (0)
+
 #define HMVIT_TRY(expr)             \
     do {                            \
         int _rc = (expr);           \
         if (_rc != HMVIT_OK) return _rc; \
     } while (0)
 
-static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st) {
+static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st, PhaseTimer* timer) {
     HMVIT_TRY(check_desc(d));
     Plan pl;
     make_plan(d, pl);
@@ -133,9 +159,11 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st) {
     for (int i = 0; i < pl.n_slots; ++i) all_types.t[i] = (int8_t)d->mode[i];
 
     // NCHW -> token-major residual stream; sampling maps of every (source, ego) pair
+    HMVIT_MARK(-1);
     HMVIT_TRY(launch_transpose(d->x, xs, pl.n_slots, C, P, st));
     HMVIT_TRY(launch_pair_affines(d->pairwise_t, ainv, pl.n_slots * L, d->H, d->W, d->discrete_ratio,
                                   d->downsample_rate, st));
+    HMVIT_MARK(HMVIT_PHASE_LAYOUT_IN);
 
     for (int it = 0; it < d->num_iters; ++it) {
         for (int s = 0; s < 2; ++s) {
@@ -158,6 +186,7 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st) {
 
             // 1. typed LayerNorm of every agent map (sources j < max_cav are all that is read)
             HMVIT_TRY(launch_layernorm(xs, xn, wt.ln_gamma, wt.ln_beta, all_types, pl.n_slots, P, C, prec, st));
+            HMVIT_MARK(HMVIT_PHASE_LN_ATTN);
 
             // 2. Q and relation-folded K/V projections (no bias: added after the gather)
             {
@@ -185,6 +214,7 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st) {
                     }
                 HMVIT_TRY(jb.flush());
             }
+            HMVIT_MARK(HMVIT_PHASE_QKV);
 
             // 3. fused warp + partition + attention for every ego
             {
@@ -202,6 +232,7 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st) {
                 }
                 HMVIT_TRY(launch_attention(ap, prec, st));
             }
+            HMVIT_MARK(HMVIT_PHASE_ATTENTION);
 
             // 4. typed output projection + residual (in place on the f32 stream)
             {
@@ -220,6 +251,7 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st) {
                     }
                 HMVIT_TRY(jb.flush());
             }
+            HMVIT_MARK(HMVIT_PHASE_OUT_PROJ);
 
             // 5. pre-norm typed FFN + residual for every agent (only the egos in the last stage)
             {
@@ -236,6 +268,7 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st) {
                                                    wt.ffn_ln_gamma, wt.ffn_ln_beta, one, 1, P, C, prec, st));
                     }
                 }
+                HMVIT_MARK(HMVIT_PHASE_LN_FFN);
                 JobBatcher j1(false, true, false, prec, st);
                 for (int b = 0; b < B; ++b)
                     for (int l = 0; l < n_ffn; ++l) {
@@ -250,6 +283,7 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st) {
                         HMVIT_TRY(j1.add(j));
                     }
                 HMVIT_TRY(j1.flush());
+                HMVIT_MARK(HMVIT_PHASE_FFN1);
                 JobBatcher j2(false, false, true, prec, st);
                 for (int b = 0; b < B; ++b)
                     for (int l = 0; l < n_ffn; ++l) {
@@ -264,12 +298,15 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st) {
                         HMVIT_TRY(j2.add(j));
                     }
                 HMVIT_TRY(j2.flush());
+                HMVIT_MARK(HMVIT_PHASE_FFN2);
             }
         }
     }
 
     if (!d->apply_head) {
-        return launch_transpose(xs, d->out, pl.n_slots, P, C, st);
+        HMVIT_TRY(launch_transpose(xs, d->out, pl.n_slots, P, C, st));
+        HMVIT_MARK(HMVIT_PHASE_LAYOUT_OUT);
+        return HMVIT_OK;
     }
 
     // mlp_head on the ego map: Linear -> GELU -> Linear, no norm, no residual
@@ -303,7 +340,10 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st) {
         }
         HMVIT_TRY(j2.flush());
     }
-    return launch_transpose(ytok, d->out, B, P, C, st);
+    HMVIT_MARK(HMVIT_PHASE_HEAD);
+    HMVIT_TRY(launch_transpose(ytok, d->out, B, P, C, st));
+    HMVIT_MARK(HMVIT_PHASE_LAYOUT_OUT);
+    return HMVIT_OK;
 }
 
 }  // namespace hmvit
@@ -324,7 +364,24 @@ size_t hmvit_fusion_workspace_bytes(const HmvitFusionDesc* desc) {
 }
 
 int hmvit_fusion_forward(const HmvitFusionDesc* desc, void* stream) {
-    return fusion_forward(desc, reinterpret_cast<hipStream_t>(stream));
+    return fusion_forward(desc, reinterpret_cast<hipStream_t>(stream), nullptr);
+}
+
+int hmvit_fusion_profile(const HmvitFusionDesc* desc, void* stream, float* phase_ms, int32_t* phase_launches) {
+    HMVIT_CHECK_ARG(phase_ms && phase_launches, "fusion_profile: null output");
+    PhaseTimer timer;
+    timer.st = reinterpret_cast<hipStream_t>(stream);
+    int rc = fusion_forward(desc, timer.st, &timer);
+    if (rc != HMVIT_OK) return rc;
+    HMVIT_CHECK_HIP(hipStreamSynchronize(timer.st));
+    for (int i = 0; i < HMVIT_NUM_PHASES; ++i) { phase_ms[i] = 0.f; phase_launches[i] = 0; }
+    for (size_t i = 1; i < timer.ev.size(); ++i) {
+        float ms = 0.f;
+        HMVIT_CHECK_HIP(hipEventElapsedTime(&ms, timer.ev[i - 1], timer.ev[i]));
+        phase_ms[timer.phase[i]] += ms;
+        phase_launches[timer.phase[i]] += 1;
+    }
+    return HMVIT_OK;
 }
 
 int hmvit_nchw_to_tokens(const float* x, float* y, int n_agents, int C, int P, void* stream) {

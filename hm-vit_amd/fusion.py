@@ -127,7 +127,7 @@ class _FusionBase(nn.Module):
             self._folded, self._folded_key = folded, key
         return self._folded
 
-    def _run(self, x, pairwise_t_matrix, mode, record_len, mask, apply_head: bool, num_iters: int):
+    def _make_desc(self, x, pairwise_t_matrix, mode, record_len, mask, apply_head: bool, num_iters: int):
         blk = self._block_cfg
         if blk["architect_mode"] != "sequential":
             if blk["architect_mode"] == "parallel":
@@ -174,11 +174,30 @@ class _FusionBase(nn.Module):
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != x.device:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
         d.workspace, d.workspace_bytes = self._workspace.data_ptr(), self._workspace.numel()
-        stream = torch.cuda.current_stream(x.device).cuda_stream
-        with torch.cuda.device(x.device):
+        return d, out, (keep, x, pw, w)
+
+    def _run(self, x, pairwise_t_matrix, mode, record_len, mask, apply_head: bool, num_iters: int):
+        d, out, keep = self._make_desc(x, pairwise_t_matrix, mode, record_len, mask, apply_head, num_iters)
+        stream = torch.cuda.current_stream(out.device).cuda_stream
+        with torch.cuda.device(out.device):
             _lib.check(_lib.lib.hmvit_fusion_forward(ctypes.byref(d), ctypes.c_void_p(stream)),
                        "hmvit_fusion_forward")
+        del keep
         return out
+
+    def _profile(self, x, pairwise_t_matrix, mode, record_len, mask, apply_head: bool, num_iters: int):
+        """One forward with a HIP event after every phase (hmvit_fusion_profile).  Returns
+        {phase: (milliseconds, launches)}; synchronises the stream."""
+        d, out, keep = self._make_desc(x, pairwise_t_matrix, mode, record_len, mask, apply_head, num_iters)
+        n = len(_lib.PHASES)
+        ms = (ctypes.c_float * n)()
+        cnt = (ctypes.c_int32 * n)()
+        stream = torch.cuda.current_stream(out.device).cuda_stream
+        with torch.cuda.device(out.device):
+            _lib.check(_lib.lib.hmvit_fusion_profile(ctypes.byref(d), ctypes.c_void_p(stream), ms, cnt),
+                       "hmvit_fusion_profile")
+        del keep
+        return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(_lib.PHASES)}
 
 
 class HeteroFusionBlock(_FusionBase):
@@ -237,3 +256,7 @@ class HeteroFusion(_FusionBase):
     def forward(self, x, pairwise_t_matrix, mode, record_len, mask):
         return self._run(x, pairwise_t_matrix, mode, record_len, mask, apply_head=True,
                          num_iters=self.num_iters)
+
+    def profile_phases(self, x, pairwise_t_matrix, mode, record_len, mask):
+        return self._profile(x, pairwise_t_matrix, mode, record_len, mask, apply_head=True,
+                             num_iters=self.num_iters)

@@ -119,6 +119,24 @@ size_t hmvit_fusion_workspace_bytes(const HmvitFusionDesc* desc);
 /* bevformer_point_pillar_hetero.py:39-49 / hetero_fusion.py:446-458 (see HmvitFusionDesc) */
 int hmvit_fusion_forward(const HmvitFusionDesc* desc, void* stream);
 
+/* Same forward with one HIP event recorded (on `stream`) after each phase; synchronises the
+ * stream before returning (the only entry point that does).  phase_ms[p] = milliseconds spent
+ * in phase p summed over its occurrences, phase_launches[p] = number of occurrences (e.g. 4
+ * attention launches for num_iters = 2).  Both arrays have HMVIT_NUM_PHASES entries. */
+#define HMVIT_PHASE_LAYOUT_IN 0   /* NCHW -> token-major + pair affines                    */
+#define HMVIT_PHASE_LN_ATTN 1     /* HeteroLayerNorm before attention                       */
+#define HMVIT_PHASE_QKV 2         /* Q / folded K,V projection GEMMs                        */
+#define HMVIT_PHASE_ATTENTION 3   /* fused warp + partition + attention                     */
+#define HMVIT_PHASE_OUT_PROJ 4    /* a_linears GEMM + residual                              */
+#define HMVIT_PHASE_LN_FFN 5      /* HeteroLayerNorm of the FFN                             */
+#define HMVIT_PHASE_FFN1 6        /* Linear + GELU                                          */
+#define HMVIT_PHASE_FFN2 7        /* Linear + residual                                      */
+#define HMVIT_PHASE_HEAD 8        /* mlp_head (two GEMMs)                                   */
+#define HMVIT_PHASE_LAYOUT_OUT 9  /* token-major -> NCHW                                    */
+#define HMVIT_NUM_PHASES 10
+int hmvit_fusion_profile(const HmvitFusionDesc* desc, void* stream, float* phase_ms,
+                         int32_t* phase_launches);
+
 /* ---- single operators (used by the parity tests; same kernels as the fused forward) ---- */
 
 /* (n_agents, C, P) f32 -> (n_agents, P, C) f32 and back: the layout change between the
