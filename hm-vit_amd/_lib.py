@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhmvit.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 PREC_F32, PREC_F16 = 0, 1
 PART_WINDOW, PART_GRID = 0, 1
 NUM_TYPES = 2
@@ -23,7 +23,7 @@ c_i32p = C.POINTER(C.c_int32)
 class StageWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "ln_gamma", "ln_beta", "w_q", "b_q", "w_kv", "b_kv", "bias_frag", "w_o", "b_o",
-        "ffn_ln_gamma", "ffn_ln_beta", "w_1", "b_1", "w_2", "b_2")]
+        "ffn_ln_gamma", "ffn_ln_beta", "w_1", "b_1", "w_2", "b_2", "img_q", "img_kv", "img_o", "img_ffn")]
 
 
 class FusionDesc(C.Structure):
@@ -37,7 +37,7 @@ class FusionDesc(C.Structure):
         ("x", C.c_void_p), ("pairwise_t", C.c_void_p), ("out", C.c_void_p),
         ("stage", StageWeights * 2),
         ("head_w1", C.c_void_p), ("head_b1", C.c_void_p), ("head_w2", C.c_void_p),
-        ("head_b2", C.c_void_p),
+        ("head_b2", C.c_void_p), ("head_img_ffn", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 

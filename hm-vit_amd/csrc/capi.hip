@@ -130,6 +130,8 @@ struct PhaseTimer {
         if (_rc != HMVIT_OK) return _rc; \
     } while (0)
 
+static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStream_t st, PhaseTimer* timer);
+
 static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st, PhaseTimer* timer) {
     HMVIT_TRY(check_desc(d));
     Plan pl;
@@ -140,6 +142,7 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st, PhaseTimer* 
         return HMVIT_ENOMEM;
     }
     HMVIT_CHECK_ARG(pl.n_slots <= kMaxSlots, "B*L=%d exceeds %d agent slots per call", pl.n_slots, kMaxSlots);
+    if (d->precision == HMVIT_PREC_F16) return fusion_forward_f16(d, pl, st, timer);
 
     const int B = pl.B, L = pl.L, C = pl.C, P = pl.P, mlp = pl.mlp, prec = d->precision;
     const size_t es = pl.es;
@@ -343,6 +346,203 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st, PhaseTimer* 
     HMVIT_MARK(HMVIT_PHASE_HEAD);
     HMVIT_TRY(launch_transpose(ytok, d->out, B, P, C, st));
     HMVIT_MARK(HMVIT_PHASE_LAYOUT_OUT);
+    return HMVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// f16-operand mode: three launches per stage (chain.hip + attn.hip), no layout kernels
+// ------------------------------------------------------------------------------------------
+struct QkvBatcher {
+    QkvParams p;
+    int n, C;
+    hipStream_t st;
+    int flush() {
+        if (n == 0) return HMVIT_OK;
+        int rc = launch_ln_qkv(p, n, C, st);
+        n = 0;
+        return rc;
+    }
+    int add(const QkvJob& j) {
+        p.job[n++] = j;
+        if (n == kMaxChainJobs) return flush();
+        return HMVIT_OK;
+    }
+};
+struct FfnBatcher {
+    FfnParams p;
+    int n, C, variant;
+    hipStream_t st;
+    int flush() {
+        if (n == 0) return HMVIT_OK;
+        int rc = launch_out_ffn(p, n, C, variant, st);
+        n = 0;
+        return rc;
+    }
+    int add(const FfnJob& j) {
+        p.job[n++] = j;
+        if (n == kMaxChainJobs) return flush();
+        return HMVIT_OK;
+    }
+};
+
+static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStream_t st, PhaseTimer* timer) {
+    HMVIT_CHECK_ARG(d->mlp_dim == d->C, "f16 mode: mlp_dim=%d must equal input_dim=%d (fused FFN kernel)", d->mlp_dim, d->C);
+    for (int s = 0; s < 2; ++s)
+        HMVIT_CHECK_ARG(d->stage[s].img_q && d->stage[s].img_kv && d->stage[s].img_o && d->stage[s].img_ffn,
+                        "f16 mode: stage %d weight images are null", s);
+    const int B = pl.B, L = pl.L, C = pl.C, P = pl.P;
+    char* ws = reinterpret_cast<char*>(d->workspace);
+    float* xs = reinterpret_cast<float*>(ws + pl.off_xs);
+    half_t* qb = reinterpret_cast<half_t*>(ws + pl.off_q);
+    half_t* kvb = reinterpret_cast<half_t*>(ws + pl.off_kv);
+    half_t* ob = reinterpret_cast<half_t*>(ws + pl.off_o);
+    float* ainv = reinterpret_cast<float*>(ws + pl.off_ainv);
+    const size_t map_elems = (size_t)P * C;
+    const size_t img_elems = (size_t)C * C;   // one (C, C) matrix image
+
+    HMVIT_MARK(-1);
+    HMVIT_TRY(launch_pair_affines(d->pairwise_t, ainv, pl.n_slots * L, d->H, d->W, d->discrete_ratio,
+                                  d->downsample_rate, st));
+    if (!d->apply_head && pl.max_cav < L) {
+        // block output covers padded agents too: they never pass through k_ln_qkv, bring them in here
+        for (int b = 0; b < B; ++b)
+            HMVIT_TRY(launch_transpose(d->x + (size_t)(b * L + pl.max_cav) * map_elems,
+                                       xs + (size_t)(b * L + pl.max_cav) * map_elems, L - pl.max_cav, C, P, st));
+    }
+    HMVIT_MARK(HMVIT_PHASE_LAYOUT_IN);
+
+    for (int it = 0; it < d->num_iters; ++it) {
+        for (int s = 0; s < 2; ++s) {
+            const HmvitStageWeights& wt = d->stage[s];
+            const bool first = it == 0 && s == 0;
+            const bool last = d->apply_head && it == d->num_iters - 1 && s == 1;
+            const int n_ego = last ? 1 : pl.max_cav;
+            const int n_src = pl.max_cav;
+            int e_of_type[HMVIT_NUM_TYPES] = {-1, -1};
+            int e_type[HMVIT_NUM_TYPES] = {0, 0};
+            int E = 0;
+            for (int b = 0; b < B; ++b)
+                for (int i = 0; i < n_ego; ++i) {
+                    const int t = d->mode[b * L + i];
+                    if (e_of_type[t] < 0) { e_of_type[t] = E; e_type[E] = t; ++E; }
+                }
+
+            // 1+2. LayerNorm + Q / folded K,V projections, activations in registers
+            {
+                QkvBatcher qb_;
+                memset(&qb_.p, 0, sizeof(qb_.p));
+                qb_.n = 0; qb_.C = C; qb_.st = st;
+                qb_.p.gamma = wt.ln_gamma; qb_.p.beta = wt.ln_beta; qb_.p.P = P; qb_.p.in_nchw = first ? 1 : 0;
+                for (int b = 0; b < B; ++b)
+                    for (int l = 0; l < pl.max_cav; ++l) {
+                        const int slot = b * L + l, t = d->mode[slot];
+                        QkvJob j;
+                        memset(&j, 0, sizeof(j));
+                        j.x = first ? d->x + (size_t)slot * map_elems : xs + (size_t)slot * map_elems;
+                        j.xs_out = xs + (size_t)slot * map_elems;
+                        j.type = t;
+                        int nm = 0;
+                        if (l < n_ego) {
+                            j.w[nm] = reinterpret_cast<const half_t*>(wt.img_q) + (size_t)t * img_elems;
+                            j.y[nm] = qb + (size_t)slot * map_elems;
+                            ++nm;
+                        }
+                        for (int e = 0; e < E; ++e) {
+                            const half_t* wkv = reinterpret_cast<const half_t*>(wt.img_kv) +
+                                                (size_t)(e_type[e] * HMVIT_NUM_TYPES + t) * 2 * img_elems;
+                            half_t* ykv = kvb + (size_t)(slot * E + e) * 2 * map_elems;
+                            j.w[nm] = wkv;             j.y[nm] = ykv;             ++nm;
+                            j.w[nm] = wkv + img_elems; j.y[nm] = ykv + map_elems; ++nm;
+                        }
+                        j.n_mat = nm;
+                        HMVIT_TRY(qb_.add(j));
+                    }
+                HMVIT_TRY(qb_.flush());
+            }
+            HMVIT_MARK(HMVIT_PHASE_QKV);
+
+            // 3. fused warp + partition + attention
+            {
+                AttnParams ap;
+                memset(&ap, 0, sizeof(ap));
+                ap.q = qb; ap.kv = kvb; ap.b_q = wt.b_q; ap.b_kv = wt.b_kv; ap.bias_frag = wt.bias_frag;
+                ap.ainv = ainv; ap.out = ob;
+                ap.B = B; ap.L = L; ap.n_ego = n_ego; ap.n_src = n_src; ap.E = E; ap.C = C; ap.H = d->H; ap.W = d->W;
+                ap.window = d->window; ap.partition = s == 0 ? HMVIT_PART_WINDOW : HMVIT_PART_GRID;
+                ap.skip_masked = d->skip_masked;
+                for (int i = 0; i < pl.n_slots; ++i) {
+                    ap.mode[i] = (int8_t)d->mode[i];
+                    ap.cav[i] = (int8_t)(d->cav_mask[i] != 0);
+                    ap.ego_e[i] = (int8_t)(e_of_type[d->mode[i]] < 0 ? 0 : e_of_type[d->mode[i]]);
+                }
+                HMVIT_TRY(launch_attention(ap, HMVIT_PREC_F16, st));
+            }
+            HMVIT_MARK(HMVIT_PHASE_ATTENTION);
+
+            // 4+5. output projection + residual + LayerNorm + FFN + residual, in place on xs
+            {
+                FfnBatcher fb;
+                memset(&fb.p, 0, sizeof(fb.p));
+                fb.n = 0; fb.C = C; fb.st = st;
+                fb.p.w_o = reinterpret_cast<const half_t*>(wt.img_o); fb.p.b_o = wt.b_o;
+                fb.p.ln_g = wt.ffn_ln_gamma; fb.p.ln_b = wt.ffn_ln_beta;
+                fb.p.w_ffn = reinterpret_cast<const half_t*>(wt.img_ffn); fb.p.b_1 = wt.b_1; fb.p.b_2 = wt.b_2;
+                fb.p.P = P;
+                fb.variant = FFN_FULL;
+                for (int b = 0; b < B; ++b)
+                    for (int i = 0; i < n_ego; ++i) {
+                        const int slot = b * L + i;
+                        FfnJob j;
+                        j.o = ob + (size_t)slot * map_elems;
+                        j.x = xs + (size_t)slot * map_elems;
+                        j.out = xs + (size_t)slot * map_elems;
+                        j.type = d->mode[slot]; j.pad = 0;
+                        HMVIT_TRY(fb.add(j));
+                    }
+                HMVIT_TRY(fb.flush());
+                if (!last && n_ego < L) {
+                    fb.variant = FFN_NO_ATTN;   // agents without an attention update (padding)
+                    for (int b = 0; b < B; ++b)
+                        for (int l = n_ego; l < L; ++l) {
+                            const int slot = b * L + l;
+                            if (d->apply_head) continue;   // never consumed by HeteroFusion
+                            FfnJob j;
+                            j.o = nullptr;
+                            j.x = xs + (size_t)slot * map_elems;
+                            j.out = xs + (size_t)slot * map_elems;
+                            j.type = d->mode[slot]; j.pad = 0;
+                            HMVIT_TRY(fb.add(j));
+                        }
+                    HMVIT_TRY(fb.flush());
+                }
+            }
+            HMVIT_MARK(HMVIT_PHASE_FFN2);
+        }
+    }
+
+    if (!d->apply_head) {
+        HMVIT_TRY(launch_transpose(xs, d->out, pl.n_slots, P, C, st));
+        HMVIT_MARK(HMVIT_PHASE_LAYOUT_OUT);
+        return HMVIT_OK;
+    }
+    HMVIT_CHECK_ARG(d->head_img_ffn && d->head_b1 && d->head_b2, "f16 mode: mlp_head image / biases are null");
+    {
+        FfnBatcher fb;
+        memset(&fb.p, 0, sizeof(fb.p));
+        fb.n = 0; fb.C = C; fb.st = st; fb.variant = FFN_HEAD_NCHW;
+        fb.p.w_ffn = reinterpret_cast<const half_t*>(d->head_img_ffn); fb.p.b_1 = d->head_b1; fb.p.b_2 = d->head_b2;
+        fb.p.P = P;
+        for (int b = 0; b < B; ++b) {
+            FfnJob j;
+            j.o = nullptr;
+            j.x = xs + (size_t)(b * L) * map_elems;
+            j.out = d->out + (size_t)b * map_elems;
+            j.type = d->mode[b * L]; j.pad = 0;
+            HMVIT_TRY(fb.add(j));
+        }
+        HMVIT_TRY(fb.flush());
+    }
+    HMVIT_MARK(HMVIT_PHASE_HEAD);
     return HMVIT_OK;
 }
 

@@ -1,0 +1,491 @@
+// Register-resident token chains (f16-operand mode): every wavefront owns 32 tokens and keeps
+// their activations in registers across LayerNorm and up to three GEMMs; only weights go through
+// LDS.  Two kernels:
+//
+//   k_ln_qkv   x (f32) -> HeteroLayerNorm -> Q | K' | V' projections -> f16 planes
+//              (base_transformer.py:138-177 + hetero_fusion.py:111-140 with the relation folds)
+//   k_out_ffn  O (f16), x (f32) -> a_linears + bias + residual -> HeteroLayerNorm ->
+//              Linear + GELU -> Linear + bias + residual -> x (f32)
+//              (hetero_fusion.py:142-152, :399-402 / :439-442, base_transformer.py:129-136,180-192);
+//              with the flags off it is mlp_head (bevformer_point_pillar_hetero.py:37,47-48)
+//              storing straight to NCHW.
+//
+// Layout trick: all products are computed transposed, D'[n][m] = sum_k W[n][k] act[m][k], with
+// v_mfma_f32_32x32x16_f16 (A operand = weight rows, B operand = tokens).  Lane (m = lane & 31,
+// hi = lane >> 5) then owns, for token m, the channels 32 b + 8 j + 4 hi + i (b = 32-channel
+// block, j < 4, i < 4) of every activation -- inputs are loaded in that pattern, accumulators
+// come out in it, and after a float->half conversion they ARE the B operand of the next GEMM
+// (k-slot 4 jj + i of step kk = 2 b + s holds channel 32 b + 16 s + 8 jj + 4 hi + i; the host
+// permutes the weight columns to match, hm-vit_amd/weights.py:weight_image).  No activation ever
+// takes an LDS round trip, and NCHW input/output is a 128-byte-per-channel access in this layout.
+//
+// Weights stream through a 2-deep LDS ring in "chunks" of one 32-row tile x all K (KK KiB), stored
+// in global memory in exactly fragment order, so staging is a linear copy and every ds_read_b128 is
+// lane-linear (conflict-free).  Loads of chunk c+1 are issued before the MFMAs of chunk c and
+// written to LDS after them (one barrier per chunk).
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace hmvit {
+
+template <int C>
+struct ChainCfg {
+    static constexpr int NB = C / 32;             // 32-channel blocks
+    static constexpr int KK = C / 16;             // MFMA k-steps over C
+    static constexpr int NT = C / 32;             // 32-row output tiles
+    static constexpr int CHUNK_HALVES = KK * 512; // one chunk: KK fragments of 64 lanes x 8 halves
+    static constexpr int PIECES = KK * 64;        // 16-byte pieces per chunk
+    static constexpr int PPT = (PIECES + 511) / 512;
+};
+
+constexpr int CHAIN_THREADS = 512;
+constexpr int CHAIN_TOKENS = 256;
+
+// ---- weight chunk ring: global -> LDS DMA (no staging registers) ----
+// The chunk is stored in global memory in LDS-image order, so wave w copies pieces
+// [(i*8 + w) * 64, +64) with one global_load_lds_dwordx4 each (LDS destination = wave-uniform
+// base + lane * 16).  Completion: the __syncthreads() that ends the iteration (hipcc drains
+// vmcnt(0) before a barrier while an LDS-DMA is in flight).
+template <int C>
+__device__ __forceinline__ void stage_chunk(const half_t* __restrict__ chunk, half_t* lds_buf) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < ChainCfg<C>::PPT; ++i) {
+        const int piece0 = (i * 8 + wave) * 64;
+        if (piece0 < ChainCfg<C>::PIECES)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(reinterpret_cast<const uint4*>(chunk) + piece0 + lane),
+                (__attribute__((address_space(3))) void*)(reinterpret_cast<uint4*>(lds_buf) + piece0), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ half8 lds_frag(const half_t* buf, int frag, int lane) {
+    return *reinterpret_cast<const half8*>(buf + (frag * 64 + lane) * 8);
+}
+
+// GELU(x) = x Phi(x) with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. f32 round-off
+// class): one exp, one rcp and a degree-5 Horner chain -- few live registers, unlike libm erff.
+__device__ __forceinline__ float gelu_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float erfc_abs = poly * t * __expf(-z * z);         // 1 - erf(|x| / sqrt 2)
+    const float phi = (x >= 0.f) ? 1.f - 0.5f * erfc_abs : 0.5f * erfc_abs;
+    return x * phi;
+}
+
+// k-steps are issued in groups of 4 fragments so that the scheduler cannot hoist a whole chunk of
+// LDS reads (64 VGPRs) above the MFMAs
+template <int KK>
+__device__ __forceinline__ void mma_chunk(float16v& acc, const half_t* buf, const half8 (&act)[KK], int lane) {
+#pragma unroll
+    for (int k0 = 0; k0 < KK; k0 += 4) {
+        half8 w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = *reinterpret_cast<const half8*>(buf + ((k0 + i) * 64 + lane) * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[i], act[k0 + i], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+// LayerNorm of the token owned by lane pair (m, hi = 0/1); v[b][j] holds channels 32b+8j+4hi+(0..3)
+template <int C>
+__device__ __forceinline__ void layer_norm_regs(float4 (&v)[C / 32][4], const float* __restrict__ lg,
+                                                const float* __restrict__ lb, int hi) {
+    constexpr int NB = C / 32;
+    float s = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += (v[b][j].x + v[b][j].y) + (v[b][j].z + v[b][j].w);
+    const float mean = pair_sum(s) * (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[b][j].x -= mean; v[b][j].y -= mean; v[b][j].z -= mean; v[b][j].w -= mean;
+            q += (v[b][j].x * v[b][j].x + v[b][j].y * v[b][j].y) + (v[b][j].z * v[b][j].z + v[b][j].w * v[b][j].w);
+        }
+    const float rstd = rsqrtf(pair_sum(q) * (1.f / C) + 1e-5f);
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 32 * b + 8 * j + 4 * hi;
+            const float4 g = *reinterpret_cast<const float4*>(lg + c);
+            const float4 be = *reinterpret_cast<const float4*>(lb + c);
+            v[b][j].x = v[b][j].x * rstd * g.x + be.x;
+            v[b][j].y = v[b][j].y * rstd * g.y + be.y;
+            v[b][j].z = v[b][j].z * rstd * g.z + be.z;
+            v[b][j].w = v[b][j].w * rstd * g.w + be.w;
+        }
+}
+
+// f32 activations -> MFMA B operands
+template <int C>
+__device__ __forceinline__ void to_operands(const float4 (&v)[C / 32][4], half8 (&act)[C / 16]) {
+#pragma unroll
+    for (int b = 0; b < C / 32; ++b)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            half8 h;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const float4 f = v[b][2 * s + jj];
+                h[4 * jj + 0] = (half_t)f.x; h[4 * jj + 1] = (half_t)f.y;
+                h[4 * jj + 2] = (half_t)f.z; h[4 * jj + 3] = (half_t)f.w;
+            }
+            act[2 * b + s] = h;
+        }
+}
+
+// LayerNorm straight from the accumulator layout into MFMA B operands (no f32 copy is kept)
+template <int C>
+__device__ __forceinline__ void ln_acc_to_operands(const float16v (&xa)[C / 32], const float* __restrict__ lg,
+                                                   const float* __restrict__ lb, int hi, half8 (&act)[C / 16]) {
+    constexpr int NT = C / 32;
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += xa[t][e];
+    const float mean = pair_sum(s) * (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float dlt = xa[t][e] - mean;
+            q = fmaf(dlt, dlt, q);
+        }
+    const float rstd = rsqrtf(pair_sum(q) * (1.f / C) + 1e-5f);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+            half8 h;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * sx + jj, c = 32 * t + 8 * j + 4 * hi;
+                const float4 g = *reinterpret_cast<const float4*>(lg + c);
+                const float4 be = *reinterpret_cast<const float4*>(lb + c);
+                h[4 * jj + 0] = (half_t)((xa[t][4 * j + 0] - mean) * rstd * g.x + be.x);
+                h[4 * jj + 1] = (half_t)((xa[t][4 * j + 1] - mean) * rstd * g.y + be.y);
+                h[4 * jj + 2] = (half_t)((xa[t][4 * j + 2] - mean) * rstd * g.z + be.z);
+                h[4 * jj + 3] = (half_t)((xa[t][4 * j + 3] - mean) * rstd * g.w + be.w);
+            }
+            act[2 * t + sx] = h;
+        }
+}
+
+// load the 128 / 64 / 32 channels of token `tok` this lane owns (tok already clamped into range:
+// one base pointer + compile-time offsets, no per-load branches)
+template <int C>
+__device__ __forceinline__ void load_token(const float* __restrict__ x, bool nchw, int P, int tok, int hi,
+                                           float4 (&v)[C / 32][4]) {
+    if (nchw) {
+        const float* xp = x + (size_t)(4 * hi) * P + tok;
+#pragma unroll
+        for (int b = 0; b < C / 32; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* q = xp + (size_t)(32 * b + 8 * j) * P;
+                v[b][j] = make_float4(q[0], q[P], q[2 * (size_t)P], q[3 * (size_t)P]);
+            }
+    } else {
+        const float* xp = x + (size_t)tok * C + 4 * hi;
+#pragma unroll
+        for (int b = 0; b < C / 32; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[b][j] = *reinterpret_cast<const float4*>(xp + 32 * b + 8 * j);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_ln_qkv
+// ------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(CHAIN_THREADS) void k_ln_qkv(QkvParams p) {
+    using Cfg = ChainCfg<C>;
+    constexpr int KK = Cfg::KK, NT = Cfg::NT;
+    // ONE LDS object (a second one would make hipcc wait for the DMA before every ds_read)
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * Cfg::CHUNK_HALVES + 4 * C];
+    half_t* ring0 = smem;
+    half_t* ring1 = smem + Cfg::CHUNK_HALVES;
+    float* lnp = reinterpret_cast<float*>(smem + 2 * Cfg::CHUNK_HALVES);   // gamma[C], beta[C]
+
+    const QkvJob& J = p.job[blockIdx.y];
+    const int P = p.P;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = lane & 31, hi = lane >> 5;
+    const int tok = blockIdx.x * CHAIN_TOKENS + wave * 32 + m;
+    const bool valid = tok < P;
+
+    for (int i = threadIdx.x; i < C; i += CHAIN_THREADS) {
+        lnp[i] = p.gamma[J.type * C + i];
+        lnp[C + i] = p.beta[J.type * C + i];
+    }
+    const int n_chunks = J.n_mat * NT;
+    stage_chunk<C>(J.w[0], ring0);
+
+    float4 v[C / 32][4];
+    load_token<C>(J.x, p.in_nchw != 0, P, min(tok, P - 1), hi, v);
+    if (p.in_nchw && valid) {
+        // first stage: also emit the token-major f32 residual stream
+        float* xo = J.xs_out + (size_t)tok * C + 4 * hi;
+#pragma unroll
+        for (int b = 0; b < C / 32; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(xo + 32 * b + 8 * j) = v[b][j];
+    }
+    __syncthreads();
+    layer_norm_regs<C>(v, lnp, lnp + C, hi);
+    half8 act[KK];
+    to_operands<C>(v, act);
+
+    for (int c = 0; c < n_chunks; ++c) {
+        const int mat = c / NT, t = c - mat * NT;
+        const half_t* buf = (c & 1) ? ring1 : ring0;
+        if (c + 1 < n_chunks) {
+            const int c1 = c + 1, mat1 = c1 / NT, t1 = c1 - mat1 * NT;
+            stage_chunk<C>(J.w[mat1] + (size_t)t1 * Cfg::CHUNK_HALVES, (c & 1) ? ring0 : ring1);
+        }
+        float16v acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        mma_chunk<KK>(acc, buf, act, lane);
+        if (valid) {
+            half_t* o = J.y[mat] + ((size_t)tok * C + 32 * t + 4 * hi);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                half4 h;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h[i] = (half_t)acc[4 * j + i];
+                *reinterpret_cast<half4*>(o + 8 * j) = h;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_out_ffn
+// ------------------------------------------------------------------------------------------
+template <int C, bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW>
+__global__ __launch_bounds__(CHAIN_THREADS) void k_out_ffn(FfnParams p) {
+    using Cfg = ChainCfg<C>;
+    constexpr int KK = Cfg::KK, NT = Cfg::NT, NH = C / 32;   // hidden width == C
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * Cfg::CHUNK_HALVES + 10 * C];
+    half_t* ring0 = smem;
+    half_t* ring1 = smem + Cfg::CHUNK_HALVES;
+    float (*vec)[C] = reinterpret_cast<float (*)[C]>(smem + 2 * Cfg::CHUNK_HALVES);   // b_o, ln g, ln b, b_1, b_2
+
+    const FfnJob& J = p.job[blockIdx.y];
+    const int P = p.P;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = lane & 31, hi = lane >> 5;
+    const int tok = blockIdx.x * CHAIN_TOKENS + wave * 32 + m;
+    const bool valid = tok < P;
+    const int ty = J.type;
+
+    for (int i = threadIdx.x; i < C; i += CHAIN_THREADS) {
+        vec[0][i] = OUTPROJ ? p.b_o[ty * C + i] : 0.f;
+        vec[1][i] = LN ? p.ln_g[ty * C + i] : 1.f;
+        vec[2][i] = LN ? p.ln_b[ty * C + i] : 0.f;
+        vec[3][i] = p.b_1[ty * C + i];
+        vec[4][i] = p.b_2[ty * C + i];
+    }
+    const half_t* wo = OUTPROJ ? p.w_o + (size_t)ty * NT * Cfg::CHUNK_HALVES : nullptr;
+    const half_t* wf = p.w_ffn + (size_t)ty * 2 * NH * Cfg::CHUNK_HALVES;
+    constexpr int N_OUT = OUTPROJ ? NT : 0;
+    constexpr int N_CHUNKS = N_OUT + 2 * NH;
+    auto chunk_ptr = [&](int c) -> const half_t* {
+        return (c < N_OUT) ? wo + (size_t)c * Cfg::CHUNK_HALVES : wf + (size_t)(c - N_OUT) * Cfg::CHUNK_HALVES;
+    };
+    stage_chunk<C>(chunk_ptr(0), ring0);
+
+    // residual stream (f32) in accumulator layout: xacc[t][4j+i] = channel 32t + 8j + 4hi + i
+    float16v xacc[NT];
+    half8 act[KK];
+    const int tok_c = min(tok, P - 1);   // out-of-range lanes read a valid token and never store
+    {
+        const float* xp = J.x + (size_t)tok_c * C + 4 * hi;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 f = *reinterpret_cast<const float4*>(xp + 32 * t + 8 * j);
+                xacc[t][4 * j + 0] = f.x; xacc[t][4 * j + 1] = f.y; xacc[t][4 * j + 2] = f.z; xacc[t][4 * j + 3] = f.w;
+            }
+    }
+    if constexpr (!OUTPROJ && !LN) {
+        // mlp_head: x itself is the operand
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) act[2 * t + sx][q] = (half_t)xacc[t][8 * sx + q];
+    }
+    if constexpr (OUTPROJ) {
+        // attention output of this token as B operands (8-byte loads in the owned-channel pattern)
+        const half_t* op = J.o + (size_t)tok_c * C + 4 * hi;
+#pragma unroll
+        for (int b = 0; b < C / 32; ++b)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                half8 h;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const half4 q = *reinterpret_cast<const half4*>(op + 32 * b + 16 * s + 8 * jj);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) h[4 * jj + i] = q[i];
+                }
+                act[2 * b + s] = h;
+            }
+    }
+    __syncthreads();
+
+    if constexpr (OUTPROJ) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 bo = *reinterpret_cast<const float4*>(&vec[0][32 * t + 8 * j + 4 * hi]);
+                xacc[t][4 * j + 0] += bo.x; xacc[t][4 * j + 1] += bo.y;
+                xacc[t][4 * j + 2] += bo.z; xacc[t][4 * j + 3] += bo.w;
+            }
+    }
+
+    // ---- phase 1: x' = x + b_o + W_o . O, one 32-channel tile per chunk (static accumulator index) ----
+    if constexpr (OUTPROJ) {
+        // rolled loop (keeps the scheduler's live ranges short); the tile result is added into the
+        // statically indexed accumulator through a wave-uniform branch chain
+#pragma unroll 1
+        for (int c = 0; c < N_OUT; ++c) {
+            const half_t* buf = (c & 1) ? ring1 : ring0;
+            stage_chunk<C>(chunk_ptr(c + 1), (c & 1) ? ring0 : ring1);   // there is always a next chunk
+            float16v acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            mma_chunk<KK>(acc, buf, act, lane);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (t == c) xacc[t] += acc;
+            __syncthreads();
+        }
+    }
+    if constexpr (LN) ln_acc_to_operands<C>(xacc, vec[1], vec[2], hi, act);
+
+    // accumulator of the second Linear starts from (residual +) b_2
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 b2 = *reinterpret_cast<const float4*>(&vec[4][32 * t + 8 * j + 4 * hi]);
+            if constexpr (RESID) {
+                xacc[t][4 * j + 0] += b2.x; xacc[t][4 * j + 1] += b2.y;
+                xacc[t][4 * j + 2] += b2.z; xacc[t][4 * j + 3] += b2.w;
+            } else {
+                xacc[t][4 * j + 0] = b2.x; xacc[t][4 * j + 1] = b2.y;
+                xacc[t][4 * j + 2] = b2.z; xacc[t][4 * j + 3] = b2.w;
+            }
+        }
+
+    // ---- phase 2: per hidden tile hc: h = GELU(W_1[hc] . xn + b_1[hc]);  x'' += W_2[:, hc] . h ----
+    // (N_OUT is even, so the W_1 chunk of every iteration sits in ring0 and the W_2 chunk in ring1)
+#pragma unroll 1
+    for (int hc = 0; hc < NH; ++hc) {
+        const half_t* w1c = wf + (size_t)(2 * hc) * Cfg::CHUNK_HALVES;
+        float16v hacc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 b1 = *reinterpret_cast<const float4*>(&vec[3][32 * hc + 8 * j + 4 * hi]);
+            hacc[4 * j + 0] = b1.x; hacc[4 * j + 1] = b1.y; hacc[4 * j + 2] = b1.z; hacc[4 * j + 3] = b1.w;
+        }
+        stage_chunk<C>(w1c + Cfg::CHUNK_HALVES, ring1);          // W_2 slice hc
+        mma_chunk<KK>(hacc, ring0, act, lane);
+        __syncthreads();
+
+        half8 hop[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) hop[s][q] = (half_t)gelu_f(hacc[8 * s + q]);
+        if (hc + 1 < NH) stage_chunk<C>(w1c + 2 * Cfg::CHUNK_HALVES, ring0);   // W_1 tile hc + 1
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                xacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(ring1, t * 2 + s, lane), hop[s], xacc[t], 0, 0, 0);
+            if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    if (valid) {
+        if constexpr (OUT_NCHW) {
+            float* op = J.out + (size_t)(4 * hi) * P + tok;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) op[(size_t)(32 * t + 8 * (e >> 2) + (e & 3)) * P] = xacc[t][e];
+        } else {
+            float* op = J.out + (size_t)tok * C + 4 * hi;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<float4*>(op + 32 * t + 8 * j) =
+                        make_float4(xacc[t][4 * j], xacc[t][4 * j + 1], xacc[t][4 * j + 2], xacc[t][4 * j + 3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+int launch_ln_qkv(const QkvParams& p, int n_jobs, int C, hipStream_t st) {
+    if (n_jobs == 0) return HMVIT_OK;
+    dim3 grid(cdiv(p.P, CHAIN_TOKENS), n_jobs), block(CHAIN_THREADS);
+    switch (C) {
+        case 64: hipLaunchKernelGGL((k_ln_qkv<64>), grid, block, 0, st, p); break;
+        case 128: hipLaunchKernelGGL((k_ln_qkv<128>), grid, block, 0, st, p); break;
+        case 256: hipLaunchKernelGGL((k_ln_qkv<256>), grid, block, 0, st, p); break;
+        default: set_error("ln_qkv: C=%d unsupported", C); return HMVIT_EINVAL;
+    }
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+template <int C>
+static int launch_out_ffn_c(const FfnParams& p, int n_jobs, int variant, hipStream_t st) {
+    dim3 grid(cdiv(p.P, CHAIN_TOKENS), n_jobs), block(CHAIN_THREADS);
+    switch (variant) {
+        case FFN_FULL: hipLaunchKernelGGL((k_out_ffn<C, true, true, true, false>), grid, block, 0, st, p); break;
+        case FFN_NO_ATTN: hipLaunchKernelGGL((k_out_ffn<C, false, true, true, false>), grid, block, 0, st, p); break;
+        case FFN_HEAD_NCHW: hipLaunchKernelGGL((k_out_ffn<C, false, false, false, true>), grid, block, 0, st, p); break;
+        default: set_error("out_ffn: bad variant %d", variant); return HMVIT_EINVAL;
+    }
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, hipStream_t st) {
+    if (n_jobs == 0) return HMVIT_OK;
+    switch (C) {
+        case 64: return launch_out_ffn_c<64>(p, n_jobs, variant, st);
+        case 128: return launch_out_ffn_c<128>(p, n_jobs, variant, st);
+        case 256: return launch_out_ffn_c<256>(p, n_jobs, variant, st);
+        default: set_error("out_ffn: C=%d unsupported", C); return HMVIT_EINVAL;
+    }
+}
+
+}  // namespace hmvit

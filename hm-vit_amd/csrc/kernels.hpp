@@ -41,6 +41,46 @@ struct GemmJobs {
 int launch_gemm(const GemmJobs& jobs, bool a_f32, bool gelu, bool out_f32, int precision,
                 hipStream_t st);
 
+// ---- chain.hip (f16 mode: register-resident token chains) ----
+constexpr int kMaxChainJobs = 16;
+struct QkvJob {
+    const float* x;          // (P, C) token-major, or (C, P) when in_nchw
+    float* xs_out;           // token-major copy written when in_nchw
+    const half_t* w[5];      // weight images (NT chunks each): [Q] K'(e0) V'(e0) [K'(e1) V'(e1)]
+    half_t* y[5];            // output planes (P, C)
+    int n_mat;
+    int type;
+};
+struct QkvParams {
+    QkvJob job[kMaxChainJobs];
+    const float* gamma;      // (T, C)
+    const float* beta;
+    int P;
+    int in_nchw;
+};
+int launch_ln_qkv(const QkvParams& p, int n_jobs, int C, hipStream_t st);
+
+struct FfnJob {
+    const half_t* o;         // (P, C) attention output (FFN_FULL)
+    const float* x;          // (P, C) residual stream in
+    float* out;              // (P, C) token-major (may alias x) or (C, P) for FFN_HEAD_NCHW
+    int type;
+    int pad;
+};
+struct FfnParams {
+    FfnJob job[kMaxChainJobs];
+    const half_t* w_o;       // (T, NT chunks)
+    const float* b_o;        // (T, C)
+    const float* ln_g;       // (T, C)
+    const float* ln_b;
+    const half_t* w_ffn;     // (T, 2 NH chunks): W_1 tile 0, W_2 slice 0, W_1 tile 1, ...
+    const float* b_1;        // (T, C)
+    const float* b_2;        // (T, C)
+    int P;
+};
+enum { FFN_FULL = 0, FFN_NO_ATTN = 1, FFN_HEAD_NCHW = 2 };
+int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, hipStream_t st);
+
 // ---- attn.hip ----
 struct AttnParams {
     const void* q;            // (B, L, P, C)

@@ -164,10 +164,10 @@ class _FusionBase(nn.Module):
         d.x, d.pairwise_t, d.out = x.data_ptr(), pw.data_ptr(), out.data_ptr()
         for s in range(2):
             for name, _ in _lib.StageWeights._fields_:
-                setattr(d.stage[s], name, w[s][name].data_ptr())
+                setattr(d.stage[s], name, w[s][name].data_ptr() if name in w[s] else None)
         if apply_head:
-            for name in ("head_w1", "head_b1", "head_w2", "head_b2"):
-                setattr(d, name, w["head"][name].data_ptr())
+            for name in ("head_w1", "head_b1", "head_w2", "head_b2", "head_img_ffn"):
+                setattr(d, name, w["head"][name].data_ptr() if name in w["head"] else None)
         need = _lib.lib.hmvit_fusion_workspace_bytes(ctypes.byref(d))
         if need == 0:
             _lib.check(-22, "hmvit_fusion_workspace_bytes")

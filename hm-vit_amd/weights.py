@@ -43,6 +43,36 @@ def bias_fragments(table: torch.Tensor, window: int) -> torch.Tensor:
     return frag.permute(3, 0, 1, 2).contiguous()
 
 
+def weight_image(w: torch.Tensor) -> torch.Tensor:
+    """(N, K) matrix -> (N/32, K/16, 64, 8) f16 fragment image (include/hmvit.h):
+    img[t][kk][lane][4 jj + i] = W[32 t + (lane & 31)][16 kk + 8 jj + 4 (lane >> 5) + i]."""
+    N, K = w.shape
+    if N % 32 or K % 16:
+        raise ValueError(f"weight_image: ({N}, {K}) must be multiples of (32, 16)")
+    dev = w.device
+    t = torch.arange(N // 32, device=dev)[:, None, None, None]
+    kk = torch.arange(K // 16, device=dev)[None, :, None, None]
+    lane = torch.arange(64, device=dev)[None, None, :, None]
+    q = torch.arange(8, device=dev)[None, None, None, :]
+    n = 32 * t + (lane & 31)
+    k = 16 * kk + 8 * (q >> 2) + 4 * (lane >> 5) + (q & 3)
+    return w[n.expand(-1, K // 16, -1, 8), k.expand(N // 32, -1, -1, -1)].to(torch.float16).contiguous()
+
+
+def ffn_image(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """Interleaved weight stream of Linear(C, C) -> GELU -> Linear(C, C) for k_out_ffn:
+    (C/32, 2, C/16, 64, 8): [hc][0] = image of W_1 rows of hidden tile hc, [hc][1] = fragments
+    (t, 2 hc + s) of the image of W_2."""
+    C = w1.shape[1]
+    if tuple(w1.shape) != (C, C) or tuple(w2.shape) != (C, C):
+        raise ValueError("the fused FFN kernel needs mlp_dim == input_dim")
+    i1 = weight_image(w1)
+    i2 = weight_image(w2)
+    nt, kk = C // 32, C // 16
+    i2 = i2.view(nt, nt, 2, 64, 8).permute(1, 0, 2, 3, 4).reshape(nt, kk, 64, 8)
+    return torch.stack([i1, i2], dim=1).contiguous()
+
+
 def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: int, window: int,
                dtype: torch.dtype) -> Dict[str, torch.Tensor]:
     """Folded tensors of one stage (which = 'window' | 'grid') in the layout of
@@ -60,7 +90,13 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
     stack = lambda fmt: torch.stack([f(fmt.format(t=t)) for t in range(NUM_TYPES)])
     out["ln_gamma"] = stack(f"{prefix}{which}_norm.net.{{t}}.weight")
     out["ln_beta"] = stack(f"{prefix}{which}_norm.net.{{t}}.bias")
-    out["w_q"] = (stack(f"{att}.q_linears.{{t}}.weight") * scale).to(dtype)
+    f16 = dtype == torch.float16
+    per_type = lambda m, fn: torch.stack([fn(m[t]) for t in range(NUM_TYPES)])
+    w_q = stack(f"{att}.q_linears.{{t}}.weight") * scale
+    if f16:
+        out["img_q"] = per_type(w_q, weight_image)
+    else:
+        out["w_q"] = w_q
     out["b_q"] = stack(f"{att}.q_linears.{{t}}.bias") * scale
 
     w_kv = torch.empty(NUM_TYPES, NUM_TYPES, 2 * C, C, device=rel_att.device)
@@ -76,16 +112,27 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
             b_kv[te, ts, :C] = torch.einsum("hpq,hq->hp", rel_att[e], bk).reshape(C)
             w_kv[te, ts, C:] = torch.einsum("hpq,hpc->hqc", rel_msg[e], wv).reshape(C, C)
             b_kv[te, ts, C:] = torch.einsum("hpq,hp->hq", rel_msg[e], bv).reshape(C)
-    out["w_kv"] = w_kv.to(dtype)
+    if f16:
+        out["img_kv"] = torch.stack([per_type(w_kv[te], weight_image) for te in range(NUM_TYPES)])
+    else:
+        out["w_kv"] = w_kv
     out["b_kv"] = b_kv
     out["bias_frag"] = bias_fragments(sd[f"{att}.relative_position_bias_table.weight"], window)
-    out["w_o"] = stack(f"{att}.a_linears.{{t}}.0.weight").to(dtype)
+    w_o = stack(f"{att}.a_linears.{{t}}.0.weight")
+    if f16:
+        out["img_o"] = per_type(w_o, weight_image)
+    else:
+        out["w_o"] = w_o
     out["b_o"] = stack(f"{att}.a_linears.{{t}}.0.bias")
     out["ffn_ln_gamma"] = stack(f"{prefix}{which}_ffd.norm.net.{{t}}.weight")
     out["ffn_ln_beta"] = stack(f"{prefix}{which}_ffd.norm.net.{{t}}.bias")
-    out["w_1"] = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.0.weight").to(dtype)
+    w_1 = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.0.weight")
+    w_2 = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.3.weight")
+    if f16:
+        out["img_ffn"] = torch.stack([ffn_image(w_1[t], w_2[t]) for t in range(NUM_TYPES)])
+    else:
+        out["w_1"], out["w_2"] = w_1, w_2
     out["b_1"] = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.0.bias")
-    out["w_2"] = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.3.weight").to(dtype)
     out["b_2"] = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.3.bias")
     return {k: v.contiguous() for k, v in out.items()}
 
@@ -93,9 +140,11 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
 def fold_head(sd: Dict[str, torch.Tensor], prefix: str, dtype: torch.dtype) -> Dict[str, torch.Tensor]:
     f = lambda k: sd[k].detach().float()
     stack = lambda fmt: torch.stack([f(fmt.format(t=t)) for t in range(NUM_TYPES)])
-    return {
-        "head_w1": stack(f"{prefix}.net.{{t}}.0.weight").to(dtype).contiguous(),
-        "head_b1": stack(f"{prefix}.net.{{t}}.0.bias").contiguous(),
-        "head_w2": stack(f"{prefix}.net.{{t}}.3.weight").to(dtype).contiguous(),
-        "head_b2": stack(f"{prefix}.net.{{t}}.3.bias").contiguous(),
-    }
+    w1, w2 = stack(f"{prefix}.net.{{t}}.0.weight"), stack(f"{prefix}.net.{{t}}.3.weight")
+    out = {"head_b1": stack(f"{prefix}.net.{{t}}.0.bias").contiguous(),
+           "head_b2": stack(f"{prefix}.net.{{t}}.3.bias").contiguous()}
+    if dtype == torch.float16:
+        out["head_img_ffn"] = torch.stack([ffn_image(w1[t], w2[t]) for t in range(NUM_TYPES)])
+    else:
+        out["head_w1"], out["head_w2"] = w1.contiguous(), w2.contiguous()
+    return out

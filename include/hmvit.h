@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HMVIT_ABI_VERSION 1
+#define HMVIT_ABI_VERSION 2
 
 #define HMVIT_OK 0
 #define HMVIT_EINVAL (-22)   /* bad argument / unsupported shape */
@@ -57,7 +57,18 @@ extern "C" {
  *   ffn_ln_*  (T, C)            f32   {window,grid}_ffd.norm, base_transformer.py:129-136
  *   w_1,b_1   (T, mlp, C),(T, mlp)    {window,grid}_ffd.fn.net[t][0], base_transformer.py:180-192
  *   w_2,b_2   (T, C, mlp),(T, C)      {window,grid}_ffd.fn.net[t][3]
- * Biases are always f32. */
+ * Biases are always f32.
+ *
+ * HMVIT_PREC_F32 reads the plain row-major matrices w_q, w_kv, w_o, w_1, w_2 (f32).
+ * HMVIT_PREC_F16 reads "fragment images" instead (the plain pointers may then be NULL): an
+ * (N, K) matrix is stored as (N/32, K/16, 64, 8) f16 with
+ *     img[t][kk][lane][4 jj + i] = W[32 t + (lane & 31)][16 kk + 8 jj + 4 (lane >> 5) + i],
+ * i.e. one 32-row tile after another, inside a tile one v_mfma_f32_32x32x16_f16 A-operand
+ * fragment after another, so that weight staging is a linear copy (hm-vit_amd/weights.py:
+ * weight_image).  img_q (T, ...), img_kv (T_ego, T_src, ...) of the (2C, C) matrix, img_o (T, ...);
+ * img_ffn (T, C/32, 2, C/16, 64, 8) interleaves, for every hidden tile hc, the image of
+ * W_1 rows [32 hc, 32 hc + 32) with the fragments (t, 2 hc + s), t < C/32, s < 2, of the image of
+ * W_2 (requires mlp_dim == C). */
 typedef struct HmvitStageWeights {
     const float* ln_gamma;
     const float* ln_beta;
@@ -74,6 +85,10 @@ typedef struct HmvitStageWeights {
     const float* b_1;
     const void* w_2;
     const float* b_2;
+    const void* img_q;
+    const void* img_kv;
+    const void* img_o;
+    const void* img_ffn;
 } HmvitStageWeights;
 
 /* One HeteroFusion / HeteroFusionBlock forward.
@@ -106,6 +121,7 @@ typedef struct HmvitFusionDesc {
     const float* head_b1;         /* (T, C)                                               */
     const void* head_w2;          /* mlp_head.net[t][3]: (T, C, C)                        */
     const float* head_b2;
+    const void* head_img_ffn;     /* f16 mode: (T, ...) image of mlp_head as img_ffn above */
     void* workspace;              /* device scratch                                       */
     size_t workspace_bytes;
 } HmvitFusionDesc;
