@@ -390,6 +390,347 @@ __global__ __launch_bounds__(HG * 64, (sizeof(T) == 2 ? 2 : 1)) void k_attention
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Persistent producer / consumer variant (f16, window 8, 4 heads = 128 channels per workgroup).
+//
+// 8 wavefronts: waves 0-3 compute (one head each, exactly as k_attention), waves 4-7 only gather.
+// While the compute waves work on key chunk c out of LDS buffer c & 1, the loader waves bilinear-
+// gather chunk c + 1 (or the next work item's query tile and first chunk) into the other buffer
+// with ALL tap loads of the chunk in flight at once (they hold no other state, so 128 VGPRs of raw
+// taps fit).  One __syncthreads() per chunk; the workgroup walks a strided list of
+// (sample, ego, window, head group) items so the pipeline never drains.  The ego's own map is
+// chunk 0 (identity transform: one tap), which keeps the item hand-over cheap.
+// ------------------------------------------------------------------------------------------
+struct PcItem {
+    int b, ego, wx, wy, hg;
+};
+
+__device__ __forceinline__ PcItem pc_decode(int item, int n_ego, int X, int Y, int NG) {
+    PcItem it;
+    it.hg = item % NG; item /= NG;
+    const int win = item % (X * Y); item /= (X * Y);
+    it.wx = win / Y; it.wy = win - it.wx * Y;
+    it.ego = item % n_ego;
+    it.b = item / n_ego;
+    return it;
+}
+
+template <int QS>
+__device__ __forceinline__ void pc_gather_q(const AttnParams& p, const PcItem& it, half_t* Qs, int ltid) {
+    const int C = p.C, H = p.H, W = p.W, L = p.L, P = H * W, X = H / 8, Y = W / 8;
+    const float* a = p.ainv + ((size_t)(it.b * L + it.ego) * L + it.ego) * 8;
+    const bool ident = a[6] != 0.f;
+    const int te = p.mode[it.b * L + it.ego];
+    const half_t* plane = reinterpret_cast<const half_t*>(p.q) + (size_t)(it.b * L + it.ego) * P * C + it.hg * 128;
+    const float* bq = p.b_q + te * C + it.hg * 128;
+    const int cl = (ltid & 15) * 8;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int n = pass * 16 + (ltid >> 4);
+        int row, col;
+        token_pixel(p.partition, 8, X, Y, it.wx, it.wy, n, row, col);
+        Taps t;
+        if (!ident) t = make_taps(a, col, row, H, W);
+        float v[1][8];
+        sample8<half_t, 1>(plane, 0, C, cl, t, ident, row * W + col, bq, 0, v);
+        store8_lds<half_t>(Qs + n * QS + cl, v[0]);
+    }
+}
+
+// source agent of chunk c for ego e: the ego itself first, then the others in order
+__device__ __forceinline__ int pc_src(int c, int ego) { return c == 0 ? ego : (c <= ego ? c - 1 : c); }
+
+template <int KS, int VS>
+__device__ __forceinline__ void pc_gather_kv(const AttnParams& p, const PcItem& it, int chunk, half_t* Ks, half_t* Vs,
+                                             float* maskadd, int* vis_slot, int ltid) {
+    const int C = p.C, H = p.H, W = p.W, L = p.L, P = H * W, X = H / 8, Y = W / 8;
+    const int src = pc_src(chunk, it.ego);
+    const float* a = p.ainv + ((size_t)(it.b * L + src) * L + it.ego) * 8;
+    const bool ident = a[6] != 0.f;
+    const bool cav = p.cav[it.b * L + src] != 0;
+    const int te = p.mode[it.b * L + it.ego], ts = p.mode[it.b * L + src];
+    const int ev = p.ego_e[it.b * L + it.ego];
+    const half_t* kpl = reinterpret_cast<const half_t*>(p.kv) + ((size_t)((it.b * L + src) * p.E + ev) * 2) * P * C + it.hg * 128;
+    const half_t* vpl = kpl + (size_t)P * C;
+    const float* bk = p.b_kv + (size_t)(te * HMVIT_NUM_TYPES + ts) * 2 * C + it.hg * 128;
+    const int cl = (ltid & 15) * 8;
+
+    float bkv[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        bkv[0][e] = bk[cl + e];
+        bkv[1][e] = bk[C + cl + e];
+    }
+
+    Taps t[4];
+    bool visible[4];
+    int self_idx[4];
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int n = pass * 16 + (ltid >> 4);
+        int row, col;
+        token_pixel(p.partition, 8, X, Y, it.wx, it.wy, n, row, col);
+        self_idx[pass] = row * W + col;
+        if (ident) {
+            t[pass].roi = 1.f;
+        } else {
+            t[pass] = make_taps(a, col, row, H, W);
+        }
+        visible[pass] = cav && (t[pass].roi != 0.f);
+    }
+    // all tap loads of the chunk are issued before the first blend
+    Raw8<half_t> raw[4][2][4];
+    if (ident) {
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass)
+            if (visible[pass]) {
+                raw[pass][0][0].load(kpl + (size_t)self_idx[pass] * C + cl);
+                raw[pass][1][0].load(vpl + (size_t)self_idx[pass] * C + cl);
+            }
+    } else {
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass)
+            if (visible[pass]) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    raw[pass][0][k].load(kpl + (size_t)t[pass].idx[k] * C + cl);
+                    raw[pass][1][k].load(vpl + (size_t)t[pass].idx[k] * C + cl);
+                }
+            }
+    }
+    bool any = false;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int kk = pass * 16 + (ltid >> 4);
+        float o[2][8];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[pl][e] = 0.f;
+        if (visible[pass]) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float acc;
+                    if (ident) {
+                        acc = raw[pass][pl][0].get(e);
+                    } else {
+                        acc = t[pass].w[0] * raw[pass][pl][0].get(e);
+#pragma unroll
+                        for (int k = 1; k < 4; ++k) acc = fmaf(t[pass].w[k], raw[pass][pl][k].get(e), acc);
+                    }
+                    o[pl][e] = acc + bkv[pl][e];
+                }
+        }
+        store8_lds<half_t>(Ks + kk * KS + cl, o[0]);
+        store8_lds<half_t>(Vs + kk * VS + cl, o[1]);
+        if ((ltid & 15) == 0) maskadd[kk] = visible[pass] ? 0.f : -INFINITY;
+        any |= visible[pass];
+    }
+    const bool wave_any = __any(any);
+    if ((ltid & 63) == 0) *vis_slot = wave_any ? 1 : 0;
+}
+
+struct PcShared {
+    static constexpr int QS = 136, KS = 136, VS = 144;
+    half_t Qs[2][64 * QS];
+    half_t Ks[2][64 * KS];
+    half_t Vs[2][64 * VS];
+    float maskadd[2][64];
+    int vis[2][4];
+};
+
+// Both role loops execute exactly one barrier in the prologue and one per (item, chunk).
+__device__ __forceinline__ void pc_loader_loop(const AttnParams& p, PcShared& sm, int lw, int ltid) {
+    constexpr int QS = PcShared::QS, KS = PcShared::KS, VS = PcShared::VS;
+    const int X = p.H / 8, Y = p.W / 8, NG = p.C / 128;
+    const int n_items = p.B * p.n_ego * X * Y * NG;
+    const int n_src = p.n_src;
+    int item = blockIdx.x;
+    PcItem it = pc_decode(item, p.n_ego, X, Y, NG);
+    pc_gather_q<QS>(p, it, sm.Qs[0], ltid);
+    pc_gather_kv<KS, VS>(p, it, 0, sm.Ks[0], sm.Vs[0], sm.maskadd[0], &sm.vis[0][lw], ltid);
+    __syncthreads();
+    int gstep = 0, qi = 0;
+    while (true) {
+        const int next_item = item + gridDim.x;
+        for (int c = 0; c < n_src; ++c) {
+            const int nb = (gstep & 1) ^ 1;
+            if (c + 1 < n_src) {
+                pc_gather_kv<KS, VS>(p, it, c + 1, sm.Ks[nb], sm.Vs[nb], sm.maskadd[nb], &sm.vis[nb][lw], ltid);
+            } else if (next_item < n_items) {
+                const PcItem nit = pc_decode(next_item, p.n_ego, X, Y, NG);
+                pc_gather_q<QS>(p, nit, sm.Qs[qi ^ 1], ltid);
+                pc_gather_kv<KS, VS>(p, nit, 0, sm.Ks[nb], sm.Vs[nb], sm.maskadd[nb], &sm.vis[nb][lw], ltid);
+            }
+            __syncthreads();
+            ++gstep;
+        }
+        if (next_item >= n_items) break;
+        item = next_item;
+        it = pc_decode(item, p.n_ego, X, Y, NG);
+        qi ^= 1;
+    }
+}
+
+__device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared& sm, int wave, int lane) {
+    constexpr int QS = PcShared::QS, KS = PcShared::KS, VS = PcShared::VS;
+    const int C = p.C, H = p.H, W = p.W, L = p.L, P = H * W;
+    const int X = H / 8, Y = W / 8, NG = C / 128;
+    const int n_items = p.B * p.n_ego * X * Y * NG;
+    const int n_src = p.n_src;
+    const int lq = lane & 15, g = lane >> 4;
+    int item = blockIdx.x;
+    __syncthreads();
+
+    float4v biasf[7];
+    int bias_head = -1;
+    half8 qh[4];
+    float m_run[4], l_run[4];
+    float4v o_acc[4][2];
+    int gstep = 0, qi = 0;
+    while (true) {
+        const PcItem it = pc_decode(item, p.n_ego, X, Y, NG);
+        const int head = it.hg * 4 + wave;
+        for (int c = 0; c < n_src; ++c) {
+            const int buf = gstep & 1;
+            if (c == 0) {
+                if (head != bias_head) {
+#pragma unroll
+                    for (int v = 0; v < 7; ++v)
+                        biasf[v] = *reinterpret_cast<const float4v*>(p.bias_frag + ((size_t)(head * 7 + v) * 64 + lane) * 4);
+                    bias_head = head;
+                }
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) {
+                    qh[qt] = *reinterpret_cast<const half8*>(sm.Qs[qi] + (qt * 16 + lq) * QS + wave * 32 + g * 8);
+                    m_run[qt] = -INFINITY;
+                    l_run[qt] = 0.f;
+                    o_acc[qt][0] = (float4v)(0.f);
+                    o_acc[qt][1] = (float4v)(0.f);
+                }
+            }
+            const bool any_visible = (sm.vis[buf][0] | sm.vis[buf][1] | sm.vis[buf][2] | sm.vis[buf][3]) != 0;
+            if (any_visible || !p.skip_masked) {
+                const half_t* Kb = sm.Ks[buf];
+                const half_t* Vb = sm.Vs[buf];
+                float4v madd[4];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) madd[kt] = *reinterpret_cast<const float4v*>(sm.maskadd[buf] + kt * 16 + 4 * g);
+                half8 kh[4], vh[2][2];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+                    kh[kt] = *reinterpret_cast<const half8*>(Kb + (kt * 16 + lq) * KS + wave * 32 + g * 8);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const half_t* base = Vb + (ks * 32 + 4 * g + (lq >> 2)) * VS + wave * 32 + dt * 16 + (lq & 3) * 4;
+                        const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                            (__attribute__((address_space(3))) fp16x4_t*)(base));
+                        const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                            (__attribute__((address_space(3))) fp16x4_t*)(base + 16 * VS));
+                        half8 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = (half_t)lo[e];
+                            v[4 + e] = (half_t)hi[e];
+                        }
+                        vh[dt][ks] = v;
+                    }
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) {
+                    float4v s[4];
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[kt], qh[qt], biasf[qt - kt + 3], 0, 0, 0) + madd[kt];
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    const float m_new = fmaxf(m_run[qt], mx);
+                    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+                    const float alpha = __expf(m_run[qt] - m_safe);
+                    float rs = 0.f;
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float e = __expf(s[kt][r] - m_safe);
+                            s[kt][r] = e;
+                            rs += e;
+                        }
+                    rs += __shfl_xor(rs, 16, 64);
+                    rs += __shfl_xor(rs, 32, 64);
+                    l_run[qt] = l_run[qt] * alpha + rs;
+                    m_run[qt] = m_new;
+                    o_acc[qt][0] *= alpha;
+                    o_acc[qt][1] *= alpha;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        half8 ph;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            ph[e] = (half_t)s[2 * ks][e];
+                            ph[4 + e] = (half_t)s[2 * ks + 1][e];
+                        }
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt)
+                            o_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dt][ks], ph, o_acc[qt][dt], 0, 0, 0);
+                    }
+                }
+            }
+            if (c == n_src - 1) {
+                half_t* outp = reinterpret_cast<half_t*>(p.out) + (size_t)(it.b * L + it.ego) * P * C;
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) {
+                    int row, col;
+                    token_pixel(p.partition, 8, X, Y, it.wx, it.wy, qt * 16 + lq, row, col);
+                    const float inv = 1.f / l_run[qt];
+                    half_t* o = outp + (size_t)(row * W + col) * C + head * 32 + 4 * g;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        half4 h;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h[r] = (half_t)(o_acc[qt][dt][r] * inv);
+                        *reinterpret_cast<half4*>(o + dt * 16) = h;
+                    }
+                }
+            }
+            __syncthreads();
+            ++gstep;
+        }
+        item += gridDim.x;
+        if (item >= n_items) break;
+        qi ^= 1;
+    }
+}
+
+__global__ __launch_bounds__(512) void k_attention_pc(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) PcShared sm;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // wave-uniform role split at the outermost level: the two loops have disjoint live ranges, so
+    // the kernel's register count is the maximum of the two roles, not their sum
+    if (wave >= 4) {
+        pc_loader_loop(p, sm, wave - 4, threadIdx.x & 255);
+    } else {
+        pc_compute_loop(p, sm, wave, threadIdx.x & 63);
+    }
+}
+
+static int launch_attn_pc(const AttnParams& p, hipStream_t st) {
+    const int n_items = p.B * p.n_ego * (p.H / 8) * (p.W / 8) * (p.C / 128);
+    int grid = 256;   // one persistent workgroup per CU (LDS ~108 KB)
+    if (grid > n_items) grid = n_items;
+    hipLaunchKernelGGL(k_attention_pc, dim3(grid), dim3(512), 0, st, p);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
 template <typename T, int WIN, int HG>
 static int launch_attn_t(const AttnParams& p, hipStream_t st) {
     const int NG = p.C / (HG * 32);
@@ -411,6 +752,7 @@ int launch_attention(const AttnParams& p, int precision, hipStream_t st) {
         return w8 ? launch_attn_t<float, 8, 2>(p, st) : launch_attn_t<float, 4, 2>(p, st);
     }
     if (p.C == 64) return w8 ? launch_attn_t<half_t, 8, 2>(p, st) : launch_attn_t<half_t, 4, 2>(p, st);
+    if (w8 && p.variant == 0) return launch_attn_pc(p, st);
     return w8 ? launch_attn_t<half_t, 8, 4>(p, st) : launch_attn_t<half_t, 4, 4>(p, st);
 }
 

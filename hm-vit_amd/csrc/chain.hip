@@ -48,15 +48,31 @@ constexpr int CHAIN_TOKENS = 256;
 // vmcnt(0) before a barrier while an LDS-DMA is in flight).
 template <int C>
 __device__ __forceinline__ void stage_chunk(const half_t* __restrict__ chunk, half_t* lds_buf) {
+    // Inline asm on purpose: hipcc must not count this DMA (it would drain vmcnt(0), i.e. also the
+    // output stores in flight, before every ds_read of the ring).  Completion is waited for by
+    // dma_wait() below, placed where the only other outstanding VMEM ops are long-issued stores.
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_buf;
 #pragma unroll
     for (int i = 0; i < ChainCfg<C>::PPT; ++i) {
         const int piece0 = (i * 8 + wave) * 64;
-        if (piece0 < ChainCfg<C>::PIECES)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(reinterpret_cast<const uint4*>(chunk) + piece0 + lane),
-                (__attribute__((address_space(3))) void*)(reinterpret_cast<uint4*>(lds_buf) + piece0), 16, 0, 0);
+        if (piece0 < ChainCfg<C>::PIECES) {
+            const uint4* gsrc = reinterpret_cast<const uint4*>(chunk) + piece0 + lane;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + piece0 * 16);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+        }
     }
+}
+
+// wait for this wave's DMA pieces (and any older store), then workgroup barrier: afterwards the
+// whole chunk is visible to every wave and the previous buffer may be overwritten
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 __device__ __forceinline__ half8 lds_frag(const half_t* buf, int frag, int lane) {
@@ -77,18 +93,18 @@ __device__ __forceinline__ float gelu_f(float x) {
     return x * phi;
 }
 
-// k-steps are issued in groups of 4 fragments so that the scheduler cannot hoist a whole chunk of
-// LDS reads (64 VGPRs) above the MFMAs
-template <int KK>
+// one chunk = KK fragments; DEPTH of them are read ahead of the MFMA that consumes them
+template <int KK, int DEPTH>
 __device__ __forceinline__ void mma_chunk(float16v& acc, const half_t* buf, const half8 (&act)[KK], int lane) {
+    static_assert(KK % DEPTH == 0, "");
+    const half_t* base = buf + lane * 8;
+    half8 w[DEPTH];
 #pragma unroll
-    for (int k0 = 0; k0 < KK; k0 += 4) {
-        half8 w[4];
+    for (int i = 0; i < DEPTH; ++i) w[i] = *reinterpret_cast<const half8*>(base + i * 512);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = *reinterpret_cast<const half8*>(buf + ((k0 + i) * 64 + lane) * 8);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[i], act[k0 + i], acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int kk = 0; kk < KK; ++kk) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[kk % DEPTH], act[kk], acc, 0, 0, 0);
+        if (kk + DEPTH < KK) w[kk % DEPTH] = *reinterpret_cast<const half8*>(base + (kk + DEPTH) * 512);
     }
 }
 
@@ -245,6 +261,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_ln_qkv(QkvParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(xo + 32 * b + 8 * j) = v[b][j];
     }
+    dma_wait();
     __syncthreads();
     layer_norm_regs<C>(v, lnp, lnp + C, hi);
     half8 act[KK];
@@ -260,7 +277,8 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_ln_qkv(QkvParams p) {
         float16v acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        mma_chunk<KK>(acc, buf, act, lane);
+        mma_chunk<KK, (KK < 8 ? KK : 8)>(acc, buf, act, lane);
+        dma_wait();
         if (valid) {
             half_t* o = J.y[mat] + ((size_t)tok * C + 32 * t + 4 * hi);
 #pragma unroll
@@ -271,7 +289,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_ln_qkv(QkvParams p) {
                 *reinterpret_cast<half4*>(o + 8 * j) = h;
             }
         }
-        __syncthreads();
+        wg_barrier();
     }
 }
 
@@ -351,6 +369,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_out_ffn(FfnParams p) {
                 act[2 * b + s] = h;
             }
     }
+    dma_wait();
     __syncthreads();
 
     if constexpr (OUTPROJ) {
@@ -375,11 +394,12 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_out_ffn(FfnParams p) {
             float16v acc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-            mma_chunk<KK>(acc, buf, act, lane);
+            mma_chunk<KK, 4>(acc, buf, act, lane);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 if (t == c) xacc[t] += acc;
-            __syncthreads();
+            dma_wait();
+            wg_barrier();
         }
     }
     if constexpr (LN) ln_acc_to_operands<C>(xacc, vec[1], vec[2], hi, act);
@@ -411,8 +431,9 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_out_ffn(FfnParams p) {
             hacc[4 * j + 0] = b1.x; hacc[4 * j + 1] = b1.y; hacc[4 * j + 2] = b1.z; hacc[4 * j + 3] = b1.w;
         }
         stage_chunk<C>(w1c + Cfg::CHUNK_HALVES, ring1);          // W_2 slice hc
-        mma_chunk<KK>(hacc, ring0, act, lane);
-        __syncthreads();
+        mma_chunk<KK, 4>(hacc, ring0, act, lane);
+        dma_wait();
+        wg_barrier();
 
         half8 hop[2];
 #pragma unroll
@@ -425,9 +446,9 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_out_ffn(FfnParams p) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
                 xacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(ring1, t * 2 + s, lane), hop[s], xacc[t], 0, 0, 0);
-            if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        dma_wait();
+        wg_barrier();
     }
 
     if (valid) {
