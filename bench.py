@@ -122,6 +122,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
     import hmvit_amd
+    from hmvit_amd.dist import max_over_ranks
     from oracle import hmvit_oracle as O      # only the seeded input generators + cpu_baseline
 
     c = CONFIGS[args.config]
@@ -151,11 +152,7 @@ def main():
             net(*scene)
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+        return max_over_ranks(dt, dev)          # job time = slowest rank (hm-vit_amd/dist.py)
 
     net = make(args.precision)
     dt = timed(net, args.steps, args.warmup)

@@ -1,0 +1,27 @@
+"""Scene sharding across ranks (one process per GPU).  The fusion path has no data-path exchange:
+scenes are independent units (batch_size 1 per GPU in the reference, train_camera.py:62-71), so the
+only collectives are the timing barrier and a MAX reduction of the wall time (RCCL on GPUs, gloo in
+the CPU tests)."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_scenes(n_scenes: int, rank: int, world: int):
+    """Round-robin scene ids of this rank (DistributedSampler-style, no padding)."""
+    return list(range(rank, n_scenes, world))
+
+
+def max_over_ranks(seconds: float, device=None) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def aggregate_throughput(units_per_rank: int, seconds: float, device=None) -> float:
+    """Whole-job units/s = units processed by all ranks / slowest rank's time."""
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    return world * units_per_rank / max_over_ranks(seconds, device)
