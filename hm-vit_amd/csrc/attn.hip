@@ -15,6 +15,8 @@
 // in the B-operand layout of the second product O^T = V^T P^T.
 //   f16 mode: v_mfma_f32_16x16x32_f16; V^T fragments come from ds_read_b64_tr_b16.
 //   f32 mode: v_mfma_f32_16x16x4_f32 (exact f32), element-granular operands, no transposes.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -412,172 +414,292 @@ __device__ __forceinline__ PcItem pc_decode(int item, int n_ego, int X, int Y, i
     it.wx = win / Y; it.wy = win - it.wx * Y;
     it.ego = item % n_ego;
     it.b = item / n_ego;
+    // the item index is wave-uniform: keep its fields in SGPRs so that the per-chunk metadata
+    // (affine record, agent types, plane bases) is fetched with scalar loads
+    it.b = __builtin_amdgcn_readfirstlane(it.b);
+    it.ego = __builtin_amdgcn_readfirstlane(it.ego);
+    it.wx = __builtin_amdgcn_readfirstlane(it.wx);
+    it.wy = __builtin_amdgcn_readfirstlane(it.wy);
+    it.hg = __builtin_amdgcn_readfirstlane(it.hg);
     return it;
 }
 
-template <int QS>
-__device__ __forceinline__ void pc_gather_q(const AttnParams& p, const PcItem& it, half_t* Qs, int ltid) {
-    const int C = p.C, H = p.H, W = p.W, L = p.L, P = H * W, X = H / 8, Y = W / 8;
-    const float* a = p.ainv + ((size_t)(it.b * L + it.ego) * L + it.ego) * 8;
-    const bool ident = a[6] != 0.f;
-    const int te = p.mode[it.b * L + it.ego];
-    const half_t* plane = reinterpret_cast<const half_t*>(p.q) + (size_t)(it.b * L + it.ego) * P * C + it.hg * 128;
-    const float* bq = p.b_q + te * C + it.hg * 128;
-    const int cl = (ltid & 15) * 8;
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        const int n = pass * 16 + (ltid >> 4);
-        int row, col;
-        token_pixel(p.partition, 8, X, Y, it.wx, it.wy, n, row, col);
-        Taps t;
-        if (!ident) t = make_taps(a, col, row, H, W);
-        float v[1][8];
-        sample8<half_t, 1>(plane, 0, C, cl, t, ident, row * W + col, bq, 0, v);
-        store8_lds<half_t>(Qs + n * QS + cl, v[0]);
-    }
-}
+template <int HG>
+struct PcShared {
+    static constexpr int CH = HG * 32;             // channels of the head group
+    static constexpr int QS = CH + 8, KS = CH + 8, VS = CH + 16;
+    static constexpr int TPK = HG * 4;             // loader lanes per key row (8 channels each)
+    static constexpr int KPW = 64 / TPK;           // keys per loader wave and pass
+    static constexpr int NK = 4 * KPW;             // keys owned by one loader wave
+    static constexpr int MAX_PAIRS = 128;      // B * L * L affine records kept in LDS
+    half_t Qs[2][64 * QS];
+    half_t Ks[2][64 * KS];
+    half_t Vs[2][64 * VS];
+    float maskadd[2][64];
+    int vis[2][HG];
+    float ainv[MAX_PAIRS * 8];                 // sampling maps of every (source, ego) pair
+    float bkv[HMVIT_NUM_TYPES * HMVIT_NUM_TYPES][2][CH];   // folded k / v biases of this head group
+    float bq[HMVIT_NUM_TYPES][CH];
+    int mode[kMaxSlots], cav[kMaxSlots], ego_e[kMaxSlots];   // copies of the kernel-argument byte arrays
+    // per loader wave: bilinear taps of its 16 keys (computed once, lane = key)
+    int tidx[HG][NK][4];
+    float tw[HG][NK][4];
+    int tself[HG][NK];
+    int tvis[HG][NK];
+    int gcount;                                // gather counter (debug trace only)
+};
 
 // source agent of chunk c for ego e: the ego itself first, then the others in order
 __device__ __forceinline__ int pc_src(int c, int ego) { return c == 0 ? ego : (c <= ego ? c - 1 : c); }
 
-template <int KS, int VS>
-__device__ __forceinline__ void pc_gather_kv(const AttnParams& p, const PcItem& it, int chunk, half_t* Ks, half_t* Vs,
-                                             float* maskadd, int* vis_slot, int ltid) {
+// debug trace: workgroup 0, one lane of one wave per role, stamps[(iter * 8 + slot)]
+#define PC_TRACE(cond, iter, slot)                                                              \
+    do {                                                                                        \
+        if (p.trace && blockIdx.x == 0 && (cond) && (iter) < 64)                                \
+            p.trace[(iter) * 8 + (slot)] = __builtin_readcyclecounter();                        \
+    } while (0)
+
+// 16 bytes of a projected map through a buffer descriptor: 32-bit byte offset per lane, plane
+// selected by the scalar offset (K' and V' share the lane offsets)
+__device__ __forceinline__ half8 buf_load8(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+
+// Gather one 64-key chunk of K'/V' (and, with WITH_Q, the query tile of the same item) into LDS.
+// Instruction diet (the loader is issue-bound): the bilinear taps of a key are computed once per
+// wave (lane = key) and redistributed through LDS instead of 16x redundantly; loads go through
+// buffer descriptors with 32-bit offsets; the folded bias is the addend of the first blend FMA.
+// Every global load of the call is issued before the first value is used.
+template <int HG, bool WITH_Q>
+__device__ __forceinline__ void pc_gather(const AttnParams& p, PcShared<HG>& sm, const PcItem& it, int chunk, int kvbuf,
+                                          int qbuf, int lw, int ltid) {
+    using SM = PcShared<HG>;
+    constexpr int QS = SM::QS, KS = SM::KS, VS = SM::VS, CH = SM::CH, TPK = SM::TPK, KPW = SM::KPW, NK = SM::NK;
     const int C = p.C, H = p.H, W = p.W, L = p.L, P = H * W, X = H / 8, Y = W / 8;
     const int src = pc_src(chunk, it.ego);
-    const float* a = p.ainv + ((size_t)(it.b * L + src) * L + it.ego) * 8;
-    const bool ident = a[6] != 0.f;
-    const bool cav = p.cav[it.b * L + src] != 0;
-    const int te = p.mode[it.b * L + it.ego], ts = p.mode[it.b * L + src];
-    const int ev = p.ego_e[it.b * L + it.ego];
-    const half_t* kpl = reinterpret_cast<const half_t*>(p.kv) + ((size_t)((it.b * L + src) * p.E + ev) * 2) * P * C + it.hg * 128;
-    const half_t* vpl = kpl + (size_t)P * C;
-    const float* bk = p.b_kv + (size_t)(te * HMVIT_NUM_TYPES + ts) * 2 * C + it.hg * 128;
-    const int cl = (ltid & 15) * 8;
+    const float* a = sm.ainv + ((it.b * L + src) * L + it.ego) * 8;
+    const int dbg = p.variant;
+    const bool ident = (a[6] != 0.f) || (dbg & 0x10);
+    const bool cav = (sm.cav[it.b * L + src] != 0) && !(dbg & 0x20);
+    const int te = __builtin_amdgcn_readfirstlane(sm.mode[it.b * L + it.ego]);
+    const int ts = __builtin_amdgcn_readfirstlane(sm.mode[it.b * L + src]);
+    const int ev = __builtin_amdgcn_readfirstlane(sm.ego_e[it.b * L + it.ego]);
+    const unsigned plane_bytes = (unsigned)P * C * 2;
+    const half_t* kpl = reinterpret_cast<const half_t*>(p.kv) + ((size_t)((it.b * L + src) * p.E + ev) * 2) * P * C + it.hg * CH;
+    const __amdgpu_buffer_rsrc_t rs_kv = __builtin_amdgcn_make_buffer_rsrc((void*)kpl, 0, 0x7fffffff, 0x00020000);
+    const int lane = ltid & 63;
+    const int cl = (ltid % TPK) * 8;
+    const int kin = ltid / TPK;                  // key row of this lane inside a 16-key pass
+    const unsigned cl_bytes = cl * 2;
+    const unsigned row_bytes = (unsigned)C * 2;
 
-    float bkv[2][8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        bkv[0][e] = bk[cl + e];
-        bkv[1][e] = bk[C + cl + e];
+    // ---- taps: lane j < NK of loader wave lw owns key (j / KPW) * 16 + KPW lw + (j % KPW) ----
+    {
+        const int j = lane % NK;
+        const int n = (j / KPW) * 16 + KPW * lw + (j % KPW);
+        int row, col;
+        token_pixel(p.partition, 8, X, Y, it.wx, it.wy, n, row, col);
+        Taps t;
+        if (ident) {
+            t.idx[0] = t.idx[1] = t.idx[2] = t.idx[3] = row * W + col;
+            t.w[0] = 1.f; t.w[1] = t.w[2] = t.w[3] = 0.f;
+            t.roi = 1.f;
+        } else {
+            t = make_taps(a, col, row, H, W);
+        }
+        if (lane < NK) {
+            *reinterpret_cast<int4*>(sm.tidx[lw][j]) = make_int4(t.idx[0], t.idx[1], t.idx[2], t.idx[3]);
+            *reinterpret_cast<float4*>(sm.tw[lw][j]) = make_float4(t.w[0], t.w[1], t.w[2], t.w[3]);
+            sm.tself[lw][j] = row * W + col;
+            sm.tvis[lw][j] = (cav && t.roi != 0.f) ? 1 : 0;
+        }
     }
-
-    Taps t[4];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read ordering
+    int4 tix[4];
+    float4 twt[4];
     bool visible[4];
     int self_idx[4];
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
-        const int n = pass * 16 + (ltid >> 4);
-        int row, col;
-        token_pixel(p.partition, 8, X, Y, it.wx, it.wy, n, row, col);
-        self_idx[pass] = row * W + col;
-        if (ident) {
-            t[pass].roi = 1.f;
-        } else {
-            t[pass] = make_taps(a, col, row, H, W);
-        }
-        visible[pass] = cav && (t[pass].roi != 0.f);
+        const int j = pass * KPW + (kin % KPW);
+        tix[pass] = *reinterpret_cast<const int4*>(sm.tidx[lw][j]);
+        twt[pass] = *reinterpret_cast<const float4*>(sm.tw[lw][j]);
+        self_idx[pass] = sm.tself[lw][j];
+        visible[pass] = sm.tvis[lw][j] != 0;
     }
-    // all tap loads of the chunk are issued before the first blend
-    Raw8<half_t> raw[4][2][4];
+
+    PC_TRACE(ltid == 0, (int)sm.gcount, 1);
+    // ---- issue phase ----
+    half8 rawq[4];
+    bool q_ident = true;
+    if constexpr (WITH_Q) {
+        const float* aq = sm.ainv + ((it.b * L + it.ego) * L + it.ego) * 8;
+        q_ident = aq[6] != 0.f;
+        const half_t* qpl = reinterpret_cast<const half_t*>(p.q) + (size_t)(it.b * L + it.ego) * P * C + it.hg * CH;
+        if (q_ident) {
+            const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)qpl, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) rawq[pass] = buf_load8(rs_q, (unsigned)self_idx[pass] * row_bytes + cl_bytes, 0);
+        } else {
+            // T[i,i] is not the identity (never produced by the reference's dataset): slow path
+            const int tq = __builtin_amdgcn_readfirstlane(te);
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int n = pass * 16 + kin;
+                int row, col;
+                token_pixel(p.partition, 8, X, Y, it.wx, it.wy, n, row, col);
+                const Taps tt = make_taps(aq, col, row, H, W);
+                float v[1][8];
+                sample8<half_t, 1>(qpl, 0, C, cl, tt, false, row * W + col, sm.bq[tq], 0, v);
+                store8_lds<half_t>(sm.Qs[qbuf] + n * QS + cl, v[0]);
+            }
+        }
+    }
+    half8 raw[4][2][4];
     if (ident) {
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass)
             if (visible[pass]) {
-                raw[pass][0][0].load(kpl + (size_t)self_idx[pass] * C + cl);
-                raw[pass][1][0].load(vpl + (size_t)self_idx[pass] * C + cl);
+                const unsigned vo = (unsigned)self_idx[pass] * row_bytes + cl_bytes;
+                raw[pass][0][0] = buf_load8(rs_kv, vo, 0);
+                raw[pass][1][0] = buf_load8(rs_kv, vo, plane_bytes);
             }
     } else {
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass)
             if (visible[pass]) {
+                const int ix[4] = {tix[pass].x, tix[pass].y, tix[pass].z, tix[pass].w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    raw[pass][0][k].load(kpl + (size_t)t[pass].idx[k] * C + cl);
-                    raw[pass][1][k].load(vpl + (size_t)t[pass].idx[k] * C + cl);
+                    const unsigned vo = (unsigned)ix[k] * row_bytes + cl_bytes;
+                    raw[pass][0][k] = buf_load8(rs_kv, vo, 0);
+                    raw[pass][1][k] = buf_load8(rs_kv, vo, plane_bytes);
                 }
             }
     }
+    PC_TRACE(ltid == 0, (int)sm.gcount, 2);
+    // ---- consume phase ----
+    if constexpr (WITH_Q) {
+        if (q_ident) {
+            const float4 b0 = *reinterpret_cast<const float4*>(&sm.bq[te][cl]);
+            const float4 b1 = *reinterpret_cast<const float4*>(&sm.bq[te][cl + 4]);
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (float)rawq[pass][e] + bb[e];
+                store8_lds<half_t>(sm.Qs[qbuf] + (pass * 16 + kin) * QS + cl, v);
+            }
+        }
+    }
+    float bkv[2][8];
+    {
+        const float* bsrc = &sm.bkv[te * HMVIT_NUM_TYPES + ts][0][0];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const float4 b0 = *reinterpret_cast<const float4*>(bsrc + pl * CH + cl);
+            const float4 b1 = *reinterpret_cast<const float4*>(bsrc + pl * CH + cl + 4);
+            bkv[pl][0] = b0.x; bkv[pl][1] = b0.y; bkv[pl][2] = b0.z; bkv[pl][3] = b0.w;
+            bkv[pl][4] = b1.x; bkv[pl][5] = b1.y; bkv[pl][6] = b1.z; bkv[pl][7] = b1.w;
+        }
+    }
+    half_t* Ks = sm.Ks[kvbuf];
+    half_t* Vs = sm.Vs[kvbuf];
     bool any = false;
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
-        const int kk = pass * 16 + (ltid >> 4);
+        const int kk = pass * 16 + kin;
         float o[2][8];
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[pl][e] = 0.f;
         if (visible[pass]) {
+            const float wk[4] = {twt[pass].x, twt[pass].y, twt[pass].z, twt[pass].w};
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float acc;
-                    if (ident) {
-                        acc = raw[pass][pl][0].get(e);
+                    if (ident || (dbg & 0x80)) {
+                        acc = (float)raw[pass][pl][0][e] + bkv[pl][e];
                     } else {
-                        acc = t[pass].w[0] * raw[pass][pl][0].get(e);
+                        acc = fmaf(wk[0], (float)raw[pass][pl][0][e], bkv[pl][e]);
 #pragma unroll
-                        for (int k = 1; k < 4; ++k) acc = fmaf(t[pass].w[k], raw[pass][pl][k].get(e), acc);
+                        for (int k = 1; k < 4; ++k) acc = fmaf(wk[k], (float)raw[pass][pl][k][e], acc);
                     }
-                    o[pl][e] = acc + bkv[pl][e];
+                    o[pl][e] = acc;
                 }
         }
         store8_lds<half_t>(Ks + kk * KS + cl, o[0]);
         store8_lds<half_t>(Vs + kk * VS + cl, o[1]);
-        if ((ltid & 15) == 0) maskadd[kk] = visible[pass] ? 0.f : -INFINITY;
+        if ((ltid % TPK) == 0) sm.maskadd[kvbuf][kk] = visible[pass] ? 0.f : -INFINITY;
         any |= visible[pass];
     }
     const bool wave_any = __any(any);
-    if ((ltid & 63) == 0) *vis_slot = wave_any ? 1 : 0;
+    if (lane == 0) sm.vis[kvbuf][lw] = wave_any ? 1 : 0;
 }
 
-struct PcShared {
-    static constexpr int QS = 136, KS = 136, VS = 144;
-    half_t Qs[2][64 * QS];
-    half_t Ks[2][64 * KS];
-    half_t Vs[2][64 * VS];
-    float maskadd[2][64];
-    int vis[2][4];
-};
-
-// Both role loops execute exactly one barrier in the prologue and one per (item, chunk).
-__device__ __forceinline__ void pc_loader_loop(const AttnParams& p, PcShared& sm, int lw, int ltid) {
-    constexpr int QS = PcShared::QS, KS = PcShared::KS, VS = PcShared::VS;
-    const int X = p.H / 8, Y = p.W / 8, NG = p.C / 128;
-    const int n_items = p.B * p.n_ego * X * Y * NG;
-    const int n_src = p.n_src;
-    int item = blockIdx.x;
-    PcItem it = pc_decode(item, p.n_ego, X, Y, NG);
-    pc_gather_q<QS>(p, it, sm.Qs[0], ltid);
-    pc_gather_kv<KS, VS>(p, it, 0, sm.Ks[0], sm.Vs[0], sm.maskadd[0], &sm.vis[0][lw], ltid);
-    __syncthreads();
-    int gstep = 0, qi = 0;
-    while (true) {
-        const int next_item = item + gridDim.x;
-        for (int c = 0; c < n_src; ++c) {
-            const int nb = (gstep & 1) ^ 1;
-            if (c + 1 < n_src) {
-                pc_gather_kv<KS, VS>(p, it, c + 1, sm.Ks[nb], sm.Vs[nb], sm.maskadd[nb], &sm.vis[nb][lw], ltid);
-            } else if (next_item < n_items) {
-                const PcItem nit = pc_decode(next_item, p.n_ego, X, Y, NG);
-                pc_gather_q<QS>(p, nit, sm.Qs[qi ^ 1], ltid);
-                pc_gather_kv<KS, VS>(p, nit, 0, sm.Ks[nb], sm.Vs[nb], sm.maskadd[nb], &sm.vis[nb][lw], ltid);
-            }
-            __syncthreads();
-            ++gstep;
-        }
-        if (next_item >= n_items) break;
-        item = next_item;
-        it = pc_decode(item, p.n_ego, X, Y, NG);
-        qi ^= 1;
+// per-workgroup tables: affine records, and the biases of the head group this workgroup serves
+// (the item stride gridDim.x is a multiple of the number of head groups, so hg never changes)
+template <int HG>
+__device__ __forceinline__ void pc_load_tables(const AttnParams& p, PcShared<HG>& sm, int hg) {
+    constexpr int CH = PcShared<HG>::CH;
+    const int n_rec = p.B * p.L * p.L * 8;
+    for (int i = threadIdx.x; i < n_rec; i += blockDim.x) sm.ainv[i] = p.ainv[i];
+    for (int i = threadIdx.x; i < HMVIT_NUM_TYPES * HMVIT_NUM_TYPES * 2 * CH; i += blockDim.x) {
+        const int e = i / (2 * CH), pl = (i / CH) & 1, c = i % CH;
+        sm.bkv[e][pl][c] = p.b_kv[(size_t)e * 2 * p.C + pl * p.C + hg * CH + c];
+    }
+    for (int i = threadIdx.x; i < HMVIT_NUM_TYPES * CH; i += blockDim.x)
+        sm.bq[i / CH][i % CH] = p.b_q[(i / CH) * p.C + hg * CH + (i % CH)];
+    if (threadIdx.x < kMaxSlots) {
+        sm.mode[threadIdx.x] = p.mode[threadIdx.x];
+        sm.cav[threadIdx.x] = p.cav[threadIdx.x];
+        sm.ego_e[threadIdx.x] = p.ego_e[threadIdx.x];
     }
 }
 
-__device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared& sm, int wave, int lane) {
-    constexpr int QS = PcShared::QS, KS = PcShared::KS, VS = PcShared::VS;
+// Both role loops execute 1 + (number of (item, chunk) pairs) barriers.  The loader is one flat
+// loop with a single gather call site (instruction-cache footprint): gather number g fills buffer
+// g & 1 and is consumed by the compute waves in the barrier interval after the one it was made in.
+template <int HG>
+__device__ __forceinline__ void pc_loader_loop(const AttnParams& p, PcShared<HG>& sm, int lw, int ltid) {
+    const int X = p.H / 8, Y = p.W / 8, NG = p.C / (HG * 32);
+    const int n_items = p.B * p.n_ego * X * Y * NG;
+    const int n_src = p.n_src;
+    int item = blockIdx.x, chunk = 0, g = 0, qi = 0;
+    PcItem it = pc_decode(item, p.n_ego, X, Y, NG);
+#pragma unroll 1
+    while (true) {
+        if (ltid == 0) sm.gcount = g;
+        PC_TRACE(ltid == 0, g, 0);
+        if (chunk == 0)
+            pc_gather<HG, true>(p, sm, it, 0, g & 1, qi, lw, ltid);
+        else
+            pc_gather<HG, false>(p, sm, it, chunk, g & 1, qi, lw, ltid);
+        PC_TRACE(ltid == 0, g, 3);
+        __syncthreads();
+        PC_TRACE(ltid == 0, g, 4);
+        ++g;
+        if (++chunk == n_src) {
+            chunk = 0;
+            item += gridDim.x;
+            if (item >= n_items) break;
+            it = pc_decode(item, p.n_ego, X, Y, NG);
+            qi ^= 1;
+        }
+    }
+    __syncthreads();   // the interval in which the compute waves consume the last chunk
+}
+
+template <int HG>
+__device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG>& sm, int wave, int lane) {
+    constexpr int QS = PcShared<HG>::QS, KS = PcShared<HG>::KS, VS = PcShared<HG>::VS;
     const int C = p.C, H = p.H, W = p.W, L = p.L, P = H * W;
-    const int X = H / 8, Y = W / 8, NG = C / 128;
+    const int X = H / 8, Y = W / 8, NG = C / (HG * 32);
     const int n_items = p.B * p.n_ego * X * Y * NG;
     const int n_src = p.n_src;
     const int lq = lane & 15, g = lane >> 4;
@@ -592,7 +714,7 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared& s
     int gstep = 0, qi = 0;
     while (true) {
         const PcItem it = pc_decode(item, p.n_ego, X, Y, NG);
-        const int head = it.hg * 4 + wave;
+        const int head = it.hg * HG + wave;
         for (int c = 0; c < n_src; ++c) {
             const int buf = gstep & 1;
             if (c == 0) {
@@ -611,8 +733,11 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared& s
                     o_acc[qt][1] = (float4v)(0.f);
                 }
             }
-            const bool any_visible = (sm.vis[buf][0] | sm.vis[buf][1] | sm.vis[buf][2] | sm.vis[buf][3]) != 0;
-            if (any_visible || !p.skip_masked) {
+            int vis_or = 0;
+#pragma unroll
+            for (int w = 0; w < HG; ++w) vis_or |= sm.vis[buf][w];
+            const bool any_visible = vis_or != 0;
+            if ((any_visible || !p.skip_masked) && !(p.variant & 0x40)) {
                 const half_t* Kb = sm.Ks[buf];
                 const half_t* Vb = sm.Vs[buf];
                 float4v madd[4];
@@ -684,6 +809,7 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared& s
                     }
                 }
             }
+            PC_TRACE(wave == 0 && lane == 0, gstep, 5);
             if (c == n_src - 1) {
                 half_t* outp = reinterpret_cast<half_t*>(p.out) + (size_t)(it.b * L + it.ego) * P * C;
 #pragma unroll
@@ -701,7 +827,9 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared& s
                     }
                 }
             }
+            PC_TRACE(wave == 0 && lane == 0, gstep, 6);
             __syncthreads();
+            PC_TRACE(wave == 0 && lane == 0, gstep, 7);
             ++gstep;
         }
         item += gridDim.x;
@@ -710,23 +838,29 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared& s
     }
 }
 
-__global__ __launch_bounds__(512) void k_attention_pc(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) PcShared sm;
+template <int HG>
+__global__ __launch_bounds__(HG * 128) void k_attention_pc(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) PcShared<HG> sm;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    pc_load_tables<HG>(p, sm, blockIdx.x % (p.C / (HG * 32)));
+    __syncthreads();
     // wave-uniform role split at the outermost level: the two loops have disjoint live ranges, so
     // the kernel's register count is the maximum of the two roles, not their sum
-    if (wave >= 4) {
-        pc_loader_loop(p, sm, wave - 4, threadIdx.x & 255);
+    if (wave >= HG) {
+        pc_loader_loop<HG>(p, sm, wave - HG, threadIdx.x & (HG * 64 - 1));
     } else {
-        pc_compute_loop(p, sm, wave, threadIdx.x & 63);
+        pc_compute_loop<HG>(p, sm, wave, threadIdx.x & 63);
     }
 }
 
+template <int HG>
 static int launch_attn_pc(const AttnParams& p, hipStream_t st) {
-    const int n_items = p.B * p.n_ego * (p.H / 8) * (p.W / 8) * (p.C / 128);
-    int grid = 256;   // one persistent workgroup per CU (LDS ~108 KB)
-    if (grid > n_items) grid = n_items;
-    hipLaunchKernelGGL(k_attention_pc, dim3(grid), dim3(512), 0, st, p);
+    const int NG = p.C / (HG * 32);
+    const int n_items = p.B * p.n_ego * (p.H / 8) * (p.W / 8) * NG;
+    // persistent: HG = 2 -> two 4-wave workgroups per CU (~70 KB LDS each), HG = 4 -> one 8-wave group
+    int grid = 256 * (HG == 2 ? 2 : 1);
+    if (grid > n_items) grid = n_items;   // both are multiples of the head-group count
+    hipLaunchKernelGGL((k_attention_pc<HG>), dim3(grid), dim3(HG * 128), 0, st, p);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }
@@ -752,7 +886,12 @@ int launch_attention(const AttnParams& p, int precision, hipStream_t st) {
         return w8 ? launch_attn_t<float, 8, 2>(p, st) : launch_attn_t<float, 4, 2>(p, st);
     }
     if (p.C == 64) return w8 ? launch_attn_t<half_t, 8, 2>(p, st) : launch_attn_t<half_t, 4, 2>(p, st);
-    if (w8 && p.variant == 0) return launch_attn_pc(p, st);
+    if (w8 && (p.variant & 1) == 0 && p.B * p.L * p.L <= PcShared<2>::MAX_PAIRS) {
+        AttnParams q = p;
+        if (const char* e = getenv("HMVIT_ATTN_DEBUG")) q.variant |= atoi(e) & ~1;   // probe switches (tools/attn_probe.py)
+        if (const char* e = getenv("HMVIT_ATTN_TRACE")) q.trace = (unsigned long long*)strtoull(e, nullptr, 0);
+        return (q.variant & 2) ? launch_attn_pc<2>(q, st) : launch_attn_pc<4>(q, st);   // 4 heads per workgroup measured faster
+    }
     return w8 ? launch_attn_t<half_t, 8, 4>(p, st) : launch_attn_t<half_t, 4, 4>(p, st);
 }
 

@@ -28,6 +28,10 @@
 
 namespace hmvit {
 
+// 4 wavefronts x 32 tokens per workgroup: two workgroups share a CU (256 VGPRs each), so one
+// group's HBM load / store phases overlap the other's MFMA phase
+constexpr int CHAIN_THREADS_C = 256;
+
 template <int C>
 struct ChainCfg {
     static constexpr int NB = C / 32;             // 32-channel blocks
@@ -35,11 +39,12 @@ struct ChainCfg {
     static constexpr int NT = C / 32;             // 32-row output tiles
     static constexpr int CHUNK_HALVES = KK * 512; // one chunk: KK fragments of 64 lanes x 8 halves
     static constexpr int PIECES = KK * 64;        // 16-byte pieces per chunk
-    static constexpr int PPT = (PIECES + 511) / 512;
+    static constexpr int PPT = (PIECES + CHAIN_THREADS_C - 1) / CHAIN_THREADS_C;
 };
 
-constexpr int CHAIN_THREADS = 512;
-constexpr int CHAIN_TOKENS = 256;
+constexpr int CHAIN_THREADS = CHAIN_THREADS_C;
+constexpr int CHAIN_WAVES = CHAIN_THREADS / 64;
+constexpr int CHAIN_TOKENS = CHAIN_WAVES * 32;
 
 // ---- weight chunk ring: global -> LDS DMA (no staging registers) ----
 // The chunk is stored in global memory in LDS-image order, so wave w copies pieces
@@ -55,7 +60,7 @@ __device__ __forceinline__ void stage_chunk(const half_t* __restrict__ chunk, ha
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_buf;
 #pragma unroll
     for (int i = 0; i < ChainCfg<C>::PPT; ++i) {
-        const int piece0 = (i * 8 + wave) * 64;
+        const int piece0 = (i * CHAIN_WAVES + wave) * 64;
         if (piece0 < ChainCfg<C>::PIECES) {
             const uint4* gsrc = reinterpret_cast<const uint4*>(chunk) + piece0 + lane;
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + piece0 * 16);
@@ -228,7 +233,7 @@ __device__ __forceinline__ void load_token(const float* __restrict__ x, bool nch
 // k_ln_qkv
 // ------------------------------------------------------------------------------------------
 template <int C>
-__global__ __launch_bounds__(CHAIN_THREADS) void k_ln_qkv(QkvParams p) {
+__global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
     using Cfg = ChainCfg<C>;
     constexpr int KK = Cfg::KK, NT = Cfg::NT;
     // ONE LDS object (a second one would make hipcc wait for the DMA before every ds_read)
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_ln_qkv(QkvParams p) {
 // k_out_ffn
 // ------------------------------------------------------------------------------------------
 template <int C, bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW>
-__global__ __launch_bounds__(CHAIN_THREADS) void k_out_ffn(FfnParams p) {
+__global__ __launch_bounds__(CHAIN_THREADS, 2) void k_out_ffn(FfnParams p) {
     using Cfg = ChainCfg<C>;
     constexpr int KK = Cfg::KK, NT = Cfg::NT, NH = C / 32;   // hidden width == C
     __shared__ __attribute__((aligned(16))) half_t smem[2 * Cfg::CHUNK_HALVES + 10 * C];

@@ -91,6 +91,7 @@ struct AttnParams {
     const float* ainv;        // (B, L_src, L_ego, 8): sampling map of pairwise_t[b, src, ego]
     void* out;                // (B, L, P, C)
     int B, L, n_ego, n_src, E, C, H, W, window, partition, skip_masked;
+    unsigned long long* trace; // optional s_memtime trace buffer (debug probe), else null
     int variant;              // 0: default kernel choice, 1: force the one-window-per-workgroup kernel
     int8_t mode[kMaxSlots];   // (B, L)
     int8_t cav[kMaxSlots];    // (B, L)
