@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhmvit.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PREC_F32, PREC_F16 = 0, 1
 PART_WINDOW, PART_GRID = 0, 1
 NUM_TYPES = 2
@@ -39,6 +39,9 @@ class FusionDesc(C.Structure):
         ("head_w1", C.c_void_p), ("head_b1", C.c_void_p), ("head_w2", C.c_void_p),
         ("head_b2", C.c_void_p), ("head_img_ffn", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("parallel", C.c_int32),
+        ("split_fc1", C.c_void_p), ("split_ln_g", C.c_void_p), ("split_ln_b", C.c_void_p),
+        ("split_fc2", C.c_void_p),
     ]
 
 

@@ -24,7 +24,7 @@ struct Plan {
     int B, L, C, H, W, P, mlp, n_slots, max_cav, E_max;
     size_t es;
     // byte offsets into the workspace
-    size_t off_xs, off_xn, off_q, off_kv, off_o, off_hid, off_ainv, off_ytok, total;
+    size_t off_xs, off_xn, off_q, off_kv, off_o, off_hid, off_ainv, off_ytok, off_xa, off_xb, off_gap, off_sw, total;
 };
 
 static int check_desc(const HmvitFusionDesc* d) {
@@ -42,6 +42,8 @@ static int check_desc(const HmvitFusionDesc* d) {
     HMVIT_CHECK_ARG(d->precision == HMVIT_PREC_F32 || d->precision == HMVIT_PREC_F16, "precision=%d", d->precision);
     HMVIT_CHECK_ARG(d->mode && d->record_len && d->cav_mask, "mode / record_len / cav_mask must be host arrays");
     HMVIT_CHECK_ARG(d->discrete_ratio * d->downsample_rate != 0.f, "discrete_ratio * downsample_rate is 0");
+    HMVIT_CHECK_ARG(!d->parallel || (d->split_fc1 && d->split_ln_g && d->split_ln_b && d->split_fc2),
+                    "architect_mode parallel: SplitAttn weights are null");
     for (int i = 0; i < d->B * d->L; ++i)
         HMVIT_CHECK_ARG(d->mode[i] >= 0 && d->mode[i] < HMVIT_NUM_TYPES, "mode[%d]=%d is not an agent type", i,
                         d->mode[i]);
@@ -74,6 +76,14 @@ static void make_plan(const HmvitFusionDesc* d, Plan& pl) {
     pl.off_o = carve(tok * pl.C * pl.es);
     pl.off_ainv = carve((size_t)pl.n_slots * pl.L * 8 * 4);
     pl.off_ytok = carve((size_t)pl.B * pl.P * pl.C * 4);
+    pl.off_xa = pl.off_xb = pl.off_gap = pl.off_sw = 0;
+    if (d->parallel) {
+        // branch outputs of the parallel block + SplitAttn scratch
+        pl.off_xa = carve(tok * pl.C * 4);
+        pl.off_xb = carve(tok * pl.C * 4);
+        pl.off_gap = carve((size_t)pl.n_slots * ((pl.P + 255) / 256) * pl.C * 4);
+        pl.off_sw = carve((size_t)pl.n_slots * 2 * pl.C * 4);
+    }
     pl.total = off;
 }
 
@@ -130,6 +140,22 @@ struct PhaseTimer {
         if (_rc != HMVIT_OK) return _rc; \
     } while (0)
 
+// SplitAttn merge at the end of a parallel-mode iteration (hetero_fusion.py:459-470): all agent
+// slots, or only the ego slots when nothing else is consumed afterwards
+static int merge_branches(const HmvitFusionDesc* d, const Plan& pl, bool ego_only, hipStream_t st) {
+    char* ws = reinterpret_cast<char*>(d->workspace);
+    SplitSlots slots;
+    memset(&slots, 0, sizeof(slots));
+    int n = 0;
+    for (int b = 0; b < pl.B; ++b)
+        for (int l = 0; l < (ego_only ? 1 : pl.L); ++l) slots.s[n++] = (int8_t)(b * pl.L + l);
+    SplitWeights sw = {d->split_fc1, d->split_ln_g, d->split_ln_b, d->split_fc2};
+    return launch_split_attn(reinterpret_cast<float*>(ws + pl.off_xa), reinterpret_cast<float*>(ws + pl.off_xb),
+                             reinterpret_cast<float*>(ws + pl.off_xs), slots, n, sw,
+                             reinterpret_cast<float*>(ws + pl.off_gap), reinterpret_cast<float*>(ws + pl.off_sw), pl.P,
+                             pl.C, st);
+}
+
 static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStream_t st, PhaseTimer* timer);
 
 static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st, PhaseTimer* timer) {
@@ -156,6 +182,9 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st, PhaseTimer* 
     float* ainv = reinterpret_cast<float*>(ws + pl.off_ainv);
     float* ytok = reinterpret_cast<float*>(ws + pl.off_ytok);
     const size_t map_elems = (size_t)P * C;
+    const bool par = d->parallel != 0;
+    float* xa = reinterpret_cast<float*>(ws + pl.off_xa);
+    float* xb = reinterpret_cast<float*>(ws + pl.off_xb);
 
     AgentTypes all_types;
     memset(&all_types, 0, sizeof(all_types));
@@ -173,7 +202,10 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st, PhaseTimer* 
             const HmvitStageWeights& wt = d->stage[s];
             // In the last stage of HeteroFusion only ego 0 is consumed (x[:, 0],
             // bevformer_point_pillar_hetero.py:47): the other egos' rows are dead code.
-            const bool last = d->apply_head && it == d->num_iters - 1 && s == 1;
+            // (parallel mode: both branches of the last iteration only feed ego 0)
+            const bool last = d->apply_head && it == d->num_iters - 1 && (par || s == 1);
+            float* x_in = xs;                                   // stage input
+            float* x_out = par ? (s == 0 ? xa : xb) : xs;       // stage output (in place when sequential)
             const int n_ego = last ? 1 : pl.max_cav;
             const int n_src = pl.max_cav;
 
@@ -188,7 +220,7 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st, PhaseTimer* 
                 }
 
             // 1. typed LayerNorm of every agent map (sources j < max_cav are all that is read)
-            HMVIT_TRY(launch_layernorm(xs, xn, wt.ln_gamma, wt.ln_beta, all_types, pl.n_slots, P, C, prec, st));
+            HMVIT_TRY(launch_layernorm(x_in, xn, wt.ln_gamma, wt.ln_beta, all_types, pl.n_slots, P, C, prec, st));
             HMVIT_MARK(HMVIT_PHASE_LN_ATTN);
 
             // 2. Q and relation-folded K/V projections (no bias: added after the gather)
@@ -247,12 +279,18 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st, PhaseTimer* 
                         j.a = ob + (size_t)slot * map_elems * es;
                         j.w = reinterpret_cast<const char*>(wt.w_o) + (size_t)t * C * C * es;
                         j.bias = wt.b_o + t * C;
-                        j.residual = xs + (size_t)slot * map_elems;
-                        j.y = xs + (size_t)slot * map_elems;
+                        j.residual = x_in + (size_t)slot * map_elems;
+                        j.y = x_out + (size_t)slot * map_elems;
                         j.M = P; j.N = C; j.K = C; j.n_per_plane = C; j.plane_stride = 0;
                         HMVIT_TRY(jb.add(j));
                     }
                 HMVIT_TRY(jb.flush());
+                if (par && !last)   // agents without an attention update enter the FFN unchanged
+                    for (int b = 0; b < B; ++b)
+                        for (int l = n_ego; l < L; ++l)
+                            HMVIT_CHECK_HIP(hipMemcpyAsync(x_out + (size_t)(b * L + l) * map_elems,
+                                                           x_in + (size_t)(b * L + l) * map_elems, map_elems * 4,
+                                                           hipMemcpyDeviceToDevice, st));
             }
             HMVIT_MARK(HMVIT_PHASE_OUT_PROJ);
 
@@ -260,14 +298,14 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st, PhaseTimer* 
             {
                 const int n_ffn = last ? 1 : L;
                 if (n_ffn == L) {
-                    HMVIT_TRY(launch_layernorm(xs, xn, wt.ffn_ln_gamma, wt.ffn_ln_beta, all_types, pl.n_slots, P, C,
+                    HMVIT_TRY(launch_layernorm(x_out, xn, wt.ffn_ln_gamma, wt.ffn_ln_beta, all_types, pl.n_slots, P, C,
                                                prec, st));
                 } else {
                     for (int b = 0; b < B; ++b) {
                         AgentTypes one;
                         memset(&one, 0, sizeof(one));
                         one.t[0] = (int8_t)d->mode[b * L];
-                        HMVIT_TRY(launch_layernorm(xs + (size_t)b * L * map_elems, xn + (size_t)b * L * map_elems * es,
+                        HMVIT_TRY(launch_layernorm(x_out + (size_t)b * L * map_elems, xn + (size_t)b * L * map_elems * es,
                                                    wt.ffn_ln_gamma, wt.ffn_ln_beta, one, 1, P, C, prec, st));
                     }
                 }
@@ -295,14 +333,18 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st, PhaseTimer* 
                         j.a = hid + (size_t)slot * P * mlp * es;
                         j.w = reinterpret_cast<const char*>(wt.w_2) + (size_t)t * C * mlp * es;
                         j.bias = wt.b_2 + t * C;
-                        j.residual = xs + (size_t)slot * map_elems;
-                        j.y = xs + (size_t)slot * map_elems;
+                        j.residual = x_out + (size_t)slot * map_elems;
+                        j.y = x_out + (size_t)slot * map_elems;
                         j.M = P; j.N = C; j.K = mlp; j.n_per_plane = C; j.plane_stride = 0;
                         HMVIT_TRY(j2.add(j));
                     }
                 HMVIT_TRY(j2.flush());
                 HMVIT_MARK(HMVIT_PHASE_FFN2);
             }
+        }
+        if (par) {
+            HMVIT_TRY(merge_branches(d, pl, d->apply_head && it == d->num_iters - 1, st));
+            HMVIT_MARK(HMVIT_PHASE_LAYOUT_OUT);
         }
     }
 
@@ -415,7 +457,9 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
         for (int s = 0; s < 2; ++s) {
             const HmvitStageWeights& wt = d->stage[s];
             const bool first = it == 0 && s == 0;
-            const bool last = d->apply_head && it == d->num_iters - 1 && s == 1;
+            const bool par = d->parallel != 0;
+            const bool last = d->apply_head && it == d->num_iters - 1 && (par || s == 1);
+            float* x_out = par ? reinterpret_cast<float*>(ws + (s == 0 ? pl.off_xa : pl.off_xb)) : xs;
             const int n_ego = last ? 1 : pl.max_cav;
             const int n_src = pl.max_cav;
             int e_of_type[HMVIT_NUM_TYPES] = {-1, -1};
@@ -495,7 +539,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                         FfnJob j;
                         j.o = ob + (size_t)slot * map_elems;
                         j.x = xs + (size_t)slot * map_elems;
-                        j.out = xs + (size_t)slot * map_elems;
+                        j.out = x_out + (size_t)slot * map_elems;
                         j.type = d->mode[slot]; j.pad = 0;
                         HMVIT_TRY(fb.add(j));
                     }
@@ -509,7 +553,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                             FfnJob j;
                             j.o = nullptr;
                             j.x = xs + (size_t)slot * map_elems;
-                            j.out = xs + (size_t)slot * map_elems;
+                            j.out = x_out + (size_t)slot * map_elems;
                             j.type = d->mode[slot]; j.pad = 0;
                             HMVIT_TRY(fb.add(j));
                         }
@@ -517,6 +561,10 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                 }
             }
             HMVIT_MARK(HMVIT_PHASE_FFN2);
+        }
+        if (d->parallel) {
+            HMVIT_TRY(merge_branches(d, pl, d->apply_head && it == d->num_iters - 1, st));
+            HMVIT_MARK(HMVIT_PHASE_LAYOUT_OUT);
         }
     }
 

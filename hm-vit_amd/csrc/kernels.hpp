@@ -81,6 +81,20 @@ struct FfnParams {
 enum { FFN_FULL = 0, FFN_NO_ATTN = 1, FFN_HEAD_NCHW = 2 };
 int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, hipStream_t st);
 
+// ---- split.hip (architect_mode == 'parallel') ----
+struct SplitSlots {
+    int8_t s[kMaxSlots];     // agent slots to merge
+};
+struct SplitWeights {
+    const float* fc1;        // (C, C)
+    const float* ln_g;       // (C)
+    const float* ln_b;
+    const float* fc2;        // (2C, C)
+};
+// partial: (n_slots, ceil(P / 256), C) f32 scratch, w: (n_slots, 2, C) f32 scratch; out may alias a or b
+int launch_split_attn(const float* a, const float* b, float* out, const SplitSlots& slots, int n_slots,
+                      const SplitWeights& sw, float* partial, float* w, int P, int C, hipStream_t st);
+
 // ---- attn.hip ----
 struct AttnParams {
     const void* q;            // (B, L, P, C)

@@ -86,6 +86,17 @@ class HeteroAttention(nn.Module):
         self.register_buffer("relative_position_index", index)
 
 
+class SplitAttn(nn.Module):
+    """Parameters of fusion_modules/split_attn.py:32-44 (radix-2 merge of the parallel branches)."""
+
+    def __init__(self, input_dim: int, num_windows: int = 2):
+        super().__init__()
+        self.fc1 = nn.Linear(input_dim, input_dim, bias=False)
+        self.bn1 = nn.LayerNorm(input_dim)
+        self.act1 = nn.ReLU()
+        self.fc2 = nn.Linear(input_dim, input_dim * num_windows, bias=False)
+
+
 class _FusionBase(nn.Module):
     """Shared launch logic.  Subclasses provide ``_block_prefix`` / ``_head_prefix`` and
     ``_block_cfg``."""
@@ -124,14 +135,17 @@ class _FusionBase(nn.Module):
                                                blk["window_size"], dtype)
             if self._head_prefix is not None:
                 folded["head"] = weights.fold_head(sd, self._head_prefix, dtype)
+            if blk["architect_mode"] == "parallel":
+                pre = f"{self._block_prefix}." if self._block_prefix else ""
+                folded["split"] = {k: sd[f"{pre}split_attn.{n}"].detach().float().contiguous()
+                                   for k, n in (("split_fc1", "fc1.weight"), ("split_ln_g", "bn1.weight"),
+                                                ("split_ln_b", "bn1.bias"), ("split_fc2", "fc2.weight"))}
             self._folded, self._folded_key = folded, key
         return self._folded
 
     def _make_desc(self, x, pairwise_t_matrix, mode, record_len, mask, apply_head: bool, num_iters: int):
         blk = self._block_cfg
-        if blk["architect_mode"] != "sequential":
-            if blk["architect_mode"] == "parallel":
-                raise NotImplementedError("architect_mode='parallel' (SplitAttn) is not built yet")
+        if blk["architect_mode"] not in ("sequential", "parallel"):
             raise ValueError(f"{blk['architect_mode']} not implemented")
         if x.device.type != "cuda":
             raise RuntimeError("hm-vit_amd runs on the GPU only (HIP kernels, no CPU fallback)")
@@ -168,6 +182,10 @@ class _FusionBase(nn.Module):
         if apply_head:
             for name in ("head_w1", "head_b1", "head_w2", "head_b2", "head_img_ffn"):
                 setattr(d, name, w["head"][name].data_ptr() if name in w["head"] else None)
+        if blk["architect_mode"] == "parallel":
+            d.parallel = 1
+            for name, t in w["split"].items():
+                setattr(d, name, t.data_ptr())
         need = _lib.lib.hmvit_fusion_workspace_bytes(ctypes.byref(d))
         if need == 0:
             _lib.check(-22, "hmvit_fusion_workspace_bytes")
@@ -212,6 +230,8 @@ class HeteroFusionBlock(_FusionBase):
         self._block_cfg = dict(config)
         self.architect_mode = config["architect_mode"]
         self.window_size = config["window_size"]
+        if self.architect_mode == "parallel":
+            self.split_attn = SplitAttn(dim, num_windows=2)
         self.downsample_rate = config["spatial_transform"]["downsample_rate"]
         self.discrete_ratio = config["spatial_transform"]["voxel_size"][0]
         args = (dim, config["dim_head"], config["drop_out"], config["agent_size"], config["window_size"])

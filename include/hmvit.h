@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HMVIT_ABI_VERSION 2
+#define HMVIT_ABI_VERSION 3
 
 #define HMVIT_OK 0
 #define HMVIT_EINVAL (-22)   /* bad argument / unsupported shape */
@@ -93,8 +93,8 @@ typedef struct HmvitStageWeights {
 
 /* One HeteroFusion / HeteroFusionBlock forward.
  * Replaces HeteroFusion.forward (opencood/models/bevformer_point_pillar_hetero.py:39-49) when
- * apply_head = 1 and HeteroFusionBlock.forward, sequential mode
- * (opencood/models/sub_modules/hetero_fusion.py:446-458) iterated num_iters times when
+ * apply_head = 1 and HeteroFusionBlock.forward (sequential or parallel mode,
+ * opencood/models/sub_modules/hetero_fusion.py:446-474) iterated num_iters times when
  * apply_head = 0. */
 typedef struct HmvitFusionDesc {
     int32_t B, L, C, H, W;        /* x is (B, L, C, H, W) f32, NCHW per agent            */
@@ -124,6 +124,14 @@ typedef struct HmvitFusionDesc {
     const void* head_img_ffn;     /* f16 mode: (T, ...) image of mlp_head as img_ffn above */
     void* workspace;              /* device scratch                                       */
     size_t workspace_bytes;
+    /* architect_mode == 'parallel' (hetero_fusion.py:459-470): local and global stage both start
+     * from the block input and are merged by SplitAttn (fusion_modules/split_attn.py:32-67).
+     * All f32 device arrays: fc1 (C, C), LayerNorm affine (C), fc2 (2C, C); no biases. */
+    int32_t parallel;             /* 0 = sequential (shipped yaml), 1 = parallel          */
+    const float* split_fc1;
+    const float* split_ln_g;
+    const float* split_ln_b;
+    const float* split_fc2;
 } HmvitFusionDesc;
 
 int hmvit_abi_version(void);

@@ -26,9 +26,10 @@ def _fusion(cfg, sd, precision):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16"])
-def test_block_g3(precision):
+@pytest.mark.parametrize("name", ["g3_block_seq.npz", "g3_block_par.npz"])
+def test_block_g3(precision, name):
     import hmvit_amd
-    g = load_golden("g3_block_seq.npz")
+    g = load_golden(name)
     sd = O.random_state_dict(g["cfg"], g["seed_weights"])
     blk = hmvit_amd.HeteroFusionBlock(g["cfg"]["hetero_fusion_block"])
     blk.precision = precision
@@ -80,6 +81,17 @@ def test_fusion_vs_oracle_native_window8(precision, modes, n_valid):
     cfg = O.make_config(256, 8, 5, voxel=0.4, downsample=4)
     sd = O.random_state_dict(cfg, seed=7)
     scene = O.synthetic_scene(5, 256, 32, 48, modes, n_valid=n_valid, seed=3, tx_step=6.0, ty_step=-4.0)
+    ref = O.hetero_fusion(*scene, sd, cfg)
+    y = _fusion(cfg, sd, precision)(*_cuda(*scene)).cpu()
+    assert rel_max_err(y, ref) < TOL[precision]
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_fusion_parallel_mode_vs_oracle(precision):
+    """architect_mode='parallel' (SplitAttn merge), 2 iterations, mixed types, window 8."""
+    cfg = O.make_config(256, 8, 4, voxel=0.4, downsample=4, arch="parallel")
+    sd = O.random_state_dict(cfg, seed=13)
+    scene = O.synthetic_scene(4, 256, 32, 32, [1, 0, 0, 1], n_valid=3, seed=6, tx_step=5.0, ty_step=-3.0)
     ref = O.hetero_fusion(*scene, sd, cfg)
     y = _fusion(cfg, sd, precision)(*_cuda(*scene)).cpu()
     assert rel_max_err(y, ref) < TOL[precision]

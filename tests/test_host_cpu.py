@@ -57,6 +57,14 @@ def test_state_dict_names_match_reference(pkg):
     net.load_state_dict(sd, strict=True)
 
 
+def test_parallel_block_state_dict_names(pkg):
+    g = load_golden("g3_block_par.npz")
+    sd = O.random_state_dict(g["cfg"], 0)
+    net = pkg.HeteroFusion(g["cfg"])
+    assert set(net.state_dict().keys()) == set(sd.keys())
+    net.load_state_dict(sd, strict=True)
+
+
 def test_cpu_tensors_raise(pkg):
     cfg = O.make_config(64, 4, 2)
     net = pkg.HeteroFusion(cfg)
