@@ -407,13 +407,20 @@ struct PcItem {
     int b, ego, wx, wy, hg;
 };
 
-__device__ __forceinline__ PcItem pc_decode(int item, int n_ego, int X, int Y, int NG) {
+__device__ __forceinline__ PcItem pc_decode(int item, int n_ego, int X, int Y, int NG, bool ego_fastest = false) {
     PcItem it;
     it.hg = item % NG; item /= NG;
-    const int win = item % (X * Y); item /= (X * Y);
-    it.wx = win / Y; it.wy = win - it.wx * Y;
-    it.ego = item % n_ego;
-    it.b = item / n_ego;
+    if (ego_fastest) {
+        it.ego = item % n_ego; item /= n_ego;
+        const int win = item % (X * Y);
+        it.b = item / (X * Y);
+        it.wx = win / Y; it.wy = win - it.wx * Y;
+    } else {
+        const int win = item % (X * Y); item /= (X * Y);
+        it.wx = win / Y; it.wy = win - it.wx * Y;
+        it.ego = item % n_ego;
+        it.b = item / n_ego;
+    }
     // the item index is wave-uniform: keep its fields in SGPRs so that the per-chunk metadata
     // (affine record, agent types, plane bases) is fetched with scalar loads
     it.b = __builtin_amdgcn_readfirstlane(it.b);
@@ -424,29 +431,36 @@ __device__ __forceinline__ PcItem pc_decode(int item, int n_ego, int X, int Y, i
     return it;
 }
 
-template <int HG>
+template <int HG, int CW, int LWX>
 struct PcShared {
     static constexpr int CH = HG * 32;             // channels of the head group
     static constexpr int QS = CH + 8, KS = CH + 8, VS = CH + 16;
     static constexpr int TPK = HG * 4;             // loader lanes per key row (8 channels each)
     static constexpr int KPW = 64 / TPK;           // keys per loader wave and pass
-    static constexpr int NK = 4 * KPW;             // keys owned by one loader wave
+    static constexpr int LWG = HG * LWX;           // loader waves
+    static constexpr int CWG = HG * CW;            // compute waves (CW per head)
+    static constexpr int KPP = LWG * KPW;          // keys gathered per pass by all loader waves
+    static constexpr int NP = 64 / KPP;            // passes per chunk
+    static constexpr int NK = NP * KPW;            // keys owned by one loader wave
+    static constexpr int NQW = 4 / CW;             // 16-query tiles per compute wave
+    static constexpr bool BIAS_LDS = CW > 1;       // relative-position bias fragments in LDS
     static constexpr int MAX_PAIRS = 128;      // B * L * L affine records kept in LDS
     half_t Qs[2][64 * QS];
     half_t Ks[2][64 * KS];
     half_t Vs[2][64 * VS];
     float maskadd[2][64];
-    int vis[2][HG];
+    int vis[2][LWG];
     float ainv[MAX_PAIRS * 8];                 // sampling maps of every (source, ego) pair
     float bkv[HMVIT_NUM_TYPES * HMVIT_NUM_TYPES][2][CH];   // folded k / v biases of this head group
     float bq[HMVIT_NUM_TYPES][CH];
     int mode[kMaxSlots], cav[kMaxSlots], ego_e[kMaxSlots];   // copies of the kernel-argument byte arrays
     // per loader wave: bilinear taps of its 16 keys (computed once, lane = key)
-    int tidx[HG][NK][4];
-    float tw[HG][NK][4];
-    int tself[HG][NK];
-    int tvis[HG][NK];
+    int tidx[LWG][NK][4];
+    float tw[LWG][NK][4];
+    int tself[LWG][NK];
+    int tvis[LWG][NK];
     int gcount;                                // gather counter (debug trace only)
+    float biasf[BIAS_LDS ? HG * 7 * 256 : 4];  // [head][variant][lane][4], accumulator order
 };
 
 // source agent of chunk c for ego e: the ego itself first, then the others in order
@@ -470,11 +484,11 @@ __device__ __forceinline__ half8 buf_load8(__amdgpu_buffer_rsrc_t rsrc, unsigned
 // wave (lane = key) and redistributed through LDS instead of 16x redundantly; loads go through
 // buffer descriptors with 32-bit offsets; the folded bias is the addend of the first blend FMA.
 // Every global load of the call is issued before the first value is used.
-template <int HG, bool WITH_Q>
-__device__ __forceinline__ void pc_gather(const AttnParams& p, PcShared<HG>& sm, const PcItem& it, int chunk, int kvbuf,
+template <int HG, int CW, int LWX, bool WITH_Q>
+__device__ __forceinline__ void pc_gather(const AttnParams& p, PcShared<HG, CW, LWX>& sm, const PcItem& it, int chunk, int kvbuf,
                                           int qbuf, int lw, int ltid) {
-    using SM = PcShared<HG>;
-    constexpr int QS = SM::QS, KS = SM::KS, VS = SM::VS, CH = SM::CH, TPK = SM::TPK, KPW = SM::KPW, NK = SM::NK;
+    using SM = PcShared<HG, CW, LWX>;
+    constexpr int QS = SM::QS, KS = SM::KS, VS = SM::VS, CH = SM::CH, TPK = SM::TPK, KPW = SM::KPW, NK = SM::NK, NP = SM::NP, KPP = SM::KPP;
     const int C = p.C, H = p.H, W = p.W, L = p.L, P = H * W, X = H / 8, Y = W / 8;
     const int src = pc_src(chunk, it.ego);
     const float* a = sm.ainv + ((it.b * L + src) * L + it.ego) * 8;
@@ -489,14 +503,14 @@ __device__ __forceinline__ void pc_gather(const AttnParams& p, PcShared<HG>& sm,
     const __amdgpu_buffer_rsrc_t rs_kv = __builtin_amdgcn_make_buffer_rsrc((void*)kpl, 0, 0x7fffffff, 0x00020000);
     const int lane = ltid & 63;
     const int cl = (ltid % TPK) * 8;
-    const int kin = ltid / TPK;                  // key row of this lane inside a 16-key pass
+    const int kin = ltid / TPK;                  // key row of this lane inside a KPP-key pass
     const unsigned cl_bytes = cl * 2;
     const unsigned row_bytes = (unsigned)C * 2;
 
-    // ---- taps: lane j < NK of loader wave lw owns key (j / KPW) * 16 + KPW lw + (j % KPW) ----
+    // ---- taps: lane j < NK of loader wave lw owns key (j / KPW) * KPP + KPW lw + (j % KPW) ----
     {
         const int j = lane % NK;
-        const int n = (j / KPW) * 16 + KPW * lw + (j % KPW);
+        const int n = (j / KPW) * KPP + KPW * lw + (j % KPW);
         int row, col;
         token_pixel(p.partition, 8, X, Y, it.wx, it.wy, n, row, col);
         Taps t;
@@ -516,22 +530,25 @@ __device__ __forceinline__ void pc_gather(const AttnParams& p, PcShared<HG>& sm,
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read ordering
-    int4 tix[4];
-    float4 twt[4];
-    bool visible[4];
-    int self_idx[4];
+    int4 tix[NP];
+    float4 twt[NP];
+    bool visible[NP];
+    int self_idx[NP];
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
+    for (int pass = 0; pass < NP; ++pass) {
         const int j = pass * KPW + (kin % KPW);
         tix[pass] = *reinterpret_cast<const int4*>(sm.tidx[lw][j]);
         twt[pass] = *reinterpret_cast<const float4*>(sm.tw[lw][j]);
         self_idx[pass] = sm.tself[lw][j];
+        if (dbg & 0x400) {   // probe: fold every access into a 2 MB (L2-resident) region
+            self_idx[pass] &= 4095; tix[pass].x &= 4095; tix[pass].y &= 4095; tix[pass].z &= 4095; tix[pass].w &= 4095;
+        }
         visible[pass] = sm.tvis[lw][j] != 0;
     }
 
     PC_TRACE(ltid == 0, (int)sm.gcount, 1);
     // ---- issue phase ----
-    half8 rawq[4];
+    half8 rawq[NP];
     bool q_ident = true;
     if constexpr (WITH_Q) {
         const float* aq = sm.ainv + ((it.b * L + it.ego) * L + it.ego) * 8;
@@ -540,13 +557,13 @@ __device__ __forceinline__ void pc_gather(const AttnParams& p, PcShared<HG>& sm,
         if (q_ident) {
             const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)qpl, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) rawq[pass] = buf_load8(rs_q, (unsigned)self_idx[pass] * row_bytes + cl_bytes, 0);
+            for (int pass = 0; pass < NP; ++pass) rawq[pass] = buf_load8(rs_q, (unsigned)self_idx[pass] * row_bytes + cl_bytes, 0);
         } else {
             // T[i,i] is not the identity (never produced by the reference's dataset): slow path
             const int tq = __builtin_amdgcn_readfirstlane(te);
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int n = pass * 16 + kin;
+            for (int pass = 0; pass < NP; ++pass) {
+                const int n = pass * KPP + kin;
                 int row, col;
                 token_pixel(p.partition, 8, X, Y, it.wx, it.wy, n, row, col);
                 const Taps tt = make_taps(aq, col, row, H, W);
@@ -556,10 +573,10 @@ __device__ __forceinline__ void pc_gather(const AttnParams& p, PcShared<HG>& sm,
             }
         }
     }
-    half8 raw[4][2][4];
+    half8 raw[NP][2][4];
     if (ident) {
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass)
+        for (int pass = 0; pass < NP; ++pass)
             if (visible[pass]) {
                 const unsigned vo = (unsigned)self_idx[pass] * row_bytes + cl_bytes;
                 raw[pass][0][0] = buf_load8(rs_kv, vo, 0);
@@ -567,7 +584,7 @@ __device__ __forceinline__ void pc_gather(const AttnParams& p, PcShared<HG>& sm,
             }
     } else {
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass)
+        for (int pass = 0; pass < NP; ++pass)
             if (visible[pass]) {
                 const int ix[4] = {tix[pass].x, tix[pass].y, tix[pass].z, tix[pass].w};
 #pragma unroll
@@ -586,11 +603,11 @@ __device__ __forceinline__ void pc_gather(const AttnParams& p, PcShared<HG>& sm,
             const float4 b1 = *reinterpret_cast<const float4*>(&sm.bq[te][cl + 4]);
             const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
+            for (int pass = 0; pass < NP; ++pass) {
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (float)rawq[pass][e] + bb[e];
-                store8_lds<half_t>(sm.Qs[qbuf] + (pass * 16 + kin) * QS + cl, v);
+                store8_lds<half_t>(sm.Qs[qbuf] + (pass * KPP + kin) * QS + cl, v);
             }
         }
     }
@@ -609,8 +626,8 @@ __device__ __forceinline__ void pc_gather(const AttnParams& p, PcShared<HG>& sm,
     half_t* Vs = sm.Vs[kvbuf];
     bool any = false;
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        const int kk = pass * 16 + kin;
+    for (int pass = 0; pass < NP; ++pass) {
+        const int kk = pass * KPP + kin;
         float o[2][8];
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
@@ -644,9 +661,9 @@ __device__ __forceinline__ void pc_gather(const AttnParams& p, PcShared<HG>& sm,
 
 // per-workgroup tables: affine records, and the biases of the head group this workgroup serves
 // (the item stride gridDim.x is a multiple of the number of head groups, so hg never changes)
-template <int HG>
-__device__ __forceinline__ void pc_load_tables(const AttnParams& p, PcShared<HG>& sm, int hg) {
-    constexpr int CH = PcShared<HG>::CH;
+template <int HG, int CW, int LWX>
+__device__ __forceinline__ void pc_load_tables(const AttnParams& p, PcShared<HG, CW, LWX>& sm, int hg) {
+    constexpr int CH = PcShared<HG, CW, LWX>::CH;
     const int n_rec = p.B * p.L * p.L * 8;
     for (int i = threadIdx.x; i < n_rec; i += blockDim.x) sm.ainv[i] = p.ainv[i];
     for (int i = threadIdx.x; i < HMVIT_NUM_TYPES * HMVIT_NUM_TYPES * 2 * CH; i += blockDim.x) {
@@ -660,26 +677,30 @@ __device__ __forceinline__ void pc_load_tables(const AttnParams& p, PcShared<HG>
         sm.cav[threadIdx.x] = p.cav[threadIdx.x];
         sm.ego_e[threadIdx.x] = p.ego_e[threadIdx.x];
     }
+    if constexpr (PcShared<HG, CW, LWX>::BIAS_LDS) {
+        const float* src = p.bias_frag + (size_t)hg * HG * 7 * 256;   // heads hg*HG .. hg*HG+HG-1 are contiguous
+        for (int i = threadIdx.x; i < HG * 7 * 256; i += blockDim.x) sm.biasf[i] = src[i];
+    }
 }
 
 // Both role loops execute 1 + (number of (item, chunk) pairs) barriers.  The loader is one flat
 // loop with a single gather call site (instruction-cache footprint): gather number g fills buffer
 // g & 1 and is consumed by the compute waves in the barrier interval after the one it was made in.
-template <int HG>
-__device__ __forceinline__ void pc_loader_loop(const AttnParams& p, PcShared<HG>& sm, int lw, int ltid) {
+template <int HG, int CW, int LWX>
+__device__ __forceinline__ void pc_loader_loop(const AttnParams& p, PcShared<HG, CW, LWX>& sm, int lw, int ltid) {
     const int X = p.H / 8, Y = p.W / 8, NG = p.C / (HG * 32);
     const int n_items = p.B * p.n_ego * X * Y * NG;
     const int n_src = p.n_src;
     int item = blockIdx.x, chunk = 0, g = 0, qi = 0;
-    PcItem it = pc_decode(item, p.n_ego, X, Y, NG);
+    PcItem it = pc_decode(item, p.n_ego, X, Y, NG, (p.variant & 0x200) != 0);
 #pragma unroll 1
     while (true) {
         if (ltid == 0) sm.gcount = g;
         PC_TRACE(ltid == 0, g, 0);
         if (chunk == 0)
-            pc_gather<HG, true>(p, sm, it, 0, g & 1, qi, lw, ltid);
+            pc_gather<HG, CW, LWX, true>(p, sm, it, 0, g & 1, qi, lw, ltid);
         else
-            pc_gather<HG, false>(p, sm, it, chunk, g & 1, qi, lw, ltid);
+            pc_gather<HG, CW, LWX, false>(p, sm, it, chunk, g & 1, qi, lw, ltid);
         PC_TRACE(ltid == 0, g, 3);
         __syncthreads();
         PC_TRACE(ltid == 0, g, 4);
@@ -688,16 +709,18 @@ __device__ __forceinline__ void pc_loader_loop(const AttnParams& p, PcShared<HG>
             chunk = 0;
             item += gridDim.x;
             if (item >= n_items) break;
-            it = pc_decode(item, p.n_ego, X, Y, NG);
+            it = pc_decode(item, p.n_ego, X, Y, NG, (p.variant & 0x200) != 0);
             qi ^= 1;
         }
     }
     __syncthreads();   // the interval in which the compute waves consume the last chunk
 }
 
-template <int HG>
-__device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG>& sm, int wave, int lane) {
-    constexpr int QS = PcShared<HG>::QS, KS = PcShared<HG>::KS, VS = PcShared<HG>::VS;
+template <int HG, int CW, int LWX>
+__device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG, CW, LWX>& sm, int wave, int lane) {
+    using SM = PcShared<HG, CW, LWX>;
+    constexpr int QS = SM::QS, KS = SM::KS, VS = SM::VS, NQW = SM::NQW, LWG = SM::LWG;
+    const int hl = wave / CW, qbase = (wave % CW) * NQW;   // head inside the group, first query tile
     const int C = p.C, H = p.H, W = p.W, L = p.L, P = H * W;
     const int X = H / 8, Y = W / 8, NG = C / (HG * 32);
     const int n_items = p.B * p.n_ego * X * Y * NG;
@@ -708,25 +731,27 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
 
     float4v biasf[7];
     int bias_head = -1;
-    half8 qh[4];
-    float m_run[4], l_run[4];
-    float4v o_acc[4][2];
+    half8 qh[NQW];
+    float m_run[NQW], l_run[NQW];
+    float4v o_acc[NQW][2];
     int gstep = 0, qi = 0;
     while (true) {
-        const PcItem it = pc_decode(item, p.n_ego, X, Y, NG);
-        const int head = it.hg * HG + wave;
+        const PcItem it = pc_decode(item, p.n_ego, X, Y, NG, (p.variant & 0x200) != 0);
+        const int head = it.hg * HG + hl;
         for (int c = 0; c < n_src; ++c) {
             const int buf = gstep & 1;
             if (c == 0) {
-                if (head != bias_head) {
+                if constexpr (!SM::BIAS_LDS) {
+                    if (head != bias_head) {
 #pragma unroll
-                    for (int v = 0; v < 7; ++v)
-                        biasf[v] = *reinterpret_cast<const float4v*>(p.bias_frag + ((size_t)(head * 7 + v) * 64 + lane) * 4);
-                    bias_head = head;
+                        for (int v = 0; v < 7; ++v)
+                            biasf[v] = *reinterpret_cast<const float4v*>(p.bias_frag + ((size_t)(head * 7 + v) * 64 + lane) * 4);
+                        bias_head = head;
+                    }
                 }
 #pragma unroll
-                for (int qt = 0; qt < 4; ++qt) {
-                    qh[qt] = *reinterpret_cast<const half8*>(sm.Qs[qi] + (qt * 16 + lq) * QS + wave * 32 + g * 8);
+                for (int qt = 0; qt < NQW; ++qt) {
+                    qh[qt] = *reinterpret_cast<const half8*>(sm.Qs[qi] + ((qbase + qt) * 16 + lq) * QS + hl * 32 + g * 8);
                     m_run[qt] = -INFINITY;
                     l_run[qt] = 0.f;
                     o_acc[qt][0] = (float4v)(0.f);
@@ -735,7 +760,7 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
             }
             int vis_or = 0;
 #pragma unroll
-            for (int w = 0; w < HG; ++w) vis_or |= sm.vis[buf][w];
+            for (int w = 0; w < LWG; ++w) vis_or |= sm.vis[buf][w];
             const bool any_visible = vis_or != 0;
             if ((any_visible || !p.skip_masked) && !(p.variant & 0x40)) {
                 const half_t* Kb = sm.Ks[buf];
@@ -746,12 +771,12 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
                 half8 kh[4], vh[2][2];
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
-                    kh[kt] = *reinterpret_cast<const half8*>(Kb + (kt * 16 + lq) * KS + wave * 32 + g * 8);
+                    kh[kt] = *reinterpret_cast<const half8*>(Kb + (kt * 16 + lq) * KS + hl * 32 + g * 8);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        const half_t* base = Vb + (ks * 32 + 4 * g + (lq >> 2)) * VS + wave * 32 + dt * 16 + (lq & 3) * 4;
+                        const half_t* base = Vb + (ks * 32 + 4 * g + (lq >> 2)) * VS + hl * 32 + dt * 16 + (lq & 3) * 4;
                         const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
                             (__attribute__((address_space(3))) fp16x4_t*)(base));
                         const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
@@ -765,11 +790,17 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
                         vh[dt][ks] = v;
                     }
 #pragma unroll
-                for (int qt = 0; qt < 4; ++qt) {
+                for (int qt = 0; qt < NQW; ++qt) {
                     float4v s[4];
 #pragma unroll
-                    for (int kt = 0; kt < 4; ++kt)
-                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[kt], qh[qt], biasf[qt - kt + 3], 0, 0, 0) + madd[kt];
+                    for (int kt = 0; kt < 4; ++kt) {
+                        float4v bias_c;
+                        if constexpr (SM::BIAS_LDS)
+                            bias_c = *reinterpret_cast<const float4v*>(sm.biasf + ((hl * 7 + (qbase + qt - kt + 3)) * 64 + lane) * 4);
+                        else
+                            bias_c = biasf[qt - kt + 3];
+                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[kt], qh[qt], bias_c, 0, 0, 0) + madd[kt];
+                    }
                     float mx = -INFINITY;
 #pragma unroll
                     for (int kt = 0; kt < 4; ++kt)
@@ -813,9 +844,9 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
             if (c == n_src - 1) {
                 half_t* outp = reinterpret_cast<half_t*>(p.out) + (size_t)(it.b * L + it.ego) * P * C;
 #pragma unroll
-                for (int qt = 0; qt < 4; ++qt) {
+                for (int qt = 0; qt < NQW; ++qt) {
                     int row, col;
-                    token_pixel(p.partition, 8, X, Y, it.wx, it.wy, qt * 16 + lq, row, col);
+                    token_pixel(p.partition, 8, X, Y, it.wx, it.wy, (qbase + qt) * 16 + lq, row, col);
                     const float inv = 1.f / l_run[qt];
                     half_t* o = outp + (size_t)(row * W + col) * C + head * 32 + 4 * g;
 #pragma unroll
@@ -838,29 +869,29 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
     }
 }
 
-template <int HG>
-__global__ __launch_bounds__(HG * 128) void k_attention_pc(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) PcShared<HG> sm;
+template <int HG, int CW, int LWX>
+__global__ __launch_bounds__((HG * CW + HG * LWX) * 64) void k_attention_pc(AttnParams p) {
+    using SM = PcShared<HG, CW, LWX>;
+    __shared__ __attribute__((aligned(16))) SM sm;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    pc_load_tables<HG>(p, sm, blockIdx.x % (p.C / (HG * 32)));
+    pc_load_tables<HG, CW, LWX>(p, sm, blockIdx.x % (p.C / (HG * 32)));
     __syncthreads();
     // wave-uniform role split at the outermost level: the two loops have disjoint live ranges, so
     // the kernel's register count is the maximum of the two roles, not their sum
-    if (wave >= HG) {
-        pc_loader_loop<HG>(p, sm, wave - HG, threadIdx.x & (HG * 64 - 1));
+    if (wave >= SM::CWG) {
+        pc_loader_loop<HG, CW, LWX>(p, sm, wave - SM::CWG, threadIdx.x - SM::CWG * 64);
     } else {
-        pc_compute_loop<HG>(p, sm, wave, threadIdx.x & 63);
+        pc_compute_loop<HG, CW, LWX>(p, sm, wave, threadIdx.x & 63);
     }
 }
 
-template <int HG>
-static int launch_attn_pc(const AttnParams& p, hipStream_t st) {
+template <int HG, int CW, int LWX>
+static int launch_attn_pc(const AttnParams& p, hipStream_t st, int wg_per_cu) {
     const int NG = p.C / (HG * 32);
     const int n_items = p.B * p.n_ego * (p.H / 8) * (p.W / 8) * NG;
-    // persistent: HG = 2 -> two 4-wave workgroups per CU (~70 KB LDS each), HG = 4 -> one 8-wave group
-    int grid = 256 * (HG == 2 ? 2 : 1);
+    int grid = 256 * wg_per_cu;           // persistent workgroups
     if (grid > n_items) grid = n_items;   // both are multiples of the head-group count
-    hipLaunchKernelGGL((k_attention_pc<HG>), dim3(grid), dim3(HG * 128), 0, st, p);
+    hipLaunchKernelGGL((k_attention_pc<HG, CW, LWX>), dim3(grid), dim3((HG * CW + HG * LWX) * 64), 0, st, p);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }
@@ -886,11 +917,16 @@ int launch_attention(const AttnParams& p, int precision, hipStream_t st) {
         return w8 ? launch_attn_t<float, 8, 2>(p, st) : launch_attn_t<float, 4, 2>(p, st);
     }
     if (p.C == 64) return w8 ? launch_attn_t<half_t, 8, 2>(p, st) : launch_attn_t<half_t, 4, 2>(p, st);
-    if (w8 && (p.variant & 1) == 0 && p.B * p.L * p.L <= PcShared<2>::MAX_PAIRS) {
+    if (w8 && (p.variant & 1) == 0 && p.B * p.L * p.L <= PcShared<4, 1, 1>::MAX_PAIRS) {
         AttnParams q = p;
         if (const char* e = getenv("HMVIT_ATTN_DEBUG")) q.variant |= atoi(e) & ~1;   // probe switches (tools/attn_probe.py)
         if (const char* e = getenv("HMVIT_ATTN_TRACE")) q.trace = (unsigned long long*)strtoull(e, nullptr, 0);
-        return (q.variant & 2) ? launch_attn_pc<2>(q, st) : launch_attn_pc<4>(q, st);   // 4 heads per workgroup measured faster
+        // wave configurations (heads per group, compute waves per head, loader waves per head):
+        //   default: 4 heads, 2 + 2 -> 16 waves of <= 128 VGPRs (4 per SIMD: VALU / LDS latency hidden by TLP)
+        //   variant bit 2: 4 heads, 1 + 1 -> 8 waves;  bit 4: 2 heads, 1 + 1, two workgroups per CU
+        if (q.variant & 2) return launch_attn_pc<4, 1, 1>(q, st, 1);
+        if (q.variant & 4) return launch_attn_pc<2, 1, 1>(q, st, 2);
+        return launch_attn_pc<4, 2, 2>(q, st, 1);
     }
     return w8 ? launch_attn_t<half_t, 8, 4>(p, st) : launch_attn_t<half_t, 4, 4>(p, st);
 }
