@@ -15,6 +15,8 @@ What is frozen:
   g5_fusion_ragged.npz  HeteroFusion, B=2, record_len=[3,2], C=64, 16x16, window 4.
   g6_fusion_cfg1.npz    HeteroFusion at BASELINE configs[0]: 2 LiDAR agents, 100x352, C=64,
                         window 4 -- output sub-sampled (every 5th row / 11th col) + moments.
+  g7_pointpillar.npz    PointPillar.forward (features only, eval BN): 2 agents x 400 pillars on a
+                        64x48 canvas; PFN output + (2, 256, 12, 16) BEV features.
 
 Weights and inputs are NOT stored where they can be regenerated bit-exactly from a numpy
 legacy RandomState seed (oracle.hmvit_oracle.random_state_dict / synthetic_scene); the
@@ -51,6 +53,7 @@ from opencood.models.sub_modules.torch_transformation_utils import (  # noqa: E4
     warp_affine)
 
 from oracle import hmvit_oracle as O  # noqa: E402  (only for the seeded input generators)
+from oracle import pointpillar_oracle as PO  # noqa: E402  (seeded pillars / weights)
 
 torch.set_grad_enabled(False)
 
@@ -183,7 +186,24 @@ def g6_fusion_cfg1():
          abs_max=y64.abs().max())
 
 
+def g7_pointpillar():
+    """PointPillar.forward (return_features), eval-mode BN with non-trivial running stats:
+    2 agents x 400 pillars on a 64 x 48 canvas -> (2, 256, 12, 16); also the PFN output."""
+    from opencood.models.point_pillar import PointPillar
+    args = PO.make_args(64, 48)
+    net = PointPillar(args).eval()
+    net.set_return_features()
+    net.load_state_dict(PO.random_state_dict(args, seed=71), strict=True)
+    vf, vc, vn = PO.synthetic_pillars(2, 400, 64, 48, args, seed=72)
+    batch = {"voxel_features": vf, "voxel_coords": vc, "voxel_num_points": vn}
+    pf = net.pillar_vfe(dict(batch))["pillar_features"]
+    y = net({"processed_lidar": batch})
+    save("g7_pointpillar.npz", seed_weights=71, seed_pillars=72, grid=np.array([64, 48]), n_agents=np.array(2),
+         n_per_agent=np.array(400), pillar_features=pf, out=y)
+
+
 if __name__ == "__main__":
+    g7_pointpillar()
     g1_attention()
     g2_warp()
     g3_block("sequential")

@@ -78,3 +78,17 @@ def test_bad_architect_mode_raises():
     sd = O.random_state_dict(O.make_config(64, 4, 2))
     with pytest.raises(ValueError):
         O.hetero_fusion(*O.synthetic_scene(2, 64, 8, 8, [1, 1]), sd, cfg)
+
+
+def test_g7_pointpillar_encoder():
+    from oracle import pointpillar_oracle as PO
+    g = load_golden("g7_pointpillar.npz")
+    nx, ny = [int(v) for v in g["grid"]]
+    args = PO.make_args(nx, ny)
+    sd = PO.random_state_dict(args, g["seed_weights"])
+    vf, vc, vn = PO.synthetic_pillars(int(g["n_agents"]), int(g["n_per_agent"]), nx, ny, args, int(g["seed_pillars"]))
+    pf = PO.pillar_vfe(vf, vn, vc, sd, args["voxel_size"], args["lidar_range"])
+    assert rel_max_err(pf, g["pillar_features"]) < TOL
+    y = PO.point_pillar_features(vf, vc, vn, sd, args, int(g["n_agents"]))
+    assert y.shape == g["out"].shape
+    assert rel_max_err(y, g["out"]) < TOL
