@@ -3,5 +3,6 @@ fuse-module API).  Import as ``hmvit_amd`` (see hmvit_amd.py at the repository r
 directory name carries a hyphen)."""
 from . import _lib  # noqa: F401  (raises ImportError when libhmvit.so is not built)
 from .fusion import HeteroFusion, HeteroFusionBlock  # noqa: F401
+from .pointpillar import PointPillar  # noqa: F401
 
-__all__ = ["HeteroFusion", "HeteroFusionBlock"]
+__all__ = ["HeteroFusion", "HeteroFusionBlock", "PointPillar"]

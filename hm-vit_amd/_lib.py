@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhmvit.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PREC_F32, PREC_F16 = 0, 1
 PART_WINDOW, PART_GRID = 0, 1
 NUM_TYPES = 2
@@ -67,6 +67,8 @@ _SIGNATURES = {
                                     C.c_int, C.c_int, C.c_void_p]),
     "hmvit_window_attention": (C.c_int, [C.c_void_p] * 6 + [c_i32p, c_i32p, c_i32p, C.c_void_p] +
                                [C.c_int] * 12 + [C.c_void_p]),
+    "hmvit_pfn_scatter": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, C.c_void_p]),
+    "hmvit_conv2d": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 14 + [C.c_void_p]),
     "hmvit_debug_tr16": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 

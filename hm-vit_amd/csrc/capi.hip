@@ -702,6 +702,40 @@ int hmvit_window_attention(const void* q, const void* kv, const float* b_q, cons
     return launch_attention(ap, precision, reinterpret_cast<hipStream_t>(stream));
 }
 
+int hmvit_pfn_scatter(const float* voxels, const int32_t* coords, const int32_t* num_points, const float* w,
+                      const float* shift, void* canvas, float* pillar_out, int n_pillars, int nx, int ny,
+                      const float* voxel_size, const float* lidar_range, int precision, void* stream) {
+    HMVIT_CHECK_ARG(voxels && coords && num_points && w && shift && (canvas || pillar_out) && voxel_size && lidar_range,
+                    "pfn_scatter: null pointer");
+    HMVIT_CHECK_ARG(n_pillars >= 0 && nx > 0 && ny > 0, "pfn_scatter: bad sizes");
+    PfnParams p;
+    p.voxels = voxels; p.coords = coords; p.num_points = num_points; p.w = w; p.shift = shift;
+    p.canvas = canvas; p.pillar_out = pillar_out; p.n_pillars = n_pillars; p.nx = nx; p.ny = ny;
+    p.vx = voxel_size[0]; p.vy = voxel_size[1]; p.vz = voxel_size[2];
+    p.x_off = voxel_size[0] / 2 + lidar_range[0];
+    p.y_off = voxel_size[1] / 2 + lidar_range[1];
+    p.z_off = voxel_size[2] / 2 + lidar_range[2];
+    return launch_pfn_scatter(p, precision, reinterpret_cast<hipStream_t>(stream));
+}
+
+int hmvit_conv2d(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int Cin, int Cout,
+                 int ksize, int stride, int pad, int relu, int y_ctot, int y_coff, int deconv_stride, int out_f32,
+                 int precision, void* stream) {
+    HMVIT_CHECK_ARG(x && w && y, "conv2d: null pointer");
+    ConvParams p;
+    p.x = x; p.w = w; p.bias = bias; p.y = y;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = p.KW = ksize; p.stride = stride; p.pad = pad;
+    p.relu = relu; p.y_ctot = y_ctot; p.y_coff = y_coff; p.deconv_s = deconv_stride; p.out_f32 = out_f32;
+    if (deconv_stride) {
+        p.Ho = H; p.Wo = W;
+    } else {
+        p.Ho = (H + 2 * pad - ksize) / stride + 1;
+        p.Wo = (W + 2 * pad - ksize) / stride + 1;
+    }
+    HMVIT_CHECK_ARG(y_ctot >= y_coff + Cout, "conv2d: output channel window [%d, %d) exceeds %d", y_coff, y_coff + Cout, y_ctot);
+    return launch_conv(p, precision, reinterpret_cast<hipStream_t>(stream));
+}
+
 int hmvit_debug_tr16(uint16_t* out, void* stream) {
     HMVIT_CHECK_ARG(out != nullptr, "debug_tr16: null pointer");
     return launch_debug_tr16(out, reinterpret_cast<hipStream_t>(stream));

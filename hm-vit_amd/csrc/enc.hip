@@ -1,0 +1,272 @@
+// LiDAR BEV encoder kernels (PointPillar branch):
+//
+//   k_pfn_scatter  PillarVFE (one PFN layer) fused with PointPillarScatter
+//                  (sub_modules/pillar_vfe.py:31-53,105-146, point_pillar_scatter.py:14-47):
+//                  HBM-bound, one wavefront per pillar, writes the dense NHWC canvas directly.
+//   k_conv         Conv2d / ConvTranspose2d(kernel = stride) + folded BatchNorm + ReLU as an
+//                  implicit GEMM on MFMA (backbones/base_bev_backbone.py:6-122,
+//                  sub_modules/downsample_conv.py:20-51): NHWC activations, the im2col row of an
+//                  output pixel is gathered on the fly (one 3x3 tap x BK input channels per K slab).
+//
+// Same tile as gemm.hip: 128 output pixels x 128 output channels per workgroup, 2x2 wavefronts,
+// v_mfma_f32_32x32x16_f16 (f16 mode) or v_mfma_f32_32x32x2_f32 (exact f32 mode).
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace hmvit {
+
+// ------------------------------------------------------------------------------------------
+// PFN + scatter
+// ------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void k_pfn_scatter(PfnParams p) {
+    __shared__ float feat[4][32][12];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int v = blockIdx.x * 4 + wave;
+    if (v >= p.n_pillars) return;
+    const int npts = p.num_points[v];
+    const int4 co = *reinterpret_cast<const int4*>(p.coords + (size_t)v * 4);   // [agent, z, y, x]
+
+    // lanes 0..31: one point each; sums of x, y, z over all 32 rows (padding rows are zero)
+    float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < 32) pt = *reinterpret_cast<const float4*>(p.voxels + ((size_t)v * 32 + lane) * 4);
+    float sx = pt.x, sy = pt.y, sz = pt.z;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        sx += __shfl_xor(sx, o, 64);
+        sy += __shfl_xor(sy, o, 64);
+        sz += __shfl_xor(sz, o, 64);
+    }
+    const float inv = 1.f / (float)npts;
+    if (lane < 32) {
+        const float m = lane < npts ? 1.f : 0.f;      // padded points are zeroed AFTER augmentation
+        float* f = feat[wave][lane];
+        f[0] = pt.x * m; f[1] = pt.y * m; f[2] = pt.z * m; f[3] = pt.w * m;
+        f[4] = (pt.x - sx * inv) * m; f[5] = (pt.y - sy * inv) * m; f[6] = (pt.z - sz * inv) * m;
+        f[7] = (pt.x - ((float)co.w * p.vx + p.x_off)) * m;
+        f[8] = (pt.y - ((float)co.z * p.vy + p.y_off)) * m;
+        f[9] = (pt.z - ((float)co.y * p.vz + p.z_off)) * m;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    // lane = output channel: Linear(10 -> 64, BN scale folded) + shift, ReLU, max over the points
+    float w[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) w[k] = p.w[lane * 10 + k];
+    const float shift = p.shift[lane];
+    float best = 0.f;   // ReLU output is >= 0
+    for (int j = 0; j < 32; ++j) {
+        const float* f = feat[wave][j];
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc = fmaf(w[k], f[k], acc);
+        best = fmaxf(best, acc + shift);
+    }
+    if (p.pillar_out) p.pillar_out[(size_t)v * 64 + lane] = best;
+    if (p.canvas) {
+        const size_t cell = ((size_t)co.x * p.ny + co.z) * p.nx + co.w + co.y;   // index z + y * nx + x
+        reinterpret_cast<TO*>(p.canvas)[cell * 64 + lane] = (TO)best;
+    }
+}
+
+int launch_pfn_scatter(const PfnParams& p, int precision, hipStream_t st) {
+    if (p.n_pillars <= 0) return HMVIT_OK;
+    dim3 grid(cdiv(p.n_pillars, 4)), block(256);
+    if (precision == HMVIT_PREC_F32)
+        hipLaunchKernelGGL((k_pfn_scatter<float>), grid, block, 0, st, p);
+    else
+        hipLaunchKernelGGL((k_pfn_scatter<half_t>), grid, block, 0, st, p);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// implicit-GEMM convolution
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct ConvCfg;
+template <>
+struct ConvCfg<half_t> {
+    static constexpr int BK = 64, LS = 72;
+};
+template <>
+struct ConvCfg<float> {
+    static constexpr int BK = 32, LS = 33;
+};
+constexpr int CBM = 128, CBN = 128;
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_conv(ConvParams p) {
+    constexpr int BK = ConvCfg<T>::BK, LS = ConvCfg<T>::LS;
+    constexpr int RPT = (sizeof(T) == 2) ? 4 : 4;        // staged rows per thread (8 chunks per row)
+    __shared__ __attribute__((aligned(16))) T As[CBM * LS];
+    __shared__ __attribute__((aligned(16))) T Ws[CBN * LS];
+
+    const int M = p.N * p.Ho * p.Wo;
+    const int Ncols = p.deconv_s ? p.deconv_s * p.deconv_s * p.Cout : p.Cout;
+    const int Ktot = p.KH * p.KW * p.Cin;
+    const int tiles_n = (Ncols + CBN - 1) / CBN;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int m0 = tm * CBM, n0 = tn * CBN;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, hi = lane >> 5;
+    const T* x = reinterpret_cast<const T*>(p.x);
+    const T* w = reinterpret_cast<const T*>(p.w);
+
+    // the rows this thread stages: decode (image, oy, ox) once
+    int rn[RPT], roy[RPT], rox[RPT];
+    bool rvalid[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int row = (tid + 256 * i) >> 3;
+        const int m = m0 + row;
+        rvalid[i] = m < M;
+        const int mm = rvalid[i] ? m : 0;
+        rn[i] = mm / (p.Ho * p.Wo);
+        const int rem = mm - rn[i] * p.Ho * p.Wo;
+        roy[i] = rem / p.Wo;
+        rox[i] = rem - roy[i] * p.Wo;
+    }
+
+    float16v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    for (int k0 = 0; k0 < Ktot; k0 += BK) {
+        const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        // ---- A slab: im2col rows gathered from the NHWC input ----
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int c = tid + 256 * i, row = c >> 3;
+            const int iy = roy[i] * p.stride + ky - p.pad, ix = rox[i] * p.stride + kx - p.pad;
+            const bool ok = rvalid[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const T* src = x + (((size_t)rn[i] * p.H + iy) * p.W + ix) * p.Cin + ci0;
+            if constexpr (sizeof(T) == 2) {
+                const int kc = (c & 7) * 8;
+                half8 v = (half8)(half_t)0;
+                if (ok) v = *reinterpret_cast<const half8*>(src + kc);
+                *reinterpret_cast<half8*>(As + row * LS + kc) = v;
+            } else {
+                const int kc = (c & 7) * 4;
+                float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) f = *reinterpret_cast<const float4*>(src + kc);
+                float* d = reinterpret_cast<float*>(As) + row * LS + kc;
+                d[0] = f.x; d[1] = f.y; d[2] = f.z; d[3] = f.w;
+            }
+        }
+        // ---- W slab ----
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int c = tid + 256 * i, row = c >> 3;
+            const bool ok = n0 + row < Ncols;
+            const T* src = w + (size_t)(n0 + row) * Ktot + k0;
+            if constexpr (sizeof(T) == 2) {
+                const int kc = (c & 7) * 8;
+                half8 v = (half8)(half_t)0;
+                if (ok) v = *reinterpret_cast<const half8*>(src + kc);
+                *reinterpret_cast<half8*>(Ws + row * LS + kc) = v;
+            } else {
+                const int kc = (c & 7) * 4;
+                float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) f = *reinterpret_cast<const float4*>(src + kc);
+                float* d = reinterpret_cast<float*>(Ws) + row * LS + kc;
+                d[0] = f.x; d[1] = f.y; d[2] = f.z; d[3] = f.w;
+            }
+        }
+        __syncthreads();
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                half8 a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    a[i] = *reinterpret_cast<const half8*>(As + (wm * 64 + i * 32 + r) * LS + kk * 16 + hi * 8);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    b[j] = *reinterpret_cast<const half8*>(Ws + (wn * 64 + j * 32 + r) * LS + kk * 16 + hi * 8);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            const float* Af = reinterpret_cast<const float*>(As);
+            const float* Wf = reinterpret_cast<const float*>(Ws);
+#pragma unroll 4
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                float a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = Af[(wm * 64 + i * 32 + r) * LS + kk * 2 + hi];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = Wf[(wn * 64 + j * 32 + r) * LS + kk * 2 + hi];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias (folded BN shift), ReLU, NHWC store with channel offset / deconv scatter ----
+    const int s = p.deconv_s;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + r;
+        if (col >= Ncols) continue;
+        const int sub = s ? col / p.Cout : 0, co = s ? col - sub * p.Cout : col;
+        const int dy = s ? sub / s : 0, dx = s ? sub - dy * s : 0;
+        const float bias = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                if (m >= M) continue;
+                float v = acc[i][j][e] + bias;
+                if (p.relu) v = fmaxf(v, 0.f);
+                size_t pix;
+                if (s) {
+                    const int n = m / (p.Ho * p.Wo), rem = m - n * p.Ho * p.Wo;
+                    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                    pix = ((size_t)n * p.Ho * s + oy * s + dy) * (p.Wo * s) + ox * s + dx;
+                } else {
+                    pix = (size_t)m;
+                }
+                const size_t o = pix * p.y_ctot + p.y_coff + co;
+                if (p.out_f32)
+                    reinterpret_cast<float*>(p.y)[o] = v;
+                else
+                    reinterpret_cast<T*>(p.y)[o] = (T)v;
+            }
+        }
+    }
+}
+
+int launch_conv(const ConvParams& p, int precision, hipStream_t st) {
+    const int bk = precision == HMVIT_PREC_F32 ? ConvCfg<float>::BK : ConvCfg<half_t>::BK;
+    HMVIT_CHECK_ARG(p.Cin > 0 && p.Cin % bk == 0, "conv: Cin=%d must be a multiple of %d", p.Cin, bk);
+    HMVIT_CHECK_ARG(p.N > 0 && p.Ho > 0 && p.Wo > 0 && p.Cout > 0 && p.KH > 0 && p.KW > 0 && p.stride > 0,
+                    "conv: bad geometry");
+    HMVIT_CHECK_ARG(!p.deconv_s || (p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0),
+                    "deconv is expressed as a 1x1 GEMM with scatter");
+    const int M = p.N * p.Ho * p.Wo;
+    const int Ncols = p.deconv_s ? p.deconv_s * p.deconv_s * p.Cout : p.Cout;
+    dim3 grid(cdiv(M, CBM) * cdiv(Ncols, CBN)), block(256);
+    if (precision == HMVIT_PREC_F32)
+        hipLaunchKernelGGL((k_conv<float>), grid, block, 0, st, p);
+    else
+        hipLaunchKernelGGL((k_conv<half_t>), grid, block, 0, st, p);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+}  // namespace hmvit

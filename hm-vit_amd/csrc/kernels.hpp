@@ -81,6 +81,32 @@ struct FfnParams {
 enum { FFN_FULL = 0, FFN_NO_ATTN = 1, FFN_HEAD_NCHW = 2 };
 int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, hipStream_t st);
 
+// ---- enc.hip (PointPillar branch) ----
+struct PfnParams {
+    const float* voxels;      // (Nv, 32, 4)
+    const int* coords;        // (Nv, 4) [agent, z, y, x]
+    const int* num_points;    // (Nv)
+    const float* w;           // (64, 10) Linear weight with the BatchNorm scale folded in
+    const float* shift;       // (64) BatchNorm shift
+    void* canvas;             // (n_agents, ny, nx, 64) NHWC, zero-filled by the caller; may be null
+    float* pillar_out;        // (Nv, 64) f32 or null
+    int n_pillars, nx, ny;
+    float vx, vy, vz, x_off, y_off, z_off;
+};
+int launch_pfn_scatter(const PfnParams& p, int precision, hipStream_t st);
+
+struct ConvParams {
+    const void* x;            // (N, H, W, Cin) NHWC
+    const void* w;            // (Ncols, KH*KW*Cin): k = (ky*KW + kx)*Cin + ci
+    const float* bias;        // (Cout) or null
+    void* y;                  // NHWC, channel stride y_ctot, first channel y_coff
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, relu;
+    int y_ctot, y_coff;
+    int deconv_s;             // > 0: ConvTranspose2d with kernel = stride = s (Ncols = s*s*Cout, Ho = H, Wo = W)
+    int out_f32;
+};
+int launch_conv(const ConvParams& p, int precision, hipStream_t st);
+
 // ---- split.hip (architect_mode == 'parallel') ----
 struct SplitSlots {
     int8_t s[kMaxSlots];     // agent slots to merge

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HMVIT_ABI_VERSION 3
+#define HMVIT_ABI_VERSION 4
 
 #define HMVIT_OK 0
 #define HMVIT_EINVAL (-22)   /* bad argument / unsupported shape */
@@ -212,6 +212,33 @@ int hmvit_window_attention(const void* q, const void* kv, const float* b_q, cons
                            const int32_t* cav_mask, const int32_t* ego_e, void* out, int B, int L,
                            int n_ego, int n_src, int E, int C, int H, int W, int window,
                            int partition, int precision, int skip_masked, void* stream);
+
+/* ---- LiDAR BEV encoder (PointPillar branch) ---- */
+
+/* PillarVFE with one PFN layer (use_norm, use_absolute_xyz, no distance) fused with
+ * PointPillarScatter (sub_modules/pillar_vfe.py:31-53,105-146, point_pillar_scatter.py:14-47).
+ *   voxels (Nv, 32, 4) f32, coords (Nv, 4) int32 [agent, z, y, x], num_points (Nv) int32;
+ *   w (64, 10) f32 = linear.weight * bn_scale[:, None], shift (64) f32 = bn_bias - bn_mean * bn_scale
+ *   (eval-mode BatchNorm1d, eps 1e-3);
+ *   canvas (n_agents, ny, nx, 64) NHWC in the precision's element type, ZERO-FILLED by the caller
+ *   (index z + y * nx + x), may be NULL; pillar_out (Nv, 64) f32, may be NULL;
+ *   voxel_size / lidar_range: host arrays of 3 / 6 floats. */
+int hmvit_pfn_scatter(const float* voxels, const int32_t* coords, const int32_t* num_points, const float* w,
+                      const float* shift, void* canvas, float* pillar_out, int n_pillars, int nx, int ny,
+                      const float* voxel_size, const float* lidar_range, int precision, void* stream);
+
+/* nn.Conv2d (square kernel) or nn.ConvTranspose2d (kernel = stride = deconv_stride) + bias + ReLU on
+ * NHWC maps as an MFMA implicit GEMM: the layers of BaseBEVBackbone with eval-mode BatchNorm2d
+ * folded into weight and bias (backbones/base_bev_backbone.py:36-87) and of DownsampleConv
+ * (sub_modules/downsample_conv.py:20-51).
+ *   x (N, H, W, Cin); w: conv (Cout, k*k*Cin) with k-index (ky*k + kx)*Cin + ci,
+ *   deconv (s*s*Cout, Cin) with row (dy*s + dx)*Cout + co; bias (Cout) f32 or NULL;
+ *   y NHWC with y_ctot channels per pixel, this layer writes channels [y_coff, y_coff + Cout)
+ *   (the backbone's torch.cat is free); out_f32 = 1 stores f32 regardless of the precision.
+ *   Cin must be a multiple of 64 (f16 mode) / 32 (f32 mode).  For deconv pass ksize 1, stride 1, pad 0. */
+int hmvit_conv2d(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int Cin, int Cout,
+                 int ksize, int stride, int pad, int relu, int y_ctot, int y_coff, int deconv_stride, int out_f32,
+                 int precision, void* stream);
 
 /* debug: lane mapping of ds_read_b64_tr_b16 (used once to pin the V-operand layout) */
 int hmvit_debug_tr16(uint16_t* out, void* stream);

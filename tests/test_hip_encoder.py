@@ -1,0 +1,117 @@
+"""GPU parity tests of the LiDAR BEV encoder (csrc/enc.hip, hm-vit_amd/pointpillar.py) against the
+golden vector frozen from the reference's PointPillar (g7) and against torch fp64 convolutions."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, rel_max_err
+from oracle import pointpillar_oracle as PO
+
+pytestmark = pytest.mark.gpu
+TOL = {"f32": 1e-4, "f16": 2e-3}   # 20+ chained f16 convolutions: looser than the fusion's 1e-3
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _golden_inputs():
+    g = load_golden("g7_pointpillar.npz")
+    nx, ny = [int(v) for v in g["grid"]]
+    args = PO.make_args(nx, ny)
+    sd = PO.random_state_dict(args, g["seed_weights"])
+    pillars = PO.synthetic_pillars(int(g["n_agents"]), int(g["n_per_agent"]), nx, ny, args, int(g["seed_pillars"]))
+    return g, args, sd, pillars
+
+
+def test_pfn_matches_golden():
+    from hmvit_amd import _lib
+    g, args, sd, (vf, vc, vn) = _golden_inputs()
+    p = "pillar_vfe.pfn_layers.0"
+    scale = sd[f"{p}.norm.weight"] / torch.sqrt(sd[f"{p}.norm.running_var"] + 1e-3)
+    w = (sd[f"{p}.linear.weight"] * scale[:, None]).contiguous().cuda()
+    shift = (sd[f"{p}.norm.bias"] - sd[f"{p}.norm.running_mean"] * scale).contiguous().cuda()
+    vf, vc, vn = vf.cuda(), vc.cuda(), vn.cuda()
+    nx, ny = [int(v) for v in g["grid"]]
+    out = torch.empty(vf.shape[0], 64, device="cuda")
+    canvas = torch.zeros(2, ny, nx, 64, device="cuda")
+    vs = (ctypes.c_float * 3)(*args["voxel_size"])
+    rng = (ctypes.c_float * 6)(*args["lidar_range"])
+    _lib.check(_lib.lib.hmvit_pfn_scatter(vf.data_ptr(), vc.data_ptr(), vn.data_ptr(), w.data_ptr(), shift.data_ptr(),
+                                          canvas.data_ptr(), out.data_ptr(), vf.shape[0], nx, ny, vs, rng, 0, _stream()), "pfn")
+    assert rel_max_err(out.cpu(), g["pillar_features"]) < 1e-5
+    ref = PO.scatter(g["pillar_features"], vc.cpu(), 2, ny, nx)                 # (2, 64, ny, nx)
+    assert rel_max_err(canvas.permute(0, 3, 1, 2).cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("cin,cout,k,stride,pad,H,W", [(64, 64, 3, 2, 1, 20, 28), (128, 256, 3, 1, 1, 9, 7),
+                                                       (384, 256, 3, 2, 1, 10, 12), (256, 14, 1, 1, 0, 6, 5)])
+def test_conv2d(prec, cin, cout, k, stride, pad, H, W):
+    from hmvit_amd import _lib
+    torch.manual_seed(cin + cout)
+    dt = torch.float32 if prec == 0 else torch.float16
+    x = torch.randn(2, cin, H, W, device="cuda").to(dt)
+    w = (torch.randn(cout, cin, k, k, device="cuda") / (cin * k * k) ** 0.5).to(dt)
+    b = torch.randn(cout, device="cuda")
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), stride, pad))
+    Ho, Wo = ref.shape[-2:]
+    y = torch.empty(2, Ho, Wo, cout + 8, device="cuda", dtype=dt).fill_(7)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    wn = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    _lib.check(_lib.lib.hmvit_conv2d(xn.data_ptr(), wn.data_ptr(), b.data_ptr(), y.data_ptr(), 2, H, W, cin, cout, k,
+                                     stride, pad, 1, cout + 8, 3, 0, 0, prec, _stream()), "conv")
+    got = y[..., 3:3 + cout].permute(0, 3, 1, 2).double()
+    assert rel_max_err(got, ref) < (2e-6 if prec == 0 else 1.5e-3)
+    assert bool((y[..., :3] == 7).all()) and bool((y[..., 3 + cout:] == 7).all())   # channel window respected
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("s", [1, 2, 4])
+def test_deconv2d(prec, s):
+    from hmvit_amd import _lib
+    torch.manual_seed(s)
+    dt = torch.float32 if prec == 0 else torch.float16
+    cin, cout, H, W = 128, 128, 5, 6
+    x = torch.randn(2, cin, H, W, device="cuda").to(dt)
+    w = (torch.randn(cin, cout, s, s, device="cuda") / cin ** 0.5).to(dt)
+    b = torch.randn(cout, device="cuda")
+    ref = F.relu(F.conv_transpose2d(x.double(), w.double(), b.double(), s))
+    y = torch.empty(2, H * s, W * s, cout, device="cuda", dtype=dt)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    wn = w.permute(2, 3, 1, 0).reshape(s * s * cout, cin).contiguous()
+    _lib.check(_lib.lib.hmvit_conv2d(xn.data_ptr(), wn.data_ptr(), b.data_ptr(), y.data_ptr(), 2, H, W, cin, cout, 1, 1,
+                                     0, 1, cout, 0, s, 0, prec, _stream()), "deconv")
+    assert rel_max_err(y.permute(0, 3, 1, 2).double(), ref) < (2e-6 if prec == 0 else 1.5e-3)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_pointpillar_encoder_matches_golden(precision):
+    import hmvit_amd
+    g, args, sd, (vf, vc, vn) = _golden_inputs()
+    net = hmvit_amd.PointPillar(args, precision=precision)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    net.set_return_features()
+    batch = {"processed_lidar": {"voxel_features": vf.cuda(), "voxel_coords": vc.cuda(), "voxel_num_points": vn.cuda()}}
+    y = net(batch).cpu()
+    assert y.shape == g["out"].shape
+    assert rel_max_err(y, g["out"]) < TOL[precision]
+
+
+def test_pointpillar_heads_and_errors():
+    import hmvit_amd
+    g, args, sd, (vf, vc, vn) = _golden_inputs()
+    net = hmvit_amd.PointPillar(args, precision="f32")
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    batch = {"processed_lidar": {"voxel_features": vf.cuda(), "voxel_coords": vc.cuda(), "voxel_num_points": vn.cuda()}}
+    out = net(batch)
+    feats = PO.point_pillar_features(vf, vc, vn, sd, args, 2)
+    psm = F.conv2d(feats, sd["cls_head.weight"], sd["cls_head.bias"])
+    rm = F.conv2d(feats, sd["reg_head.weight"], sd["reg_head.bias"])
+    assert rel_max_err(out["psm"].cpu(), psm) < 1e-4 and rel_max_err(out["rm"].cpu(), rm) < 1e-4
+    with pytest.raises(RuntimeError):
+        net.train()(batch)
