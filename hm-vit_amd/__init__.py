@@ -4,5 +4,6 @@ directory name carries a hyphen)."""
 from . import _lib  # noqa: F401  (raises ImportError when libhmvit.so is not built)
 from .fusion import HeteroFusion, HeteroFusionBlock  # noqa: F401
 from .pointpillar import PointPillar  # noqa: F401
+from .decoder import HeteroDecoder  # noqa: F401
 
-__all__ = ["HeteroFusion", "HeteroFusionBlock", "PointPillar"]
+__all__ = ["HeteroFusion", "HeteroFusionBlock", "PointPillar", "HeteroDecoder"]

@@ -1,0 +1,115 @@
+"""Drop-in ``HeteroDecoder`` (detection tail) backed by libhmvit's implicit-GEMM convolution.
+
+Mirror of ``opencood/models/sub_modules/hetero_decoder.py:7-89`` (+ ``naive_decoder.py:7-92``): same params
+dict, ``forward(x, mode, use_upsample=False) -> (psm, rm)``, same ``state_dict`` keys.  Only the
+``use_upsample=False`` form the HM-ViT model uses (``bevformer_point_pillar_hetero.py:125``) is built.
+Eval mode only (BatchNorm folded); no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+from torch import nn
+
+from . import _lib
+
+_PREC = {"f32": _lib.PREC_F32, "f16": _lib.PREC_F16}
+
+
+class NaiveDecoder(nn.Module):
+    def __init__(self, params: dict):
+        super().__init__()
+        self.num_ch_dec, self.num_layer, self.input_dim = params["num_ch_dec"], params["num_layer"], params["input_dim"]
+        layers = []
+        for i in range(self.num_layer - 1, -1, -1):
+            cin = self.input_dim if i == self.num_layer - 1 else self.num_ch_dec[i + 1]
+            cout = self.num_ch_dec[i]
+            layers += [nn.Conv2d(cin, cout, 3, 1, 1), nn.BatchNorm2d(cout), nn.ReLU(True),
+                       nn.Conv2d(cout, cout, 3, 1, 1), nn.BatchNorm2d(cout), nn.ReLU(True)]
+        self.decoder = nn.ModuleList(layers)
+
+
+class HeteroDecoder(nn.Module):
+    def __init__(self, params: dict, precision: str = "f16"):
+        super().__init__()
+        dim = params["num_ch_dec"][0]
+        self.camera_decoder = NaiveDecoder(params)
+        self.lidar_decoder = NaiveDecoder(params)
+        self.camera_cls_head = nn.Conv2d(dim, params["anchor_number"], kernel_size=1)
+        self.camera_reg_head = nn.Conv2d(dim, 7 * params["anchor_number"], kernel_size=1)
+        self.lidar_cls_head = nn.Conv2d(dim, params["anchor_number"], kernel_size=1)
+        self.lidar_reg_head = nn.Conv2d(dim, 7 * params["anchor_number"], kernel_size=1)
+        self.precision = precision
+        self._prep, self._prep_key = None, None
+
+    def _prepare(self, device, prec):
+        tensors = list(self.parameters()) + list(self.buffers())
+        key = (prec, str(device)) + tuple((t.data_ptr(), t._version) for t in tensors)
+        if key == self._prep_key:
+            return self._prep
+        dt = torch.float32 if prec == _lib.PREC_F32 else torch.float16
+
+        def conv(c, bn=None):
+            w, b = c.weight.detach().float(), c.bias.detach().float()
+            if bn is not None:
+                s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+                w, b = w * s[:, None, None, None], (b - bn.running_mean.detach().float()) * s + bn.bias.detach().float()
+            return dict(w=w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous(), b=b.contiguous(),
+                        cin=w.shape[1], cout=w.shape[0], k=w.shape[2], pad=c.padding[0])
+
+        prep = {}
+        for t, name in ((0, "camera"), (1, "lidar")):
+            dec = getattr(self, f"{name}_decoder").decoder
+            prep[t] = {"convs": [conv(dec[i], dec[i + 1]) for i in range(0, len(dec), 3)],
+                       "cls": conv(getattr(self, f"{name}_cls_head")), "reg": conv(getattr(self, f"{name}_reg_head"))}
+        self._prep, self._prep_key = prep, key
+        return prep
+
+    def forward(self, x, mode, use_upsample=True):
+        if use_upsample:
+            raise NotImplementedError("HeteroDecoder: only use_upsample=False (the HM-ViT path) is built")
+        if x.device.type != "cuda":
+            raise RuntimeError("hm-vit_amd runs on the GPU only (HIP kernels, no CPU fallback)")
+        if self.training:
+            raise RuntimeError("hmvit_amd.HeteroDecoder folds BatchNorm statistics: call .eval() (inference only)")
+        B, L1, C, H, W = x.shape
+        ego = [int(v) for v in (mode[:, 0].tolist() if mode.device.type == "cpu" else mode[:, 0].cpu().tolist())]
+        for v in ego:
+            if v not in (0, 1):
+                raise ValueError(f"Mode but be either 1 or 0 but received {v}")
+        dev = x.device
+        prec = _PREC[self.precision]
+        dt = torch.float32 if prec == _lib.PREC_F32 else torch.float16
+        prep = self._prepare(dev, prec)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        A = self.camera_cls_head.out_channels
+        psm = torch.empty(B, A, H, W, device=dev, dtype=torch.float32)
+        rm = torch.empty(B, 7 * A, H, W, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            for t in (0, 1):
+                idx = [b for b in range(B) if ego[b] == t]
+                if not idx:
+                    continue
+                n = len(idx)
+                xin = x[idx, 0].detach().float().contiguous()                    # (n, C, H, W)
+                tok = torch.empty(n, H, W, C, device=dev, dtype=torch.float32)
+                _lib.check(_lib.lib.hmvit_nchw_to_tokens(xin.data_ptr(), tok.data_ptr(), n, C, H * W, stream), "nchw_to_tokens")
+                cur = tok.to(dt)
+                for layer in prep[t]["convs"]:
+                    y = torch.empty(n, H, W, layer["cout"], device=dev, dtype=dt)
+                    _lib.check(_lib.lib.hmvit_conv2d(cur.data_ptr(), layer["w"].data_ptr(), layer["b"].data_ptr(),
+                                                     y.data_ptr(), n, H, W, layer["cin"], layer["cout"], layer["k"], 1,
+                                                     layer["pad"], 1, layer["cout"], 0, 0, 0, prec, stream), "conv2d")
+                    cur = y
+                for head, dst in (("cls", psm), ("reg", rm)):
+                    layer = prep[t][head]
+                    y = torch.empty(n, H, W, layer["cout"], device=dev, dtype=torch.float32)
+                    _lib.check(_lib.lib.hmvit_conv2d(cur.data_ptr(), layer["w"].data_ptr(), layer["b"].data_ptr(),
+                                                     y.data_ptr(), n, H, W, layer["cin"], layer["cout"], 1, 1, 0, 0,
+                                                     layer["cout"], 0, 0, 1, prec, stream), "conv2d(head)")
+                    out = torch.empty(n, layer["cout"], H, W, device=dev, dtype=torch.float32)
+                    _lib.check(_lib.lib.hmvit_tokens_to_nchw(y.data_ptr(), out.data_ptr(), n, layer["cout"], H * W, stream),
+                               "tokens_to_nchw")
+                    dst[idx] = out
+        return psm, rm

@@ -17,6 +17,7 @@ What is frozen:
                         window 4 -- output sub-sampled (every 5th row / 11th col) + moments.
   g7_pointpillar.npz    PointPillar.forward (features only, eval BN): 2 agents x 400 pillars on a
                         64x48 canvas; PFN output + (2, 256, 12, 16) BEV features.
+  g8_decoder.npz        HeteroDecoder.forward (no upsample), 3 samples with ego types 1,0,1, 12x10.
 
 Weights and inputs are NOT stored where they can be regenerated bit-exactly from a numpy
 legacy RandomState seed (oracle.hmvit_oracle.random_state_dict / synthetic_scene); the
@@ -54,6 +55,7 @@ from opencood.models.sub_modules.torch_transformation_utils import (  # noqa: E4
 
 from oracle import hmvit_oracle as O  # noqa: E402  (only for the seeded input generators)
 from oracle import pointpillar_oracle as PO  # noqa: E402  (seeded pillars / weights)
+from oracle import decoder_oracle as DO  # noqa: E402  (seeded weights)
 
 torch.set_grad_enabled(False)
 
@@ -202,7 +204,21 @@ def g7_pointpillar():
          n_per_agent=np.array(400), pillar_features=pf, out=y)
 
 
+def g8_decoder():
+    """HeteroDecoder.forward (use_upsample=False), eval-mode BN, B=3 with ego types 1, 0, 1."""
+    from opencood.models.sub_modules.hetero_decoder import HeteroDecoder
+    params = DO.make_params()
+    net = HeteroDecoder(params).eval()
+    net.load_state_dict(DO.random_state_dict(params, seed=81), strict=True)
+    rs = np.random.RandomState(82)
+    x = torch.from_numpy(rs.standard_normal((3, 1, 256, 12, 10)).astype(np.float32))
+    mode = torch.tensor([[1, 0], [0, 1], [1, 1]])
+    psm, rm = net(x, mode, use_upsample=False)
+    save("g8_decoder.npz", seed_weights=81, seed_x=82, mode=mode, psm=psm, rm=rm)
+
+
 if __name__ == "__main__":
+    g8_decoder()
     g7_pointpillar()
     g1_attention()
     g2_warp()

@@ -115,3 +115,21 @@ def test_pointpillar_heads_and_errors():
     assert rel_max_err(out["psm"].cpu(), psm) < 1e-4 and rel_max_err(out["rm"].cpu(), rm) < 1e-4
     with pytest.raises(RuntimeError):
         net.train()(batch)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_hetero_decoder_matches_golden(precision):
+    import numpy as np
+    import hmvit_amd
+    from oracle import decoder_oracle as DO
+    g = load_golden("g8_decoder.npz")
+    params = DO.make_params()
+    net = hmvit_amd.HeteroDecoder(params, precision=precision)
+    net.load_state_dict(DO.random_state_dict(params, g["seed_weights"]), strict=True)
+    net = net.cuda().eval()
+    x = torch.from_numpy(np.random.RandomState(int(g["seed_x"])).standard_normal((3, 1, 256, 12, 10)).astype(np.float32))
+    psm, rm = net(x.cuda(), g["mode"].cuda(), use_upsample=False)
+    assert rel_max_err(psm.cpu(), g["psm"]) < TOL[precision]
+    assert rel_max_err(rm.cpu(), g["rm"]) < TOL[precision]
+    with pytest.raises(NotImplementedError):
+        net(x.cuda(), g["mode"].cuda())

@@ -92,3 +92,14 @@ def test_g7_pointpillar_encoder():
     y = PO.point_pillar_features(vf, vc, vn, sd, args, int(g["n_agents"]))
     assert y.shape == g["out"].shape
     assert rel_max_err(y, g["out"]) < TOL
+
+
+def test_g8_hetero_decoder():
+    import numpy as np
+    from oracle import decoder_oracle as DO
+    g = load_golden("g8_decoder.npz")
+    params = DO.make_params()
+    sd = DO.random_state_dict(params, g["seed_weights"])
+    x = torch.from_numpy(np.random.RandomState(int(g["seed_x"])).standard_normal((3, 1, 256, 12, 10)).astype(np.float32))
+    psm, rm = DO.hetero_decoder(x, g["mode"], sd, params)
+    assert rel_max_err(psm, g["psm"]) < TOL and rel_max_err(rm, g["rm"]) < TOL
