@@ -5,5 +5,6 @@ from . import _lib  # noqa: F401  (raises ImportError when libhmvit.so is not bu
 from .fusion import HeteroFusion, HeteroFusionBlock  # noqa: F401
 from .pointpillar import PointPillar  # noqa: F401
 from .decoder import HeteroDecoder  # noqa: F401
+from .model import BevformerPointPillarHetero  # noqa: F401
 
-__all__ = ["HeteroFusion", "HeteroFusionBlock", "PointPillar", "HeteroDecoder"]
+__all__ = ["HeteroFusion", "HeteroFusionBlock", "PointPillar", "HeteroDecoder", "BevformerPointPillarHetero"]

@@ -18,6 +18,8 @@ What is frozen:
   g7_pointpillar.npz    PointPillar.forward (features only, eval BN): 2 agents x 400 pillars on a
                         64x48 canvas; PFN output + (2, 256, 12, 16) BEV features.
   g8_decoder.npz        HeteroDecoder.forward (no upsample), 3 samples with ego types 1,0,1, 12x10.
+  g9_model.npz          BevformerPointPillarHetero.forward, LiDAR-only batch B=2, record_len [3,2]:
+                        pillars -> PointPillar -> regroup -> HeteroFusion -> HeteroDecoder -> psm / rm.
 
 Weights and inputs are NOT stored where they can be regenerated bit-exactly from a numpy
 legacy RandomState seed (oracle.hmvit_oracle.random_state_dict / synthetic_scene); the
@@ -34,6 +36,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
 sys.path.insert(0, "/root/reference")
 
 
@@ -56,6 +59,7 @@ from opencood.models.sub_modules.torch_transformation_utils import (  # noqa: E4
 from oracle import hmvit_oracle as O  # noqa: E402  (only for the seeded input generators)
 from oracle import pointpillar_oracle as PO  # noqa: E402  (seeded pillars / weights)
 from oracle import decoder_oracle as DO  # noqa: E402  (seeded weights)
+from model_fixture import model_batch, model_config, model_state_dict  # noqa: E402
 
 torch.set_grad_enabled(False)
 
@@ -204,6 +208,28 @@ def g7_pointpillar():
          n_per_agent=np.array(400), pillar_features=pf, out=y)
 
 
+def g9_model():
+    """BevformerPointPillarHetero.forward on a LiDAR-only batch (the camera branch is never entered;
+    BEVFormerWrapper is replaced by an empty module so that the reference class can be constructed)."""
+    import opencood.models.bevformer_point_pillar_hetero as M
+
+    class NoCamera(torch.nn.Module):
+        def __init__(self, cfg):
+            super().__init__()
+
+        def set_return_features(self):
+            pass
+
+    M.BEVFormerWrapper = NoCamera
+    cfg = model_config()
+    net = M.BevformerPointPillarHetero(cfg).eval()
+    sd = model_state_dict(cfg, 91)
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    out = net(model_batch(cfg, 95))
+    save("g9_model.npz", seed_weights=91, seed_batch=95, psm=out["psm"], rm=out["rm"])
+
+
 def g8_decoder():
     """HeteroDecoder.forward (use_upsample=False), eval-mode BN, B=3 with ego types 1, 0, 1."""
     from opencood.models.sub_modules.hetero_decoder import HeteroDecoder
@@ -218,6 +244,7 @@ def g8_decoder():
 
 
 if __name__ == "__main__":
+    g9_model()
     g8_decoder()
     g7_pointpillar()
     g1_attention()
