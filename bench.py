@@ -185,6 +185,10 @@ def main():
             cnt = runs[0][name][1]
             if cnt:
                 phases[name] = {"ms_total": round(ms, 4), "launches": cnt}
+        if "out_proj" not in phases and "ffn2" in phases:
+            # f16 mode: one fused kernel per stage does out-proj + LayerNorm + FFN (reported as "ffn2"),
+            # and LayerNorm + Q/K/V projections run as "qkv_gemm"
+            work["ffn2"] = ("mfma", work["out_proj"][1] + work["ffn1"][1] + work["ffn2"][1])
         dom = max(phases, key=lambda k: phases[k]["ms_total"])
         kind, per_launch = work[dom]
         avg_s = phases[dom]["ms_total"] / phases[dom]["launches"] * 1e-3
@@ -192,10 +196,25 @@ def main():
             achieved, peak, unit = per_launch / avg_s / 1e12, PEAK[args.precision], "TFLOP/s"
         else:
             achieved, peak, unit = per_launch / avg_s / 1e9, PEAK_HBM, "GB/s"
+        # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC pass of the same command
+        # (FETCH_SIZE with the gfx950 x2 wide-read correction + WRITE_SIZE; profiles/pmc_traffic.json is
+        # written by tools/pmc_traffic.py from that pass; null when it has not been collected)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath) and args.config == "cfg2" and args.precision == "f16":
+            traffic = json.load(open(tpath)).get(dom)
         result["roofline"] = {"kernel": dom, "bound": kind, "achieved": achieved, "peak": peak, "unit": unit,
-                              "frac": achieved / peak, "traffic": None,
+                              "frac": achieved / peak, "traffic": traffic,
                               "avg_launch_ms": avg_s * 1e3,
                               "algorithmic_per_launch": per_launch}
+        if dom == "attention":
+            # the same kernel against the HBM roof: compulsory bytes = Q in + every K'/V' map once + O out
+            L_, C_, P_ = c["L"], c["C"], c["H"] * c["W"]
+            n_st = 2 * args.num_iters
+            comp = ((n_st - 1) * (L_ * P_ * C_ * es * 2 + L_ * 2 * P_ * C_ * es) +
+                    (P_ * C_ * es * 2 + L_ * 2 * P_ * C_ * es)) / n_st
+            result["roofline"]["hbm_view"] = {"algorithmic_bytes_per_launch": comp, "achieved_GBps": comp / avg_s / 1e9,
+                                              "peak_GBps": PEAK_HBM, "frac": comp / avg_s / 1e9 / PEAK_HBM}
         result["phases"] = phases
         if not args.no_strict and world == 1 and args.precision == "f16":
             del net
