@@ -38,7 +38,7 @@ def bench(tag, dbg):
     print(f"{tag:40s} dbg={dbg:#04x}  {e0.elapsed_time(e1) / 5:.3f} ms", flush=True)
 
 for tag, dbg in [("baseline 16 waves (8 compute + 8 loader)", 0), ("8 waves (4 + 4)", 2), ("1 tap (all visible)", 0x10), ("no loads (all masked)", 0x20),
-                 ("no compute", 0x40), ("no blend (4 taps loaded)", 0x80), ("ego-interleaved item order", 0x200), ("L2-resident region", 0x400), ("L2-resident + 1 tap", 0x410), ("1 tap + no compute", 0x50),
+                 ("no compute", 0x40), ("no blend (4 taps loaded)", 0x80), ("ego-major item order (old)", 0x200), ("no loader priority", 0x800), ("L2-resident region", 0x400), ("L2-resident + 1 tap", 0x410), ("1 tap + no compute", 0x50),
                  ("no loads + no compute", 0x60)]:
     bench(tag, dbg)
 
