@@ -323,13 +323,13 @@ __global__ __launch_bounds__(HG * 64, (sizeof(T) == 2 ? 2 : 1)) void k_attention
                 const float m_new = fmaxf(m_run[qt], mx);
                 const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
                 float alpha, rs = 0.f;
-                if constexpr (F16) alpha = __expf(m_run[qt] - m_safe); else alpha = expf(m_run[qt] - m_safe);
+                if constexpr (F16) alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_safe); else alpha = expf(m_run[qt] - m_safe);   // f16 mode: logits are in log2 units
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float e;
-                        if constexpr (F16) e = __expf(s[kt][r] - m_safe); else e = expf(s[kt][r] - m_safe);
+                        if constexpr (F16) e = __builtin_amdgcn_exp2f(s[kt][r] - m_safe); else e = expf(s[kt][r] - m_safe);
                         s[kt][r] = e;
                         rs += e;
                     }
@@ -655,8 +655,11 @@ __device__ __forceinline__ void pc_gather(const AttnParams& p, PcShared<HG, CW, 
         if ((ltid % TPK) == 0) sm.maskadd[kvbuf][kk] = visible[pass] ? 0.f : -INFINITY;
         any |= visible[pass];
     }
-    const bool wave_any = __any(any);
-    if (lane == 0) sm.vis[kvbuf][lw] = wave_any ? 1 : 0;
+    bool allv = true;
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) allv &= visible[pass];
+    const bool wave_any = __any(any), wave_all = __all(allv);
+    if (lane == 0) sm.vis[kvbuf][lw] = (wave_any ? 1 : 0) | (wave_all ? 2 : 0);   // bit 0: some key visible, bit 1: all
 }
 
 // per-workgroup tables: affine records, and the biases of the head group this workgroup serves
@@ -732,8 +735,9 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
     float4v biasf[7];
     int bias_head = -1;
     half8 qh[NQW];
-    float m_run[NQW], l_run[NQW];
-    float4v o_acc[NQW][2];
+    float m_run[NQW];
+    float4v o_acc[NQW][2], l_acc[NQW];
+    const half8 ones = (half8)(half_t)1.0f;
     int gstep = 0, qi = 0;
     while (true) {
         const PcItem it = pc_decode(item, p.n_ego, X, Y, NG, (p.variant & 0x200) == 0);
@@ -753,21 +757,29 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
                 for (int qt = 0; qt < NQW; ++qt) {
                     qh[qt] = *reinterpret_cast<const half8*>(sm.Qs[qi] + ((qbase + qt) * 16 + lq) * QS + hl * 32 + g * 8);
                     m_run[qt] = -INFINITY;
-                    l_run[qt] = 0.f;
+                    l_acc[qt] = (float4v)(0.f);
                     o_acc[qt][0] = (float4v)(0.f);
                     o_acc[qt][1] = (float4v)(0.f);
                 }
             }
-            int vis_or = 0;
+            int vis_or = 0, vis_and = 3;
 #pragma unroll
-            for (int w = 0; w < LWG; ++w) vis_or |= sm.vis[buf][w];
-            const bool any_visible = vis_or != 0;
+            for (int w = 0; w < LWG; ++w) {
+                vis_or |= sm.vis[buf][w];
+                vis_and &= sm.vis[buf][w];
+            }
+            const bool any_visible = (vis_or & 1) != 0;
+            const bool all_visible = (vis_and & 2) != 0;     // no key of the chunk is masked: skip the mask add
             if ((any_visible || !p.skip_masked) && !(p.variant & 0x40)) {
                 const half_t* Kb = sm.Ks[buf];
                 const half_t* Vb = sm.Vs[buf];
                 float4v madd[4];
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt) madd[kt] = *reinterpret_cast<const float4v*>(sm.maskadd[buf] + kt * 16 + 4 * g);
+                for (int kt = 0; kt < 4; ++kt) madd[kt] = (float4v)(0.f);
+                if (!all_visible) {
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt) madd[kt] = *reinterpret_cast<const float4v*>(sm.maskadd[buf] + kt * 16 + 4 * g);
+                }
                 half8 kh[4], vh[2][2];
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
@@ -799,7 +811,11 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
                             bias_c = *reinterpret_cast<const float4v*>(sm.biasf + ((hl * 7 + (qbase + qt - kt + 3)) * 64 + lane) * 4);
                         else
                             bias_c = biasf[qt - kt + 3];
-                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[kt], qh[qt], bias_c, 0, 0, 0) + madd[kt];
+                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[kt], qh[qt], bias_c, 0, 0, 0);
+                    }
+                    if (!all_visible) {
+#pragma unroll
+                        for (int kt = 0; kt < 4; ++kt) s[kt] += madd[kt];
                     }
                     float mx = -INFINITY;
 #pragma unroll
@@ -810,22 +826,16 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
                     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                     const float m_new = fmaxf(m_run[qt], mx);
                     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-                    const float alpha = __expf(m_run[qt] - m_safe);
-                    float rs = 0.f;
+                    // logits are in log2 units (log2 e folded into W_q and the bias fragments on the host)
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_safe);
 #pragma unroll
                     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float e = __expf(s[kt][r] - m_safe);
-                            s[kt][r] = e;
-                            rs += e;
-                        }
-                    rs += __shfl_xor(rs, 16, 64);
-                    rs += __shfl_xor(rs, 32, 64);
-                    l_run[qt] = l_run[qt] * alpha + rs;
+                        for (int r = 0; r < 4; ++r) s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - m_safe);
                     m_run[qt] = m_new;
                     o_acc[qt][0] *= alpha;
                     o_acc[qt][1] *= alpha;
+                    l_acc[qt] *= alpha;
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         half8 ph;
@@ -837,6 +847,9 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
 #pragma unroll
                         for (int dt = 0; dt < 2; ++dt)
                             o_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dt][ks], ph, o_acc[qt][dt], 0, 0, 0);
+                        // softmax denominator on the matrix core: an all-ones "V^T" tile makes every
+                        // accumulator row the sum over keys of (the f16-rounded) P for this lane's query
+                        l_acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, ph, l_acc[qt], 0, 0, 0);
                     }
                 }
             }
@@ -847,7 +860,7 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
                 for (int qt = 0; qt < NQW; ++qt) {
                     int row, col;
                     token_pixel(p.partition, 8, X, Y, it.wx, it.wy, (qbase + qt) * 16 + lq, row, col);
-                    const float inv = 1.f / l_run[qt];
+                    const float inv = 1.f / l_acc[qt][0];
                     half_t* o = outp + (size_t)(row * W + col) * C + head * 32 + 4 * g;
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) {

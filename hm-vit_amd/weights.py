@@ -82,7 +82,10 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
     f = lambda k: sd[k].detach().float()
     C = f(f"{att}.q_linears.0.weight").shape[0]
     M = C // dim_head
-    scale = dim_head ** -0.5
+    f16 = dtype == torch.float16
+    # f16 kernels evaluate the softmax with exp2: log2(e) rides on the q scale and on the position bias
+    LOG2E = 1.4426950408889634
+    scale = dim_head ** -0.5 * (LOG2E if f16 else 1.0)
     rel_att = f(f"{att}.relation_att")     # (4, M, d, d) [e, h, p, q]
     rel_msg = f(f"{att}.relation_msg")
 
@@ -90,7 +93,6 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
     stack = lambda fmt: torch.stack([f(fmt.format(t=t)) for t in range(NUM_TYPES)])
     out["ln_gamma"] = stack(f"{prefix}{which}_norm.net.{{t}}.weight")
     out["ln_beta"] = stack(f"{prefix}{which}_norm.net.{{t}}.bias")
-    f16 = dtype == torch.float16
     per_type = lambda m, fn: torch.stack([fn(m[t]) for t in range(NUM_TYPES)])
     w_q = stack(f"{att}.q_linears.{{t}}.weight") * scale
     if f16:
@@ -117,7 +119,7 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
     else:
         out["w_kv"] = w_kv
     out["b_kv"] = b_kv
-    out["bias_frag"] = bias_fragments(sd[f"{att}.relative_position_bias_table.weight"], window)
+    out["bias_frag"] = bias_fragments(sd[f"{att}.relative_position_bias_table.weight"], window) * (LOG2E if f16 else 1.0)
     w_o = stack(f"{att}.a_linears.{{t}}.0.weight")
     if f16:
         out["img_o"] = per_type(w_o, weight_image)

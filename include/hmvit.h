@@ -46,6 +46,8 @@ extern "C" {
  * f16 according to the precision mode, except where noted.  All device pointers.
  *   ln_*      (T, C)            f32   HeteroLayerNorm affine, base_transformer.py:172-177
  *   w_q       (T, C, C)               q_linears[t].weight * dim_head^-0.5, hetero_fusion.py:111-140,217
+ *                                     (f16 mode: w_q, b_q and bias_frag additionally carry log2(e): the
+ *                                     f16 kernels evaluate the softmax with exp2)
  *   b_q       (T, C)            f32   q_linears[t].bias   * dim_head^-0.5
  *   w_kv      (T_ego, T_src, 2C, C)   rows [0,C): blockdiag_h(relation_att[e,h]) k_linears[ts].weight
  *                                     rows [C,2C): blockdiag_h(relation_msg[e,h]^T) v_linears[ts].weight,
