@@ -98,19 +98,53 @@ __device__ __forceinline__ float gelu_f(float x) {
     return x * phi;
 }
 
-// one chunk = KK fragments; DEPTH of them are read ahead of the MFMA that consumes them
+// One chunk = KK weight fragments.  hipcc re-serialises a source-level prefetch into
+// "ds_read x2, wait, mfma, wait, mfma" (it minimises registers), exposing the LDS latency on every
+// pair of MFMAs; the reads are therefore issued from inline asm (invisible to its scheduler) DEPTH
+// ahead of their MFMA, with hand-counted s_waitcnt lgkmcnt and a sched_barrier after every wait so that
+// no compiler instruction (in particular no SMEM load, which shares the counter and returns out of
+// order) can move into the counted region.
+template <int OFF>
+__device__ __forceinline__ void lds_read_frag(half8& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N));
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int KK, int DEPTH, int kk = 0>
+struct MmaSteps {
+    static __device__ __forceinline__ void run(float16v& acc, unsigned addr, const half8 (&act)[KK], half8 (&w)[DEPTH]) {
+        constexpr int outstanding = (KK - kk - 1) < (DEPTH - 1) ? (KK - kk - 1) : (DEPTH - 1);
+        lgkm_wait<outstanding>();
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[kk % DEPTH], act[kk], acc, 0, 0, 0);
+        if constexpr (kk + DEPTH < KK) {
+            __builtin_amdgcn_sched_barrier(0);
+            lds_read_frag<(kk + DEPTH) * 1024>(w[kk % DEPTH], addr);
+        }
+        if constexpr (kk + 1 < KK) MmaSteps<KK, DEPTH, kk + 1>::run(acc, addr, act, w);
+    }
+};
+template <int DEPTH, int i = 0>
+struct MmaPrologue {
+    static __device__ __forceinline__ void run(unsigned addr, half8 (&w)[DEPTH]) {
+        lds_read_frag<i * 1024>(w[i], addr);
+        if constexpr (i + 1 < DEPTH) MmaPrologue<DEPTH, i + 1>::run(addr, w);
+    }
+};
+
 template <int KK, int DEPTH>
 __device__ __forceinline__ void mma_chunk(float16v& acc, const half_t* buf, const half8 (&act)[KK], int lane) {
-    static_assert(KK % DEPTH == 0, "");
-    const half_t* base = buf + lane * 8;
+    static_assert(KK % DEPTH == 0 && DEPTH <= 15, "");
+    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)(buf + lane * 8);
     half8 w[DEPTH];
-#pragma unroll
-    for (int i = 0; i < DEPTH; ++i) w[i] = *reinterpret_cast<const half8*>(base + i * 512);
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[kk % DEPTH], act[kk], acc, 0, 0, 0);
-        if (kk + DEPTH < KK) w[kk % DEPTH] = *reinterpret_cast<const half8*>(base + (kk + DEPTH) * 512);
-    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // nothing of the compiler's in the LGKM queue
+    __builtin_amdgcn_sched_barrier(0);
+    MmaPrologue<DEPTH>::run(addr, w);
+    MmaSteps<KK, DEPTH>::run(acc, addr, act, w);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 __device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
