@@ -454,12 +454,12 @@ struct PcShared {
     float bkv[HMVIT_NUM_TYPES * HMVIT_NUM_TYPES][2][CH];   // folded k / v biases of this head group
     float bq[HMVIT_NUM_TYPES][CH];
     int mode[kMaxSlots], cav[kMaxSlots], ego_e[kMaxSlots];   // copies of the kernel-argument byte arrays
-    // per loader wave: bilinear taps of its 16 keys (computed once, lane = key)
-    int tidx[LWG][NK][4];
-    float tw[LWG][NK][4];
-    int tself[LWG][NK];
-    int tvis[LWG][NK];
-    int gcount;                                // gather counter (debug trace only)
+    // per loader wave: bilinear taps of its NK keys for TG consecutive chunks, computed in one
+    // shot (lane = (chunk, key)); a tap that needs no load (zero weight, masked key) has index -1
+    static constexpr int TG = 4;
+    int tidx[LWG][TG][NK][4];
+    float tw[LWG][TG][NK][4];
+    int tvis[LWG][TG][NK];
     float biasf[BIAS_LDS ? HG * 7 * 256 : 4];  // [head][variant][lane][4], accumulator order
 };
 
@@ -473,193 +473,110 @@ __device__ __forceinline__ int pc_src(int c, int ego) { return c == 0 ? ego : (c
             p.trace[(iter) * 8 + (slot)] = __builtin_readcyclecounter();                        \
     } while (0)
 
-// 16 bytes of a projected map through a buffer descriptor: 32-bit byte offset per lane, plane
-// selected by the scalar offset (K' and V' share the lane offsets)
-__device__ __forceinline__ half8 buf_load8(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+// 16 bytes of a projected map through a STRUCTURED buffer descriptor (record = the C channels of
+// one token): the address base + soffset + index * stride + offset is formed by the texture
+// addresser, so a tap costs the loader no VALU instruction, and an index outside [0, tokens) - the
+// tables use -1 - returns zeros (range check probed on gfx950 in tools/probe/sbuf_probe.hip).
+// hipcc has no builtin for the idxen form; the LLVM intrinsic is bound by name.
+typedef int int4v __attribute__((ext_vector_type(4)));
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+__device__ uint4v llvm_struct_buffer_load_b128(int4v rsrc, int vindex, int voffset, int soffset, int aux) __asm(
+    "llvm.amdgcn.struct.buffer.load.v4i32");
+
+__device__ __forceinline__ int4v token_rsrc(const void* base, int stride_bytes, int n_tokens) {
+    const unsigned long long a = (unsigned long long)base;
+    int4v rs;
+    rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    rs.y = __builtin_amdgcn_readfirstlane((int)(((unsigned)(a >> 32) & 0xffffu) | ((unsigned)stride_bytes << 16)));
+    rs.z = n_tokens;
+    rs.w = 0x00020000;
+    return rs;
+}
+__device__ __forceinline__ half8 tok_load8(int4v rs, int token, int off_bytes, int soff) {
+    return __builtin_bit_cast(half8, llvm_struct_buffer_load_b128(rs, token, off_bytes, soff, 0));
 }
 
-// Gather one 64-key chunk of K'/V' (and, with WITH_Q, the query tile of the same item) into LDS.
-// Instruction diet (the loader is issue-bound): the bilinear taps of a key are computed once per
-// wave (lane = key) and redistributed through LDS instead of 16x redundantly; loads go through
-// buffer descriptors with 32-bit offsets; the folded bias is the addend of the first blend FMA.
-// Every global load of the call is issued before the first value is used.
-template <int HG, int CW, int LWX, bool WITH_Q>
-__device__ __forceinline__ void pc_gather(const AttnParams& p, PcShared<HG, CW, LWX>& sm, const PcItem& it, int chunk, int kvbuf,
-                                          int qbuf, int lw, int ltid) {
-    using SM = PcShared<HG, CW, LWX>;
-    constexpr int QS = SM::QS, KS = SM::KS, VS = SM::VS, CH = SM::CH, TPK = SM::TPK, KPW = SM::KPW, NK = SM::NK, NP = SM::NP, KPP = SM::KPP;
-    const int C = p.C, H = p.H, W = p.W, L = p.L, P = H * W, X = H / 8, Y = W / 8;
+// wave-uniform description of one gather = (work item, key chunk)
+struct PcGather {
+    PcItem it;
+    int4v rs_kv, rs_q;
+    int chunk, kvbuf, qbuf, te, tsel;
+    bool valid, q_ident;
+};
+
+template <int HG, int CW, int LWX>
+__device__ __forceinline__ PcGather pc_describe(const AttnParams& p, const PcShared<HG, CW, LWX>& sm, const PcItem& it, int chunk,
+                                                int g, int qi, bool valid) {
+    constexpr int CH = PcShared<HG, CW, LWX>::CH;
+    const int L = p.L, P = p.H * p.W, C = p.C;
+    PcGather G;
+    G.it = it; G.chunk = chunk; G.kvbuf = g & 1; G.qbuf = qi; G.valid = valid;
     const int src = pc_src(chunk, it.ego);
-    const float* a = sm.ainv + ((it.b * L + src) * L + it.ego) * 8;
-    const int dbg = p.variant;
-    const bool ident = (a[6] != 0.f) || (dbg & 0x10);
-    const bool cav = (sm.cav[it.b * L + src] != 0) && !(dbg & 0x20);
     const int te = __builtin_amdgcn_readfirstlane(sm.mode[it.b * L + it.ego]);
     const int ts = __builtin_amdgcn_readfirstlane(sm.mode[it.b * L + src]);
     const int ev = __builtin_amdgcn_readfirstlane(sm.ego_e[it.b * L + it.ego]);
-    const unsigned plane_bytes = (unsigned)P * C * 2;
+    G.te = te; G.tsel = te * HMVIT_NUM_TYPES + ts;
     const half_t* kpl = reinterpret_cast<const half_t*>(p.kv) + ((size_t)((it.b * L + src) * p.E + ev) * 2) * P * C + it.hg * CH;
-    const __amdgpu_buffer_rsrc_t rs_kv = __builtin_amdgcn_make_buffer_rsrc((void*)kpl, 0, 0x7fffffff, 0x00020000);
-    const int lane = ltid & 63;
-    const int cl = (ltid % TPK) * 8;
-    const int kin = ltid / TPK;                  // key row of this lane inside a KPP-key pass
-    const unsigned cl_bytes = cl * 2;
-    const unsigned row_bytes = (unsigned)C * 2;
+    const half_t* qpl = reinterpret_cast<const half_t*>(p.q) + (size_t)(it.b * L + it.ego) * P * C + it.hg * CH;
+    G.rs_kv = token_rsrc(kpl, C * 2, P);
+    G.rs_q = token_rsrc(qpl, C * 2, P);
+    G.q_ident = __builtin_amdgcn_readfirstlane(__float_as_int(sm.ainv[((it.b * L + it.ego) * L + it.ego) * 8 + 6])) != 0;
+    return G;
+}
 
-    // ---- taps: lane j < NK of loader wave lw owns key (j / KPW) * KPP + KPW lw + (j % KPW) ----
-    {
-        const int j = lane % NK;
-        const int n = (j / KPW) * KPP + KPW * lw + (j % KPW);
-        int row, col;
-        token_pixel(p.partition, 8, X, Y, it.wx, it.wy, n, row, col);
-        Taps t;
-        if (ident) {
-            t.idx[0] = t.idx[1] = t.idx[2] = t.idx[3] = row * W + col;
-            t.w[0] = 1.f; t.w[1] = t.w[2] = t.w[3] = 0.f;
-            t.roi = 1.f;
-        } else {
-            t = make_taps(a, col, row, H, W);
-        }
-        if (lane < NK) {
-            *reinterpret_cast<int4*>(sm.tidx[lw][j]) = make_int4(t.idx[0], t.idx[1], t.idx[2], t.idx[3]);
-            *reinterpret_cast<float4*>(sm.tw[lw][j]) = make_float4(t.w[0], t.w[1], t.w[2], t.w[3]);
-            sm.tself[lw][j] = row * W + col;
-            sm.tvis[lw][j] = (cav && t.roi != 0.f) ? 1 : 0;
+// Bilinear taps of this loader wave's keys for chunks [chunk0, chunk0 + TG) of one item.
+template <int HG, int CW, int LWX>
+__device__ __forceinline__ void pc_taps(const AttnParams& p, PcShared<HG, CW, LWX>& sm, const PcItem& it, int chunk0, int lw, int lane) {
+    using SM = PcShared<HG, CW, LWX>;
+    constexpr int KPW = SM::KPW, NK = SM::NK, KPP = SM::KPP, TG = SM::TG;
+    const int H = p.H, W = p.W, L = p.L, X = H / 8, Y = W / 8;
+    const int dbg = p.variant;
+#pragma unroll
+    for (int base = 0; base < TG * NK; base += 64) {
+        const int e = base + lane;
+        const int c = e / NK, j = e % NK;
+        const int chunk = chunk0 + c;
+        if (e < TG * NK && chunk < p.n_src) {
+            const int src = pc_src(chunk, it.ego);
+            const float* a = sm.ainv + ((it.b * L + src) * L + it.ego) * 8;
+            const int n = (j / KPW) * KPP + KPW * lw + (j % KPW);
+            int row, col;
+            token_pixel(p.partition, 8, X, Y, it.wx, it.wy, n, row, col);
+            const bool cav = (sm.cav[it.b * L + src] != 0) && !(dbg & 0x20);
+            int ix[4];
+            float w[4];
+            bool vis;
+            if ((a[6] != 0.f) || (dbg & 0x10)) {   // identity map: the key's own pixel
+                ix[0] = row * W + col; ix[1] = ix[2] = ix[3] = -1;
+                w[0] = 1.f; w[1] = w[2] = w[3] = 0.f;
+                vis = cav;
+            } else {
+                const Taps t = make_taps(a, col, row, H, W);
+                vis = cav && t.roi != 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ix[k] = (t.w[k] != 0.f) ? t.idx[k] : -1;
+                    w[k] = t.w[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!vis) ix[k] = -1;
+                else if ((dbg & 0x400) && ix[k] >= 0) ix[k] &= 4095;   // probe: L2-resident footprint
+            }
+            *reinterpret_cast<int4*>(sm.tidx[lw][c][j]) = make_int4(ix[0], ix[1], ix[2], ix[3]);
+            *reinterpret_cast<float4*>(sm.tw[lw][c][j]) = make_float4(w[0], w[1], w[2], w[3]);
+            sm.tvis[lw][c][j] = vis ? 1 : 0;
         }
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read ordering
-    int4 tix[NP];
-    float4 twt[NP];
-    bool visible[NP];
-    int self_idx[NP];
-#pragma unroll
-    for (int pass = 0; pass < NP; ++pass) {
-        const int j = pass * KPW + (kin % KPW);
-        tix[pass] = *reinterpret_cast<const int4*>(sm.tidx[lw][j]);
-        twt[pass] = *reinterpret_cast<const float4*>(sm.tw[lw][j]);
-        self_idx[pass] = sm.tself[lw][j];
-        if (dbg & 0x400) {   // probe: fold every access into a 2 MB (L2-resident) region
-            self_idx[pass] &= 4095; tix[pass].x &= 4095; tix[pass].y &= 4095; tix[pass].z &= 4095; tix[pass].w &= 4095;
-        }
-        visible[pass] = sm.tvis[lw][j] != 0;
-    }
+}
 
-    PC_TRACE(ltid == 0, (int)sm.gcount, 1);
-    // ---- issue phase ----
-    half8 rawq[NP];
-    bool q_ident = true;
-    if constexpr (WITH_Q) {
-        const float* aq = sm.ainv + ((it.b * L + it.ego) * L + it.ego) * 8;
-        q_ident = aq[6] != 0.f;
-        const half_t* qpl = reinterpret_cast<const half_t*>(p.q) + (size_t)(it.b * L + it.ego) * P * C + it.hg * CH;
-        if (q_ident) {
-            const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)qpl, 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-            for (int pass = 0; pass < NP; ++pass) rawq[pass] = buf_load8(rs_q, (unsigned)self_idx[pass] * row_bytes + cl_bytes, 0);
-        } else {
-            // T[i,i] is not the identity (never produced by the reference's dataset): slow path
-            const int tq = __builtin_amdgcn_readfirstlane(te);
-#pragma unroll
-            for (int pass = 0; pass < NP; ++pass) {
-                const int n = pass * KPP + kin;
-                int row, col;
-                token_pixel(p.partition, 8, X, Y, it.wx, it.wy, n, row, col);
-                const Taps tt = make_taps(aq, col, row, H, W);
-                float v[1][8];
-                sample8<half_t, 1>(qpl, 0, C, cl, tt, false, row * W + col, sm.bq[tq], 0, v);
-                store8_lds<half_t>(sm.Qs[qbuf] + n * QS + cl, v[0]);
-            }
-        }
-    }
-    half8 raw[NP][2][4];
-    if (ident) {
-#pragma unroll
-        for (int pass = 0; pass < NP; ++pass)
-            if (visible[pass]) {
-                const unsigned vo = (unsigned)self_idx[pass] * row_bytes + cl_bytes;
-                raw[pass][0][0] = buf_load8(rs_kv, vo, 0);
-                raw[pass][1][0] = buf_load8(rs_kv, vo, plane_bytes);
-            }
-    } else {
-#pragma unroll
-        for (int pass = 0; pass < NP; ++pass)
-            if (visible[pass]) {
-                const int ix[4] = {tix[pass].x, tix[pass].y, tix[pass].z, tix[pass].w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned vo = (unsigned)ix[k] * row_bytes + cl_bytes;
-                    raw[pass][0][k] = buf_load8(rs_kv, vo, 0);
-                    raw[pass][1][k] = buf_load8(rs_kv, vo, plane_bytes);
-                }
-            }
-    }
-    PC_TRACE(ltid == 0, (int)sm.gcount, 2);
-    // ---- consume phase ----
-    if constexpr (WITH_Q) {
-        if (q_ident) {
-            const float4 b0 = *reinterpret_cast<const float4*>(&sm.bq[te][cl]);
-            const float4 b1 = *reinterpret_cast<const float4*>(&sm.bq[te][cl + 4]);
-            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-            for (int pass = 0; pass < NP; ++pass) {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (float)rawq[pass][e] + bb[e];
-                store8_lds<half_t>(sm.Qs[qbuf] + (pass * KPP + kin) * QS + cl, v);
-            }
-        }
-    }
-    float bkv[2][8];
-    {
-        const float* bsrc = &sm.bkv[te * HMVIT_NUM_TYPES + ts][0][0];
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-            const float4 b0 = *reinterpret_cast<const float4*>(bsrc + pl * CH + cl);
-            const float4 b1 = *reinterpret_cast<const float4*>(bsrc + pl * CH + cl + 4);
-            bkv[pl][0] = b0.x; bkv[pl][1] = b0.y; bkv[pl][2] = b0.z; bkv[pl][3] = b0.w;
-            bkv[pl][4] = b1.x; bkv[pl][5] = b1.y; bkv[pl][6] = b1.z; bkv[pl][7] = b1.w;
-        }
-    }
-    half_t* Ks = sm.Ks[kvbuf];
-    half_t* Vs = sm.Vs[kvbuf];
-    bool any = false;
-#pragma unroll
-    for (int pass = 0; pass < NP; ++pass) {
-        const int kk = pass * KPP + kin;
-        float o[2][8];
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[pl][e] = 0.f;
-        if (visible[pass]) {
-            const float wk[4] = {twt[pass].x, twt[pass].y, twt[pass].z, twt[pass].w};
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float acc;
-                    if (ident || (dbg & 0x80)) {
-                        acc = (float)raw[pass][pl][0][e] + bkv[pl][e];
-                    } else {
-                        acc = fmaf(wk[0], (float)raw[pass][pl][0][e], bkv[pl][e]);
-#pragma unroll
-                        for (int k = 1; k < 4; ++k) acc = fmaf(wk[k], (float)raw[pass][pl][k][e], acc);
-                    }
-                    o[pl][e] = acc;
-                }
-        }
-        store8_lds<half_t>(Ks + kk * KS + cl, o[0]);
-        store8_lds<half_t>(Vs + kk * VS + cl, o[1]);
-        if ((ltid % TPK) == 0) sm.maskadd[kvbuf][kk] = visible[pass] ? 0.f : -INFINITY;
-        any |= visible[pass];
-    }
-    bool allv = true;
-#pragma unroll
-    for (int pass = 0; pass < NP; ++pass) allv &= visible[pass];
-    const bool wave_any = __any(any), wave_all = __all(allv);
-    if (lane == 0) sm.vis[kvbuf][lw] = (wave_any ? 1 : 0) | (wave_all ? 2 : 0);   // bit 0: some key visible, bit 1: all
+__device__ __forceinline__ void pc_wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // per-workgroup tables: affine records, and the biases of the head group this workgroup serves
@@ -686,37 +603,142 @@ __device__ __forceinline__ void pc_load_tables(const AttnParams& p, PcShared<HG,
     }
 }
 
-// Both role loops execute 1 + (number of (item, chunk) pairs) barriers.  The loader is one flat
-// loop with a single gather call site (instruction-cache footprint): gather number g fills buffer
-// g & 1 and is consumed by the compute waves in the barrier interval after the one it was made in.
+// Loader role.  Both role loops execute 1 + (number of (item, chunk) gathers) barriers; gather g
+// fills K/V buffer g & 1 and is consumed by the compute waves in the barrier interval after the one
+// it was stored in.
+//
+// The loop is software-pipelined at the granularity of a PASS (KPW keys per wave = 8 tap loads of
+// 16 B per lane): the loads of a pass of gather g + 1 are issued right after the same pass of gather g
+// has been blended out of its registers, so a full chunk of tap loads (NP passes) is always in flight
+// across the blend, the barrier and the tap arithmetic - the loader never sits in an empty-queue wait.
+// Everything inside the loop body is unconditional (masked keys / zero-weight taps / "no query tile
+// for this chunk" are index -1 = zero-returning out-of-range records), so the compiler's vmcnt
+// bookkeeping stays exact across the back edge.  The loader's barrier is the raw s_barrier preceded by
+// an LDS-only wait: __syncthreads() would drain the in-flight taps (vmcnt(0)) every chunk.
 template <int HG, int CW, int LWX>
 __device__ __forceinline__ void pc_loader_loop(const AttnParams& p, PcShared<HG, CW, LWX>& sm, int lw, int ltid) {
+    using SM = PcShared<HG, CW, LWX>;
+    constexpr int QS = SM::QS, KS = SM::KS, VS = SM::VS, CH = SM::CH, TPK = SM::TPK, KPW = SM::KPW, NP = SM::NP, KPP = SM::KPP, TG = SM::TG;
     const int X = p.H / 8, Y = p.W / 8, NG = p.C / (HG * 32);
     const int n_items = p.B * p.n_ego * X * Y * NG;
     const int n_src = p.n_src;
+    const int plane_bytes = p.H * p.W * p.C * 2;
+    const int lane = ltid & 63;
+    const int cl = (ltid % TPK) * 8, cl_bytes = cl * 2;
+    const int kin = ltid / TPK;                  // key row of this lane inside a KPP-key pass
+    const int kj = kin % KPW;                    // ... inside this wave's share of the pass
+    const bool ego_fastest = (p.variant & 0x200) == 0;
+
+    half8 R[NP][2][4], RQ[NP];
+    float4 Wt[NP];
+    int vflag[NP];
+
+    auto issue = [&](int pass, const PcGather& G) {
+        const int c = G.chunk % TG, j = pass * KPW + kj;
+        int4 ix = *reinterpret_cast<const int4*>(sm.tidx[lw][c][j]);
+        Wt[pass] = *reinterpret_cast<const float4*>(sm.tw[lw][c][j]);
+        vflag[pass] = sm.tvis[lw][c][j];
+        int qtok = -1;
+        if (G.chunk == 0 && G.q_ident) {
+            int row, col;
+            token_pixel(p.partition, 8, X, Y, G.it.wx, G.it.wy, pass * KPP + kin, row, col);
+            qtok = row * p.W + col;
+        }
+        if (!G.valid) { ix = make_int4(-1, -1, -1, -1); qtok = -1; }
+        const int ixa[4] = {ix.x, ix.y, ix.z, ix.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            R[pass][0][k] = tok_load8(G.rs_kv, ixa[k], cl_bytes, 0);
+            R[pass][1][k] = tok_load8(G.rs_kv, ixa[k], cl_bytes, plane_bytes);
+        }
+        RQ[pass] = tok_load8(G.rs_q, qtok, cl_bytes, 0);
+    };
+
+    bool any = false, allv = true;
+    auto blend = [&](int pass, const PcGather& G) {
+        const int kk = pass * KPP + kin;
+        const float wk[4] = {Wt[pass].x, Wt[pass].y, Wt[pass].z, Wt[pass].w};
+        const float* bsrc = &sm.bkv[G.tsel][0][0];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const float4 b0 = *reinterpret_cast<const float4*>(bsrc + pl * CH + cl);
+            const float4 b1 = *reinterpret_cast<const float4*>(bsrc + pl * CH + cl + 4);
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float acc = fmaf(wk[0], (float)R[pass][pl][0][e], bb[e]);
+#pragma unroll
+                for (int k = 1; k < 4; ++k) acc = fmaf(wk[k], (float)R[pass][pl][k][e], acc);
+                o[e] = acc;
+            }
+            if (pl == 0) store8_lds<half_t>(sm.Ks[G.kvbuf] + kk * KS + cl, o);
+            else store8_lds<half_t>(sm.Vs[G.kvbuf] + kk * VS + cl, o);
+        }
+        if (G.chunk == 0) {
+            if (G.q_ident) {
+                const float4 b0 = *reinterpret_cast<const float4*>(&sm.bq[G.te][cl]);
+                const float4 b1 = *reinterpret_cast<const float4*>(&sm.bq[G.te][cl + 4]);
+                const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (float)RQ[pass][e] + bb[e];
+                store8_lds<half_t>(sm.Qs[G.qbuf] + kk * QS + cl, v);
+            } else {
+                // T[i,i] is not the identity (never produced by the reference's dataset): slow path
+                const float* aq = sm.ainv + ((G.it.b * p.L + G.it.ego) * p.L + G.it.ego) * 8;
+                const half_t* qpl = reinterpret_cast<const half_t*>(p.q) + (size_t)(G.it.b * p.L + G.it.ego) * p.H * p.W * p.C + G.it.hg * CH;
+                int row, col;
+                token_pixel(p.partition, 8, X, Y, G.it.wx, G.it.wy, kk, row, col);
+                const Taps tt = make_taps(aq, col, row, p.H, p.W);
+                float v[1][8];
+                sample8<half_t, 1>(qpl, 0, p.C, cl, tt, false, row * p.W + col, sm.bq[G.te], 0, v);
+                store8_lds<half_t>(sm.Qs[G.qbuf] + kk * QS + cl, v[0]);
+            }
+        }
+        const bool vis = vflag[pass] != 0;
+        if ((ltid % TPK) == 0) sm.maskadd[G.kvbuf][kk] = vis ? 0.f : -INFINITY;
+        any |= vis;
+        allv &= vis;
+    };
+
     int item = blockIdx.x, chunk = 0, g = 0, qi = 0;
-    PcItem it = pc_decode(item, p.n_ego, X, Y, NG, (p.variant & 0x200) == 0);
+    PcItem it = pc_decode(item, p.n_ego, X, Y, NG, ego_fastest);
+    PcGather G = pc_describe<HG, CW, LWX>(p, sm, it, 0, 0, 0, true);
+    pc_taps<HG, CW, LWX>(p, sm, it, 0, lw, lane);
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) issue(pass, G);
+
 #pragma unroll 1
     while (true) {
-        if (ltid == 0) sm.gcount = g;
-        PC_TRACE(ltid == 0, g, 0);
-        if (chunk == 0)
-            pc_gather<HG, CW, LWX, true>(p, sm, it, 0, g & 1, qi, lw, ltid);
-        else
-            pc_gather<HG, CW, LWX, false>(p, sm, it, chunk, g & 1, qi, lw, ltid);
-        PC_TRACE(ltid == 0, g, 3);
-        __syncthreads();
-        PC_TRACE(ltid == 0, g, 4);
-        ++g;
+        // the gather after this one
+        bool nvalid = true;
         if (++chunk == n_src) {
             chunk = 0;
             item += gridDim.x;
-            if (item >= n_items) break;
-            it = pc_decode(item, p.n_ego, X, Y, NG, (p.variant & 0x200) == 0);
+            nvalid = item < n_items;
+            if (nvalid) it = pc_decode(item, p.n_ego, X, Y, NG, ego_fastest);
             qi ^= 1;
         }
+        const PcGather N = pc_describe<HG, CW, LWX>(p, sm, it, chunk, g + 1, qi, nvalid);
+        if (nvalid && (chunk % TG) == 0) pc_taps<HG, CW, LWX>(p, sm, it, chunk, lw, lane);
+        any = false; allv = true;
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
+            __builtin_amdgcn_sched_barrier(0);
+            blend(pass, G);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(pass, N);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool wave_any = __any(any), wave_all = __all(allv);
+        if (lane == 0) sm.vis[G.kvbuf][lw] = (wave_any ? 1 : 0) | (wave_all ? 2 : 0);   // bit 0: some key visible, bit 1: all
+        pc_wg_barrier();
+        if (!nvalid) break;
+        G = N;
+        ++g;
     }
-    __syncthreads();   // the interval in which the compute waves consume the last chunk
+    pc_wg_barrier();   // the interval in which the compute waves consume the last chunk
 }
 
 template <int HG, int CW, int LWX>
