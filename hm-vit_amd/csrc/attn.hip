@@ -458,7 +458,7 @@ struct PcShared {
     // shot (lane = (chunk, key)); a tap that needs no load (zero weight, masked key) has index -1
     static constexpr int TG = 4;
     int tidx[LWG][TG][NK][4];
-    float tw[LWG][TG][NK][4];
+    unsigned tw[LWG][TG][NK][4];                  // tap weights as packed f16 pairs (w, w)
     int tvis[LWG][TG][NK];
     float biasf[BIAS_LDS ? HG * 7 * 256 : 4];  // [head][variant][lane][4], accumulator order
 };
@@ -526,6 +526,12 @@ __device__ __forceinline__ PcGather pc_describe(const AttnParams& p, const PcSha
     return G;
 }
 
+// bits of the f16 pair (w, w)
+__device__ __forceinline__ unsigned pack_ww(float w) {
+    const half2v h = half2v{(half_t)w, (half_t)w};
+    return __builtin_bit_cast(unsigned, h);
+}
+
 // Bilinear taps of this loader wave's keys for chunks [chunk0, chunk0 + TG) of one item.
 template <int HG, int CW, int LWX>
 __device__ __forceinline__ void pc_taps(const AttnParams& p, PcShared<HG, CW, LWX>& sm, const PcItem& it, int chunk0, int lw, int lane) {
@@ -567,7 +573,7 @@ __device__ __forceinline__ void pc_taps(const AttnParams& p, PcShared<HG, CW, LW
                 else if ((dbg & 0x400) && ix[k] >= 0) ix[k] &= 4095;   // probe: L2-resident footprint
             }
             *reinterpret_cast<int4*>(sm.tidx[lw][c][j]) = make_int4(ix[0], ix[1], ix[2], ix[3]);
-            *reinterpret_cast<float4*>(sm.tw[lw][c][j]) = make_float4(w[0], w[1], w[2], w[3]);
+            *reinterpret_cast<uint4v*>(sm.tw[lw][c][j]) = uint4v{pack_ww(w[0]), pack_ww(w[1]), pack_ww(w[2]), pack_ww(w[3])};
             sm.tvis[lw][c][j] = vis ? 1 : 0;
         }
     }
@@ -575,16 +581,43 @@ __device__ __forceinline__ void pc_taps(const AttnParams& p, PcShared<HG, CW, LW
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read ordering
 }
 
-// d = w * (float)half(pair.lo / pair.hi) + acc
-__device__ __forceinline__ float fma_mix_lo(float w, unsigned pair, float acc) {
-    float d;
-    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(d) : "v"(w), "v"(pair), "v"(acc));
-    return d;
+// bias + sum_k w[k] * tap_k over NT taps for the 8 channels of a lane, in packed f16 (v_pk_fma_f16: two
+// channels per instruction, half the VALU time of f32 FMAs on converted inputs).  Each of the NT roundings
+// is half an f16 ulp of a value that is stored as f16 anyway; against the oracle the end-to-end error of the
+// f16 mode moved from 4.5e-4 to at most 4.8e-4 (tools/err_report.py).  NT = 1 with w = 1 is the exact x + b.
+template <int NT>
+__device__ __forceinline__ half8 blend_h(const half8 bias, const half8 (&taps)[4], const uint4v w2) {
+    half8 o;
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+        half2v acc = half2v{bias[2 * e2], bias[2 * e2 + 1]};
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const half2v x = half2v{taps[k][2 * e2], taps[k][2 * e2 + 1]};
+            const unsigned wk = w2[k];   // (bit_cast straight from the vector element is miscompiled by hipcc 7.2: it always reads element 0)
+            acc = __builtin_elementwise_fma(__builtin_bit_cast(half2v, wk), x, acc);
+        }
+        o[2 * e2] = acc[0]; o[2 * e2 + 1] = acc[1];
+    }
+    return o;
 }
-__device__ __forceinline__ float fma_mix_hi(float w, unsigned pair, float acc) {
-    float d;
-    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(w), "v"(pair), "v"(acc));
-    return d;
+
+// query row + folded bias, summed in f32 (|b_q| can be an order of magnitude above |q|: rounding it to f16
+// first would shift every logit of the head)
+__device__ __forceinline__ half8 add_bias_f32(const half8 x, const float* bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(bias);
+    const float4 b1 = *reinterpret_cast<const float4*>(bias + 4);
+    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)x[e] + bb[e]);
+    return o;
+}
+
+__device__ __forceinline__ half8 to_half8(const float* v) {
+    const float4 b0 = *reinterpret_cast<const float4*>(v);
+    const float4 b1 = *reinterpret_cast<const float4*>(v + 4);
+    return half8{(half_t)b0.x, (half_t)b0.y, (half_t)b0.z, (half_t)b0.w, (half_t)b1.x, (half_t)b1.y, (half_t)b1.z, (half_t)b1.w};
 }
 
 __device__ __forceinline__ void pc_wg_barrier() {
@@ -644,13 +677,13 @@ __device__ __forceinline__ void pc_loader_loop_general(const AttnParams& p, PcSh
     const bool ego_fastest = (p.variant & 0x200) == 0;
 
     half8 R[NP][2][4], RQ[NP];
-    float4 Wt[NP];
+    uint4v Wt[NP];
     int vflag[NP];
 
     auto issue = [&](int pass, const PcGather& G) {
         const int c = G.slot, j = pass * KPW + kj;
         int4 ix = *reinterpret_cast<const int4*>(sm.tidx[lw][c][j]);
-        Wt[pass] = *reinterpret_cast<const float4*>(sm.tw[lw][c][j]);
+        Wt[pass] = *reinterpret_cast<const uint4v*>(sm.tw[lw][c][j]);
         vflag[pass] = sm.tvis[lw][c][j];
         int qtok = -1;
         if (G.chunk == 0 && G.q_ident) {
@@ -671,39 +704,13 @@ __device__ __forceinline__ void pc_loader_loop_general(const AttnParams& p, PcSh
     bool any = false, allv = true;
     auto blend = [&](int pass, const PcGather& G) {
         const int kk = pass * KPP + kin;
-        const float wk[4] = {Wt[pass].x, Wt[pass].y, Wt[pass].z, Wt[pass].w};
-        const float* bsrc = &sm.bkv[G.tsel][0][0];
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-            const float4 b0 = *reinterpret_cast<const float4*>(bsrc + pl * CH + cl);
-            const float4 b1 = *reinterpret_cast<const float4*>(bsrc + pl * CH + cl + 4);
-            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-            // v_fma_mix_f32 reads the f16 tap straight out of the loaded register pair (f32 weight and
-            // accumulator): 4 instructions per channel instead of 4 conversions + 4 FMAs
-            float o[8];
-#pragma unroll
-            for (int e2 = 0; e2 < 4; ++e2) {
-                float lo = bb[2 * e2], hi = bb[2 * e2 + 1];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned pr = __builtin_bit_cast(uint4v, R[pass][pl][k])[e2];
-                    lo = fma_mix_lo(wk[k], pr, lo);
-                    hi = fma_mix_hi(wk[k], pr, hi);
-                }
-                o[2 * e2] = lo; o[2 * e2 + 1] = hi;
-            }
-            if (pl == 0) store8_lds<half_t>(sm.Ks[G.kvbuf] + kk * KS + cl, o);
-            else store8_lds<half_t>(sm.Vs[G.kvbuf] + kk * VS + cl, o);
-        }
+        *reinterpret_cast<half8*>(sm.Ks[G.kvbuf] + kk * KS + cl) =
+            blend_h<4>(to_half8(&sm.bkv[G.tsel][0][cl]), R[pass][0], Wt[pass]);
+        *reinterpret_cast<half8*>(sm.Vs[G.kvbuf] + kk * VS + cl) =
+            blend_h<4>(to_half8(&sm.bkv[G.tsel][1][cl]), R[pass][1], Wt[pass]);
         if (G.chunk == 0) {
             if (G.q_ident) {
-                const float4 b0 = *reinterpret_cast<const float4*>(&sm.bq[G.te][cl]);
-                const float4 b1 = *reinterpret_cast<const float4*>(&sm.bq[G.te][cl + 4]);
-                const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (float)RQ[pass][e] + bb[e];
-                store8_lds<half_t>(sm.Qs[G.qbuf] + kk * QS + cl, v);
+                *reinterpret_cast<half8*>(sm.Qs[G.qbuf] + kk * QS + cl) = add_bias_f32(RQ[pass], &sm.bq[G.te][cl]);
             } else {
                 // T[i,i] is not the identity (never produced by the reference's dataset): slow path
                 const float* aq = sm.ainv + ((G.it.b * p.L + G.it.ego) * p.L + G.it.ego) * 8;
@@ -784,14 +791,14 @@ __device__ __forceinline__ void pc_loader_loop_fast(const AttnParams& p, PcShare
     const bool ego_fastest = (p.variant & 0x200) == 0;
 
     half8 R[NP][2][4];
-    float4 Wt[NP];
+    uint4v Wt[NP];
     int vflag[NP];
     bool any = false, allv = true;
 
     auto issueG = [&](int pass, const PcGather& G) {
         const int j = pass * KPW + kj;
         const int4 ix = *reinterpret_cast<const int4*>(sm.tidx[lw][G.slot][j]);
-        Wt[pass] = *reinterpret_cast<const float4*>(sm.tw[lw][G.slot][j]);
+        Wt[pass] = *reinterpret_cast<const uint4v*>(sm.tw[lw][G.slot][j]);
         vflag[pass] = sm.tvis[lw][G.slot][j];
         const int ixa[4] = {ix.x, ix.y, ix.z, ix.w};
 #pragma unroll
@@ -810,31 +817,15 @@ __device__ __forceinline__ void pc_loader_loop_fast(const AttnParams& p, PcShare
         R[pass][1][0] = tok_load8(G.rs_kv, tk, cl_bytes, plane_bytes);
         R[pass][0][1] = tok_load8(G.rs_q, tq, cl_bytes, 0);
     };
-    // out[e] = sum_k w[k] * tap_k[e] + bias[e] for the 8 channels of this lane
-    auto blend_store = [&](half_t* dst, const float* bias, const half8 (&taps)[4], const float (&wk)[4], int ntaps) {
-        const float4 b0 = *reinterpret_cast<const float4*>(bias);
-        const float4 b1 = *reinterpret_cast<const float4*>(bias + 4);
-        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        float o[8];
-#pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) {
-            float lo = bb[2 * e2], hi = bb[2 * e2 + 1];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < ntaps) {
-                    const unsigned pr = __builtin_bit_cast(uint4v, taps[k])[e2];
-                    lo = fma_mix_lo(wk[k], pr, lo);
-                    hi = fma_mix_hi(wk[k], pr, hi);
-                }
-            o[2 * e2] = lo; o[2 * e2 + 1] = hi;
-        }
-        store8_lds<half_t>(dst, o);
+    half8 bias_k, bias_v;   // folded biases of the chunk being blended
+    auto load_bias = [&](const PcGather& G) {
+        bias_k = to_half8(&sm.bkv[G.tsel][0][cl]);
+        bias_v = to_half8(&sm.bkv[G.tsel][1][cl]);
     };
     auto blendG = [&](int pass, const PcGather& G) {
         const int kk = pass * KPP + kin;
-        const float wk[4] = {Wt[pass].x, Wt[pass].y, Wt[pass].z, Wt[pass].w};
-        blend_store(sm.Ks[G.kvbuf] + kk * KS + cl, &sm.bkv[G.tsel][0][cl], R[pass][0], wk, 4);
-        blend_store(sm.Vs[G.kvbuf] + kk * VS + cl, &sm.bkv[G.tsel][1][cl], R[pass][1], wk, 4);
+        *reinterpret_cast<half8*>(sm.Ks[G.kvbuf] + kk * KS + cl) = blend_h<4>(bias_k, R[pass][0], Wt[pass]);
+        *reinterpret_cast<half8*>(sm.Vs[G.kvbuf] + kk * VS + cl) = blend_h<4>(bias_v, R[pass][1], Wt[pass]);
         const bool vis = vflag[pass] != 0;
         if ((ltid % TPK) == 0) sm.maskadd[G.kvbuf][kk] = vis ? 0.f : -INFINITY;
         any |= vis;
@@ -842,11 +833,9 @@ __device__ __forceinline__ void pc_loader_loop_fast(const AttnParams& p, PcShare
     };
     auto blendI = [&](int pass, const PcGather& G) {
         const int kk = pass * KPP + kin;
-        const float one[4] = {1.f, 1.f, 1.f, 1.f};
-        const half8 qtap[4] = {R[pass][0][1], R[pass][0][1], R[pass][0][1], R[pass][0][1]};
-        blend_store(sm.Ks[G.kvbuf] + kk * KS + cl, &sm.bkv[G.tsel][0][cl], R[pass][0], one, 1);
-        blend_store(sm.Vs[G.kvbuf] + kk * VS + cl, &sm.bkv[G.tsel][1][cl], R[pass][1], one, 1);
-        blend_store(sm.Qs[G.qbuf] + kk * QS + cl, &sm.bq[G.te][cl], qtap, one, 1);
+        *reinterpret_cast<half8*>(sm.Ks[G.kvbuf] + kk * KS + cl) = add_bias_f32(R[pass][0][0], &sm.bkv[G.tsel][0][cl]);
+        *reinterpret_cast<half8*>(sm.Vs[G.kvbuf] + kk * VS + cl) = add_bias_f32(R[pass][1][0], &sm.bkv[G.tsel][1][cl]);
+        *reinterpret_cast<half8*>(sm.Qs[G.qbuf] + kk * QS + cl) = add_bias_f32(R[pass][0][1], &sm.bq[G.te][cl]);
         if ((ltid % TPK) == 0) sm.maskadd[G.kvbuf][kk] = G.self_vis ? 0.f : -INFINITY;
     };
     auto publish = [&](const PcGather& G, bool some, bool every) {
@@ -856,6 +845,18 @@ __device__ __forceinline__ void pc_loader_loop_fast(const AttnParams& p, PcShare
         pc_wg_barrier();
     };
 
+#ifdef PC_PHASES
+    // probe build: cycles spent per phase of the G -> G body, summed over the launch (workgroup 0, loader wave 0)
+    unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+#define PC_PH(i)                                                   \
+    do {                                                           \
+        const unsigned long long t_ = __builtin_readcyclecounter(); \
+        tacc[i] += t_ - tlast;                                     \
+        tlast = t_;                                                \
+    } while (0)
+#else
+#define PC_PH(i)
+#endif
     int item = blockIdx.x, g = 0, qi = 0;
     PcItem it = pc_decode(item, p.n_ego, X, Y, NG, ego_fastest);
     PcGather G = pc_describe<HG, CW, LWX>(p, sm, it, 0, 0, 0, true);
@@ -871,6 +872,7 @@ __device__ __forceinline__ void pc_loader_loop_fast(const AttnParams& p, PcShare
             pc_taps<HG, CW, LWX>(p, sm, it, 1, lw, lane);
             N = pc_describe<HG, CW, LWX>(p, sm, it, 1, g + 1, qi, true);
             N.slot = 0;
+            load_bias(G);
 #pragma unroll
             for (int pass = 0; pass < NP; ++pass) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -883,18 +885,30 @@ __device__ __forceinline__ void pc_loader_loop_fast(const AttnParams& p, PcShare
             // chunks 1 .. n_src - 2 while the following one is requested
 #pragma unroll 1
             for (int chunk = 1; chunk + 1 < n_src; ++chunk) {
+#ifdef PC_PHASES
+                tlast = __builtin_readcyclecounter();
+#endif
                 if ((chunk % TG) == 0) pc_taps<HG, CW, LWX>(p, sm, it, chunk + 1, lw, lane);
                 N = pc_describe<HG, CW, LWX>(p, sm, it, chunk + 1, g + 1, qi, true);
                 N.slot = chunk % TG;
                 any = false; allv = true;
+                load_bias(G);
+                PC_PH(0);
 #pragma unroll
                 for (int pass = 0; pass < NP; ++pass) {
                     __builtin_amdgcn_sched_barrier(0);
                     blendG(pass, G);
                     __builtin_amdgcn_sched_barrier(0);
+                    PC_PH(1 + 2 * pass);
                     issueG(pass, N);
+                    __builtin_amdgcn_sched_barrier(0);
+                    PC_PH(2 + 2 * pass);
                 }
                 publish(G, any, allv);
+                PC_PH(9);
+#ifdef PC_PHASES
+                tacc[10] += 1;
+#endif
                 G = N; ++g;
             }
         }
@@ -904,6 +918,7 @@ __device__ __forceinline__ void pc_loader_loop_fast(const AttnParams& p, PcShare
         if (nvalid) it = pc_decode(item, p.n_ego, X, Y, NG, ego_fastest);
         qi ^= 1;
         N = pc_describe<HG, CW, LWX>(p, sm, it, 0, g + 1, qi, nvalid);
+        load_bias(G);
         if (n_src > 1) {
             any = false; allv = true;
 #pragma unroll
@@ -928,6 +943,10 @@ __device__ __forceinline__ void pc_loader_loop_fast(const AttnParams& p, PcShare
         G = N; ++g;
     }
     pc_wg_barrier();   // the interval in which the compute waves consume the last chunk
+#ifdef PC_PHASES
+    if (p.trace && blockIdx.x == 0 && ltid == 0)
+        for (int i = 0; i < 12; ++i) p.trace[i] = tacc[i];
+#endif
 }
 
 template <int HG, int CW, int LWX>
@@ -1150,12 +1169,14 @@ int launch_attention(const AttnParams& p, int precision, hipStream_t st) {
         return w8 ? launch_attn_t<float, 8, 2>(p, st) : launch_attn_t<float, 4, 2>(p, st);
     }
     if (p.C == 64) return w8 ? launch_attn_t<half_t, 8, 2>(p, st) : launch_attn_t<half_t, 4, 2>(p, st);
-    if (w8 && (p.variant & 1) == 0 && p.B * p.L * p.L <= PcShared<4, 1, 1>::MAX_PAIRS) {
+    int variant = p.variant;
+    if (const char* e = getenv("HMVIT_ATTN_DEBUG")) variant ^= atoi(e);   // probe switches (tools/attn_probe.py, tools/attn_diff.py)
+    if (w8 && (variant & 1) == 0 && p.B * p.L * p.L <= PcShared<4, 1, 1>::MAX_PAIRS) {
         AttnParams q = p;
+        q.variant = variant;
         // item order: egos interleaved per window for the local partition (cross-ego cache reuse of the
-        // gathered rows, measured -10 %), ego-major for the dilated grid partition (measured +6 % otherwise)
-        if (p.partition == HMVIT_PART_GRID) q.variant |= 0x200;
-        if (const char* e = getenv("HMVIT_ATTN_DEBUG")) q.variant ^= atoi(e) & ~1;   // probe switches (tools/attn_probe.py)
+        // gathered rows), ego-major for the dilated grid partition
+        if (p.partition == HMVIT_PART_GRID) q.variant ^= 0x200;
         if (const char* e = getenv("HMVIT_ATTN_TRACE")) q.trace = (unsigned long long*)strtoull(e, nullptr, 0);
         // wave configurations (heads per group, compute waves per head, loader waves per head):
         //   default: 4 heads, 1 + 1 -> 8 waves of <= 256 VGPRs: a loader wave keeps 4 passes = 32 tap loads

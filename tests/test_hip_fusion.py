@@ -97,6 +97,34 @@ def test_fusion_parallel_mode_vs_oracle(precision):
     assert rel_max_err(y, ref) < TOL[precision]
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_fusion_nonidentity_self_transform(precision):
+    """pairwise_t[b, i, i] != I never comes out of the reference's datasets but its forward does not
+    assume it (every (i, j) pair is warped, hetero_fusion.py:245-262): the f16 attention kernel takes
+    its general loader loop for such a scene."""
+    cfg = O.make_config(256, 8, 3, voxel=0.4, downsample=4)
+    sd = O.random_state_dict(cfg, seed=17)
+    x, pw, mode, rl, mask = O.synthetic_scene(3, 256, 32, 48, [1, 0, 1], seed=8, tx_step=5.0, ty_step=-3.0)
+    pw = pw.clone()
+    for i in range(3):
+        pw[0, i, i] = O.rigid(0.05 * (i + 1), 1.5 * (i + 1), -0.7 * i).to(pw.dtype)
+    scene = (x, pw, mode, rl, mask)
+    ref = O.hetero_fusion(*scene, sd, cfg)
+    y = _fusion(cfg, sd, precision)(*_cuda(*scene)).cpu()
+    assert rel_max_err(y, ref) < TOL[precision]
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_fusion_batch2_window8_c256(precision):
+    """B = 2 scenes in one call through the persistent attention kernel (items span both scenes)."""
+    cfg = O.make_config(256, 8, 3, voxel=0.4, downsample=4)
+    sd = O.random_state_dict(cfg, seed=19)
+    scene = O.synthetic_scene(3, 256, 32, 32, [0, 1, 1], n_valid=3, seed=10, B=2, tx_step=6.0, ty_step=2.0)
+    ref = O.hetero_fusion(*scene, sd, cfg)
+    y = _fusion(cfg, sd, precision)(*_cuda(*scene)).cpu()
+    assert rel_max_err(y, ref) < TOL[precision]
+
+
 def test_skip_masked_is_exact():
     cfg = O.make_config(64, 8, 3)
     sd = O.random_state_dict(cfg, seed=9)

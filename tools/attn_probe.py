@@ -56,3 +56,17 @@ if os.environ.get("TRACE"):
         r = [int(v) - base if int(v) else -1 for v in t[i]]
         print(f"{i:3d} " + " ".join(f"{v:8d}" for v in r))
     del os.environ["HMVIT_ATTN_TRACE"]
+
+# ---- per-phase cycle sums of the loader's G -> G body (library built with -DPC_PHASES) ----
+if os.environ.get("PHASES"):
+    tr = torch.zeros(64, dtype=torch.int64, device=dev)
+    os.environ["HMVIT_ATTN_DEBUG"] = os.environ.get("TRACE_DBG", "0")
+    os.environ["HMVIT_ATTN_TRACE"] = hex(tr.data_ptr())
+    run(); torch.cuda.synchronize()
+    t = tr.cpu().tolist()
+    n = max(t[10], 1)
+    names = ["describe/taps", "blend0", "issue0", "blend1", "issue1", "blend2", "issue2", "blend3", "issue3", "publish+barrier"]
+    print("G->G bodies:", n, " cycles per body:", sum(t[:10]) / n)
+    for nm, v in zip(names, t[:10]):
+        print(f"  {nm:16s} {v / n:8.1f}")
+    del os.environ["HMVIT_ATTN_TRACE"]
