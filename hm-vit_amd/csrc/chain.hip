@@ -319,13 +319,16 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
         mma_chunk<KK, (KK < 8 ? KK : 8)>(acc, buf, act, lane);
         dma_wait();
         if (valid) {
-            half_t* o = J.y[mat] + ((size_t)tok * C + 32 * t + 4 * hi);
+            // the images of this kernel order the rows of a tile so that the lane's 16 results are two runs
+            // of 8 consecutive channels (weights.py store_row_order): 2 x 16-byte stores, adjacent for the
+            // lane pair of a token, instead of 4 x 8 (the store path is issue-bound)
+            half_t* o = J.y[mat] + ((size_t)tok * C + 32 * t + 8 * hi);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                half4 h;
+            for (int s = 0; s < 2; ++s) {
+                half8 h;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) h[i] = (half_t)acc[4 * j + i];
-                *reinterpret_cast<half4*>(o + 8 * j) = h;
+                for (int i = 0; i < 8; ++i) h[i] = (half_t)acc[8 * s + i];
+                *reinterpret_cast<half8*>(o + 16 * s) = h;
             }
         }
         wg_barrier();

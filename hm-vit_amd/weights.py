@@ -43,9 +43,19 @@ def bias_fragments(table: torch.Tensor, window: int) -> torch.Tensor:
     return frag.permute(3, 0, 1, 2).contiguous()
 
 
-def weight_image(w: torch.Tensor) -> torch.Tensor:
+def store_row_order(r):
+    """Channel (inside a 32-channel tile) computed by MFMA output row r of the projections whose results
+    go to memory as f16 (img_q / img_kv).  An accumulator lane (token m, half hi) owns rows 8 j + 4 hi + i;
+    with this order they are the channels 16 (j >> 1) + 8 hi + 4 (j & 1) + i, i.e. two runs of eight
+    consecutive channels, so the lane stores 2 x 16 bytes instead of 4 x 8 (csrc/chain.hip k_ln_qkv)."""
+    j, hi, i = r >> 3, (r >> 2) & 1, r & 3
+    return 16 * (j >> 1) + 8 * hi + 4 * (j & 1) + i
+
+
+def weight_image(w: torch.Tensor, store_rows: bool = False) -> torch.Tensor:
     """(N, K) matrix -> (N/32, K/16, 64, 8) f16 fragment image (include/hmvit.h):
-    img[t][kk][lane][4 jj + i] = W[32 t + (lane & 31)][16 kk + 8 jj + 4 (lane >> 5) + i]."""
+    img[t][kk][lane][4 jj + i] = W[32 t + row(lane & 31)][16 kk + 8 jj + 4 (lane >> 5) + i],
+    row(r) = r, or store_row_order(r) for the images of k_ln_qkv."""
     N, K = w.shape
     if N % 32 or K % 16:
         raise ValueError(f"weight_image: ({N}, {K}) must be multiples of (32, 16)")
@@ -54,7 +64,8 @@ def weight_image(w: torch.Tensor) -> torch.Tensor:
     kk = torch.arange(K // 16, device=dev)[None, :, None, None]
     lane = torch.arange(64, device=dev)[None, None, :, None]
     q = torch.arange(8, device=dev)[None, None, None, :]
-    n = 32 * t + (lane & 31)
+    r = lane & 31
+    n = 32 * t + (store_row_order(r) if store_rows else r)
     k = 16 * kk + 8 * (q >> 2) + 4 * (lane >> 5) + (q & 3)
     return w[n.expand(-1, K // 16, -1, 8), k.expand(N // 32, -1, -1, -1)].to(torch.float16).contiguous()
 
@@ -96,7 +107,7 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
     per_type = lambda m, fn: torch.stack([fn(m[t]) for t in range(NUM_TYPES)])
     w_q = stack(f"{att}.q_linears.{{t}}.weight") * scale
     if f16:
-        out["img_q"] = per_type(w_q, weight_image)
+        out["img_q"] = per_type(w_q, lambda m: weight_image(m, store_rows=True))
     else:
         out["w_q"] = w_q
     out["b_q"] = stack(f"{att}.q_linears.{{t}}.bias") * scale
@@ -115,7 +126,7 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
             w_kv[te, ts, C:] = torch.einsum("hpq,hpc->hqc", rel_msg[e], wv).reshape(C, C)
             b_kv[te, ts, C:] = torch.einsum("hpq,hp->hq", rel_msg[e], bv).reshape(C)
     if f16:
-        out["img_kv"] = torch.stack([per_type(w_kv[te], weight_image) for te in range(NUM_TYPES)])
+        out["img_kv"] = torch.stack([per_type(w_kv[te], lambda m: weight_image(m, store_rows=True)) for te in range(NUM_TYPES)])
     else:
         out["w_kv"] = w_kv
     out["b_kv"] = b_kv

@@ -68,6 +68,9 @@ extern "C" {
  * i.e. one 32-row tile after another, inside a tile one v_mfma_f32_32x32x16_f16 A-operand
  * fragment after another, so that weight staging is a linear copy (hm-vit_amd/weights.py:
  * weight_image).  img_q (T, ...), img_kv (T_ego, T_src, ...) of the (2C, C) matrix, img_o (T, ...);
+ * img_q and img_kv (results stored to memory as f16) take row(r) = 16 (j >> 1) + 8 hi + 4 (j & 1) + i
+ * for r = 8 j + 4 hi + i in place of (lane & 31), which makes the 16 results of an accumulator lane two
+ * runs of 8 consecutive channels = two 16-byte stores (weights.py: store_row_order);
  * img_ffn (T, C/32, 2, C/16, 64, 8) interleaves, for every hidden tile hc, the image of
  * W_1 rows [32 hc, 32 hc + 32) with the fragments (t, 2 hc + s), t < C/32, s < 2, of the image of
  * W_2 (requires mlp_dim == C). */
