@@ -1018,7 +1018,9 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        const half_t* base = Vb + (ks * 32 + 4 * g + (lq >> 2)) * VS + hl * 32 + dt * 16 + (lq & 3) * 4;
+                        // V^T tile dt takes the head's channels 8 q4 + 4 dt + r (q4 = lq & 3) as its rows 4 q4 + r, so
+                        // that an accumulator lane ends up with 8 consecutive channels over the two tiles
+                        const half_t* base = Vb + (ks * 32 + 4 * g + (lq >> 2)) * VS + hl * 32 + (lq & 3) * 8 + dt * 4;
                         const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
                             (__attribute__((address_space(3))) fp16x4_t*)(base));
                         const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
@@ -1091,14 +1093,13 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
                     int row, col;
                     token_pixel(p.partition, 8, X, Y, it.wx, it.wy, (qbase + qt) * 16 + lq, row, col);
                     const float inv = 1.f / l_acc[qt][0];
-                    half_t* o = outp + (size_t)(row * W + col) * C + head * 32 + 4 * g;
+                    half_t* o = outp + (size_t)(row * W + col) * C + head * 32 + 8 * g;
+                    half8 h;
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        half4 h;
+                    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) h[r] = (half_t)(o_acc[qt][dt][r] * inv);
-                        *reinterpret_cast<half4*>(o + dt * 16) = h;
-                    }
+                        for (int r = 0; r < 4; ++r) h[4 * dt + r] = (half_t)(o_acc[qt][dt][r] * inv);
+                    *reinterpret_cast<half8*>(o) = h;   // one 16-byte store per query row and lane
                 }
             }
             PC_TRACE(wave == 0 && lane == 0, gstep, 6);
