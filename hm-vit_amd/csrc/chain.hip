@@ -395,21 +395,11 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_out_ffn(FfnParams p) {
                 for (int q = 0; q < 8; ++q) act[2 * t + sx][q] = (half_t)xacc[t][8 * sx + q];
     }
     if constexpr (OUTPROJ) {
-        // attention output of this token as B operands (8-byte loads in the owned-channel pattern)
-        const half_t* op = J.o + (size_t)tok_c * C + 4 * hi;
+        // attention output of this token as B operands: img_o is built with the linear K order (weights.py
+        // weight_image(linear_k)), so fragment kk of lane (m, hi) is the 8 channels 16 kk + 8 hi + (0..7)
+        const half_t* op = J.o + (size_t)tok_c * C + 8 * hi;
 #pragma unroll
-        for (int b = 0; b < C / 32; ++b)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                half8 h;
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const half4 q = *reinterpret_cast<const half4*>(op + 32 * b + 16 * s + 8 * jj);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) h[4 * jj + i] = q[i];
-                }
-                act[2 * b + s] = h;
-            }
+        for (int kk = 0; kk < KK; ++kk) act[kk] = *reinterpret_cast<const half8*>(op + 16 * kk);
     }
     dma_wait();
     __syncthreads();

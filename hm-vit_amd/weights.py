@@ -52,10 +52,12 @@ def store_row_order(r):
     return 16 * (j >> 1) + 8 * hi + 4 * (j & 1) + i
 
 
-def weight_image(w: torch.Tensor, store_rows: bool = False) -> torch.Tensor:
+def weight_image(w: torch.Tensor, store_rows: bool = False, linear_k: bool = False) -> torch.Tensor:
     """(N, K) matrix -> (N/32, K/16, 64, 8) f16 fragment image (include/hmvit.h):
     img[t][kk][lane][4 jj + i] = W[32 t + row(lane & 31)][16 kk + 8 jj + 4 (lane >> 5) + i],
-    row(r) = r, or store_row_order(r) for the images of k_ln_qkv."""
+    row(r) = r, or store_row_order(r) for the images of k_ln_qkv.  ``linear_k`` (img_o, whose operand is
+    loaded from memory rather than taken from an accumulator) uses the K index
+    16 kk + 8 (lane >> 5) + 4 jj + i instead: 8 consecutive input channels per lane = one 16-byte load."""
     N, K = w.shape
     if N % 32 or K % 16:
         raise ValueError(f"weight_image: ({N}, {K}) must be multiples of (32, 16)")
@@ -66,7 +68,10 @@ def weight_image(w: torch.Tensor, store_rows: bool = False) -> torch.Tensor:
     q = torch.arange(8, device=dev)[None, None, None, :]
     r = lane & 31
     n = 32 * t + (store_row_order(r) if store_rows else r)
-    k = 16 * kk + 8 * (q >> 2) + 4 * (lane >> 5) + (q & 3)
+    if linear_k:
+        k = 16 * kk + 8 * (lane >> 5) + q
+    else:
+        k = 16 * kk + 8 * (q >> 2) + 4 * (lane >> 5) + (q & 3)
     return w[n.expand(-1, K // 16, -1, 8), k.expand(N // 32, -1, -1, -1)].to(torch.float16).contiguous()
 
 
@@ -133,7 +138,7 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
     out["bias_frag"] = bias_fragments(sd[f"{att}.relative_position_bias_table.weight"], window) * (LOG2E if f16 else 1.0)
     w_o = stack(f"{att}.a_linears.{{t}}.0.weight")
     if f16:
-        out["img_o"] = per_type(w_o, weight_image)
+        out["img_o"] = per_type(w_o, lambda m: weight_image(m, linear_k=True))
     else:
         out["w_o"] = w_o
     out["b_o"] = stack(f"{att}.a_linears.{{t}}.0.bias")

@@ -71,6 +71,7 @@ extern "C" {
  * img_q and img_kv (results stored to memory as f16) take row(r) = 16 (j >> 1) + 8 hi + 4 (j & 1) + i
  * for r = 8 j + 4 hi + i in place of (lane & 31), which makes the 16 results of an accumulator lane two
  * runs of 8 consecutive channels = two 16-byte stores (weights.py: store_row_order);
+ * img_o (operand read from memory) takes the K index 16 kk + 8 (lane >> 5) + 4 jj + i instead;
  * img_ffn (T, C/32, 2, C/16, 64, 8) interleaves, for every hidden tile hc, the image of
  * W_1 rows [32 hc, 32 hc + 32) with the fragments (t, 2 hc + s), t < C/32, s < 2, of the image of
  * W_2 (requires mlp_dim == C). */
