@@ -43,6 +43,12 @@ struct ChainCfg {
 };
 
 constexpr int CHAIN_THREADS = CHAIN_THREADS_C;
+#ifndef FFN_DEPTH
+#define FFN_DEPTH 4
+#endif
+#ifndef FFN_WG_PER_CU
+#define FFN_WG_PER_CU 2
+#endif
 constexpr int CHAIN_WAVES = CHAIN_THREADS / 64;
 constexpr int CHAIN_TOKENS = CHAIN_WAVES * 32;
 
@@ -58,6 +64,9 @@ __device__ __forceinline__ void stage_chunk(const half_t* __restrict__ chunk, ha
     // dma_wait() below, placed where the only other outstanding VMEM ops are long-issued stores.
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_buf;
+#ifdef NO_DMA
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < ChainCfg<C>::PPT; ++i) {
         const int piece0 = (i * CHAIN_WAVES + wave) * 64;
@@ -147,6 +156,38 @@ __device__ __forceinline__ void mma_chunk(float16v& acc, const half_t* buf, cons
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// Two token tiles per wave: every weight fragment read from LDS feeds two MFMAs (independent accumulators).
+// One fragment is 1 KB per 32x32x16 MFMA, i.e. with one tile per wave the LDS (128 B/clk) saturates exactly
+// at the MFMA peak and in practice well below it (measured: 2860 cycles per 16-MFMA tile step, 36 % MFMA
+// busy); the second tile halves the LDS bytes per flop.
+template <int KK, int DEPTH, int kk = 0>
+struct MmaSteps2 {
+    static __device__ __forceinline__ void run(float16v& acc0, float16v& acc1, unsigned addr, const half8 (&act0)[KK],
+                                               const half8 (&act1)[KK], half8 (&w)[DEPTH]) {
+        constexpr int outstanding = (KK - kk - 1) < (DEPTH - 1) ? (KK - kk - 1) : (DEPTH - 1);
+        lgkm_wait<outstanding>();
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[kk % DEPTH], act0[kk], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[kk % DEPTH], act1[kk], acc1, 0, 0, 0);
+        if constexpr (kk + DEPTH < KK) {
+            __builtin_amdgcn_sched_barrier(0);
+            lds_read_frag<(kk + DEPTH) * 1024>(w[kk % DEPTH], addr);
+        }
+        if constexpr (kk + 1 < KK) MmaSteps2<KK, DEPTH, kk + 1>::run(acc0, acc1, addr, act0, act1, w);
+    }
+};
+template <int KK, int DEPTH>
+__device__ __forceinline__ void mma_chunk2(float16v& acc0, float16v& acc1, const half_t* buf, const half8 (&act0)[KK],
+                                           const half8 (&act1)[KK], int lane) {
+    static_assert(KK % DEPTH == 0 && DEPTH <= 15, "");
+    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)(buf + lane * 8);
+    half8 w[DEPTH];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    MmaPrologue<DEPTH>::run(addr, w);
+    MmaSteps2<KK, DEPTH>::run(acc0, acc1, addr, act0, act1, w);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 __device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
 // LayerNorm of the token owned by lane pair (m, hi = 0/1); v[b][j] holds channels 32b+8j+4hi+(0..3)
@@ -201,6 +242,51 @@ __device__ __forceinline__ void to_operands(const float4 (&v)[C / 32][4], half8 
         }
 }
 
+// LayerNorm + conversion to MFMA B operands in one sweep: v[b] dies as act[2b], act[2b+1] are produced
+// (scheduling fences keep the compiler from hoisting all gamma / beta reads, which costs ~60 live registers)
+template <int C>
+__device__ __forceinline__ void ln_to_operands(float4 (&v)[C / 32][4], const float* __restrict__ lg, const float* __restrict__ lb,
+                                               int hi, half8 (&act)[C / 16]) {
+    constexpr int NB = C / 32;
+    float s = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += (v[b][j].x + v[b][j].y) + (v[b][j].z + v[b][j].w);
+    const float mean = pair_sum(s) * (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float dx = v[b][j].x - mean, dy = v[b][j].y - mean, dz = v[b][j].z - mean, dw = v[b][j].w - mean;
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+    const float rstd = rsqrtf(pair_sum(q) * (1.f / C) + 1e-5f);
+    const float shift = -mean * rstd;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+            half8 h;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * sx + jj, c = 32 * b + 8 * j + 4 * hi;
+                const float4 g = *reinterpret_cast<const float4*>(lg + c);
+                const float4 be = *reinterpret_cast<const float4*>(lb + c);
+                const float4 f = v[b][j];
+                h[4 * jj + 0] = (half_t)(fmaf(f.x, rstd, shift) * g.x + be.x);
+                h[4 * jj + 1] = (half_t)(fmaf(f.y, rstd, shift) * g.y + be.y);
+                h[4 * jj + 2] = (half_t)(fmaf(f.z, rstd, shift) * g.z + be.z);
+                h[4 * jj + 3] = (half_t)(fmaf(f.w, rstd, shift) * g.w + be.w);
+            }
+            asm volatile("" : "+v"(h));   // pin: the optimizer otherwise sinks the normalisation to the first use
+            act[2 * b + sx] = h;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // LayerNorm straight from the accumulator layout into MFMA B operands (no f32 copy is kept)
 template <int C>
 __device__ __forceinline__ void ln_acc_to_operands(const float16v (&xa)[C / 32], const float* __restrict__ lg,
@@ -221,23 +307,29 @@ __device__ __forceinline__ void ln_acc_to_operands(const float16v (&xa)[C / 32],
             q = fmaf(dlt, dlt, q);
         }
     const float rstd = rsqrtf(pair_sum(q) * (1.f / C) + 1e-5f);
+    const float shift = -mean * rstd;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx) {
+            __builtin_amdgcn_sched_barrier(0);
             half8 h;
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = 2 * sx + jj, c = 32 * t + 8 * j + 4 * hi;
                 const float4 g = *reinterpret_cast<const float4*>(lg + c);
                 const float4 be = *reinterpret_cast<const float4*>(lb + c);
-                h[4 * jj + 0] = (half_t)((xa[t][4 * j + 0] - mean) * rstd * g.x + be.x);
-                h[4 * jj + 1] = (half_t)((xa[t][4 * j + 1] - mean) * rstd * g.y + be.y);
-                h[4 * jj + 2] = (half_t)((xa[t][4 * j + 2] - mean) * rstd * g.z + be.z);
-                h[4 * jj + 3] = (half_t)((xa[t][4 * j + 3] - mean) * rstd * g.w + be.w);
+                // x * rstd + shift, not (x - mean) * rstd: the latter shares (x - mean) with the variance pass and
+                // hipcc then keeps all C centred values alive next to the accumulators (32 spilled registers)
+                h[4 * jj + 0] = (half_t)(fmaf(xa[t][4 * j + 0], rstd, shift) * g.x + be.x);
+                h[4 * jj + 1] = (half_t)(fmaf(xa[t][4 * j + 1], rstd, shift) * g.y + be.y);
+                h[4 * jj + 2] = (half_t)(fmaf(xa[t][4 * j + 2], rstd, shift) * g.z + be.z);
+                h[4 * jj + 3] = (half_t)(fmaf(xa[t][4 * j + 3], rstd, shift) * g.w + be.w);
             }
+            asm volatile("" : "+v"(h));   // pin (see ln_to_operands)
             act[2 * t + sx] = h;
         }
+    // (the fences below keep hipcc from hoisting all 64 gamma / beta reads ahead of the arithmetic)
 }
 
 // load the 128 / 64 / 32 channels of token `tok` this lane owns (tok already clamped into range:
@@ -288,6 +380,17 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
         lnp[C + i] = p.beta[J.type * C + i];
     }
     const int n_chunks = J.n_mat * NT;
+#ifdef CHAIN_PHASES
+    unsigned tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = (unsigned)__builtin_readcyclecounter();
+#define CH_PH(i)                                                   \
+    do {                                                           \
+        const unsigned t_ = (unsigned)__builtin_readcyclecounter(); \
+        tacc[i] += t_ - tlast;                                     \
+        tlast = t_;                                                \
+    } while (0)
+#else
+#define CH_PH(i)
+#endif
     stage_chunk<C>(J.w[0], ring0);
 
     float4 v[C / 32][4];
@@ -300,11 +403,15 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(xo + 32 * b + 8 * j) = v[b][j];
     }
+    CH_PH(0);
     dma_wait();
+    CH_PH(1);
     __syncthreads();
+    CH_PH(2);
     layer_norm_regs<C>(v, lnp, lnp + C, hi);
     half8 act[KK];
     to_operands<C>(v, act);
+    CH_PH(3);
 
     for (int c = 0; c < n_chunks; ++c) {
         const int mat = c / NT, t = c - mat * NT;
@@ -313,12 +420,23 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
             const int c1 = c + 1, mat1 = c1 / NT, t1 = c1 - mat1 * NT;
             stage_chunk<C>(J.w[mat1] + (size_t)t1 * Cfg::CHUNK_HALVES, (c & 1) ? ring0 : ring1);
         }
+        CH_PH(2);
         float16v acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#ifndef NO_MFMA
         mma_chunk<KK, (KK < 8 ? KK : 8)>(acc, buf, act, lane);
+#else
+        acc[0] = (float)act[c & 15][0];
+#endif
+        CH_PH(4);
         dma_wait();
+        CH_PH(5);
+#ifdef NO_QKV_STORES
+        if (valid && P < 0) {
+#else
         if (valid) {
+#endif
             // the images of this kernel order the rows of a tile so that the lane's 16 results are two runs
             // of 8 consecutive channels (weights.py store_row_order): 2 x 16-byte stores, adjacent for the
             // lane pair of a token, instead of 4 x 8 (the store path is issue-bound)
@@ -331,6 +449,80 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
                 *reinterpret_cast<half8*>(o + 16 * s) = h;
             }
         }
+        CH_PH(6);
+        wg_barrier();
+        CH_PH(7);
+    }
+#ifdef CHAIN_PHASES
+    if (p.trace && blockIdx.x == 1000 && blockIdx.y == 0 && threadIdx.x == 0)
+        for (int i = 0; i < 8; ++i) p.trace[i] = tacc[i];
+#endif
+}
+
+// k_ln_qkv with two 32-token tiles per wave (256 tokens per workgroup), C = 256
+template <int C>
+__global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv2(QkvParams p) {
+    using Cfg = ChainCfg<C>;
+    constexpr int KK = Cfg::KK, NT = Cfg::NT;
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * Cfg::CHUNK_HALVES + 4 * C];
+    half_t* ring0 = smem;
+    half_t* ring1 = smem + Cfg::CHUNK_HALVES;
+    float* lnp = reinterpret_cast<float*>(smem + 2 * Cfg::CHUNK_HALVES);   // gamma[C], beta[C]
+
+    const QkvJob& J = p.job[blockIdx.y];
+    const int P = p.P;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = lane & 31, hi = lane >> 5;
+    const int tok0 = blockIdx.x * (2 * CHAIN_TOKENS) + wave * 32 + m;
+
+    for (int i = threadIdx.x; i < C; i += CHAIN_THREADS) {
+        lnp[i] = p.gamma[J.type * C + i];
+        lnp[C + i] = p.beta[J.type * C + i];
+    }
+    const int n_chunks = J.n_mat * NT;
+    stage_chunk<C>(J.w[0], ring0);
+    __syncthreads();
+
+    half8 act[2][KK];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int tok = tok0 + tt * CHAIN_TOKENS;
+        float4 v[C / 32][4];
+        load_token<C>(J.x, false, P, min(tok, P - 1), hi, v);   // token-major input only (see launch_ln_qkv)
+        ln_to_operands<C>(v, lnp, lnp + C, hi, act[tt]);
+        // keep the second tile's 128 f32 registers from being loaded before the first tile's have died
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    dma_wait();
+    wg_barrier();
+
+    for (int c = 0; c < n_chunks; ++c) {
+        const int mat = c / NT, t = c - mat * NT;
+        const half_t* buf = (c & 1) ? ring1 : ring0;
+        if (c + 1 < n_chunks) {
+            const int c1 = c + 1, mat1 = c1 / NT, t1 = c1 - mat1 * NT;
+            stage_chunk<C>(J.w[mat1] + (size_t)t1 * Cfg::CHUNK_HALVES, (c & 1) ? ring0 : ring1);
+        }
+        float16v acc0, acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+        mma_chunk2<KK, 4>(acc0, acc1, buf, act[0], act[1], lane);
+        dma_wait();
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int tok = tok0 + tt * CHAIN_TOKENS;
+            if (tok < P) {
+                half_t* o = J.y[mat] + ((size_t)tok * C + 32 * t + 8 * hi);   // rows in store order (weights.py)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    half8 h;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) h[i] = (half_t)(tt == 0 ? acc0[8 * s2 + i] : acc1[8 * s2 + i]);
+                    *reinterpret_cast<half8*>(o + 16 * s2) = h;
+                }
+            }
+        }
         wg_barrier();
     }
 }
@@ -339,7 +531,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
 // k_out_ffn
 // ------------------------------------------------------------------------------------------
 template <int C, bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW>
-__global__ __launch_bounds__(CHAIN_THREADS, 2) void k_out_ffn(FfnParams p) {
+__global__ __launch_bounds__(CHAIN_THREADS, FFN_WG_PER_CU) void k_out_ffn(FfnParams p) {
     using Cfg = ChainCfg<C>;
     constexpr int KK = Cfg::KK, NT = Cfg::NT, NH = C / 32;   // hidden width == C
     __shared__ __attribute__((aligned(16))) half_t smem[2 * Cfg::CHUNK_HALVES + 10 * C];
@@ -354,6 +546,20 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_out_ffn(FfnParams p) {
     const int tok = blockIdx.x * CHAIN_TOKENS + wave * 32 + m;
     const bool valid = tok < P;
     const int ty = J.type;
+#ifdef FFN_PHASES
+    // probe build: per-phase cycle sums of wave 0 in LDS (one ds_add per stamp; stamps kept out of registers)
+    __shared__ unsigned ph_acc[16];
+    if (threadIdx.x < 16) ph_acc[threadIdx.x] = 0;
+    unsigned ph_last = (unsigned)__builtin_readcyclecounter();
+#define FF_PH(i)                                                              \
+    do {                                                                      \
+        const unsigned t_ = (unsigned)__builtin_readcyclecounter();           \
+        if (threadIdx.x == 0) atomicAdd(&ph_acc[i], t_ - ph_last);            \
+        ph_last = t_;                                                         \
+    } while (0)
+#else
+#define FF_PH(i)
+#endif
 
     for (int i = threadIdx.x; i < C; i += CHAIN_THREADS) {
         vec[0][i] = OUTPROJ ? p.b_o[ty * C + i] : 0.f;
@@ -401,18 +607,22 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_out_ffn(FfnParams p) {
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) act[kk] = *reinterpret_cast<const half8*>(op + 16 * kk);
     }
+    FF_PH(0);
     dma_wait();
     __syncthreads();
+    FF_PH(1);
 
     if constexpr (OUTPROJ) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float4 bo = *reinterpret_cast<const float4*>(&vec[0][32 * t + 8 * j + 4 * hi]);
                 xacc[t][4 * j + 0] += bo.x; xacc[t][4 * j + 1] += bo.y;
                 xacc[t][4 * j + 2] += bo.z; xacc[t][4 * j + 3] += bo.w;
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     // ---- phase 1: x' = x + b_o + W_o . O, one 32-channel tile per chunk (static accumulator index) ----
@@ -426,7 +636,9 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_out_ffn(FfnParams p) {
             float16v acc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-            mma_chunk<KK, 4>(acc, buf, act, lane);
+#ifndef FFN_NO_MFMA
+            mma_chunk<KK, FFN_DEPTH>(acc, buf, act, lane);
+#endif
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 if (t == c) xacc[t] += acc;
@@ -434,7 +646,9 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_out_ffn(FfnParams p) {
             wg_barrier();
         }
     }
+    FF_PH(2);
     if constexpr (LN) ln_acc_to_operands<C>(xacc, vec[1], vec[2], hi, act);
+    FF_PH(3);
 
     // accumulator of the second Linear starts from (residual +) b_2
 #pragma unroll
@@ -449,6 +663,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_out_ffn(FfnParams p) {
                 xacc[t][4 * j + 0] = b2.x; xacc[t][4 * j + 1] = b2.y;
                 xacc[t][4 * j + 2] = b2.z; xacc[t][4 * j + 3] = b2.w;
             }
+            if (j == 3) __builtin_amdgcn_sched_barrier(0);
         }
 
     // ---- phase 2: per hidden tile hc: h = GELU(W_1[hc] . xn + b_1[hc]);  x'' += W_2[:, hc] . h ----
@@ -463,27 +678,46 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_out_ffn(FfnParams p) {
             hacc[4 * j + 0] = b1.x; hacc[4 * j + 1] = b1.y; hacc[4 * j + 2] = b1.z; hacc[4 * j + 3] = b1.w;
         }
         stage_chunk<C>(w1c + Cfg::CHUNK_HALVES, ring1);          // W_2 slice hc
-        mma_chunk<KK, 4>(hacc, ring0, act, lane);
+#ifndef FFN_NO_MFMA
+        mma_chunk<KK, FFN_DEPTH>(hacc, ring0, act, lane);
+#endif
+        FF_PH(4);
         dma_wait();
         wg_barrier();
+        FF_PH(5);
 
         half8 hop[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
+#ifndef FFN_NO_GELU
             for (int q = 0; q < 8; ++q) hop[s][q] = (half_t)gelu_f(hacc[8 * s + q]);
+#else
+            for (int q = 0; q < 8; ++q) hop[s][q] = (half_t)hacc[8 * s + q];
+#endif
         if (hc + 1 < NH) stage_chunk<C>(w1c + 2 * Cfg::CHUNK_HALVES, ring0);   // W_1 tile hc + 1
+        FF_PH(6);
+#ifndef FFN_NO_MFMA
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
                 xacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(ring1, t * 2 + s, lane), hop[s], xacc[t], 0, 0, 0);
         }
+#else
+        xacc[hc][0] += (float)hop[0][0] + (float)hop[1][3];
+#endif
+        FF_PH(7);
         dma_wait();
         wg_barrier();
+        FF_PH(8);
     }
 
+#ifdef FFN_NO_STORES
+    if (valid && P < 0) {
+#else
     if (valid) {
+#endif
         if constexpr (OUT_NCHW) {
             float* op = J.out + (size_t)(4 * hi) * P + tok;
 #pragma unroll
@@ -500,18 +734,41 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_out_ffn(FfnParams p) {
                         make_float4(xacc[t][4 * j], xacc[t][4 * j + 1], xacc[t][4 * j + 2], xacc[t][4 * j + 3]);
         }
     }
+#ifdef FFN_PHASES
+    FF_PH(9);
+    __syncthreads();
+    if (p.trace && blockIdx.x == 1000 && blockIdx.y == 0 && threadIdx.x < 16) p.trace[threadIdx.x] = ph_acc[threadIdx.x];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-int launch_ln_qkv(const QkvParams& p, int n_jobs, int C, hipStream_t st) {
+int launch_ln_qkv(const QkvParams& p_in, int n_jobs, int C, hipStream_t st) {
+    QkvParams p = p_in;
+    p.trace = nullptr;
+#ifdef CHAIN_PHASES
+    if (const char* e = getenv("HMVIT_QKV_TRACE")) p.trace = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
     if (n_jobs == 0) return HMVIT_OK;
     dim3 grid(cdiv(p.P, CHAIN_TOKENS), n_jobs), block(CHAIN_THREADS);
     switch (C) {
         case 64: hipLaunchKernelGGL((k_ln_qkv<64>), grid, block, 0, st, p); break;
         case 128: hipLaunchKernelGGL((k_ln_qkv<128>), grid, block, 0, st, p); break;
-        case 256: hipLaunchKernelGGL((k_ln_qkv<256>), grid, block, 0, st, p); break;
+        case 256:
+#if defined(CHAIN_PHASES) || defined(ONE_TILE)
+            if (true) {
+#else
+            if (p.in_nchw) {
+#endif
+                // first stage (NCHW input, also emits the token-major residual stream): one tile per wave
+                hipLaunchKernelGGL((k_ln_qkv<256>), grid, block, 0, st, p);
+            } else {
+                // two token tiles per wave: 256 tokens per workgroup
+                dim3 grid2(cdiv(p.P, 2 * CHAIN_TOKENS), n_jobs);
+                hipLaunchKernelGGL((k_ln_qkv2<256>), grid2, block, 0, st, p);
+            }
+            break;
         default: set_error("ln_qkv: C=%d unsupported", C); return HMVIT_EINVAL;
     }
     HMVIT_CHECK_LAUNCH();
@@ -531,7 +788,12 @@ static int launch_out_ffn_c(const FfnParams& p, int n_jobs, int variant, hipStre
     return HMVIT_OK;
 }
 
-int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, hipStream_t st) {
+int launch_out_ffn(const FfnParams& p_in, int n_jobs, int C, int variant, hipStream_t st) {
+    FfnParams p = p_in;
+    p.trace = nullptr;
+#ifdef FFN_PHASES
+    if (const char* e = getenv("HMVIT_FFN_TRACE")) p.trace = (unsigned*)strtoull(e, nullptr, 0);
+#endif
     if (n_jobs == 0) return HMVIT_OK;
     switch (C) {
         case 64: return launch_out_ffn_c<64>(p, n_jobs, variant, st);

@@ -57,6 +57,7 @@ struct QkvParams {
     const float* beta;
     int P;
     int in_nchw;
+    unsigned long long* trace;   // probe builds (-DCHAIN_PHASES) only
 };
 int launch_ln_qkv(const QkvParams& p, int n_jobs, int C, hipStream_t st);
 
@@ -77,6 +78,7 @@ struct FfnParams {
     const float* b_1;        // (T, C)
     const float* b_2;        // (T, C)
     int P;
+    unsigned* trace;         // probe builds (-DFFN_PHASES) only
 };
 enum { FFN_FULL = 0, FFN_NO_ATTN = 1, FFN_HEAD_NCHW = 2 };
 int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, hipStream_t st);
