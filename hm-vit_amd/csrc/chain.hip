@@ -612,19 +612,6 @@ __global__ __launch_bounds__(CHAIN_THREADS, FFN_WG_PER_CU) void k_out_ffn(FfnPar
     __syncthreads();
     FF_PH(1);
 
-    if constexpr (OUTPROJ) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 bo = *reinterpret_cast<const float4*>(&vec[0][32 * t + 8 * j + 4 * hi]);
-                xacc[t][4 * j + 0] += bo.x; xacc[t][4 * j + 1] += bo.y;
-                xacc[t][4 * j + 2] += bo.z; xacc[t][4 * j + 3] += bo.w;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-
     // ---- phase 1: x' = x + b_o + W_o . O, one 32-channel tile per chunk (static accumulator index) ----
     if constexpr (OUTPROJ) {
         // rolled loop (keeps the scheduler's live ranges short); the tile result is added into the
@@ -633,9 +620,12 @@ __global__ __launch_bounds__(CHAIN_THREADS, FFN_WG_PER_CU) void k_out_ffn(FfnPar
         for (int c = 0; c < N_OUT; ++c) {
             const half_t* buf = (c & 1) ? ring1 : ring0;
             stage_chunk<C>(chunk_ptr(c + 1), (c & 1) ? ring0 : ring1);   // there is always a next chunk
-            float16v acc;
+            float16v acc;   // starts from the out-projection bias of the tile
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            for (int j = 0; j < 4; ++j) {
+                const float4 bo = *reinterpret_cast<const float4*>(&vec[0][32 * c + 8 * j + 4 * hi]);
+                acc[4 * j + 0] = bo.x; acc[4 * j + 1] = bo.y; acc[4 * j + 2] = bo.z; acc[4 * j + 3] = bo.w;
+            }
 #ifndef FFN_NO_MFMA
             mma_chunk<KK, FFN_DEPTH>(acc, buf, act, lane);
 #endif
