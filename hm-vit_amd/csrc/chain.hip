@@ -156,38 +156,6 @@ __device__ __forceinline__ void mma_chunk(float16v& acc, const half_t* buf, cons
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// Two token tiles per wave: every weight fragment read from LDS feeds two MFMAs (independent accumulators).
-// One fragment is 1 KB per 32x32x16 MFMA, i.e. with one tile per wave the LDS (128 B/clk) saturates exactly
-// at the MFMA peak and in practice well below it (measured: 2860 cycles per 16-MFMA tile step, 36 % MFMA
-// busy); the second tile halves the LDS bytes per flop.
-template <int KK, int DEPTH, int kk = 0>
-struct MmaSteps2 {
-    static __device__ __forceinline__ void run(float16v& acc0, float16v& acc1, unsigned addr, const half8 (&act0)[KK],
-                                               const half8 (&act1)[KK], half8 (&w)[DEPTH]) {
-        constexpr int outstanding = (KK - kk - 1) < (DEPTH - 1) ? (KK - kk - 1) : (DEPTH - 1);
-        lgkm_wait<outstanding>();
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[kk % DEPTH], act0[kk], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[kk % DEPTH], act1[kk], acc1, 0, 0, 0);
-        if constexpr (kk + DEPTH < KK) {
-            __builtin_amdgcn_sched_barrier(0);
-            lds_read_frag<(kk + DEPTH) * 1024>(w[kk % DEPTH], addr);
-        }
-        if constexpr (kk + 1 < KK) MmaSteps2<KK, DEPTH, kk + 1>::run(acc0, acc1, addr, act0, act1, w);
-    }
-};
-template <int KK, int DEPTH>
-__device__ __forceinline__ void mma_chunk2(float16v& acc0, float16v& acc1, const half_t* buf, const half8 (&act0)[KK],
-                                           const half8 (&act1)[KK], int lane) {
-    static_assert(KK % DEPTH == 0 && DEPTH <= 15, "");
-    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)(buf + lane * 8);
-    half8 w[DEPTH];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    MmaPrologue<DEPTH>::run(addr, w);
-    MmaSteps2<KK, DEPTH>::run(acc0, acc1, addr, act0, act1, w);
-    __builtin_amdgcn_sched_barrier(0);
-}
-
 __device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
 // LayerNorm of the token owned by lane pair (m, hi = 0/1); v[b][j] holds channels 32b+8j+4hi+(0..3)
@@ -242,51 +210,6 @@ __device__ __forceinline__ void to_operands(const float4 (&v)[C / 32][4], half8 
         }
 }
 
-// LayerNorm + conversion to MFMA B operands in one sweep: v[b] dies as act[2b], act[2b+1] are produced
-// (scheduling fences keep the compiler from hoisting all gamma / beta reads, which costs ~60 live registers)
-template <int C>
-__device__ __forceinline__ void ln_to_operands(float4 (&v)[C / 32][4], const float* __restrict__ lg, const float* __restrict__ lb,
-                                               int hi, half8 (&act)[C / 16]) {
-    constexpr int NB = C / 32;
-    float s = 0.f;
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s += (v[b][j].x + v[b][j].y) + (v[b][j].z + v[b][j].w);
-    const float mean = pair_sum(s) * (1.f / C);
-    float q = 0.f;
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float dx = v[b][j].x - mean, dy = v[b][j].y - mean, dz = v[b][j].z - mean, dw = v[b][j].w - mean;
-            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-        }
-    const float rstd = rsqrtf(pair_sum(q) * (1.f / C) + 1e-5f);
-    const float shift = -mean * rstd;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-#pragma unroll
-        for (int sx = 0; sx < 2; ++sx) {
-            half8 h;
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int j = 2 * sx + jj, c = 32 * b + 8 * j + 4 * hi;
-                const float4 g = *reinterpret_cast<const float4*>(lg + c);
-                const float4 be = *reinterpret_cast<const float4*>(lb + c);
-                const float4 f = v[b][j];
-                h[4 * jj + 0] = (half_t)(fmaf(f.x, rstd, shift) * g.x + be.x);
-                h[4 * jj + 1] = (half_t)(fmaf(f.y, rstd, shift) * g.y + be.y);
-                h[4 * jj + 2] = (half_t)(fmaf(f.z, rstd, shift) * g.z + be.z);
-                h[4 * jj + 3] = (half_t)(fmaf(f.w, rstd, shift) * g.w + be.w);
-            }
-            asm volatile("" : "+v"(h));   // pin: the optimizer otherwise sinks the normalisation to the first use
-            act[2 * b + sx] = h;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 // LayerNorm straight from the accumulator layout into MFMA B operands (no f32 copy is kept)
 template <int C>
 __device__ __forceinline__ void ln_acc_to_operands(const float16v (&xa)[C / 32], const float* __restrict__ lg,
@@ -326,7 +249,7 @@ __device__ __forceinline__ void ln_acc_to_operands(const float16v (&xa)[C / 32],
                 h[4 * jj + 2] = (half_t)(fmaf(xa[t][4 * j + 2], rstd, shift) * g.z + be.z);
                 h[4 * jj + 3] = (half_t)(fmaf(xa[t][4 * j + 3], rstd, shift) * g.w + be.w);
             }
-            asm volatile("" : "+v"(h));   // pin (see ln_to_operands)
+            asm volatile("" : "+v"(h));   // pin: the optimizer otherwise sinks the normalisation to the first use
             act[2 * t + sx] = h;
         }
     // (the fences below keep hipcc from hoisting all 64 gamma / beta reads ahead of the arithmetic)
@@ -457,74 +380,6 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
     if (p.trace && blockIdx.x == 1000 && blockIdx.y == 0 && threadIdx.x == 0)
         for (int i = 0; i < 8; ++i) p.trace[i] = tacc[i];
 #endif
-}
-
-// k_ln_qkv with two 32-token tiles per wave (256 tokens per workgroup), C = 256
-template <int C>
-__global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv2(QkvParams p) {
-    using Cfg = ChainCfg<C>;
-    constexpr int KK = Cfg::KK, NT = Cfg::NT;
-    __shared__ __attribute__((aligned(16))) half_t smem[2 * Cfg::CHUNK_HALVES + 4 * C];
-    half_t* ring0 = smem;
-    half_t* ring1 = smem + Cfg::CHUNK_HALVES;
-    float* lnp = reinterpret_cast<float*>(smem + 2 * Cfg::CHUNK_HALVES);   // gamma[C], beta[C]
-
-    const QkvJob& J = p.job[blockIdx.y];
-    const int P = p.P;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int m = lane & 31, hi = lane >> 5;
-    const int tok0 = blockIdx.x * (2 * CHAIN_TOKENS) + wave * 32 + m;
-
-    for (int i = threadIdx.x; i < C; i += CHAIN_THREADS) {
-        lnp[i] = p.gamma[J.type * C + i];
-        lnp[C + i] = p.beta[J.type * C + i];
-    }
-    const int n_chunks = J.n_mat * NT;
-    stage_chunk<C>(J.w[0], ring0);
-    __syncthreads();
-
-    half8 act[2][KK];
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-        const int tok = tok0 + tt * CHAIN_TOKENS;
-        float4 v[C / 32][4];
-        load_token<C>(J.x, false, P, min(tok, P - 1), hi, v);   // token-major input only (see launch_ln_qkv)
-        ln_to_operands<C>(v, lnp, lnp + C, hi, act[tt]);
-        // keep the second tile's 128 f32 registers from being loaded before the first tile's have died
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    dma_wait();
-    wg_barrier();
-
-    for (int c = 0; c < n_chunks; ++c) {
-        const int mat = c / NT, t = c - mat * NT;
-        const half_t* buf = (c & 1) ? ring1 : ring0;
-        if (c + 1 < n_chunks) {
-            const int c1 = c + 1, mat1 = c1 / NT, t1 = c1 - mat1 * NT;
-            stage_chunk<C>(J.w[mat1] + (size_t)t1 * Cfg::CHUNK_HALVES, (c & 1) ? ring0 : ring1);
-        }
-        float16v acc0, acc1;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
-        mma_chunk2<KK, 4>(acc0, acc1, buf, act[0], act[1], lane);
-        dma_wait();
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int tok = tok0 + tt * CHAIN_TOKENS;
-            if (tok < P) {
-                half_t* o = J.y[mat] + ((size_t)tok * C + 32 * t + 8 * hi);   // rows in store order (weights.py)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    half8 h;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) h[i] = (half_t)(tt == 0 ? acc0[8 * s2 + i] : acc1[8 * s2 + i]);
-                    *reinterpret_cast<half8*>(o + 16 * s2) = h;
-                }
-            }
-        }
-        wg_barrier();
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -745,20 +600,7 @@ int launch_ln_qkv(const QkvParams& p_in, int n_jobs, int C, hipStream_t st) {
     switch (C) {
         case 64: hipLaunchKernelGGL((k_ln_qkv<64>), grid, block, 0, st, p); break;
         case 128: hipLaunchKernelGGL((k_ln_qkv<128>), grid, block, 0, st, p); break;
-        case 256:
-#if defined(CHAIN_PHASES) || defined(ONE_TILE)
-            if (true) {
-#else
-            if (p.in_nchw) {
-#endif
-                // first stage (NCHW input, also emits the token-major residual stream): one tile per wave
-                hipLaunchKernelGGL((k_ln_qkv<256>), grid, block, 0, st, p);
-            } else {
-                // two token tiles per wave: 256 tokens per workgroup
-                dim3 grid2(cdiv(p.P, 2 * CHAIN_TOKENS), n_jobs);
-                hipLaunchKernelGGL((k_ln_qkv2<256>), grid2, block, 0, st, p);
-            }
-            break;
+        case 256: hipLaunchKernelGGL((k_ln_qkv<256>), grid, block, 0, st, p); break;
         default: set_error("ln_qkv: C=%d unsupported", C); return HMVIT_EINVAL;
     }
     HMVIT_CHECK_LAUNCH();
