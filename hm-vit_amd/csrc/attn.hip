@@ -407,28 +407,43 @@ struct PcItem {
     int b, ego, wx, wy, hg;
 };
 
-__device__ __forceinline__ PcItem pc_decode(int item, int n_ego, int X, int Y, int NG, bool ego_fastest = false) {
-    PcItem it;
-    it.hg = item % NG; item /= NG;
-    if (ego_fastest) {
-        it.ego = item % n_ego; item /= n_ego;
-        const int win = item % (X * Y);
-        it.b = item / (X * Y);
-        it.wx = win / Y; it.wy = win - it.wx * Y;
-    } else {
-        const int win = item % (X * Y); item /= (X * Y);
-        it.wx = win / Y; it.wy = win - it.wx * Y;
-        it.ego = item % n_ego;
-        it.b = item / n_ego;
+// Work schedule of the persistent kernel.  Workgroup b runs on XCD b % 8 (the usual round-robin placement; only
+// speed depends on it) and each XCD has its own L2, so the gridDim / 8 workgroups of an XCD take, per step, the
+// windows of ONE tile of TH x 8 adjacent windows (times the head groups): neighbouring windows gather
+// overlapping rows of the source maps - in the dilated grid partition the keys of window (wx, wy + 1) are the
+// right-hand neighbours of the keys of (wx, wy), i.e. three of its four bilinear taps - and with a
+// window-index-strided assignment those re-reads always landed in another XCD's L2 (measured: 7.5 GB fetched
+// per grid launch for 0.7 GB of K'/V').  Step k of XCD x is tile k * 8 + x of the (sample, ego, tile) list.
+// Returns false when the list is exhausted; windows of a border tile that fall outside the map are skipped.
+__device__ __forceinline__ bool pc_fetch(const AttnParams& p, int X, int Y, int NG, bool ego_fastest, int& k, PcItem& it) {
+    const int wpx = gridDim.x >> 3, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int TH = wpx / NG / 8;                       // tile = TH x 8 windows
+    const int ntx = (X + TH - 1) / TH, nty = (Y + 7) / 8, n_super = ntx * nty, total = p.B * p.n_ego * n_super;
+    const int t = j / NG;
+    while (true) {
+        ++k;
+        int s = k * 8 + x;
+        if (s >= total) return false;
+        int tile, ego;
+        if (ego_fastest) {
+            ego = s % p.n_ego; s /= p.n_ego;
+            tile = s % n_super; s /= n_super;
+        } else {
+            tile = s % n_super; s /= n_super;
+            ego = s % p.n_ego; s /= p.n_ego;
+        }
+        const int wx = (tile / nty) * TH + (t >> 3), wy = (tile % nty) * 8 + (t & 7);
+        if (wx < X && wy < Y) {
+            // wave-uniform: keep the fields in SGPRs so that the per-chunk metadata (affine record, agent
+            // types, plane bases) is fetched with scalar loads
+            it.b = __builtin_amdgcn_readfirstlane(s);
+            it.ego = __builtin_amdgcn_readfirstlane(ego);
+            it.wx = __builtin_amdgcn_readfirstlane(wx);
+            it.wy = __builtin_amdgcn_readfirstlane(wy);
+            it.hg = __builtin_amdgcn_readfirstlane(j % NG);
+            return true;
+        }
     }
-    // the item index is wave-uniform: keep its fields in SGPRs so that the per-chunk metadata
-    // (affine record, agent types, plane bases) is fetched with scalar loads
-    it.b = __builtin_amdgcn_readfirstlane(it.b);
-    it.ego = __builtin_amdgcn_readfirstlane(it.ego);
-    it.wx = __builtin_amdgcn_readfirstlane(it.wx);
-    it.wy = __builtin_amdgcn_readfirstlane(it.wy);
-    it.hg = __builtin_amdgcn_readfirstlane(it.hg);
-    return it;
 }
 
 template <int HG, int CW, int LWX>
@@ -667,7 +682,6 @@ __device__ __forceinline__ void pc_loader_loop_general(const AttnParams& p, PcSh
     using SM = PcShared<HG, CW, LWX>;
     constexpr int QS = SM::QS, KS = SM::KS, VS = SM::VS, CH = SM::CH, TPK = SM::TPK, KPW = SM::KPW, NP = SM::NP, KPP = SM::KPP, TG = SM::TG;
     const int X = p.H / 8, Y = p.W / 8, NG = p.C / (HG * 32);
-    const int n_items = p.B * p.n_ego * X * Y * NG;
     const int n_src = p.n_src;
     const int plane_bytes = p.H * p.W * p.C * 2;
     const int lane = ltid & 63;
@@ -729,8 +743,9 @@ __device__ __forceinline__ void pc_loader_loop_general(const AttnParams& p, PcSh
         allv &= vis;
     };
 
-    int item = blockIdx.x, chunk = 0, g = 0, qi = 0;
-    PcItem it = pc_decode(item, p.n_ego, X, Y, NG, ego_fastest);
+    int item = -1, chunk = 0, g = 0, qi = 0;
+    PcItem it;
+    if (!pc_fetch(p, X, Y, NG, ego_fastest, item, it)) { pc_wg_barrier(); return; }
     PcGather G = pc_describe<HG, CW, LWX>(p, sm, it, 0, 0, 0, true);
     pc_taps<HG, CW, LWX>(p, sm, it, 0, lw, lane);
 #pragma unroll
@@ -742,9 +757,7 @@ __device__ __forceinline__ void pc_loader_loop_general(const AttnParams& p, PcSh
         bool nvalid = true;
         if (++chunk == n_src) {
             chunk = 0;
-            item += gridDim.x;
-            nvalid = item < n_items;
-            if (nvalid) it = pc_decode(item, p.n_ego, X, Y, NG, ego_fastest);
+            nvalid = pc_fetch(p, X, Y, NG, ego_fastest, item, it);
             qi ^= 1;
         }
         const PcGather N = pc_describe<HG, CW, LWX>(p, sm, it, chunk, g + 1, qi, nvalid);
@@ -781,7 +794,6 @@ __device__ __forceinline__ void pc_loader_loop_fast(const AttnParams& p, PcShare
     using SM = PcShared<HG, CW, LWX>;
     constexpr int QS = SM::QS, KS = SM::KS, VS = SM::VS, CH = SM::CH, TPK = SM::TPK, KPW = SM::KPW, NP = SM::NP, KPP = SM::KPP, TG = SM::TG;
     const int X = p.H / 8, Y = p.W / 8, NG = p.C / (HG * 32);
-    const int n_items = p.B * p.n_ego * X * Y * NG;
     const int n_src = p.n_src;
     const int plane_bytes = p.H * p.W * p.C * 2;
     const int lane = ltid & 63;
@@ -857,8 +869,9 @@ __device__ __forceinline__ void pc_loader_loop_fast(const AttnParams& p, PcShare
 #else
 #define PC_PH(i)
 #endif
-    int item = blockIdx.x, g = 0, qi = 0;
-    PcItem it = pc_decode(item, p.n_ego, X, Y, NG, ego_fastest);
+    int item = -1, g = 0, qi = 0;
+    PcItem it;
+    if (!pc_fetch(p, X, Y, NG, ego_fastest, item, it)) { pc_wg_barrier(); return; }
     PcGather G = pc_describe<HG, CW, LWX>(p, sm, it, 0, 0, 0, true);
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) issueI(pass, G);
@@ -913,9 +926,7 @@ __device__ __forceinline__ void pc_loader_loop_fast(const AttnParams& p, PcShare
             }
         }
         // last chunk of the item while chunk 0 of the next item is requested
-        item += gridDim.x;
-        nvalid = item < n_items;
-        if (nvalid) it = pc_decode(item, p.n_ego, X, Y, NG, ego_fastest);
+        nvalid = pc_fetch(p, X, Y, NG, ego_fastest, item, it);
         qi ^= 1;
         N = pc_describe<HG, CW, LWX>(p, sm, it, 0, g + 1, qi, nvalid);
         load_bias(G);
@@ -956,11 +967,12 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
     const int hl = wave / CW, qbase = (wave % CW) * NQW;   // head inside the group, first query tile
     const int C = p.C, H = p.H, W = p.W, L = p.L, P = H * W;
     const int X = H / 8, Y = W / 8, NG = C / (HG * 32);
-    const int n_items = p.B * p.n_ego * X * Y * NG;
     const int n_src = p.n_src;
     const int lq = lane & 15, g = lane >> 4;
-    int item = blockIdx.x;
+    int item = -1;
+    PcItem it;
     __syncthreads();
+    if (!pc_fetch(p, X, Y, NG, (p.variant & 0x200) == 0, item, it)) return;
 
     float4v biasf[7];
     int bias_head = -1;
@@ -970,7 +982,6 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
     const half8 ones = (half8)(half_t)1.0f;
     int gstep = 0, qi = 0;
     while (true) {
-        const PcItem it = pc_decode(item, p.n_ego, X, Y, NG, (p.variant & 0x200) == 0);
         const int head = it.hg * HG + hl;
         for (int c = 0; c < n_src; ++c) {
             const int buf = gstep & 1;
@@ -1107,8 +1118,7 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
             PC_TRACE(wave == 0 && lane == 0, gstep, 7);
             ++gstep;
         }
-        item += gridDim.x;
-        if (item >= n_items) break;
+        if (!pc_fetch(p, X, Y, NG, (p.variant & 0x200) == 0, item, it)) break;
         qi ^= 1;
     }
 }
@@ -1118,7 +1128,7 @@ __global__ __launch_bounds__((HG * CW + HG * LWX) * 64) void k_attention_pc(Attn
     using SM = PcShared<HG, CW, LWX>;
     __shared__ __attribute__((aligned(16))) SM sm;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    pc_load_tables<HG, CW, LWX>(p, sm, blockIdx.x % (p.C / (HG * 32)));
+    pc_load_tables<HG, CW, LWX>(p, sm, (blockIdx.x >> 3) % (p.C / (HG * 32)));   // head group of this workgroup (pc_fetch)
     __syncthreads();
     // wave-uniform role split at the outermost level: the two loops have disjoint live ranges, so
     // the kernel's register count is the maximum of the two roles, not their sum
@@ -1140,10 +1150,7 @@ __global__ __launch_bounds__((HG * CW + HG * LWX) * 64) void k_attention_pc(Attn
 
 template <int HG, int CW, int LWX>
 static int launch_attn_pc(const AttnParams& p, hipStream_t st, int wg_per_cu) {
-    const int NG = p.C / (HG * 32);
-    const int n_items = p.B * p.n_ego * (p.H / 8) * (p.W / 8) * NG;
-    int grid = 256 * wg_per_cu;           // persistent workgroups
-    if (grid > n_items) grid = n_items;   // both are multiples of the head-group count
+    const int grid = 256 * wg_per_cu;     // persistent workgroups: 8 XCDs x (a tile of windows x head groups), see pc_fetch
     hipLaunchKernelGGL((k_attention_pc<HG, CW, LWX>), dim3(grid), dim3((HG * CW + HG * LWX) * 64), 0, st, p);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
