@@ -453,56 +453,74 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
     }
     HMVIT_MARK(HMVIT_PHASE_LAYOUT_IN);
 
+    // ---- per-stage descriptions ----
+    struct StageInfo {
+        bool last;
+        int n_ego, E;
+        int e_of_type[HMVIT_NUM_TYPES], e_type[HMVIT_NUM_TYPES];
+    };
+    const bool par = d->parallel != 0;
+    auto stage_info = [&](int it, int s) {
+        StageInfo si;
+        si.last = d->apply_head && it == d->num_iters - 1 && (par || s == 1);
+        si.n_ego = si.last ? 1 : pl.max_cav;
+        si.E = 0;
+        for (int t = 0; t < HMVIT_NUM_TYPES; ++t) { si.e_of_type[t] = -1; si.e_type[t] = 0; }
+        for (int b = 0; b < B; ++b)
+            for (int i = 0; i < si.n_ego; ++i) {
+                const int t = d->mode[b * L + i];
+                if (si.e_of_type[t] < 0) { si.e_of_type[t] = si.E; si.e_type[si.E] = t; ++si.E; }
+            }
+        return si;
+    };
+    // LayerNorm + Q / folded K', V' projections of agent `slot` for the stage (wt, si)
+    auto qkv_job = [&](const HmvitStageWeights& wt, const StageInfo& si, int slot, int l, bool first) {
+        const int t = d->mode[slot];
+        QkvJob j;
+        memset(&j, 0, sizeof(j));
+        j.x = first ? d->x + (size_t)slot * map_elems : xs + (size_t)slot * map_elems;
+        j.xs_out = xs + (size_t)slot * map_elems;
+        j.type = t;
+        int nm = 0;
+        if (l < si.n_ego) {
+            j.w[nm] = reinterpret_cast<const half_t*>(wt.img_q) + (size_t)t * img_elems;
+            j.y[nm] = qb + (size_t)slot * map_elems;
+            ++nm;
+        }
+        for (int e = 0; e < si.E; ++e) {
+            const half_t* wkv = reinterpret_cast<const half_t*>(wt.img_kv) +
+                                (size_t)(si.e_type[e] * HMVIT_NUM_TYPES + t) * 2 * img_elems;
+            half_t* ykv = kvb + (size_t)(slot * si.E + e) * 2 * map_elems;
+            j.w[nm] = wkv;             j.y[nm] = ykv;             ++nm;
+            j.w[nm] = wkv + img_elems; j.y[nm] = ykv + map_elems; ++nm;
+        }
+        j.n_mat = nm;
+        return j;
+    };
+
+    bool qkv_done = false;   // this stage's Q / K' / V' were produced by the previous stage's fused tail
     for (int it = 0; it < d->num_iters; ++it) {
         for (int s = 0; s < 2; ++s) {
             const HmvitStageWeights& wt = d->stage[s];
             const bool first = it == 0 && s == 0;
-            const bool par = d->parallel != 0;
-            const bool last = d->apply_head && it == d->num_iters - 1 && (par || s == 1);
+            const StageInfo si = stage_info(it, s);
+            const bool last = si.last;
             float* x_out = par ? reinterpret_cast<float*>(ws + (s == 0 ? pl.off_xa : pl.off_xb)) : xs;
-            const int n_ego = last ? 1 : pl.max_cav;
+            const int n_ego = si.n_ego, E = si.E;
             const int n_src = pl.max_cav;
-            int e_of_type[HMVIT_NUM_TYPES] = {-1, -1};
-            int e_type[HMVIT_NUM_TYPES] = {0, 0};
-            int E = 0;
-            for (int b = 0; b < B; ++b)
-                for (int i = 0; i < n_ego; ++i) {
-                    const int t = d->mode[b * L + i];
-                    if (e_of_type[t] < 0) { e_of_type[t] = E; e_type[E] = t; ++E; }
-                }
+            const int* e_of_type = si.e_of_type;
 
             // 1+2. LayerNorm + Q / folded K,V projections, activations in registers
-            {
+            if (!qkv_done) {
                 QkvBatcher qb_;
                 memset(&qb_.p, 0, sizeof(qb_.p));
                 qb_.n = 0; qb_.C = C; qb_.st = st;
                 qb_.p.gamma = wt.ln_gamma; qb_.p.beta = wt.ln_beta; qb_.p.P = P; qb_.p.in_nchw = first ? 1 : 0;
                 for (int b = 0; b < B; ++b)
-                    for (int l = 0; l < pl.max_cav; ++l) {
-                        const int slot = b * L + l, t = d->mode[slot];
-                        QkvJob j;
-                        memset(&j, 0, sizeof(j));
-                        j.x = first ? d->x + (size_t)slot * map_elems : xs + (size_t)slot * map_elems;
-                        j.xs_out = xs + (size_t)slot * map_elems;
-                        j.type = t;
-                        int nm = 0;
-                        if (l < n_ego) {
-                            j.w[nm] = reinterpret_cast<const half_t*>(wt.img_q) + (size_t)t * img_elems;
-                            j.y[nm] = qb + (size_t)slot * map_elems;
-                            ++nm;
-                        }
-                        for (int e = 0; e < E; ++e) {
-                            const half_t* wkv = reinterpret_cast<const half_t*>(wt.img_kv) +
-                                                (size_t)(e_type[e] * HMVIT_NUM_TYPES + t) * 2 * img_elems;
-                            half_t* ykv = kvb + (size_t)(slot * E + e) * 2 * map_elems;
-                            j.w[nm] = wkv;             j.y[nm] = ykv;             ++nm;
-                            j.w[nm] = wkv + img_elems; j.y[nm] = ykv + map_elems; ++nm;
-                        }
-                        j.n_mat = nm;
-                        HMVIT_TRY(qb_.add(j));
-                    }
+                    for (int l = 0; l < pl.max_cav; ++l) HMVIT_TRY(qb_.add(qkv_job(wt, si, b * L + l, l, first)));
                 HMVIT_TRY(qb_.flush());
             }
+            qkv_done = false;
             HMVIT_MARK(HMVIT_PHASE_QKV);
 
             // 3. fused warp + partition + attention
@@ -523,8 +541,11 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
             }
             HMVIT_MARK(HMVIT_PHASE_ATTENTION);
 
-            // 4+5. output projection + residual + LayerNorm + FFN + residual, in place on xs
+            // 4+5. output projection + residual + LayerNorm + FFN + residual, in place on xs; in the sequential
+            // block the next stage's LayerNorm + projections ride on the same kernel (k_out_ffn_qkv)
             {
+                const bool has_next = !(it == d->num_iters - 1 && s == 1);
+                const bool fuse = !par && has_next && !last && C == 256 && !getenv("HMVIT_NO_FUSE");
                 FfnBatcher fb;
                 memset(&fb.p, 0, sizeof(fb.p));
                 fb.n = 0; fb.C = C; fb.st = st;
@@ -533,17 +554,42 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                 fb.p.w_ffn = reinterpret_cast<const half_t*>(wt.img_ffn); fb.p.b_1 = wt.b_1; fb.p.b_2 = wt.b_2;
                 fb.p.P = P;
                 fb.variant = FFN_FULL;
-                for (int b = 0; b < B; ++b)
-                    for (int i = 0; i < n_ego; ++i) {
-                        const int slot = b * L + i;
-                        FfnJob j;
-                        j.o = ob + (size_t)slot * map_elems;
-                        j.x = xs + (size_t)slot * map_elems;
-                        j.out = x_out + (size_t)slot * map_elems;
-                        j.type = d->mode[slot]; j.pad = 0;
-                        HMVIT_TRY(fb.add(j));
-                    }
-                HMVIT_TRY(fb.flush());
+                if (fuse) {
+                    const int it2 = s == 1 ? it + 1 : it, s2 = 1 - s;
+                    const HmvitStageWeights& wn = d->stage[s2];
+                    const StageInfo sn = stage_info(it2, s2);
+                    QkvParams qp;
+                    memset(&qp, 0, sizeof(qp));
+                    qp.gamma = wn.ln_gamma; qp.beta = wn.ln_beta; qp.P = P; qp.in_nchw = 0;
+                    int n = 0;
+                    for (int b = 0; b < B; ++b)
+                        for (int i = 0; i < n_ego; ++i) {   // n_ego == max_cav here: every source agent of the next stage
+                            const int slot = b * L + i;
+                            FfnJob j;
+                            j.o = ob + (size_t)slot * map_elems;
+                            j.x = xs + (size_t)slot * map_elems;
+                            j.out = x_out + (size_t)slot * map_elems;
+                            j.type = d->mode[slot];
+                            j.pad = (sn.last && i >= sn.n_ego) ? 1 : 0;   // x'' of a pure K/V source of the pruned stage is never read
+                            fb.p.job[n] = j;
+                            qp.job[n] = qkv_job(wn, sn, slot, i, false);
+                            if (++n == kMaxChainJobs) { HMVIT_TRY(launch_out_ffn_qkv(fb.p, qp, n, C, st)); n = 0; }
+                        }
+                    HMVIT_TRY(launch_out_ffn_qkv(fb.p, qp, n, C, st));
+                    qkv_done = true;
+                } else {
+                    for (int b = 0; b < B; ++b)
+                        for (int i = 0; i < n_ego; ++i) {
+                            const int slot = b * L + i;
+                            FfnJob j;
+                            j.o = ob + (size_t)slot * map_elems;
+                            j.x = xs + (size_t)slot * map_elems;
+                            j.out = x_out + (size_t)slot * map_elems;
+                            j.type = d->mode[slot]; j.pad = 0;
+                            HMVIT_TRY(fb.add(j));
+                        }
+                    HMVIT_TRY(fb.flush());
+                }
                 if (!last && n_ego < L) {
                     fb.variant = FFN_NO_ATTN;   // agents without an attention update (padding)
                     for (int b = 0; b < B; ++b)

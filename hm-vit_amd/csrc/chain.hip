@@ -43,12 +43,6 @@ struct ChainCfg {
 };
 
 constexpr int CHAIN_THREADS = CHAIN_THREADS_C;
-#ifndef FFN_DEPTH
-#define FFN_DEPTH 4
-#endif
-#ifndef FFN_WG_PER_CU
-#define FFN_WG_PER_CU 2
-#endif
 constexpr int CHAIN_WAVES = CHAIN_THREADS / 64;
 constexpr int CHAIN_TOKENS = CHAIN_WAVES * 32;
 
@@ -64,9 +58,6 @@ __device__ __forceinline__ void stage_chunk(const half_t* __restrict__ chunk, ha
     // dma_wait() below, placed where the only other outstanding VMEM ops are long-issued stores.
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_buf;
-#ifdef NO_DMA
-    return;
-#endif
 #pragma unroll
     for (int i = 0; i < ChainCfg<C>::PPT; ++i) {
         const int piece0 = (i * CHAIN_WAVES + wave) * 64;
@@ -303,17 +294,6 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
         lnp[C + i] = p.beta[J.type * C + i];
     }
     const int n_chunks = J.n_mat * NT;
-#ifdef CHAIN_PHASES
-    unsigned tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = (unsigned)__builtin_readcyclecounter();
-#define CH_PH(i)                                                   \
-    do {                                                           \
-        const unsigned t_ = (unsigned)__builtin_readcyclecounter(); \
-        tacc[i] += t_ - tlast;                                     \
-        tlast = t_;                                                \
-    } while (0)
-#else
-#define CH_PH(i)
-#endif
     stage_chunk<C>(J.w[0], ring0);
 
     float4 v[C / 32][4];
@@ -326,15 +306,11 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(xo + 32 * b + 8 * j) = v[b][j];
     }
-    CH_PH(0);
     dma_wait();
-    CH_PH(1);
     __syncthreads();
-    CH_PH(2);
     layer_norm_regs<C>(v, lnp, lnp + C, hi);
     half8 act[KK];
     to_operands<C>(v, act);
-    CH_PH(3);
 
     for (int c = 0; c < n_chunks; ++c) {
         const int mat = c / NT, t = c - mat * NT;
@@ -343,23 +319,12 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
             const int c1 = c + 1, mat1 = c1 / NT, t1 = c1 - mat1 * NT;
             stage_chunk<C>(J.w[mat1] + (size_t)t1 * Cfg::CHUNK_HALVES, (c & 1) ? ring0 : ring1);
         }
-        CH_PH(2);
         float16v acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#ifndef NO_MFMA
         mma_chunk<KK, (KK < 8 ? KK : 8)>(acc, buf, act, lane);
-#else
-        acc[0] = (float)act[c & 15][0];
-#endif
-        CH_PH(4);
         dma_wait();
-        CH_PH(5);
-#ifdef NO_QKV_STORES
-        if (valid && P < 0) {
-#else
         if (valid) {
-#endif
             // the images of this kernel order the rows of a tile so that the lane's 16 results are two runs
             // of 8 consecutive channels (weights.py store_row_order): 2 x 16-byte stores, adjacent for the
             // lane pair of a token, instead of 4 x 8 (the store path is issue-bound)
@@ -372,21 +337,20 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
                 *reinterpret_cast<half8*>(o + 16 * s) = h;
             }
         }
-        CH_PH(6);
         wg_barrier();
-        CH_PH(7);
     }
-#ifdef CHAIN_PHASES
-    if (p.trace && blockIdx.x == 1000 && blockIdx.y == 0 && threadIdx.x == 0)
-        for (int i = 0; i < 8; ++i) p.trace[i] = tacc[i];
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
 // k_out_ffn
 // ------------------------------------------------------------------------------------------
-template <int C, bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW>
-__global__ __launch_bounds__(CHAIN_THREADS, FFN_WG_PER_CU) void k_out_ffn(FfnParams p) {
+// The body serves two kernels: k_out_ffn (one stage's tail) and k_out_ffn_qkv, which appends the NEXT stage's
+// LayerNorm + Q / K' / V' projections while the updated residual row x'' is still in the accumulators: the
+// residual stream is then read once instead of twice per stage (and not written at all for agents that the
+// pruned last stage only uses as K / V sources).  `qp` = the k_ln_qkv parameters of the next stage, job j of
+// both lists is the same agent.
+template <int C, bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW, bool QKV>
+__device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams* qp) {
     using Cfg = ChainCfg<C>;
     constexpr int KK = Cfg::KK, NT = Cfg::NT, NH = C / 32;   // hidden width == C
     __shared__ __attribute__((aligned(16))) half_t smem[2 * Cfg::CHUNK_HALVES + 10 * C];
@@ -401,20 +365,6 @@ __global__ __launch_bounds__(CHAIN_THREADS, FFN_WG_PER_CU) void k_out_ffn(FfnPar
     const int tok = blockIdx.x * CHAIN_TOKENS + wave * 32 + m;
     const bool valid = tok < P;
     const int ty = J.type;
-#ifdef FFN_PHASES
-    // probe build: per-phase cycle sums of wave 0 in LDS (one ds_add per stamp; stamps kept out of registers)
-    __shared__ unsigned ph_acc[16];
-    if (threadIdx.x < 16) ph_acc[threadIdx.x] = 0;
-    unsigned ph_last = (unsigned)__builtin_readcyclecounter();
-#define FF_PH(i)                                                              \
-    do {                                                                      \
-        const unsigned t_ = (unsigned)__builtin_readcyclecounter();           \
-        if (threadIdx.x == 0) atomicAdd(&ph_acc[i], t_ - ph_last);            \
-        ph_last = t_;                                                         \
-    } while (0)
-#else
-#define FF_PH(i)
-#endif
 
     for (int i = threadIdx.x; i < C; i += CHAIN_THREADS) {
         vec[0][i] = OUTPROJ ? p.b_o[ty * C + i] : 0.f;
@@ -462,10 +412,8 @@ __global__ __launch_bounds__(CHAIN_THREADS, FFN_WG_PER_CU) void k_out_ffn(FfnPar
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) act[kk] = *reinterpret_cast<const half8*>(op + 16 * kk);
     }
-    FF_PH(0);
     dma_wait();
     __syncthreads();
-    FF_PH(1);
 
     // ---- phase 1: x' = x + b_o + W_o . O, one 32-channel tile per chunk (static accumulator index) ----
     if constexpr (OUTPROJ) {
@@ -481,9 +429,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, FFN_WG_PER_CU) void k_out_ffn(FfnPar
                 const float4 bo = *reinterpret_cast<const float4*>(&vec[0][32 * c + 8 * j + 4 * hi]);
                 acc[4 * j + 0] = bo.x; acc[4 * j + 1] = bo.y; acc[4 * j + 2] = bo.z; acc[4 * j + 3] = bo.w;
             }
-#ifndef FFN_NO_MFMA
-            mma_chunk<KK, FFN_DEPTH>(acc, buf, act, lane);
-#endif
+            mma_chunk<KK, 4>(acc, buf, act, lane);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 if (t == c) xacc[t] += acc;
@@ -491,9 +437,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, FFN_WG_PER_CU) void k_out_ffn(FfnPar
             wg_barrier();
         }
     }
-    FF_PH(2);
     if constexpr (LN) ln_acc_to_operands<C>(xacc, vec[1], vec[2], hi, act);
-    FF_PH(3);
 
     // accumulator of the second Linear starts from (residual +) b_2
 #pragma unroll
@@ -523,78 +467,106 @@ __global__ __launch_bounds__(CHAIN_THREADS, FFN_WG_PER_CU) void k_out_ffn(FfnPar
             hacc[4 * j + 0] = b1.x; hacc[4 * j + 1] = b1.y; hacc[4 * j + 2] = b1.z; hacc[4 * j + 3] = b1.w;
         }
         stage_chunk<C>(w1c + Cfg::CHUNK_HALVES, ring1);          // W_2 slice hc
-#ifndef FFN_NO_MFMA
-        mma_chunk<KK, FFN_DEPTH>(hacc, ring0, act, lane);
-#endif
-        FF_PH(4);
+        mma_chunk<KK, 4>(hacc, ring0, act, lane);
         dma_wait();
         wg_barrier();
-        FF_PH(5);
 
         half8 hop[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-#ifndef FFN_NO_GELU
             for (int q = 0; q < 8; ++q) hop[s][q] = (half_t)gelu_f(hacc[8 * s + q]);
-#else
-            for (int q = 0; q < 8; ++q) hop[s][q] = (half_t)hacc[8 * s + q];
-#endif
         if (hc + 1 < NH) stage_chunk<C>(w1c + 2 * Cfg::CHUNK_HALVES, ring0);   // W_1 tile hc + 1
-        FF_PH(6);
-#ifndef FFN_NO_MFMA
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
                 xacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(ring1, t * 2 + s, lane), hop[s], xacc[t], 0, 0, 0);
         }
-#else
-        xacc[hc][0] += (float)hop[0][0] + (float)hop[1][3];
-#endif
-        FF_PH(7);
         dma_wait();
         wg_barrier();
-        FF_PH(8);
     }
 
-#ifdef FFN_NO_STORES
-    if (valid && P < 0) {
-#else
-    if (valid) {
-#endif
-        if constexpr (OUT_NCHW) {
-            float* op = J.out + (size_t)(4 * hi) * P + tok;
+    auto store_x = [&]() {
+        if (valid && !(QKV && J.pad)) {   // pad = 1: x'' is not needed in memory (fused launch before the pruned stage)
+            if constexpr (OUT_NCHW) {
+                float* op = J.out + (size_t)(4 * hi) * P + tok;
+    #pragma unroll
+                for (int t = 0; t < NT; ++t)
+    #pragma unroll
+                    for (int e = 0; e < 16; ++e) op[(size_t)(32 * t + 8 * (e >> 2) + (e & 3)) * P] = xacc[t][e];
+            } else {
+                float* op = J.out + (size_t)tok * C + 4 * hi;
+    #pragma unroll
+                for (int t = 0; t < NT; ++t)
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<float4*>(op + 32 * t + 8 * j) =
+                            make_float4(xacc[t][4 * j], xacc[t][4 * j + 1], xacc[t][4 * j + 2], xacc[t][4 * j + 3]);
+            }
+        }
+    };
+    if constexpr (!QKV) store_x();
+
+    if constexpr (QKV) {
+        // ---- next stage: LayerNorm(x'') -> Q / K' / V' tiles, exactly k_ln_qkv's loop ----
+        const QkvJob& Q = qp->job[blockIdx.y];
+        const int n_chunks = Q.n_mat * NT;
+        if (n_chunks > 0) {
+            // both ring buffers and vec[1..2] are free here (last use before the barrier that ended phase 2)
+            for (int i = threadIdx.x; i < C; i += CHAIN_THREADS) {
+                vec[1][i] = qp->gamma[ty * C + i];
+                vec[2][i] = qp->beta[ty * C + i];
+            }
+            stage_chunk<C>(Q.w[0], ring0);
+            dma_wait();
+            __syncthreads();
+            ln_acc_to_operands<C>(xacc, vec[1], vec[2], hi, act);
+            store_x();   // x'' leaves while the first tiles are computed (the stores are not waited for here)
+            for (int c = 0; c < n_chunks; ++c) {
+                const int mat = c / NT, t = c - mat * NT;
+                const half_t* buf = (c & 1) ? ring1 : ring0;
+                if (c + 1 < n_chunks) {
+                    const int c1 = c + 1, mat1 = c1 / NT, t1 = c1 - mat1 * NT;
+                    stage_chunk<C>(Q.w[mat1] + (size_t)t1 * Cfg::CHUNK_HALVES, (c & 1) ? ring0 : ring1);
+                }
+                float16v acc;
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                mma_chunk<KK, 4>(acc, buf, act, lane);
+                dma_wait();
+                if (valid) {
+                    half_t* o = Q.y[mat] + ((size_t)tok * C + 32 * t + 8 * hi);   // rows in store order (weights.py)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) op[(size_t)(32 * t + 8 * (e >> 2) + (e & 3)) * P] = xacc[t][e];
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        half8 h;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) h[i] = (half_t)acc[8 * s2 + i];
+                        *reinterpret_cast<half8*>(o + 16 * s2) = h;
+                    }
+                }
+                wg_barrier();
+            }
         } else {
-            float* op = J.out + (size_t)tok * C + 4 * hi;
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    *reinterpret_cast<float4*>(op + 32 * t + 8 * j) =
-                        make_float4(xacc[t][4 * j], xacc[t][4 * j + 1], xacc[t][4 * j + 2], xacc[t][4 * j + 3]);
+            store_x();
         }
     }
-#ifdef FFN_PHASES
-    FF_PH(9);
-    __syncthreads();
-    if (p.trace && blockIdx.x == 1000 && blockIdx.y == 0 && threadIdx.x < 16) p.trace[threadIdx.x] = ph_acc[threadIdx.x];
-#endif
+}
+
+template <int C, bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW>
+__global__ __launch_bounds__(CHAIN_THREADS, 2) void k_out_ffn(FfnParams p) {
+    out_ffn_body<C, OUTPROJ, LN, RESID, OUT_NCHW, false>(p, nullptr);
+}
+
+template <int C>
+__global__ __launch_bounds__(CHAIN_THREADS, 2) void k_out_ffn_qkv(FfnParams p, QkvParams q) {
+    out_ffn_body<C, true, true, true, false, true>(p, &q);
 }
 
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-int launch_ln_qkv(const QkvParams& p_in, int n_jobs, int C, hipStream_t st) {
-    QkvParams p = p_in;
-    p.trace = nullptr;
-#ifdef CHAIN_PHASES
-    if (const char* e = getenv("HMVIT_QKV_TRACE")) p.trace = (unsigned long long*)strtoull(e, nullptr, 0);
-#endif
+int launch_ln_qkv(const QkvParams& p, int n_jobs, int C, hipStream_t st) {
     if (n_jobs == 0) return HMVIT_OK;
     dim3 grid(cdiv(p.P, CHAIN_TOKENS), n_jobs), block(CHAIN_THREADS);
     switch (C) {
@@ -620,12 +592,16 @@ static int launch_out_ffn_c(const FfnParams& p, int n_jobs, int variant, hipStre
     return HMVIT_OK;
 }
 
-int launch_out_ffn(const FfnParams& p_in, int n_jobs, int C, int variant, hipStream_t st) {
-    FfnParams p = p_in;
-    p.trace = nullptr;
-#ifdef FFN_PHASES
-    if (const char* e = getenv("HMVIT_FFN_TRACE")) p.trace = (unsigned*)strtoull(e, nullptr, 0);
-#endif
+int launch_out_ffn_qkv(const FfnParams& p, const QkvParams& q, int n_jobs, int C, hipStream_t st) {
+    if (n_jobs == 0) return HMVIT_OK;
+    HMVIT_CHECK_ARG(C == 256, "out_ffn_qkv: C=%d unsupported (256)", C);
+    dim3 grid(cdiv(p.P, CHAIN_TOKENS), n_jobs), block(CHAIN_THREADS);
+    hipLaunchKernelGGL((k_out_ffn_qkv<256>), grid, block, 0, st, p, q);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, hipStream_t st) {
     if (n_jobs == 0) return HMVIT_OK;
     switch (C) {
         case 64: return launch_out_ffn_c<64>(p, n_jobs, variant, st);

@@ -57,7 +57,6 @@ struct QkvParams {
     const float* beta;
     int P;
     int in_nchw;
-    unsigned long long* trace;   // probe builds (-DCHAIN_PHASES) only
 };
 int launch_ln_qkv(const QkvParams& p, int n_jobs, int C, hipStream_t st);
 
@@ -78,10 +77,12 @@ struct FfnParams {
     const float* b_1;        // (T, C)
     const float* b_2;        // (T, C)
     int P;
-    unsigned* trace;         // probe builds (-DFFN_PHASES) only
 };
 enum { FFN_FULL = 0, FFN_NO_ATTN = 1, FFN_HEAD_NCHW = 2 };
 int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, hipStream_t st);
+// k_out_ffn (FFN_FULL) of a stage fused with k_ln_qkv of the next one; job j of both lists = the same agent;
+// FfnJob::pad = 1 suppresses the store of the updated residual row
+int launch_out_ffn_qkv(const FfnParams& p, const QkvParams& q, int n_jobs, int C, hipStream_t st);
 
 // ---- enc.hip (PointPillar branch) ----
 struct PfnParams {
