@@ -10,6 +10,7 @@
 //
 // Same tile as gemm.hip: 128 output pixels x 128 output channels per workgroup, 2x2 wavefronts,
 // v_mfma_f32_32x32x16_f16 (f16 mode) or v_mfma_f32_32x32x2_f32 (exact f32 mode).
+#include <type_traits>
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -137,49 +138,51 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    for (int k0 = 0; k0 < Ktot; k0 += BK) {
+    // global -> registers (the next K slab is fetched while the current one is multiplied), registers -> LDS
+    using Vec = typename std::conditional<sizeof(T) == 2, half8, float4v>::type;   // 16 bytes of a row
+    constexpr int VE = 16 / sizeof(T);
+    Vec ra[RPT], rw[RPT];
+    auto load_slab = [&](int k0) {
         const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        // ---- A slab: im2col rows gathered from the NHWC input ----
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
-            const int c = tid + 256 * i, row = c >> 3;
+            const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * VE;
+            // A slab: im2col rows gathered from the NHWC input
             const int iy = roy[i] * p.stride + ky - p.pad, ix = rox[i] * p.stride + kx - p.pad;
             const bool ok = rvalid[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            const T* src = x + (((size_t)rn[i] * p.H + iy) * p.W + ix) * p.Cin + ci0;
-            if constexpr (sizeof(T) == 2) {
-                const int kc = (c & 7) * 8;
-                half8 v = (half8)(half_t)0;
-                if (ok) v = *reinterpret_cast<const half8*>(src + kc);
-                *reinterpret_cast<half8*>(As + row * LS + kc) = v;
-            } else {
-                const int kc = (c & 7) * 4;
-                float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) f = *reinterpret_cast<const float4*>(src + kc);
-                float* d = reinterpret_cast<float*>(As) + row * LS + kc;
-                d[0] = f.x; d[1] = f.y; d[2] = f.z; d[3] = f.w;
-            }
+            ra[i] = (Vec)(T)0;
+            if (ok) ra[i] = *reinterpret_cast<const Vec*>(x + (((size_t)rn[i] * p.H + iy) * p.W + ix) * p.Cin + ci0 + kc);
+            // W slab
+            rw[i] = (Vec)(T)0;
+            if (n0 + row < Ncols) rw[i] = *reinterpret_cast<const Vec*>(w + (size_t)(n0 + row) * Ktot + k0 + kc);
         }
-        // ---- W slab ----
+    };
+    auto store_slab = [&]() {
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
-            const int c = tid + 256 * i, row = c >> 3;
-            const bool ok = n0 + row < Ncols;
-            const T* src = w + (size_t)(n0 + row) * Ktot + k0;
+            const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * VE;
             if constexpr (sizeof(T) == 2) {
-                const int kc = (c & 7) * 8;
-                half8 v = (half8)(half_t)0;
-                if (ok) v = *reinterpret_cast<const half8*>(src + kc);
-                *reinterpret_cast<half8*>(Ws + row * LS + kc) = v;
+                *reinterpret_cast<half8*>(As + row * LS + kc) = ra[i];
+                *reinterpret_cast<half8*>(Ws + row * LS + kc) = rw[i];
             } else {
-                const int kc = (c & 7) * 4;
-                float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) f = *reinterpret_cast<const float4*>(src + kc);
-                float* d = reinterpret_cast<float*>(Ws) + row * LS + kc;
-                d[0] = f.x; d[1] = f.y; d[2] = f.z; d[3] = f.w;
+                // LS = 33 floats: rows are not 16-byte aligned
+                float* da = reinterpret_cast<float*>(As) + row * LS + kc;
+                float* dw = reinterpret_cast<float*>(Ws) + row * LS + kc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { da[e] = ra[i][e]; dw[e] = rw[i][e]; }
             }
         }
-        __syncthreads();
+    };
+
+    load_slab(0);
+    store_slab();
+    __syncthreads();
+    for (int k0 = 0; k0 < Ktot; k0 += BK) {
+        const bool more = k0 + BK < Ktot;
+        if (more) load_slab(k0 + BK);
+        // D[channel][pixel]: the weights are the A operand, so that an accumulator lane owns one output pixel and
+        // runs of 4 consecutive channels (vector stores in the epilogue instead of 2-byte ones)
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk) {
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], a[i], acc[i][j], 0, 0, 0);
             }
         } else {
             const float* Af = reinterpret_cast<const float*>(As);
@@ -210,44 +213,71 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
             }
         }
         __syncthreads();
+        if (more) {
+            store_slab();
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: bias (folded BN shift), ReLU, NHWC store with channel offset / deconv scatter ----
+    // lane (r, hi) owns output pixel m0 + wm*64 + i*32 + r and, per tile j, the channels 8 q + 4 hi + (0..3)
     const int s = p.deconv_s;
+    const bool vec_ok = (p.Cout % 4 == 0) && (p.y_coff % 4 == 0) && (p.y_ctot % 4 == 0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + r;
-        if (col >= Ncols) continue;
-        const int sub = s ? col / p.Cout : 0, co = s ? col - sub * p.Cout : col;
-        const int dy = s ? sub / s : 0, dx = s ? sub - dy * s : 0;
-        const float bias = p.bias ? p.bias[co] : 0.f;
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + r;
+        if (m >= M) continue;
+        const int n = m / (p.Ho * p.Wo), rem = m - n * p.Ho * p.Wo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                if (m >= M) continue;
-                float v = acc[i][j][e] + bias;
-                if (p.relu) v = fmaxf(v, 0.f);
-                size_t pix;
-                if (s) {
-                    const int n = m / (p.Ho * p.Wo), rem = m - n * p.Ho * p.Wo;
-                    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-                    pix = ((size_t)n * p.Ho * s + oy * s + dy) * (p.Wo * s) + ox * s + dx;
-                } else {
-                    pix = (size_t)m;
-                }
+            for (int q = 0; q < 4; ++q) {
+                const int col = n0 + wn * 64 + j * 32 + 8 * q + 4 * hi;
+                if (col >= Ncols) continue;
+                const int sub = s ? col / p.Cout : 0, co = s ? col - sub * p.Cout : col;
+                const int dy = s ? sub / s : 0, dx = s ? sub - dy * s : 0;
+                const size_t pix = s ? ((size_t)n * p.Ho * s + oy * s + dy) * (p.Wo * s) + ox * s + dx : (size_t)m;
                 const size_t o = pix * p.y_ctot + p.y_coff + co;
-                if (p.out_f32)
-                    reinterpret_cast<float*>(p.y)[o] = v;
-                else
-                    reinterpret_cast<T*>(p.y)[o] = (T)v;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[i][j][4 * q + e] + ((p.bias && col + e < Ncols) ? p.bias[co + e] : 0.f);
+                    if (p.relu) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (vec_ok && col + 3 < Ncols) {
+                    if (p.out_f32) {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else if constexpr (sizeof(T) == 2) {
+                        half4 h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
+                        *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.y) + o) = h;
+                    } else {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                } else {
+                    // ragged channel count: element stores (the channels of one `sub` block stay together only when
+                    // Cout is a multiple of 4, so recompute the scatter per element)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ce = col + e;
+                        if (ce >= Ncols) continue;
+                        const int sube = s ? ce / p.Cout : 0, coe = s ? ce - sube * p.Cout : ce;
+                        const int dye = s ? sube / s : 0, dxe = s ? sube - dye * s : 0;
+                        const size_t pixe = s ? ((size_t)n * p.Ho * s + oy * s + dye) * (p.Wo * s) + ox * s + dxe : (size_t)m;
+                        const size_t oe = pixe * p.y_ctot + p.y_coff + coe;
+                        float ve = acc[i][j][4 * q + e] + (p.bias ? p.bias[coe] : 0.f);
+                        if (p.relu) ve = fmaxf(ve, 0.f);
+                        if (p.out_f32) reinterpret_cast<float*>(p.y)[oe] = ve;
+                        else reinterpret_cast<T*>(p.y)[oe] = (T)ve;
+                    }
+                }
             }
-        }
     }
 }
 
