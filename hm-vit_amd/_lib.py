@@ -69,6 +69,12 @@ _SIGNATURES = {
                                [C.c_int] * 12 + [C.c_void_p]),
     "hmvit_pfn_scatter": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, C.c_void_p]),
     "hmvit_conv2d": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 14 + [C.c_void_p]),
+    "hmvit_box_decode": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int] + [C.c_void_p] * 4 +
+                         [C.c_int, C.c_void_p]),
+    "hmvit_nms_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "hmvit_nms_rotated": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_float, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
+    "hmvit_quad_iou": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "hmvit_debug_tr16": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 

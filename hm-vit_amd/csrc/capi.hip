@@ -782,6 +782,48 @@ int hmvit_conv2d(const void* x, const void* w, const float* bias, void* y, int N
     return launch_conv(p, precision, reinterpret_cast<hipStream_t>(stream));
 }
 
+/* ---- detection post-processing (post.hip) ---- */
+
+int hmvit_box_decode(const float* psm, const float* rm, const float* anchors, const float* transform, int H, int W, int A,
+                     float score_threshold, int order_hwl, float* corners, float* scores, int32_t* index, int32_t* count,
+                     int capacity, void* stream) {
+    HMVIT_CHECK_ARG(psm && rm && anchors && corners && scores && index && count && H > 0 && W > 0 && A > 0 && capacity > 0,
+                    "box_decode: bad argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HMVIT_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), st));
+    BoxDecodeParams p;
+    p.psm = psm; p.rm = rm; p.anchors = anchors; p.T = transform; p.H = H; p.W = W; p.A = A; p.thresh = score_threshold;
+    p.order_hwl = order_hwl; p.corners = corners; p.scores = scores; p.index = index; p.count = count; p.capacity = capacity;
+    return launch_box_decode(p, st);
+}
+
+size_t hmvit_nms_workspace_bytes(int n) {
+    if (n <= 0) return 256;
+    const size_t K = n < 1000 ? n : 1000;
+    return align_up((size_t)n * 4, 256) + align_up(K * 4, 256) + align_up(K * K * 4, 256);
+}
+
+int hmvit_nms_rotated(const float* corners, const float* scores, const int32_t* index, int n, float iou_threshold,
+                      const float* range_xy, void* workspace, size_t workspace_bytes, int32_t* keep, int32_t* n_keep,
+                      void* stream) {
+    HMVIT_CHECK_ARG(n >= 0 && range_xy && keep && n_keep, "nms_rotated: bad argument");
+    HMVIT_CHECK_ARG(n == 0 || (corners && scores && workspace), "nms_rotated: null buffer");
+    HMVIT_CHECK_ARG(workspace_bytes >= hmvit_nms_workspace_bytes(n), "nms_rotated: workspace too small");
+    const size_t K = n < 1000 ? n : 1000;
+    char* ws = reinterpret_cast<char*>(workspace);
+    int* rank = reinterpret_cast<int*>(ws);
+    int* sorted = reinterpret_cast<int*>(ws + align_up((size_t)n * 4, 256));
+    float* iou = reinterpret_cast<float*>(ws + align_up((size_t)n * 4, 256) + align_up(K * 4, 256));
+    return launch_nms_rotated(corners, scores, index, n, iou_threshold, range_xy, rank, sorted, iou, keep, n_keep,
+                              reinterpret_cast<hipStream_t>(stream));
+}
+
+int hmvit_quad_iou(const float* a, const float* b, int na, int nb, int stride_box, int stride_pt, float* iou, void* stream) {
+    HMVIT_CHECK_ARG(na >= 0 && nb >= 0 && stride_box >= 4 * stride_pt && stride_pt >= 2, "quad_iou: bad argument");
+    HMVIT_CHECK_ARG(na == 0 || nb == 0 || (a && b && iou), "quad_iou: null buffer");
+    return launch_quad_iou(a, b, na, nb, stride_box, stride_pt, iou, reinterpret_cast<hipStream_t>(stream));
+}
+
 int hmvit_debug_tr16(uint16_t* out, void* stream) {
     HMVIT_CHECK_ARG(out != nullptr, "debug_tr16: null pointer");
     return launch_debug_tr16(out, reinterpret_cast<hipStream_t>(stream));

@@ -143,4 +143,24 @@ struct AttnParams {
 int launch_attention(const AttnParams& p, int precision, hipStream_t st);
 int launch_debug_tr16(uint16_t* out, hipStream_t st);
 
+// ---- post.hip (detection post-processing) ----
+struct BoxDecodeParams {
+    const float* psm;       // (A, H, W) logits
+    const float* rm;        // (7A, H, W) anchor deltas
+    const float* anchors;   // (H, W, A, 7)
+    const float* T;         // (4, 4) row-major projection into the ego frame, or null
+    int H, W, A;
+    float thresh;
+    int order_hwl;
+    float* corners;         // (capacity, 8, 3)
+    float* scores;          // (capacity)
+    int* index;             // (capacity) anchor index of the candidate
+    int* count;             // device counter, zeroed by the launcher's caller
+    int capacity;
+};
+int launch_box_decode(const BoxDecodeParams& p, hipStream_t st);
+int launch_quad_iou(const float* a, const float* b, int na, int nb, int stride_box, int stride_pt, float* iou, hipStream_t st);
+int launch_nms_rotated(const float* corners, const float* scores, const int* index, int n, float thresh, const float* range4,
+                       int* rank, int* sorted, float* iou, int* keep, int* n_keep, hipStream_t st);
+
 }  // namespace hmvit

@@ -246,6 +246,35 @@ int hmvit_conv2d(const void* x, const void* w, const float* bias, void* y, int N
                  int ksize, int stride, int pad, int relu, int y_ctot, int y_coff, int deconv_stride, int out_f32,
                  int precision, void* stream);
 
+/* ---- detection post-processing ---- */
+
+/* VoxelPostprocessor.post_process up to the candidate list, for one agent's head outputs
+ * (opencood/data_utils/post_processor/voxel_postprocessor.py:232-330, delta_to_boxes3d :355-396;
+ * box_utils.py boxes_to_corners_3d :139-184, project_box3d :258-296, remove_large_pred_bbx :722-751,
+ * remove_bbx_abnormal_z :754-772).
+ *   psm (A, H, W) f32 logits, rm (7A, H, W) f32, anchors (H, W, A, 7) f32 [x y z h w l yaw] (order_hwl = 1) or
+ *   [x y z l h w yaw]; transform: (4, 4) row-major DEVICE matrix into the ego frame, or NULL (no_post_projection).
+ *   Anchors with sigmoid(psm) > score_threshold that pass both sanity filters are appended (unordered) to
+ *   corners (capacity, 8, 3), scores (capacity), index (capacity: anchor index (h W + w) A + a); *count (device)
+ *   receives the number found (may exceed capacity: only `capacity` are stored). */
+int hmvit_box_decode(const float* psm, const float* rm, const float* anchors, const float* transform, int H, int W, int A,
+                     float score_threshold, int order_hwl, float* corners, float* scores, int32_t* index, int32_t* count,
+                     int capacity, void* stream);
+
+/* box_utils.nms_rotated (:575-620) + get_mask_for_boxes_within_range_torch (:326-357): the candidates are ranked by
+ * (score descending, index ascending), the top 1000 go through greedy suppression at polygon IoU > iou_threshold
+ * (IoU of the convex quadrilaterals of corners 0..3, x / y), and the survivors whose 8 corners all lie in
+ * range_xy = host {x_lo, y_lo, x_hi, y_hi} are written to keep[] in pick order; *n_keep (device) = their number.
+ * index may be NULL (ties then break by position). */
+size_t hmvit_nms_workspace_bytes(int n);
+int hmvit_nms_rotated(const float* corners, const float* scores, const int32_t* index, int n, float iou_threshold,
+                      const float* range_xy, void* workspace, size_t workspace_bytes, int32_t* keep, int32_t* n_keep,
+                      void* stream);
+
+/* iou (na, nb) f32 of convex quadrilaterals: corner k of box i at a[i * stride_box + k * stride_pt + {0, 1}]
+ * (common_utils.compute_iou :120-139 with shapely replaced by Sutherland-Hodgman clipping; eval_utils.py:144-196). */
+int hmvit_quad_iou(const float* a, const float* b, int na, int nb, int stride_box, int stride_pt, float* iou, void* stream);
+
 /* debug: lane mapping of ds_read_b64_tr_b16 (used once to pin the V-operand layout) */
 int hmvit_debug_tr16(uint16_t* out, void* stream);
 

@@ -20,6 +20,11 @@ What is frozen:
   g8_decoder.npz        HeteroDecoder.forward (no upsample), 3 samples with ego types 1,0,1, 12x10.
   g9_model.npz          BevformerPointPillarHetero.forward, LiDAR-only batch B=2, record_len [3,2]:
                         pillars -> PointPillar -> regroup -> HeteroFusion -> HeteroDecoder -> psm / rm.
+  g10_postprocess.npz   VoxelPostprocessor.post_process (2 agents, one projected by a rigid transform) on seeded head
+                        outputs over a 32x48x2 anchor grid, and eval_utils.caluclate_tp_fp / calculate_ap over two
+                        frames at IoU 0.3 / 0.5 / 0.7.  shapely is absent: its Polygon is replaced by the convex
+                        clipper of oracle/postprocess_oracle.py, so everything but the polygon intersection is the
+                        reference's own arithmetic.
 
 Weights and inputs are NOT stored where they can be regenerated bit-exactly from a numpy
 legacy RandomState seed (oracle.hmvit_oracle.random_state_dict / synthetic_scene); the
@@ -243,7 +248,58 @@ def g8_decoder():
     save("g8_decoder.npz", seed_weights=81, seed_x=82, mode=mode, psm=psm, rm=rm)
 
 
+def g10_postprocess():
+    """Reference post-processing + AP with shapely.Polygon replaced by the oracle's convex clipper."""
+    import re
+    from oracle import postprocess_oracle as PPO
+    gt_line = [l for l in open("/root/reference/opencood/data_utils/datasets/__init__.py") if l.startswith("GT_RANGE")][0]
+    gt_range = json.loads(re.search(r"\[.*?\]", gt_line).group(0))
+    assert gt_range == PPO.GT_RANGE, gt_range
+    _stub("opencood.visualization"); _stub("opencood.visualization.vis_utils")
+    _stub("opencood.utils.box_overlaps", bbox_overlaps=None)
+    _stub("cv2"); _stub("mmcv", Config=object, DictAction=object)
+    _stub("opencood.data_utils.datasets", GT_RANGE=gt_range)   # the real package pulls open3d / cv2 in
+    import opencood.utils.common_utils as cu
+    cu.Polygon = PPO.Polygon
+    from opencood.data_utils.post_processor.voxel_postprocessor import VoxelPostprocessor
+    from opencood.utils import eval_utils
+
+    params = PPO.make_params(W=96, H=64)
+    pp = VoxelPostprocessor(params, train=False)
+    anchors = pp.generate_anchor_box()
+    assert np.array_equal(anchors, PPO.generate_anchor_box(params))
+    T1 = np.eye(4, dtype=np.float32)
+    c, s = np.cos(0.3), np.sin(0.3)
+    T1[:2, :2] = [[c, -s], [s, c]]
+    T1[:3, 3] = [5.0, -3.0, 0.2]
+    stat = {t: {"tp": [], "fp": [], "gt": 0} for t in (0.3, 0.5, 0.7)}
+    frames = []
+    for seed0 in (101, 103):
+        psm0, rm0, _, gt = PPO.synthetic_heads(params, seed=seed0, n_obj=14)
+        psm1, rm1, _, _ = PPO.synthetic_heads(params, seed=seed0 + 1, n_obj=6)
+        data = {"ego": {"anchor_box": torch.from_numpy(anchors), "transformation_matrix": torch.eye(4)},
+                "7": {"anchor_box": torch.from_numpy(anchors), "transformation_matrix": torch.from_numpy(T1)}}
+        out = {"ego": {"psm": torch.from_numpy(psm0), "rm": torch.from_numpy(rm0)},
+               "7": {"psm": torch.from_numpy(psm1), "rm": torch.from_numpy(rm1)}}
+        boxes, scores = pp.post_process(data, out)
+        frames.append((boxes.numpy(), scores.numpy()))
+        for t in stat:
+            eval_utils.caluclate_tp_fp(boxes, scores, torch.from_numpy(gt), stat, t)
+    tp = {t: list(stat[t]["tp"]) for t in stat}
+    fp = {t: list(stat[t]["fp"]) for t in stat}
+    ap = {t: eval_utils.calculate_ap(stat, t)[0] for t in stat}
+    save("g10_postprocess.npz", seeds=np.array([101, 103]), T1=T1,
+         boxes0=frames[0][0], scores0=frames[0][1], boxes1=frames[1][0], scores1=frames[1][1],
+         tp30=np.array(tp[0.3]), tp50=np.array(tp[0.5]), tp70=np.array(tp[0.7]),
+         fp30=np.array(fp[0.3]), fp50=np.array(fp[0.5]), fp70=np.array(fp[0.7]),
+         ap=np.array([ap[0.3], ap[0.5], ap[0.7]]), gt_total=np.array(stat[0.5]["gt"]))
+    print("g10: boxes", frames[0][0].shape, frames[1][0].shape, "AP", ap)
+
+
 if __name__ == "__main__":
+    if "g10" in sys.argv[1:]:
+        g10_postprocess()
+        sys.exit(0)
     g9_model()
     g8_decoder()
     g7_pointpillar()

@@ -1,0 +1,104 @@
+"""HIP detection post-processing (hm-vit_amd/postprocess.py, csrc/post.hip) against the oracle and the golden run of the
+reference (tests/golden/g10_postprocess.npz).  Everything goes through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import postprocess_oracle as PPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _rot_boxes(rs, n, spread=6.0):
+    ctr = rs.uniform(-spread, spread, (n, 2))
+    size = rs.uniform(0.8, 4.5, (n, 2))
+    yaw = rs.uniform(-np.pi, np.pi, n)
+    tmpl = np.array([[1, -1], [1, 1], [-1, 1], [-1, -1]], float) / 2
+    c, s = np.cos(yaw), np.sin(yaw)
+    loc = tmpl[None] * size[:, None]
+    x = loc[..., 0] * c[:, None] - loc[..., 1] * s[:, None] + ctr[:, None, 0]
+    y = loc[..., 0] * s[:, None] + loc[..., 1] * c[:, None] + ctr[:, None, 1]
+    return np.stack([x, y], -1).astype(np.float32)
+
+
+def test_quad_iou_vs_oracle():
+    import hmvit_amd
+    rs = np.random.RandomState(5)
+    a, b = _rot_boxes(rs, 40), _rot_boxes(rs, 55)
+    b[0] = a[0]                                     # identical
+    b[1] = a[1][::-1]                               # same box, clockwise corner order
+    b[2] = a[2] + 100.0                             # disjoint
+    b[3] = (a[3] - a[3].mean(0)) * 0.5 + a[3].mean(0)   # contained
+    ref = PPO.quad_iou(a, b)
+    got = hmvit_amd.quad_iou(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 2e-5
+    assert abs(got[0, 0] - 1.0) < 1e-5 and abs(got[1, 1] - 1.0) < 1e-5 and got[2, 2] == 0.0 and abs(got[3, 3] - 0.25) < 1e-5
+    # (N, 8, 3) corner layout: only the first four corners' x / y count
+    a3 = np.concatenate([np.concatenate([a, a], 1), np.zeros((40, 8, 1), np.float32)], -1)
+    b3 = np.concatenate([np.concatenate([b, b], 1), np.ones((55, 8, 1), np.float32)], -1)
+    got3 = hmvit_amd.quad_iou(torch.from_numpy(a3).cuda(), torch.from_numpy(b3).cuda()).cpu().numpy()
+    assert np.abs(got3 - ref).max() < 2e-5
+
+
+def _frames(g):
+    params = PPO.make_params(W=96, H=64)
+    anchors = PPO.generate_anchor_box(params)
+    out = []
+    for seed0 in g["seeds"]:
+        psm0, rm0, _, gt = PPO.synthetic_heads(params, seed=int(seed0), n_obj=14)
+        psm1, rm1, _, _ = PPO.synthetic_heads(params, seed=int(seed0) + 1, n_obj=6)
+        out.append((psm0, rm0, psm1, rm1, gt))
+    return params, anchors, out
+
+
+def test_post_process_and_ap_vs_golden():
+    """VoxelPostprocessor.post_process with two agents (one projected into the ego frame) and the AP over two frames."""
+    import hmvit_amd
+    g = load_golden("g10_postprocess.npz")
+    params, anchors, frames = _frames(g)
+    pp = hmvit_amd.VoxelPostprocessor(params, train=False)
+    assert np.array_equal(pp.generate_anchor_box(), anchors)
+    stat = {t: {"tp": [], "fp": [], "gt": 0} for t in (0.3, 0.5, 0.7)}
+    for k, (psm0, rm0, psm1, rm1, gt) in enumerate(frames):
+        data = {"ego": {"anchor_box": torch.from_numpy(anchors), "transformation_matrix": torch.eye(4)},
+                "7": {"anchor_box": torch.from_numpy(anchors), "transformation_matrix": g["T1"]}}
+        out = {"ego": {"psm": torch.from_numpy(psm0).cuda(), "rm": torch.from_numpy(rm0).cuda()},
+               "7": {"psm": torch.from_numpy(psm1).cuda(), "rm": torch.from_numpy(rm1).cuda()}}
+        boxes, scores = pp.post_process(data, out)
+        assert boxes.is_cuda and boxes.shape == g[f"boxes{k}"].shape
+        assert float((boxes.cpu() - g[f"boxes{k}"]).abs().max()) < 1e-4       # same boxes in the same (pick) order
+        assert float((scores.cpu() - g[f"scores{k}"]).abs().max()) < 1e-6
+        for t in stat:
+            hmvit_amd.caluclate_tp_fp(boxes, scores, torch.from_numpy(gt).cuda(), stat, t)
+    for t, tag in ((0.3, "30"), (0.5, "50"), (0.7, "70")):
+        assert stat[t]["tp"] == g["tp" + tag].tolist() and stat[t]["fp"] == g["fp" + tag].tolist()
+    ap = [hmvit_amd.calculate_ap(stat, t)[0] for t in (0.3, 0.5, 0.7)]
+    assert np.allclose(ap, g["ap"].numpy(), atol=1e-12)
+
+
+def test_post_process_edge_cases():
+    import hmvit_amd
+    params = PPO.make_params(W=64, H=48)
+    pp = hmvit_amd.VoxelPostprocessor(params, train=False)
+    anchors = pp.generate_anchor_box()
+    Hs, Ws, A = anchors.shape[:3]
+    data = {"ego": {"anchor_box": torch.from_numpy(anchors), "transformation_matrix": torch.eye(4)}}
+    # nothing above the score threshold -> (None, None), as the reference
+    out = {"ego": {"psm": torch.full((1, A, Hs, Ws), -9.0).cuda(), "rm": torch.zeros(1, 7 * A, Hs, Ws).cuda()}}
+    assert pp.post_process(data, out) == (None, None)
+    # every anchor fires with a distinct score: 1536 > 1000 candidates, the NMS keeps the top 1000 by score and the
+    # result equals the oracle's
+    rs = np.random.RandomState(3)
+    n = A * Hs * Ws
+    psm = (1.0 + 3.0 * rs.permutation(n) / n).astype(np.float32).reshape(1, A, Hs, Ws)
+    rm = (0.02 * rs.randn(1, 7 * A, Hs, Ws)).astype(np.float32)
+    out = {"ego": {"psm": torch.from_numpy(psm).cuda(), "rm": torch.from_numpy(rm).cuda()}}
+    boxes, scores = pp.post_process(data, out)
+    ref_b, ref_s = PPO.post_process(params, [{"psm": psm, "rm": rm, "anchor_box": anchors, "transformation_matrix": None}])
+    assert boxes.shape == ref_b.shape
+    assert np.abs(boxes.cpu().numpy() - ref_b).max() < 1e-4 and np.abs(scores.cpu().numpy() - ref_s).max() < 1e-6
+    # CPU tensors are refused (no CPU path)
+    with pytest.raises(RuntimeError):
+        pp.post_process(data, {"ego": {"psm": torch.from_numpy(psm), "rm": torch.from_numpy(rm)}})

@@ -1,5 +1,6 @@
 """The CPU oracle (oracle/hmvit_oracle.py) replayed against golden vectors frozen from the
 imported reference (tests/golden/make_goldens.py).  CPU-only; pins the oracle."""
+import numpy as np
 import pytest
 import torch
 
@@ -103,3 +104,37 @@ def test_g8_hetero_decoder():
     x = torch.from_numpy(np.random.RandomState(int(g["seed_x"])).standard_normal((3, 1, 256, 12, 10)).astype(np.float32))
     psm, rm = DO.hetero_decoder(x, g["mode"], sd, params)
     assert rel_max_err(psm, g["psm"]) < TOL and rel_max_err(rm, g["rm"]) < TOL
+
+
+def _g10_frames(g):
+    from oracle import postprocess_oracle as PPO
+    params = PPO.make_params(W=96, H=64)
+    anchors = PPO.generate_anchor_box(params)
+    frames = []
+    for seed0 in g["seeds"]:
+        psm0, rm0, _, gt = PPO.synthetic_heads(params, seed=int(seed0), n_obj=14)
+        psm1, rm1, _, _ = PPO.synthetic_heads(params, seed=int(seed0) + 1, n_obj=6)
+        frames.append((psm0, rm0, psm1, rm1, gt))
+    return params, anchors, frames
+
+
+def test_g10_postprocess_and_ap():
+    """post_process (decode, filters, rotated NMS, range mask) and the AP bookkeeping against the reference's own run
+    (shapely's polygon intersection replaced by the oracle's clipper on both sides, see the module header)."""
+    from oracle import postprocess_oracle as PPO
+    g = load_golden("g10_postprocess.npz")
+    params, anchors, frames = _g10_frames(g)
+    stat = {t: {"tp": [], "fp": [], "gt": 0} for t in (0.3, 0.5, 0.7)}
+    for k, (psm0, rm0, psm1, rm1, gt) in enumerate(frames):
+        boxes, scores = PPO.post_process(params, [
+            {"psm": psm0, "rm": rm0, "anchor_box": anchors, "transformation_matrix": np.eye(4, dtype=np.float32)},
+            {"psm": psm1, "rm": rm1, "anchor_box": anchors, "transformation_matrix": g["T1"].numpy()}])
+        ref_b, ref_s = g[f"boxes{k}"].numpy(), g[f"scores{k}"].numpy()
+        assert boxes.shape == ref_b.shape
+        assert np.abs(boxes - ref_b).max() < 1e-4 and np.abs(scores - ref_s).max() < 1e-6
+        for t in stat:
+            PPO.caluclate_tp_fp(boxes, scores, gt, stat, t)
+    for t, tag in ((0.3, "30"), (0.5, "50"), (0.7, "70")):
+        assert stat[t]["tp"] == g["tp" + tag].numpy().tolist() and stat[t]["fp"] == g["fp" + tag].numpy().tolist()
+    ap = [PPO.calculate_ap(stat, t)[0] for t in (0.3, 0.5, 0.7)]
+    assert np.allclose(ap, g["ap"].numpy(), atol=1e-12)
