@@ -446,6 +446,13 @@ __device__ __forceinline__ bool pc_fetch(const AttnParams& p, int X, int Y, int 
     }
 }
 
+// bit c = chunk c of the item has at least one visible key (k_tile_vis); all ones when the table is not in use
+__device__ __forceinline__ unsigned pc_item_vis(const AttnParams& p, const PcItem& it, int X, int Y, bool enabled) {
+    if (!enabled || !p.vis_mask) return 0xffffffffu;
+    const int pos = ((it.b * p.n_ego + it.ego) * X + it.wx) * Y + it.wy;
+    return __builtin_amdgcn_readfirstlane((unsigned)p.vis_mask[pos]) | 1u;
+}
+
 template <int HG, int CW, int LWX>
 struct PcShared {
     static constexpr int CH = HG * 32;             // channels of the head group
@@ -857,34 +864,33 @@ __device__ __forceinline__ void pc_loader_loop_fast(const AttnParams& p, PcShare
         pc_wg_barrier();
     };
 
-#ifdef PC_PHASES
-    // probe build: cycles spent per phase of the G -> G body, summed over the launch (workgroup 0, loader wave 0)
-    unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
-#define PC_PH(i)                                                   \
-    do {                                                           \
-        const unsigned long long t_ = __builtin_readcyclecounter(); \
-        tacc[i] += t_ - tlast;                                     \
-        tlast = t_;                                                \
-    } while (0)
-#else
-#define PC_PH(i)
-#endif
     int item = -1, g = 0, qi = 0;
     PcItem it;
     if (!pc_fetch(p, X, Y, NG, ego_fastest, item, it)) { pc_wg_barrier(); return; }
+    unsigned vis = pc_item_vis(p, it, X, Y, true);   // chunks of the item with at least one visible key (bit 0 = the ego)
     PcGather G = pc_describe<HG, CW, LWX>(p, sm, it, 0, 0, 0, true);
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) issueI(pass, G);
 
+    // Per item: identity chunk, then the VISIBLE general chunks (chunks without a visible key are skipped by both
+    // roles - no loads, no blend, no barrier), then on to the next item.  The control flow keeps the shape
+    // I -> G, loop G -> G, G -> I (or I -> I) with straight-line bodies, which is what lets hipcc keep the 128 tap
+    // registers in place and its vmcnt bookkeeping exact.
+    const unsigned chunk_bits = (1u << n_src) - 1u;
 #pragma unroll 1
     while (true) {
         bool nvalid;
         PcGather N;
-        if (n_src > 1) {
-            // chunk 0 (identity) while chunk 1 is requested
-            pc_taps<HG, CW, LWX>(p, sm, it, 1, lw, lane);
-            N = pc_describe<HG, CW, LWX>(p, sm, it, 1, g + 1, qi, true);
-            N.slot = 0;
+        unsigned rest = vis & ~1u & chunk_bits;
+        const bool has_general = rest != 0;
+        if (has_general) {
+            // identity chunk while the first visible general chunk is requested
+            int c = __builtin_ctz(rest);
+            rest &= rest - 1;
+            int tap_group = (c - 1) / TG;       // group of TG chunks whose taps are in the LDS tables
+            pc_taps<HG, CW, LWX>(p, sm, it, 1 + tap_group * TG, lw, lane);
+            N = pc_describe<HG, CW, LWX>(p, sm, it, c, g + 1, qi, true);
+            N.slot = (c - 1) % TG;
             load_bias(G);
 #pragma unroll
             for (int pass = 0; pass < NP; ++pass) {
@@ -895,42 +901,37 @@ __device__ __forceinline__ void pc_loader_loop_fast(const AttnParams& p, PcShare
             }
             publish(G, G.self_vis, G.self_vis);
             G = N; ++g;
-            // chunks 1 .. n_src - 2 while the following one is requested
+            // general chunks while the following visible one is requested
 #pragma unroll 1
-            for (int chunk = 1; chunk + 1 < n_src; ++chunk) {
-#ifdef PC_PHASES
-                tlast = __builtin_readcyclecounter();
-#endif
-                if ((chunk % TG) == 0) pc_taps<HG, CW, LWX>(p, sm, it, chunk + 1, lw, lane);
-                N = pc_describe<HG, CW, LWX>(p, sm, it, chunk + 1, g + 1, qi, true);
-                N.slot = chunk % TG;
+            while (rest) {
+                c = __builtin_ctz(rest);
+                rest &= rest - 1;
+                if ((c - 1) / TG != tap_group) {
+                    tap_group = (c - 1) / TG;
+                    pc_taps<HG, CW, LWX>(p, sm, it, 1 + tap_group * TG, lw, lane);
+                }
+                N = pc_describe<HG, CW, LWX>(p, sm, it, c, g + 1, qi, true);
+                N.slot = (c - 1) % TG;
                 any = false; allv = true;
                 load_bias(G);
-                PC_PH(0);
 #pragma unroll
                 for (int pass = 0; pass < NP; ++pass) {
                     __builtin_amdgcn_sched_barrier(0);
                     blendG(pass, G);
                     __builtin_amdgcn_sched_barrier(0);
-                    PC_PH(1 + 2 * pass);
                     issueG(pass, N);
-                    __builtin_amdgcn_sched_barrier(0);
-                    PC_PH(2 + 2 * pass);
                 }
                 publish(G, any, allv);
-                PC_PH(9);
-#ifdef PC_PHASES
-                tacc[10] += 1;
-#endif
                 G = N; ++g;
             }
         }
         // last chunk of the item while chunk 0 of the next item is requested
         nvalid = pc_fetch(p, X, Y, NG, ego_fastest, item, it);
+        if (nvalid) vis = pc_item_vis(p, it, X, Y, true);
         qi ^= 1;
         N = pc_describe<HG, CW, LWX>(p, sm, it, 0, g + 1, qi, nvalid);
         load_bias(G);
-        if (n_src > 1) {
+        if (has_general) {
             any = false; allv = true;
 #pragma unroll
             for (int pass = 0; pass < NP; ++pass) {
@@ -954,14 +955,10 @@ __device__ __forceinline__ void pc_loader_loop_fast(const AttnParams& p, PcShare
         G = N; ++g;
     }
     pc_wg_barrier();   // the interval in which the compute waves consume the last chunk
-#ifdef PC_PHASES
-    if (p.trace && blockIdx.x == 0 && ltid == 0)
-        for (int i = 0; i < 12; ++i) p.trace[i] = tacc[i];
-#endif
 }
 
 template <int HG, int CW, int LWX>
-__device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG, CW, LWX>& sm, int wave, int lane) {
+__device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG, CW, LWX>& sm, int wave, int lane, bool use_vis) {
     using SM = PcShared<HG, CW, LWX>;
     constexpr int QS = SM::QS, KS = SM::KS, VS = SM::VS, NQW = SM::NQW, LWG = SM::LWG;
     const int hl = wave / CW, qbase = (wave % CW) * NQW;   // head inside the group, first query tile
@@ -983,7 +980,11 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
     int gstep = 0, qi = 0;
     while (true) {
         const int head = it.hg * HG + hl;
+        // chunks without a visible key are skipped by the loader and here alike (pc_item_vis)
+        const unsigned vis = pc_item_vis(p, it, X, Y, use_vis) & ((1u << n_src) - 1u);
+        const int c_last = 31 - __builtin_clz(vis);
         for (int c = 0; c < n_src; ++c) {
+            if (!((vis >> c) & 1u)) continue;
             const int buf = gstep & 1;
             if (c == 0) {
                 if constexpr (!SM::BIAS_LDS) {
@@ -1097,7 +1098,7 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
                 }
             }
             PC_TRACE(wave == 0 && lane == 0, gstep, 5);
-            if (c == n_src - 1) {
+            if (c == c_last) {
                 half_t* outp = reinterpret_cast<half_t*>(p.out) + (size_t)(it.b * L + it.ego) * P * C;
 #pragma unroll
                 for (int qt = 0; qt < NQW; ++qt) {
@@ -1132,19 +1133,21 @@ __global__ __launch_bounds__((HG * CW + HG * LWX) * 64) void k_attention_pc(Attn
     __syncthreads();
     // wave-uniform role split at the outermost level: the two loops have disjoint live ranges, so
     // the kernel's register count is the maximum of the two roles, not their sum
+    // (workgroup-uniform) are all self transforms the identity?  Selects the loader loop; the loop that handles
+    // general self transforms walks every chunk, so the visibility table is only honoured with the fast one
+    bool self_ident = true;
+    for (int s = threadIdx.x & 63; s < p.B * p.L; s += 64) self_ident &= sm.ainv[(s * p.L + s % p.L) * 8 + 6] != 0.f;
+    const bool fast = __all(self_ident) && !(p.variant & 0x1000);
     if (wave >= SM::CWG) {
         // loader waves outrank the compute waves on their SIMD: the sooner the gather's loads are
         // issued, the more of the memory round trip overlaps with the compute waves' MFMA / softmax
         if (!(p.variant & 0x800)) __builtin_amdgcn_s_setprio(3);
-        // (wave-uniform) are all self transforms the identity?
-        bool self_ident = true;
-        for (int s = threadIdx.x & 63; s < p.B * p.L; s += 64) self_ident &= sm.ainv[(s * p.L + s % p.L) * 8 + 6] != 0.f;
-        if (__all(self_ident) && !(p.variant & 0x1000))
+        if (fast)
             pc_loader_loop_fast<HG, CW, LWX>(p, sm, wave - SM::CWG, threadIdx.x - SM::CWG * 64);
         else
             pc_loader_loop_general<HG, CW, LWX>(p, sm, wave - SM::CWG, threadIdx.x - SM::CWG * 64);
     } else {
-        pc_compute_loop<HG, CW, LWX>(p, sm, wave, threadIdx.x & 63);
+        pc_compute_loop<HG, CW, LWX>(p, sm, wave, threadIdx.x & 63, fast);
     }
 }
 
@@ -1161,6 +1164,43 @@ static int launch_attn_t(const AttnParams& p, hipStream_t st) {
     const int NG = p.C / (HG * 32);
     dim3 grid((p.H / WIN) * (p.W / WIN) * NG, p.n_ego, p.B);
     hipLaunchKernelGGL((k_attention<T, WIN, HG>), grid, dim3(HG * 64), 0, st, p);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Which (ego, window, source) tiles have any visible key?  One wave per window, lane = key: the same tap
+// arithmetic as the loader (make_taps' nearest-pixel ROI test x the agent-validity mask).  In the local stage of
+// cfg2 a third of the (ego, source != ego, window) tiles lie entirely outside the source's field of view; the
+// persistent kernel skips them outright (the reference computes them densely and masks them to -inf: same result,
+// tests/test_hip_fusion.py::test_skip_masked_is_exact).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_vis(AttnParams p, unsigned char* __restrict__ vis_mask) {
+    const int X = p.H / 8, Y = p.W / 8, n_pos = p.B * p.n_ego * X * Y;
+    const int pos = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pos >= n_pos) return;
+    int r = pos;
+    const int wy = r % Y; r /= Y;
+    const int wx = r % X; r /= X;
+    const int ego = r % p.n_ego, b = r / p.n_ego;
+    int row, col;
+    token_pixel(p.partition, 8, X, Y, wx, wy, lane, row, col);
+    unsigned mask = 0;
+    for (int c = 0; c < p.n_src; ++c) {
+        const int src = pc_src(c, ego);
+        const float* a = p.ainv + ((size_t)(b * p.L + src) * p.L + ego) * 8;
+        bool vis = p.cav[b * p.L + src] != 0;
+        if (a[6] == 0.f) vis = vis && make_taps(a, col, row, p.H, p.W).roi != 0.f;
+        if (__any(vis)) mask |= 1u << c;
+    }
+    if (lane == 0) vis_mask[pos] = (unsigned char)mask;
+}
+
+int launch_tile_vis(const AttnParams& p, unsigned char* vis_mask, hipStream_t st) {
+    HMVIT_CHECK_ARG(p.n_src <= 8 && p.window == 8, "tile_vis: n_src=%d (<= 8), window=%d (8)", p.n_src, p.window);
+    const int n_pos = p.B * p.n_ego * (p.H / 8) * (p.W / 8);
+    if (n_pos <= 0) return HMVIT_OK;
+    hipLaunchKernelGGL(k_tile_vis, dim3(cdiv(n_pos, 4)), dim3(256), 0, st, p, vis_mask);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }

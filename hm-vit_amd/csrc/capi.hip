@@ -24,7 +24,7 @@ struct Plan {
     int B, L, C, H, W, P, mlp, n_slots, max_cav, E_max;
     size_t es;
     // byte offsets into the workspace
-    size_t off_xs, off_xn, off_q, off_kv, off_o, off_hid, off_ainv, off_ytok, off_xa, off_xb, off_gap, off_sw, total;
+    size_t off_xs, off_xn, off_q, off_kv, off_o, off_hid, off_ainv, off_ytok, off_xa, off_xb, off_gap, off_sw, off_vis, total;
 };
 
 static int check_desc(const HmvitFusionDesc* d) {
@@ -76,6 +76,7 @@ static void make_plan(const HmvitFusionDesc* d, Plan& pl) {
     pl.off_o = carve(tok * pl.C * pl.es);
     pl.off_ainv = carve((size_t)pl.n_slots * pl.L * 8 * 4);
     pl.off_ytok = carve((size_t)pl.B * pl.P * pl.C * 4);
+    pl.off_vis = carve((size_t)pl.n_slots * pl.P / 64 + 256);   // visible-chunk bits of the attention windows
     pl.off_xa = pl.off_xb = pl.off_gap = pl.off_sw = 0;
     if (d->parallel) {
         // branch outputs of the parallel block + SplitAttn scratch
@@ -536,6 +537,12 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                     ap.mode[i] = (int8_t)d->mode[i];
                     ap.cav[i] = (int8_t)(d->cav_mask[i] != 0);
                     ap.ego_e[i] = (int8_t)(e_of_type[d->mode[i]] < 0 ? 0 : e_of_type[d->mode[i]]);
+                }
+                if (d->skip_masked && d->window == 8 && C > 64 && n_src <= 8 && !getenv("HMVIT_ATTN_DEBUG")) {
+                    // tiles without a visible key are skipped by the persistent kernel (launch_tile_vis)
+                    unsigned char* vis = reinterpret_cast<unsigned char*>(ws + pl.off_vis);
+                    HMVIT_TRY(launch_tile_vis(ap, vis, st));
+                    ap.vis_mask = vis;
                 }
                 HMVIT_TRY(launch_attention(ap, HMVIT_PREC_F16, st));
             }

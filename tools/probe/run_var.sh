@@ -1,5 +1,5 @@
 for v in ${VARS:-0}; do
-HMVIT_ATTN_DEBUG=$v python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-strict > gpurun_out/b$v.log 2>&1
+env $( [ "$v" != "0" ] && echo HMVIT_ATTN_DEBUG=$v ) python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-strict > gpurun_out/b$v.log 2>&1
 python - <<PY
 import json
 l=[x for x in open("gpurun_out/b$v.log") if x.startswith("{")]
