@@ -16,6 +16,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                 reference) timed on the host cores on a bounded crop of the same workload,
   phases        per-phase milliseconds of one forward (HIP events on the launch stream),
   strict_f32    scenes/s of the exact-f32 MFMA mode, for reference.
+  dense_masked_tiles  scenes/s with skip_masked off: `value` skips (ego, source, window) key tiles in which every key
+                is masked (outside the source's field of view); this is the same forward without that shortcut.
 """
 import argparse
 import json
@@ -171,7 +173,9 @@ def main():
                                f"{args.num_iters} iters, {c['voxel'] * c['downsample']:.1f} m/px; "
                                "HeteroFusion.forward, inputs resident in HBM",
                    "parallelism": f"{world} independent scene replica(s), no data-path collective",
-                   "tolerance": "1e-3 rel-max vs the CPU oracle (tests/test_hip_fusion.py)"},
+                   "tolerance": "1e-3 rel-max vs the CPU oracle (tests/test_hip_fusion.py)",
+                   "masked_tiles": "key tiles whose 64 keys are all masked are skipped (identical output); "
+                                   "dense figure in dense_masked_tiles"},
     }
 
     if rank == 0:
@@ -216,6 +220,14 @@ def main():
             result["roofline"]["hbm_view"] = {"algorithmic_bytes_per_launch": comp, "achieved_GBps": comp / avg_s / 1e9,
                                               "peak_GBps": PEAK_HBM, "frac": comp / avg_s / 1e9 / PEAK_HBM}
         result["phases"] = phases
+        if not args.no_strict and world == 1:
+            # a path that skips fully masked key tiles reports the dense figure too (same outputs,
+            # tests/test_hip_fusion.py::test_skip_masked_is_exact)
+            net.skip_masked = False
+            k = max(2, args.steps // 4)
+            result["dense_masked_tiles"] = {"value": k / timed(net, k, 1), "unit": "scenes/s",
+                                            "note": "every (ego, source, window) tile computed, masked keys at -inf"}
+            net.skip_masked = True
         if not args.no_strict and world == 1 and args.precision == "f16":
             del net
             torch.cuda.empty_cache()
