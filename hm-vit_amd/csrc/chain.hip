@@ -269,6 +269,36 @@ __device__ __forceinline__ void load_token(const float* __restrict__ x, bool nch
     }
 }
 
+// Coalesced stores of the projected tiles.  An accumulator lane owns one token and 2 x 8 channels of a 32-channel tile:
+// stored directly, a wave instruction writes 32 separate 32-byte pieces (measured: 3.9 TB/s for this pattern against
+// 6.0 TB/s for whole rows, tools/probe/xstore_probe.hip).  Instead four consecutive tiles (128 channels = 256 bytes per
+// token) are parked in a per-wave LDS buffer and written out as rows: every store instruction then covers 4 tokens x 256
+// contiguous bytes.  The buffer is private to the wave (LDS executes a wave's accesses in order: no barrier), rows are
+// padded by 16 bytes so that the 32 token rows of a write do not fall into the same banks.
+constexpr int STG_ROW = 128 + 8;              // halves per staged token row
+constexpr int STG_WAVE = 32 * STG_ROW;        // halves per wave
+
+__device__ __forceinline__ void stage_tile(half_t* stg, int m, int hi, int t4, const float16v& acc) {
+    half_t* d = stg + m * STG_ROW + 32 * t4 + 8 * hi;   // rows in store order (weights.py store_row_order)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        half8 h;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = (half_t)acc[8 * s + i];
+        *reinterpret_cast<half8*>(d + 16 * s) = h;
+    }
+}
+
+// y: first token row of the wave in the output plane, already offset to the 128-channel group
+__device__ __forceinline__ void flush_tiles(const half_t* stg, half_t* y, int lane, int n_tok, int C) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int token = 4 * k + (lane >> 4), piece = lane & 15;
+        const half8 v = *reinterpret_cast<const half8*>(stg + token * STG_ROW + piece * 8);
+        if (token < n_tok) *reinterpret_cast<half8*>(y + (size_t)token * C + piece * 8) = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // k_ln_qkv
 // ------------------------------------------------------------------------------------------
@@ -277,7 +307,8 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
     using Cfg = ChainCfg<C>;
     constexpr int KK = Cfg::KK, NT = Cfg::NT;
     // ONE LDS object (a second one would make hipcc wait for the DMA before every ds_read)
-    __shared__ __attribute__((aligned(16))) half_t smem[2 * Cfg::CHUNK_HALVES + 4 * C];
+    constexpr bool STAGED = C == 256;   // coalesced stores through LDS (stage_tile / flush_tiles)
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * Cfg::CHUNK_HALVES + 4 * C + (STAGED ? CHAIN_WAVES * STG_WAVE : 0)];
     half_t* ring0 = smem;
     half_t* ring1 = smem + Cfg::CHUNK_HALVES;
     float* lnp = reinterpret_cast<float*>(smem + 2 * Cfg::CHUNK_HALVES);   // gamma[C], beta[C]
@@ -324,7 +355,14 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         mma_chunk<KK, (KK < 8 ? KK : 8)>(acc, buf, act, lane);
         dma_wait();
-        if (valid) {
+        if constexpr (STAGED) {
+            half_t* stg = smem + 2 * Cfg::CHUNK_HALVES + 4 * C + wave * STG_WAVE;
+            stage_tile(stg, m, hi, t & 3, acc);
+            if ((t & 3) == 3) {
+                const int tok_w = blockIdx.x * CHAIN_TOKENS + wave * 32;
+                flush_tiles(stg, J.y[mat] + (size_t)tok_w * C + 128 * (t >> 2), lane, P - tok_w, C);
+            }
+        } else if (valid) {
             // the images of this kernel order the rows of a tile so that the lane's 16 results are two runs
             // of 8 consecutive channels (weights.py store_row_order): 2 x 16-byte stores, adjacent for the
             // lane pair of a token, instead of 4 x 8 (the store path is issue-bound)
@@ -353,7 +391,8 @@ template <int C, bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW, bool QKV>
 __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams* qp) {
     using Cfg = ChainCfg<C>;
     constexpr int KK = Cfg::KK, NT = Cfg::NT, NH = C / 32;   // hidden width == C
-    __shared__ __attribute__((aligned(16))) half_t smem[2 * Cfg::CHUNK_HALVES + 10 * C];
+    constexpr bool STAGED = QKV && C == 256;   // coalesced Q / K' / V' stores through LDS (stage_tile / flush_tiles)
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * Cfg::CHUNK_HALVES + 10 * C + (STAGED ? CHAIN_WAVES * STG_WAVE : 0)];
     half_t* ring0 = smem;
     half_t* ring1 = smem + Cfg::CHUNK_HALVES;
     float (*vec)[C] = reinterpret_cast<float (*)[C]>(smem + 2 * Cfg::CHUNK_HALVES);   // b_o, ln g, ln b, b_1, b_2
@@ -506,6 +545,30 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
             }
         }
     };
+    // the same rows, two 32-channel tiles (256 bytes per token) at a time through the wave's staging buffer: every
+    // store instruction covers 4 tokens x 256 contiguous bytes (see stage_tile / flush_tiles)
+    auto store_x_staged = [&](half_t* stg_h) {
+        if (J.pad) return;
+        float* stg = reinterpret_cast<float*>(stg_h);            // 32 rows of 64 floats + 4 floats of padding
+        constexpr int ROW = STG_ROW / 2;
+        const int tok_w = blockIdx.x * CHAIN_TOKENS + wave * 32, n_tok = P - tok_w;
+    #pragma unroll
+        for (int t2 = 0; t2 < NT / 2; ++t2) {
+    #pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+    #pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<float4*>(stg + m * ROW + 32 * tt + 8 * j + 4 * hi) =
+                        make_float4(xacc[2 * t2 + tt][4 * j], xacc[2 * t2 + tt][4 * j + 1], xacc[2 * t2 + tt][4 * j + 2],
+                                    xacc[2 * t2 + tt][4 * j + 3]);
+    #pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int token = 4 * k + (lane >> 4), piece = lane & 15;
+                const float4 v = *reinterpret_cast<const float4*>(stg + token * ROW + piece * 4);
+                if (token < n_tok) *reinterpret_cast<float4*>(J.out + (size_t)(tok_w + token) * C + 64 * t2 + piece * 4) = v;
+            }
+        }
+    };
     if constexpr (!QKV) store_x();
 
     if constexpr (QKV) {
@@ -522,7 +585,9 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
             dma_wait();
             __syncthreads();
             ln_acc_to_operands<C>(xacc, vec[1], vec[2], hi, act);
-            store_x();   // x'' leaves while the first tiles are computed (the stores are not waited for here)
+            // x'' leaves while the first tiles are computed (the stores are not waited for here)
+            if constexpr (STAGED) store_x_staged(smem + 2 * Cfg::CHUNK_HALVES + 10 * C + wave * STG_WAVE);
+            else store_x();
             for (int c = 0; c < n_chunks; ++c) {
                 const int mat = c / NT, t = c - mat * NT;
                 const half_t* buf = (c & 1) ? ring1 : ring0;
@@ -535,7 +600,14 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
                 for (int e = 0; e < 16; ++e) acc[e] = 0.f;
                 mma_chunk<KK, 4>(acc, buf, act, lane);
                 dma_wait();
-                if (valid) {
+                if constexpr (STAGED) {
+                    half_t* stg = smem + 2 * Cfg::CHUNK_HALVES + 10 * C + wave * STG_WAVE;
+                    stage_tile(stg, m, hi, t & 3, acc);
+                    if ((t & 3) == 3) {
+                        const int tok_w = blockIdx.x * CHAIN_TOKENS + wave * 32;
+                        flush_tiles(stg, Q.y[mat] + (size_t)tok_w * C + 128 * (t >> 2), lane, P - tok_w, C);
+                    }
+                } else if (valid) {
                     half_t* o = Q.y[mat] + ((size_t)tok * C + 32 * t + 8 * hi);   // rows in store order (weights.py)
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
