@@ -1173,7 +1173,7 @@ static int launch_attn_t(const AttnParams& p, hipStream_t st) {
 // arithmetic as the loader (make_taps' nearest-pixel ROI test x the agent-validity mask).  In the local stage of
 // cfg2 a third of the (ego, source != ego, window) tiles lie entirely outside the source's field of view; the
 // persistent kernel skips them outright (the reference computes them densely and masks them to -inf: same result,
-// tests/test_hip_fusion.py::test_skip_masked_is_exact).
+// tests/test_hip_fusion.py::test_skip_masked_tiles_is_exact_f16).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_tile_vis(AttnParams p, unsigned char* __restrict__ vis_mask) {
     const int X = p.H / 8, Y = p.W / 8, n_pos = p.B * p.n_ego * X * Y;

@@ -125,6 +125,17 @@ def test_fusion_batch2_window8_c256(precision):
     assert rel_max_err(y, ref) < TOL[precision]
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_fusion_c128_window8(precision):
+    """C = 128 (4 heads): one head group per workgroup in the persistent attention kernel, unfused chain kernels."""
+    cfg = O.make_config(128, 8, 3, voxel=0.4, downsample=4)
+    sd = O.random_state_dict(cfg, seed=29)
+    scene = O.synthetic_scene(3, 128, 32, 48, [1, 0, 1], seed=12, tx_step=5.0, ty_step=-3.0)
+    ref = O.hetero_fusion(*scene, sd, cfg)
+    y = _fusion(cfg, sd, precision)(*_cuda(*scene)).cpu()
+    assert rel_max_err(y, ref) < TOL[precision]
+
+
 def test_skip_masked_is_exact():
     cfg = O.make_config(64, 8, 3)
     sd = O.random_state_dict(cfg, seed=9)
@@ -135,6 +146,22 @@ def test_skip_masked_is_exact():
     net.skip_masked = False
     b = net(*scene)
     assert torch.equal(a, b)
+
+
+def test_skip_masked_tiles_is_exact_f16():
+    """C = 256, f16: (ego, source, window) tiles without a visible key are skipped by the persistent kernel's loader
+    and compute waves (k_tile_vis); the output must be bit-identical to computing them densely behind the -inf mask."""
+    cfg = O.make_config(256, 8, 4, voxel=0.4, downsample=4)
+    sd = O.random_state_dict(cfg, seed=31)
+    scene = _cuda(*O.synthetic_scene(4, 256, 64, 64, [1, 0, 1, 1], seed=14, tx_step=40.0, ty_step=-25.0))
+    net = _fusion(cfg, sd, "f16")
+    net.skip_masked = True
+    a = net(*scene)
+    net.skip_masked = False
+    b = net(*scene)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    ref = O.hetero_fusion(*[t.cpu() for t in scene], sd, cfg)
+    assert rel_max_err(a.cpu(), ref) < TOL["f16"]
 
 
 def test_inputs_not_mutated_and_repeatable():
