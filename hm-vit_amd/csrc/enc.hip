@@ -95,14 +95,20 @@ template <>
 struct ConvCfg<float> {
     static constexpr int BK = 32, LS = 33;
 };
-constexpr int CBM = 128, CBN = 128;
+constexpr int CBM = 128;
 
-template <typename T>
+// CBN = 128 or 64 output channels per workgroup (64: the 64-channel layers of the first backbone block would leave half
+// of a 128-wide tile empty).  2 x 2 wavefronts, each 64 pixels x CBN / 2 channels.  The K slabs are double-buffered in
+// LDS: slab k + 1 travels global -> registers while slab k is multiplied, registers -> the other buffer afterwards, one
+// barrier per slab.
+template <typename T, int CBN>
 __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
     constexpr int BK = ConvCfg<T>::BK, LS = ConvCfg<T>::LS;
-    constexpr int RPT = (sizeof(T) == 2) ? 4 : 4;        // staged rows per thread (8 chunks per row)
-    __shared__ __attribute__((aligned(16))) T As[CBM * LS];
-    __shared__ __attribute__((aligned(16))) T Ws[CBN * LS];
+    constexpr int RPT = 4;               // staged A rows per thread (8 chunks per row)
+    constexpr int RPW = CBN / 32;        // staged W rows per thread
+    constexpr int NJ = CBN / 64;         // 32-channel MFMA tiles per wave
+    __shared__ __attribute__((aligned(16))) T As[2][CBM * LS];
+    __shared__ __attribute__((aligned(16))) T Ws[2][CBN * LS];
 
     const int M = p.N * p.Ho * p.Wo;
     const int Ncols = p.deconv_s ? p.deconv_s * p.deconv_s * p.Cout : p.Cout;
@@ -130,55 +136,67 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
         rox[i] = rem - roy[i] * p.Wo;
     }
 
-    float16v acc[2][2];
+    float16v acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // global -> registers (the next K slab is fetched while the current one is multiplied), registers -> LDS
     using Vec = typename std::conditional<sizeof(T) == 2, half8, float4v>::type;   // 16 bytes of a row
     constexpr int VE = 16 / sizeof(T);
-    Vec ra[RPT], rw[RPT];
+    Vec ra[RPT], rw[RPW];
     auto load_slab = [&](int k0) {
         const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * VE;
+            const int c = tid + 256 * i, kc = (c & 7) * VE;
             // A slab: im2col rows gathered from the NHWC input
             const int iy = roy[i] * p.stride + ky - p.pad, ix = rox[i] * p.stride + kx - p.pad;
             const bool ok = rvalid[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             ra[i] = (Vec)(T)0;
             if (ok) ra[i] = *reinterpret_cast<const Vec*>(x + (((size_t)rn[i] * p.H + iy) * p.W + ix) * p.Cin + ci0 + kc);
-            // W slab
+        }
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * VE;
             rw[i] = (Vec)(T)0;
             if (n0 + row < Ncols) rw[i] = *reinterpret_cast<const Vec*>(w + (size_t)(n0 + row) * Ktot + k0 + kc);
         }
     };
-    auto store_slab = [&]() {
+    auto store_slab = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * VE;
             if constexpr (sizeof(T) == 2) {
-                *reinterpret_cast<half8*>(As + row * LS + kc) = ra[i];
-                *reinterpret_cast<half8*>(Ws + row * LS + kc) = rw[i];
+                *reinterpret_cast<half8*>(As[buf] + row * LS + kc) = ra[i];
             } else {
-                // LS = 33 floats: rows are not 16-byte aligned
-                float* da = reinterpret_cast<float*>(As) + row * LS + kc;
-                float* dw = reinterpret_cast<float*>(Ws) + row * LS + kc;
+                float* da = reinterpret_cast<float*>(As[buf]) + row * LS + kc;   // LS = 33 floats: rows are not 16-byte aligned
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { da[e] = ra[i][e]; dw[e] = rw[i][e]; }
+                for (int e = 0; e < 4; ++e) da[e] = ra[i][e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * VE;
+            if constexpr (sizeof(T) == 2) {
+                *reinterpret_cast<half8*>(Ws[buf] + row * LS + kc) = rw[i];
+            } else {
+                float* dw = reinterpret_cast<float*>(Ws[buf]) + row * LS + kc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dw[e] = rw[i][e];
             }
         }
     };
 
     load_slab(0);
-    store_slab();
+    store_slab(0);
     __syncthreads();
-    for (int k0 = 0; k0 < Ktot; k0 += BK) {
+    int cur = 0;
+    for (int k0 = 0; k0 < Ktot; k0 += BK, cur ^= 1) {
         const bool more = k0 + BK < Ktot;
         if (more) load_slab(k0 + BK);
         // D[channel][pixel]: the weights are the A operand, so that an accumulator lane owns one output pixel and
@@ -186,41 +204,38 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk) {
-                half8 a[2], b[2];
+                half8 a[2], b[NJ];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    a[i] = *reinterpret_cast<const half8*>(As + (wm * 64 + i * 32 + r) * LS + kk * 16 + hi * 8);
+                    a[i] = *reinterpret_cast<const half8*>(As[cur] + (wm * 64 + i * 32 + r) * LS + kk * 16 + hi * 8);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    b[j] = *reinterpret_cast<const half8*>(Ws + (wn * 64 + j * 32 + r) * LS + kk * 16 + hi * 8);
+                for (int j = 0; j < NJ; ++j)
+                    b[j] = *reinterpret_cast<const half8*>(Ws[cur] + (wn * (CBN / 2) + j * 32 + r) * LS + kk * 16 + hi * 8);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], a[i], acc[i][j], 0, 0, 0);
             }
         } else {
-            const float* Af = reinterpret_cast<const float*>(As);
-            const float* Wf = reinterpret_cast<const float*>(Ws);
+            const float* Af = reinterpret_cast<const float*>(As[cur]);
+            const float* Wf = reinterpret_cast<const float*>(Ws[cur]);
 #pragma unroll 4
             for (int kk = 0; kk < BK / 2; ++kk) {
-                float a[2], b[2];
+                float a[2], b[NJ];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) a[i] = Af[(wm * 64 + i * 32 + r) * LS + kk * 2 + hi];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) b[j] = Wf[(wn * 64 + j * 32 + r) * LS + kk * 2 + hi];
+                for (int j = 0; j < NJ; ++j) b[j] = Wf[(wn * (CBN / 2) + j * 32 + r) * LS + kk * 2 + hi];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
             }
         }
+        if (more) store_slab(cur ^ 1);   // that buffer was last read before the previous barrier
         __syncthreads();
-        if (more) {
-            store_slab();
-            __syncthreads();
-        }
     }
 
     // ---- epilogue: bias (folded BN shift), ReLU, NHWC store with channel offset / deconv scatter ----
@@ -234,10 +249,10 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
         const int n = m / (p.Ho * p.Wo), rem = m - n * p.Ho * p.Wo;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int col = n0 + wn * 64 + j * 32 + 8 * q + 4 * hi;
+                const int col = n0 + wn * (CBN / 2) + j * 32 + 8 * q + 4 * hi;
                 if (col >= Ncols) continue;
                 const int sub = s ? col / p.Cout : 0, co = s ? col - sub * p.Cout : col;
                 const int dy = s ? sub / s : 0, dx = s ? sub - dy * s : 0;
@@ -290,11 +305,15 @@ int launch_conv(const ConvParams& p, int precision, hipStream_t st) {
                     "deconv is expressed as a 1x1 GEMM with scatter");
     const int M = p.N * p.Ho * p.Wo;
     const int Ncols = p.deconv_s ? p.deconv_s * p.deconv_s * p.Cout : p.Cout;
-    dim3 grid(cdiv(M, CBM) * cdiv(Ncols, CBN)), block(256);
-    if (precision == HMVIT_PREC_F32)
-        hipLaunchKernelGGL((k_conv<float>), grid, block, 0, st, p);
-    else
-        hipLaunchKernelGGL((k_conv<half_t>), grid, block, 0, st, p);
+    const bool narrow = Ncols <= 64;
+    dim3 grid(cdiv(M, CBM) * cdiv(Ncols, narrow ? 64 : 128)), block(256);
+    if (precision == HMVIT_PREC_F32) {
+        if (narrow) hipLaunchKernelGGL((k_conv<float, 64>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((k_conv<float, 128>), grid, block, 0, st, p);
+    } else {
+        if (narrow) hipLaunchKernelGGL((k_conv<half_t, 64>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((k_conv<half_t, 128>), grid, block, 0, st, p);
+    }
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }
