@@ -446,11 +446,16 @@ __device__ __forceinline__ bool pc_fetch(const AttnParams& p, int X, int Y, int 
     }
 }
 
-// bit c = chunk c of the item has at least one visible key (k_tile_vis); all ones when the table is not in use
+// bit c = chunk c of the item has at least one visible key (k_tile_vis); all ones when the table is not in use.
+// A scalar load on purpose: a vector load of this wave-uniform word would be followed by s_waitcnt vmcnt(0), i.e. it
+// would drain the loader's in-flight taps once per item.
 __device__ __forceinline__ unsigned pc_item_vis(const AttnParams& p, const PcItem& it, int X, int Y, bool enabled) {
     if (!enabled || !p.vis_mask) return 0xffffffffu;
     const int pos = ((it.b * p.n_ego + it.ego) * X + it.wx) * Y + it.wy;
-    return __builtin_amdgcn_readfirstlane((unsigned)p.vis_mask[pos]) | 1u;
+    const unsigned* a = p.vis_mask + pos;
+    unsigned v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(a) : "memory");
+    return v | 1u;
 }
 
 template <int HG, int CW, int LWX>
@@ -1175,7 +1180,7 @@ static int launch_attn_t(const AttnParams& p, hipStream_t st) {
 // persistent kernel skips them outright (the reference computes them densely and masks them to -inf: same result,
 // tests/test_hip_fusion.py::test_skip_masked_tiles_is_exact_f16).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tile_vis(AttnParams p, unsigned char* __restrict__ vis_mask) {
+__global__ __launch_bounds__(256) void k_tile_vis(AttnParams p, unsigned* __restrict__ vis_mask) {
     const int X = p.H / 8, Y = p.W / 8, n_pos = p.B * p.n_ego * X * Y;
     const int pos = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (pos >= n_pos) return;
@@ -1193,10 +1198,10 @@ __global__ __launch_bounds__(256) void k_tile_vis(AttnParams p, unsigned char* _
         if (a[6] == 0.f) vis = vis && make_taps(a, col, row, p.H, p.W).roi != 0.f;
         if (__any(vis)) mask |= 1u << c;
     }
-    if (lane == 0) vis_mask[pos] = (unsigned char)mask;
+    if (lane == 0) vis_mask[pos] = mask;
 }
 
-int launch_tile_vis(const AttnParams& p, unsigned char* vis_mask, hipStream_t st) {
+int launch_tile_vis(const AttnParams& p, unsigned* vis_mask, hipStream_t st) {
     HMVIT_CHECK_ARG(p.n_src <= 8 && p.window == 8, "tile_vis: n_src=%d (<= 8), window=%d (8)", p.n_src, p.window);
     const int n_pos = p.B * p.n_ego * (p.H / 8) * (p.W / 8);
     if (n_pos <= 0) return HMVIT_OK;

@@ -76,7 +76,7 @@ static void make_plan(const HmvitFusionDesc* d, Plan& pl) {
     pl.off_o = carve(tok * pl.C * pl.es);
     pl.off_ainv = carve((size_t)pl.n_slots * pl.L * 8 * 4);
     pl.off_ytok = carve((size_t)pl.B * pl.P * pl.C * 4);
-    pl.off_vis = carve((size_t)pl.n_slots * pl.P / 64 + 256);   // visible-chunk bits of the attention windows
+    pl.off_vis = carve((size_t)pl.n_slots * pl.P / 64 * 4 + 256);   // visible-chunk bits of the attention windows
     pl.off_xa = pl.off_xb = pl.off_gap = pl.off_sw = 0;
     if (d->parallel) {
         // branch outputs of the parallel block + SplitAttn scratch
@@ -540,7 +540,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                 }
                 if (d->skip_masked && d->window == 8 && C > 64 && n_src <= 8 && !getenv("HMVIT_ATTN_DEBUG")) {
                     // tiles without a visible key are skipped by the persistent kernel (launch_tile_vis)
-                    unsigned char* vis = reinterpret_cast<unsigned char*>(ws + pl.off_vis);
+                    unsigned* vis = reinterpret_cast<unsigned*>(ws + pl.off_vis);
                     HMVIT_TRY(launch_tile_vis(ap, vis, st));
                     ap.vis_mask = vis;
                 }

@@ -136,13 +136,13 @@ struct AttnParams {
     int B, L, n_ego, n_src, E, C, H, W, window, partition, skip_masked;
     unsigned long long* trace; // optional s_memtime trace buffer (debug probe), else null
     int variant;              // 0: default kernel choice, 1: force the one-window-per-workgroup kernel
-    const unsigned char* vis_mask;   // optional (B * n_ego * H/8 * W/8): visible-chunk bits per window (launch_tile_vis)
+    const unsigned* vis_mask;        // optional (B * n_ego * H/8 * W/8): visible-chunk bits per window (launch_tile_vis)
     int8_t mode[kMaxSlots];   // (B, L)
     int8_t cav[kMaxSlots];    // (B, L)
     int8_t ego_e[kMaxSlots];  // (B, L): K/V variant used by ego (b, i)
 };
 int launch_attention(const AttnParams& p, int precision, hipStream_t st);
-int launch_tile_vis(const AttnParams& p, unsigned char* vis_mask, hipStream_t st);
+int launch_tile_vis(const AttnParams& p, unsigned* vis_mask, hipStream_t st);
 int launch_debug_tr16(uint16_t* out, hipStream_t st);
 
 // ---- post.hip (detection post-processing) ----
