@@ -393,15 +393,15 @@ __global__ __launch_bounds__(HG * 64, (sizeof(T) == 2 ? 2 : 1)) void k_attention
 }
 
 // ------------------------------------------------------------------------------------------
-// Persistent producer / consumer variant (f16, window 8, 4 heads = 128 channels per workgroup).
+// Persistent producer / consumer variant (f16, window 8, 4 heads = 128 channels per workgroup): k_attention_pc.
 //
-// 8 wavefronts: waves 0-3 compute (one head each, exactly as k_attention), waves 4-7 only gather.
-// While the compute waves work on key chunk c out of LDS buffer c & 1, the loader waves bilinear-
-// gather chunk c + 1 (or the next work item's query tile and first chunk) into the other buffer
-// with ALL tap loads of the chunk in flight at once (they hold no other state, so 128 VGPRs of raw
-// taps fit).  One __syncthreads() per chunk; the workgroup walks a strided list of
-// (sample, ego, window, head group) items so the pipeline never drains.  The ego's own map is
-// chunk 0 (identity transform: one tap), which keeps the item hand-over cheap.
+// 8 wavefronts: waves 0-3 compute (one head each, exactly as k_attention), waves 4-7 only gather.  While the compute
+// waves work on key chunk g out of LDS buffer g & 1, the loader waves blend chunk g + 1 (or the next item's query tile
+// and identity chunk) into the other buffer; one barrier per chunk.  256 workgroups walk a tiled schedule of
+// (sample, ego, window, head group) items (pc_fetch) so the pipeline never drains.  The loader is the critical role
+// and is organised for memory-level parallelism and instruction count: see pc_loader_loop_general (pass-granular
+// software pipeline, structured buffer loads, unconditional body), pc_loader_loop_fast (identity chunk as a copy,
+// visible chunks only), pc_taps (taps of all chunks of an item in one shot), blend_h (packed-f16 4-tap sum).
 // ------------------------------------------------------------------------------------------
 struct PcItem {
     int b, ego, wx, wy, hg;
