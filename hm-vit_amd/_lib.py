@@ -75,6 +75,8 @@ _SIGNATURES = {
     "hmvit_nms_rotated": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_float, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "hmvit_quad_iou": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "hmvit_voxelize_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "hmvit_voxelize": (C.c_int, [C.c_void_p, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int, C.c_void_p, C.c_size_t] + [C.c_void_p] * 5),
     "hmvit_debug_tr16": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 

@@ -831,6 +831,38 @@ int hmvit_quad_iou(const float* a, const float* b, int na, int nb, int stride_bo
     return launch_quad_iou(a, b, na, nb, stride_box, stride_pt, iou, reinterpret_cast<hipStream_t>(stream));
 }
 
+/* ---- pillariser (vox.hip) ---- */
+
+size_t hmvit_voxelize_workspace_bytes(int n_points, int nx, int ny, int nz) {
+    const size_t cells = (size_t)nx * ny * nz, n = n_points > 0 ? n_points : 1;
+    return 3 * align_up(n * 4, 256) + 4 * align_up(cells * 4, 256);
+}
+
+int hmvit_voxelize(const float* points, int n_points, const float* voxel_size, const float* lidar_range, int max_points,
+                   int max_voxels, void* workspace, size_t workspace_bytes, float* voxels, int32_t* coords, int32_t* num_points,
+                   int32_t* n_voxels, void* stream) {
+    HMVIT_CHECK_ARG(n_points >= 0 && voxel_size && lidar_range && max_points > 0 && max_voxels > 0 && workspace && voxels &&
+                    coords && num_points && n_voxels && (n_points == 0 || points), "voxelize: bad argument");
+    VoxParams p;
+    p.points = points; p.n_points = n_points;
+    int grid[3];
+    for (int k = 0; k < 3; ++k) {
+        p.rmin[k] = lidar_range[k]; p.vsize[k] = voxel_size[k];
+        grid[k] = (int)lroundf((lidar_range[3 + k] - lidar_range[k]) / voxel_size[k]);   // sp_voxel_preprocessor.py:28-30
+        HMVIT_CHECK_ARG(grid[k] > 0, "voxelize: empty grid on axis %d", k);
+    }
+    p.nx = grid[0]; p.ny = grid[1]; p.nz = grid[2]; p.max_points = max_points; p.max_voxels = max_voxels;
+    HMVIT_CHECK_ARG(workspace_bytes >= hmvit_voxelize_workspace_bytes(n_points, p.nx, p.ny, p.nz), "voxelize: workspace too small");
+    const size_t cells = (size_t)p.nx * p.ny * p.nz, n = n_points > 0 ? n_points : 1;
+    char* ws = reinterpret_cast<char*>(workspace);
+    const size_t sn = align_up(n * 4, 256), sc = align_up(cells * 4, 256);
+    p.cell = reinterpret_cast<int*>(ws); p.placed = reinterpret_cast<int*>(ws + sn); p.scan = reinterpret_cast<int*>(ws + 2 * sn);
+    p.first = reinterpret_cast<int*>(ws + 3 * sn); p.count = reinterpret_cast<int*>(ws + 3 * sn + sc);
+    p.cmin = reinterpret_cast<int*>(ws + 3 * sn + 2 * sc); p.vox_id = reinterpret_cast<int*>(ws + 3 * sn + 3 * sc);
+    p.voxels = voxels; p.coords = coords; p.num_points = num_points; p.n_voxels = n_voxels;
+    return launch_voxelize(p, reinterpret_cast<hipStream_t>(stream));
+}
+
 int hmvit_debug_tr16(uint16_t* out, void* stream) {
     HMVIT_CHECK_ARG(out != nullptr, "debug_tr16: null pointer");
     return launch_debug_tr16(out, reinterpret_cast<hipStream_t>(stream));

@@ -165,4 +165,26 @@ int launch_quad_iou(const float* a, const float* b, int na, int nb, int stride_b
 int launch_nms_rotated(const float* corners, const float* scores, const int* index, int n, float thresh, const float* range4,
                        int* rank, int* sorted, float* iou, int* keep, int* n_keep, hipStream_t st);
 
+// ---- vox.hip (pillariser) ----
+struct VoxParams {
+    const float* points;    // (n_points, 4)
+    int n_points;
+    float rmin[3], vsize[3];
+    int nx, ny, nz, max_points, max_voxels;
+    // workspace
+    int* cell;              // (n_points) linear cell or -1
+    int* placed;            // (n_points)
+    int* scan;              // (n_points)
+    int* first;             // (cells) first point of the cell
+    int* count;             // (cells)
+    int* cmin;              // (cells) bidding array
+    int* vox_id;            // (cells)
+    // outputs
+    float* voxels;          // (max_voxels, max_points, 4), zero padded
+    int* coords;            // (max_voxels, 3) z, y, x
+    int* num_points;        // (max_voxels)
+    int* n_voxels;          // device scalar
+};
+int launch_voxelize(const VoxParams& p, hipStream_t st);
+
 }  // namespace hmvit

@@ -275,6 +275,20 @@ int hmvit_nms_rotated(const float* corners, const float* scores, const int32_t* 
  * (common_utils.compute_iou :120-139 with shapely replaced by Sutherland-Hodgman clipping; eval_utils.py:144-196). */
 int hmvit_quad_iou(const float* a, const float* b, int na, int nb, int stride_box, int stride_pt, float* iou, void* stream);
 
+/* ---- pillariser ---- */
+
+/* spconv.utils.Point2VoxelCPU3d.point_to_voxel as called by SpVoxelPreprocessor.preprocess
+ * (opencood/data_utils/pre_processor/sp_voxel_preprocessor.py:34-57; spconv-cu113, third party, version unpinned), same
+ * deterministic result as its sequential algorithm: voxels in order of first appearance, points in input order, at most
+ * max_points per voxel and max_voxels voxels.
+ *   points (n_points, 4) f32 device; voxel_size / lidar_range: host arrays of 3 / 6 floats (grid = round(extent / size));
+ *   voxels (max_voxels, max_points, 4) f32 zero padded, coords (max_voxels, 3) int32 [z, y, x], num_points (max_voxels)
+ *   int32, *n_voxels device int32 = voxels produced. */
+size_t hmvit_voxelize_workspace_bytes(int n_points, int nx, int ny, int nz);
+int hmvit_voxelize(const float* points, int n_points, const float* voxel_size, const float* lidar_range, int max_points,
+                   int max_voxels, void* workspace, size_t workspace_bytes, float* voxels, int32_t* coords, int32_t* num_points,
+                   int32_t* n_voxels, void* stream);
+
 /* debug: lane mapping of ds_read_b64_tr_b16 (used once to pin the V-operand layout) */
 int hmvit_debug_tr16(uint16_t* out, void* stream);
 

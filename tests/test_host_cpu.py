@@ -126,3 +126,22 @@ def test_bias_fragments_layout(pkg):
                     for r in range(4):
                         q, k = qt * 16 + (lane & 15), kt * 16 + 4 * (lane >> 4) + r
                         assert torch.equal(frag[:, v, lane, r], full[:, q, k])
+
+
+def test_voxelizer_oracle_properties():
+    """The pillariser oracle restates spconv's sequential algorithm (third party, absent: parity unpinned); what can be
+    checked without it are the algorithm's defining properties."""
+    import numpy as np
+    from oracle import voxelizer_oracle as VO
+    rng = [-12.8, -9.6, -3, 12.8, 9.6, 1]
+    cloud = VO.synthetic_cloud(6000, rng, seed=7)
+    v, c, n = VO.point_to_voxel(cloud, [0.4, 0.4, 4], rng, 8, 500)
+    assert len(v) == 500 and n.max() == 8 and n.min() >= 1
+    assert len({tuple(x) for x in c}) == len(c)                       # one voxel per cell
+    for k in range(0, 500, 37):                                       # points lie in their voxel's cell, padding is zero
+        pts = v[k, : n[k]]
+        cell = np.floor((pts[:, :3] - np.float32(rng[:3])) / np.float32([0.4, 0.4, 4])).astype(int)
+        assert (cell[:, ::-1] == c[k]).all() and not v[k, n[k]:].any()
+    # first appearance order: the first point of voxel k precedes the first point of voxel k + 1 in the input
+    first = [int(np.nonzero((cloud == v[k, 0]).all(1))[0][0]) for k in range(0, 500, 23)]
+    assert first == sorted(first)
