@@ -47,3 +47,47 @@ def test_camera_agents_need_a_camera_encoder():
     batch["mode"][0, 1] = 0
     with pytest.raises(NotImplementedError):
         net(batch)
+
+
+def test_full_inference_chain_on_device():
+    """Raw points -> pillariser -> PointPillar -> HeteroFusion -> HeteroDecoder -> VoxelPostprocessor, every stage on the GPU
+    (what inference_camera.py does per frame, opencood/tools/inference_camera.py:145-195).  The model's head outputs are
+    pinned by g9; here the chain is checked stage against stage: the pillars equal the sequential algorithm's, and the boxes
+    the HIP post-processor makes from the HIP head outputs equal the oracle's boxes from the same head outputs (the score
+    threshold is lowered so that a random-weight model fires on a few hundred anchors)."""
+    import numpy as np
+    import hmvit_amd
+    from model_fixture import model_config, model_state_dict
+    from oracle import hmvit_oracle as O
+    from oracle import postprocess_oracle as PPO
+    from oracle import voxelizer_oracle as VO
+    cfg = model_config()
+    largs = cfg["lidar"]
+    pre = hmvit_amd.SpVoxelPreprocessor({"cav_lidar_range": largs["lidar_range"],
+                                         "args": {"voxel_size": largs["voxel_size"], "max_points_per_voxel": 32,
+                                                  "max_voxel_train": 32000, "max_voxel_test": 70000}}, train=False)
+    clouds = [VO.synthetic_cloud(4000, largs["lidar_range"], seed=40 + i) for i in range(3)]
+    pillars = [pre.preprocess(c) for c in clouds]
+    rv, rc, rn = VO.point_to_voxel(clouds[1], largs["voxel_size"], largs["lidar_range"], 32, 70000)
+    assert np.array_equal(pillars[1]["voxel_features"].cpu().numpy(), rv) and np.array_equal(pillars[1]["voxel_coords"].cpu().numpy(), rc)
+    lidar = pre.collate_batch(pillars)
+    _, pw, _, _, _ = O.synthetic_scene(3, 1, 1, 1, [1, 1, 1], seed=0, B=1, tx_step=3.0, ty_step=-2.0)
+    batch = {"mode": torch.ones(1, 3, dtype=torch.float64).cuda(), "record_len": torch.tensor([3]).cuda(),
+             "pairwise_t_matrix": pw.cuda(), "processed_lidar": lidar}
+    net = hmvit_amd.BevformerPointPillarHetero(cfg, precision="f32")
+    net.load_state_dict(model_state_dict(cfg, 91), strict=False)
+    out = net.cuda().eval()(batch)
+    psm, rm = out["psm"], out["rm"]
+    assert torch.isfinite(psm).all() and torch.isfinite(rm).all()
+    A, Hs, Ws = psm.shape[1], psm.shape[2], psm.shape[3]
+    params = PPO.make_params(W=Ws * 2, H=Hs * 2)
+    params["target_args"]["score_threshold"] = float(torch.sigmoid(psm).flatten().kthvalue(psm.numel() - 150).values)
+    pp = hmvit_amd.VoxelPostprocessor(params, train=False)
+    anchors = pp.generate_anchor_box()
+    assert anchors.shape[:3] == (Hs, Ws, A)
+    data = {"ego": {"anchor_box": torch.from_numpy(anchors), "transformation_matrix": torch.eye(4)}}
+    boxes, scores = pp.post_process(data, {"ego": {"psm": psm, "rm": rm}})
+    ref_b, ref_s = PPO.post_process(params, [{"psm": psm.cpu().numpy(), "rm": rm.cpu().numpy(), "anchor_box": anchors,
+                                              "transformation_matrix": None}])
+    assert boxes is not None and boxes.shape == ref_b.shape and boxes.shape[0] > 0
+    assert np.abs(boxes.cpu().numpy() - ref_b).max() < 1e-4 and np.abs(scores.cpu().numpy() - ref_s).max() < 1e-6
