@@ -37,9 +37,14 @@ def bench(tag, dbg):
     e1.record(); torch.cuda.synchronize()
     print(f"{tag:40s} dbg={dbg:#04x}  {e0.elapsed_time(e1) / 5:.3f} ms", flush=True)
 
-for tag, dbg in [("baseline 16 waves (8 compute + 8 loader)", 0), ("8 waves (4 + 4)", 2), ("1 tap (all visible)", 0x10), ("no loads (all masked)", 0x20),
-                 ("no compute", 0x40), ("no blend (4 taps loaded)", 0x80), ("ego-major item order (old)", 0x200), ("no loader priority", 0x800), ("L2-resident region", 0x400), ("L2-resident + 1 tap", 0x410), ("1 tap + no compute", 0x50),
-                 ("no loads + no compute", 0x60)]:
+VARIANTS = [("default: 8 waves (4 compute + 4 loader)", 0), ("16 waves (8 + 8)", 2), ("1 tap (all visible)", 0x10),
+            ("no loads (all masked)", 0x20), ("no compute", 0x40), ("other item order", 0x200), ("no loader priority", 0x800),
+            ("L2-resident region", 0x400), ("1 tap + no compute", 0x50), ("no loads + no compute", 0x60),
+            ("general loader loop", 0x1000)]
+if os.environ.get("ONLY"):
+    want = [int(v, 0) for v in os.environ["ONLY"].split(",")]
+    VARIANTS = [v for v in VARIANTS if v[1] in want]
+for tag, dbg in VARIANTS:
     bench(tag, dbg)
 
 # ---- cycle trace of workgroup 0 (csrc/attn.hip PC_TRACE): slots 0 iter start, 1 taps done,
@@ -57,16 +62,3 @@ if os.environ.get("TRACE"):
         print(f"{i:3d} " + " ".join(f"{v:8d}" for v in r))
     del os.environ["HMVIT_ATTN_TRACE"]
 
-# ---- per-phase cycle sums of the loader's G -> G body (library built with -DPC_PHASES) ----
-if os.environ.get("PHASES"):
-    tr = torch.zeros(64, dtype=torch.int64, device=dev)
-    os.environ["HMVIT_ATTN_DEBUG"] = os.environ.get("TRACE_DBG", "0")
-    os.environ["HMVIT_ATTN_TRACE"] = hex(tr.data_ptr())
-    run(); torch.cuda.synchronize()
-    t = tr.cpu().tolist()
-    n = max(t[10], 1)
-    names = ["describe/taps", "blend0", "issue0", "blend1", "issue1", "blend2", "issue2", "blend3", "issue3", "publish+barrier"]
-    print("G->G bodies:", n, " cycles per body:", sum(t[:10]) / n)
-    for nm, v in zip(names, t[:10]):
-        print(f"  {nm:16s} {v / n:8.1f}")
-    del os.environ["HMVIT_ATTN_TRACE"]
