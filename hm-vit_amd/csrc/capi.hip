@@ -863,6 +863,32 @@ int hmvit_voxelize(const float* points, int n_points, const float* voxel_size, c
     return launch_voxelize(p, reinterpret_cast<hipStream_t>(stream));
 }
 
+/* ---- camera -> BEV lift (cvt.hip) ---- */
+
+int hmvit_cvt_embed(int mode, const float* I_inv, const float* E_inv, const float* grid, const float* w_in, const float* w_bias,
+                    const float* w_cam, const float* x, float* out, int n_agents, int n_cam, int H, int W, int dim,
+                    float image_w, float image_h, void* stream) {
+    HMVIT_CHECK_ARG((mode == 0 || mode == 1) && E_inv && w_in && w_cam && out && n_agents > 0 && n_cam > 0 && H > 1 && W > 1,
+                    "cvt_embed: bad argument");
+    HMVIT_CHECK_ARG(mode == 1 ? grid != nullptr : I_inv != nullptr, "cvt_embed: missing %s", mode ? "grid" : "I_inv");
+    CvtEmbedParams p;
+    p.mode = mode; p.bn = n_agents * n_cam; p.n_cam = n_cam; p.P = H * W; p.H = H; p.W = W; p.dim = dim;
+    p.img_w = image_w; p.img_h = image_h; p.I_inv = I_inv; p.E_inv = E_inv; p.grid = grid; p.w_in = w_in; p.w_bias = w_bias;
+    p.w_cam = w_cam; p.x = x; p.out = out;
+    return launch_cvt_embed(p, reinterpret_cast<hipStream_t>(stream));
+}
+
+int hmvit_bn_relu_tokens(const float* x, const float* scale, const float* shift, float* y, int n, int C, int P, void* stream) {
+    HMVIT_CHECK_ARG(x && scale && shift && y && n > 0 && C > 0 && P > 0, "bn_relu_tokens: bad argument");
+    return launch_bn_relu_tokens(x, scale, shift, y, n, C, P, reinterpret_cast<hipStream_t>(stream));
+}
+
+int hmvit_cross_attention(const float* q, const float* k, const float* v, float* out, int n_agents, int n_cam, int Q, int K,
+                          int heads, int dim_head, void* stream) {
+    HMVIT_CHECK_ARG(q && k && v && out && n_agents > 0 && n_cam > 0 && Q > 0 && K > 0 && heads > 0, "cross_attention: bad argument");
+    return launch_cross_attention(q, k, v, out, n_agents, n_cam, Q, K, heads, dim_head, reinterpret_cast<hipStream_t>(stream));
+}
+
 int hmvit_debug_tr16(uint16_t* out, void* stream) {
     HMVIT_CHECK_ARG(out != nullptr, "debug_tr16: null pointer");
     return launch_debug_tr16(out, reinterpret_cast<hipStream_t>(stream));

@@ -1,0 +1,159 @@
+// Kernels of the camera -> BEV lift (CVT encoder): the parts of CrossViewAttention.forward
+// (opencood/models/sub_modules/cvt_modules.py:216-280) and CrossAttention.forward (:118-173) that are not plain
+// LayerNorm / Linear (those run on k_layernorm / the GEMM of gemm.hip).  Correctness-first f32 versions.
+//
+//   k_cvt_embed       camera-aware positional embeddings: image-ray embedding of every feature pixel (img_embed(E_inv
+//                     [I_inv pixel; 1]) - cam_embed(camera centre), L2-normalised over channels, :236-250) and the BEV
+//                     query embedding (bev_embed(world xy) - cam_embed(centre), normalised, + x, :252-269)
+//   k_bn_relu_tokens  BatchNorm2d (eval) + ReLU of feature_linear / feature_proj (:197-207), NCHW -> token-major
+//   k_cross_attention softmax over the keys of ALL cameras of one agent, queries differ per camera (:148-158)
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace hmvit {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// one wave per output token; lane owns channels lane, lane + 64, ...
+__global__ __launch_bounds__(256) void k_cvt_embed(CvtEmbedParams p) {
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n_tok = p.bn * p.P;
+    if (tok >= n_tok) return;
+    const int bn = tok / p.P, pix = tok - bn * p.P;
+    const float* E = p.E_inv + (size_t)bn * 16;
+    float in[4];
+    int nin;
+    if (p.mode == 0) {
+        // image plane: generate_grid(h, w) scaled by the image size (square maps: x along columns, y along rows)
+        const int row = pix / p.W, col = pix - row * p.W;
+        const float px = p.img_w * ((float)col / (float)(p.W - 1)), py = p.img_h * ((float)row / (float)(p.H - 1));
+        const float* I = p.I_inv + (size_t)bn * 9;
+        const float cam[4] = {I[0] * px + I[1] * py + I[2], I[3] * px + I[4] * py + I[5], I[6] * px + I[7] * py + I[8], 1.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) in[r] = E[4 * r] * cam[0] + E[4 * r + 1] * cam[1] + E[4 * r + 2] * cam[2] + E[4 * r + 3] * cam[3];
+        nin = 4;
+    } else {
+        in[0] = p.grid[pix]; in[1] = p.grid[p.P + pix]; in[2] = in[3] = 0.f;
+        nin = 2;
+    }
+    const float ctr[4] = {E[3], E[7], E[11], E[15]};
+    float sq = 0.f;
+    float e[8];
+    for (int k = 0, c = lane; c < p.dim; c += 64, ++k) {
+        float v = p.w_bias ? p.w_bias[c] : 0.f;
+        for (int r = 0; r < nin; ++r) v = fmaf(p.w_in[c * nin + r], in[r], v);
+        float ce = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ce = fmaf(p.w_cam[c * 4 + r], ctr[r], ce);
+        e[k] = v - ce;
+        sq = fmaf(e[k], e[k], sq);
+    }
+    const float inv = 1.f / (sqrtf(wave_sum(sq)) + 1e-7f);
+    for (int k = 0, c = lane; c < p.dim; c += 64, ++k) {
+        float v = e[k] * inv;
+        if (p.x) v += p.x[((size_t)(bn / p.n_cam) * p.dim + c) * p.P + pix];    // query = query_pos + x[:, None]
+        p.out[(size_t)tok * p.dim + c] = v;
+    }
+}
+
+int launch_cvt_embed(const CvtEmbedParams& p, hipStream_t st) {
+    HMVIT_CHECK_ARG(p.dim > 0 && p.dim <= 512, "cvt_embed: dim=%d (1..512)", p.dim);
+    const int n_tok = p.bn * p.P;
+    if (n_tok <= 0) return HMVIT_OK;
+    hipLaunchKernelGGL(k_cvt_embed, dim3(cdiv(n_tok, 4)), dim3(256), 0, st, p);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+// x (n, C, P) -> y (n, P, C) = relu(x * scale[c] + shift[c]); 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void k_bn_relu_tokens(const float* __restrict__ x, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, float* __restrict__ y, int C, int P) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, pp = p0 + tx;
+        float v = 0.f;
+        if (c < C && pp < P) v = fmaxf(fmaf(x[((size_t)n * C + c) * P + pp], scale[c], shift[c]), 0.f);
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int pp = p0 + r, c = c0 + tx;
+        if (pp < P && c < C) y[((size_t)n * P + pp) * C + c] = tile[tx][r];
+    }
+}
+
+int launch_bn_relu_tokens(const float* x, const float* scale, const float* shift, float* y, int n, int C, int P, hipStream_t st) {
+    if (n <= 0) return HMVIT_OK;
+    hipLaunchKernelGGL(k_bn_relu_tokens, dim3(cdiv(P, 32), cdiv(C, 32), n), dim3(256), 0, st, x, scale, shift, y, C, P);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+// q (b, n, Q, heads * 32), k (b, n, K, heads * 32), v (b, n * K, heads * 32) -> out (b, Q, heads * 32).
+// One thread per query (64 per workgroup), one head per workgroup; K / V tiles of 64 keys staged in LDS; online softmax
+// over the n cameras' keys.
+__global__ __launch_bounds__(64) void k_cross_attention(const float* __restrict__ q, const float* __restrict__ k,
+                                                        const float* __restrict__ v, float* __restrict__ out, int n_cam, int Q,
+                                                        int K, int heads, float scale) {
+    constexpr int D = 32;
+    __shared__ float Ks[64][D + 1], Vs[64][D + 1];
+    const int b = blockIdx.z, head = blockIdx.y, qi = blockIdx.x * 64 + threadIdx.x;
+    const int HD = heads * D;
+    const bool valid = qi < Q;
+    float acc[D], m_run = -INFINITY, l_run = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = 0.f;
+    for (int cam = 0; cam < n_cam; ++cam) {
+        float qv[D];
+        const float* qp = q + (((size_t)(b * n_cam + cam) * Q + (valid ? qi : 0)) * HD + head * D);
+#pragma unroll
+        for (int d = 0; d < D; ++d) qv[d] = qp[d] * scale;
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            const int kk = k0 + threadIdx.x;
+            __syncthreads();
+            if (kk < K) {
+                const float* kp = k + (((size_t)(b * n_cam + cam) * K + kk) * HD + head * D);
+                const float* vp = v + (((size_t)b * n_cam * K + (size_t)cam * K + kk) * HD + head * D);
+#pragma unroll
+                for (int d = 0; d < D; ++d) { Ks[threadIdx.x][d] = kp[d]; Vs[threadIdx.x][d] = vp[d]; }
+            }
+            __syncthreads();
+            const int cnt = min(64, K - k0);
+            for (int j = 0; j < cnt; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int d = 0; d < D; ++d) s = fmaf(qv[d], Ks[j][d], s);
+                const float m_new = fmaxf(m_run, s);
+                const float alpha = __expf(m_run - m_new), pj = __expf(s - m_new);
+                l_run = l_run * alpha + pj;
+#pragma unroll
+                for (int d = 0; d < D; ++d) acc[d] = fmaf(acc[d], alpha, pj * Vs[j][d]);
+                m_run = m_new;
+            }
+        }
+    }
+    if (valid) {
+        float* op = out + (((size_t)b * Q + qi) * HD + head * D);
+        const float inv = 1.f / l_run;
+#pragma unroll
+        for (int d = 0; d < D; ++d) op[d] = acc[d] * inv;
+    }
+}
+
+int launch_cross_attention(const float* q, const float* k, const float* v, float* out, int b, int n_cam, int Q, int K, int heads,
+                           int dim_head, hipStream_t st) {
+    HMVIT_CHECK_ARG(dim_head == 32, "cross_attention: dim_head=%d (32)", dim_head);
+    if (b <= 0 || Q <= 0) return HMVIT_OK;
+    hipLaunchKernelGGL(k_cross_attention, dim3(cdiv(Q, 64), heads, b), dim3(64), 0, st, q, k, v, out, n_cam, Q, K, heads,
+                       1.f / sqrtf((float)dim_head));
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+}  // namespace hmvit

@@ -187,4 +187,23 @@ struct VoxParams {
 };
 int launch_voxelize(const VoxParams& p, hipStream_t st);
 
+// ---- cvt.hip (camera -> BEV lift) ----
+struct CvtEmbedParams {
+    int mode;               // 0: image-ray embedding of feature pixels, 1: BEV query embedding (+ x)
+    int bn, n_cam, P, H, W, dim;   // bn = agents * cameras; P = H * W tokens per map
+    float img_w, img_h;
+    const float* I_inv;     // (bn, 3, 3), mode 0
+    const float* E_inv;     // (bn, 4, 4)
+    const float* grid;      // (2+, P) BEV cell coordinates, mode 1
+    const float* w_in;      // (dim, 4) img_embed or (dim, 2) bev_embed
+    const float* w_bias;    // (dim) bev_embed bias or null
+    const float* w_cam;     // (dim, 4) cam_embed
+    const float* x;         // (agents, dim, P) added to the query embedding, or null
+    float* out;             // (bn, P, dim)
+};
+int launch_cvt_embed(const CvtEmbedParams& p, hipStream_t st);
+int launch_bn_relu_tokens(const float* x, const float* scale, const float* shift, float* y, int n, int C, int P, hipStream_t st);
+int launch_cross_attention(const float* q, const float* k, const float* v, float* out, int b, int n_cam, int Q, int K, int heads,
+                           int dim_head, hipStream_t st);
+
 }  // namespace hmvit

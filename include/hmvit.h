@@ -289,6 +289,28 @@ int hmvit_voxelize(const float* points, int n_points, const float* voxel_size, c
                    int max_voxels, void* workspace, size_t workspace_bytes, float* voxels, int32_t* coords, int32_t* num_points,
                    int32_t* n_voxels, void* stream);
 
+/* ---- camera -> BEV lift: the non-GEMM parts of CrossViewAttention (cvt_modules.py:95-280) ---- */
+
+/* Camera-aware positional embeddings (cvt_modules.py:229-269), all f32, outputs token-major (n_agents * n_cam, H * W, dim):
+ *   mode 0: normalize(img_embed(E_inv [I_inv [px, py, 1]; 1]) - cam_embed(E_inv[:, 3])) for every pixel of an H x W feature
+ *           map (pixel plane of generate_grid scaled by image_w / image_h; square maps), w_in = img_embed.weight (dim, 4);
+ *   mode 1: normalize(bev_embed(grid xy) - cam_embed(E_inv[:, 3])) + x, grid (>= 2, H * W) = BEVEmbedding.grid, w_in =
+ *           bev_embed.weight (dim, 2), w_bias its bias, x (n_agents, dim, H * W) NCHW or NULL.
+ * I_inv (n_agents * n_cam, 3, 3), E_inv (n_agents * n_cam, 4, 4), w_cam = cam_embed.weight (dim, 4). */
+int hmvit_cvt_embed(int mode, const float* I_inv, const float* E_inv, const float* grid, const float* w_in, const float* w_bias,
+                    const float* w_cam, const float* x, float* out, int n_agents, int n_cam, int H, int W, int dim,
+                    float image_w, float image_h, void* stream);
+
+/* y (n, P, C) = relu(x (n, C, P) * scale[c] + shift[c]): eval-mode BatchNorm2d + ReLU in front of the 1x1 convolutions of
+ * feature_linear / feature_proj (cvt_modules.py:197-207), with the NCHW -> token-major transpose. */
+int hmvit_bn_relu_tokens(const float* x, const float* scale, const float* shift, float* y, int n, int C, int P, void* stream);
+
+/* CrossAttention core (cvt_modules.py:148-158): q (n_agents, n_cam, Q, heads * 32), k (n_agents, n_cam, K, heads * 32),
+ * v (n_agents, n_cam * K, heads * 32) f32 -> out (n_agents, Q, heads * 32); logits q_cam . k_cam / sqrt(32), one softmax over
+ * the keys of all cameras. */
+int hmvit_cross_attention(const float* q, const float* k, const float* v, float* out, int n_agents, int n_cam, int Q, int K,
+                          int heads, int dim_head, void* stream);
+
 /* debug: lane mapping of ds_read_b64_tr_b16 (used once to pin the V-operand layout) */
 int hmvit_debug_tr16(uint16_t* out, void* stream);
 

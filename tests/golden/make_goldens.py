@@ -20,6 +20,9 @@ What is frozen:
   g8_decoder.npz        HeteroDecoder.forward (no upsample), 3 samples with ego types 1,0,1, 12x10.
   g9_model.npz          BevformerPointPillarHetero.forward, LiDAR-only batch B=2, record_len [3,2]:
                         pillars -> PointPillar -> regroup -> HeteroFusion -> HeteroDecoder -> psm / rm.
+  g11_cross_view.npz    CrossViewAttention.forward (cvt_modules.py:176-280, eval BatchNorm) with the grid of a BEVEmbedding:
+                        2 agents x 4 cameras, feature maps (64, 12, 12), BEV queries 8 x 8, dim 128, 4 heads; also the
+                        no_image_features / no-skip variant.  torchvision (absent) is stubbed: Bottleneck is not used here.
   g10_postprocess.npz   VoxelPostprocessor.post_process (2 agents, one projected by a rigid transform) on seeded head
                         outputs over a 32x48x2 anchor grid, and eval_utils.caluclate_tp_fp / calculate_ap over two
                         frames at IoU 0.3 / 0.5 / 0.7.  shapely is absent: its Polygon is replaced by the convex
@@ -296,7 +299,35 @@ def g10_postprocess():
     print("g10: boxes", frames[0][0].shape, frames[1][0].shape, "AP", ap)
 
 
+def g11_cross_view():
+    """CrossViewAttention + BEVEmbedding.grid of the reference, seeded weights / inputs from oracle/cvt_oracle.py."""
+    from oracle import cvt_oracle as CO
+    _stub("torchvision"); _stub("torchvision.models"); _stub("torchvision.models.resnet", Bottleneck=object)
+    from opencood.models.sub_modules.cvt_modules import BEVEmbedding, CrossViewAttention
+    out = {}
+    for tag, no_feat, skip in (("a", False, True), ("b", True, False)):
+        cfg = CO.make_config()
+        cfg["no_image_features"], cfg["skip"] = no_feat, skip
+        net = CrossViewAttention(12, 12, 64, 128, cfg).eval()
+        sd = CO.random_state_dict(64, 128, cfg, seed=111)
+        own = net.state_dict()
+        load = {k: v for k, v in sd.items() if k in own}
+        missing = [k for k in own if k not in load and "num_batches_tracked" not in k]
+        assert not missing, missing
+        net.load_state_dict(load, strict=False)
+        bev = BEVEmbedding(128, 1.0, 64, 64, 100.0, 100.0, 0.0, [128, 128, 64])
+        assert torch.allclose(bev.grid, CO.bev_grid(64, 64, 100.0, 100.0, 0.0, 3))
+        x, feat, I_inv, E_inv = CO.synthetic_inputs(2, 4, 64, 12, 12, 128, 8, 8, seed=112)
+        with torch.no_grad():
+            y = net(x, bev, feat, I_inv, E_inv)
+        out["y_" + tag] = y
+    save("g11_cross_view.npz", seed_weights=111, seed_inputs=112, **out)
+
+
 if __name__ == "__main__":
+    if "g11" in sys.argv[1:]:
+        g11_cross_view()
+        sys.exit(0)
     if "g10" in sys.argv[1:]:
         g10_postprocess()
         sys.exit(0)

@@ -138,3 +138,15 @@ def test_g10_postprocess_and_ap():
         assert stat[t]["tp"] == g["tp" + tag].numpy().tolist() and stat[t]["fp"] == g["fp" + tag].numpy().tolist()
     ap = [PPO.calculate_ap(stat, t)[0] for t in (0.3, 0.5, 0.7)]
     assert np.allclose(ap, g["ap"].numpy(), atol=1e-12)
+
+
+def test_g11_cross_view_attention():
+    from oracle import cvt_oracle as CO
+    g = load_golden("g11_cross_view.npz")
+    for tag, no_feat, skip in (("a", False, True), ("b", True, False)):
+        cfg = CO.make_config()
+        cfg["no_image_features"], cfg["skip"] = no_feat, skip
+        sd = CO.random_state_dict(64, 128, cfg, seed=int(g["seed_weights"]))
+        x, feat, I_inv, E_inv = CO.synthetic_inputs(2, 4, 64, 12, 12, 128, 8, 8, seed=int(g["seed_inputs"]))
+        y = CO.cross_view_attention(x, CO.bev_grid(64, 64, 100.0, 100.0, 0.0, 3), feat, I_inv, E_inv, sd, cfg)
+        assert rel_max_err(y, g["y_" + tag]) < TOL
