@@ -500,6 +500,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
     };
 
     bool qkv_done = false;   // this stage's Q / K' / V' were produced by the previous stage's fused tail
+    bool head_done = false;  // mlp_head rode on the last stage's tail
     for (int it = 0; it < d->num_iters; ++it) {
         for (int s = 0; s < 2; ++s) {
             const HmvitStageWeights& wt = d->stage[s];
@@ -584,6 +585,22 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                         }
                     HMVIT_TRY(launch_out_ffn_qkv(fb.p, qp, n, C, st));
                     qkv_done = true;
+                } else if (last && !par && C == 256 && d->head_img_ffn && !getenv("HMVIT_NO_FUSE")) {
+                    // last stage: only the ego row is alive and mlp_head follows immediately (k_out_ffn_head)
+                    fb.p.w_head = reinterpret_cast<const half_t*>(d->head_img_ffn); fb.p.hb_1 = d->head_b1; fb.p.hb_2 = d->head_b2;
+                    int n = 0;
+                    for (int b = 0; b < B; ++b) {
+                        const int slot = b * L;
+                        FfnJob j;
+                        j.o = ob + (size_t)slot * map_elems;
+                        j.x = xs + (size_t)slot * map_elems;
+                        j.out = d->out + (size_t)b * map_elems;
+                        j.type = d->mode[slot]; j.pad = 0;
+                        fb.p.job[n] = j;
+                        if (++n == kMaxChainJobs) { HMVIT_TRY(launch_out_ffn_head(fb.p, n, C, st)); n = 0; }
+                    }
+                    HMVIT_TRY(launch_out_ffn_head(fb.p, n, C, st));
+                    head_done = true;
                 } else {
                     for (int b = 0; b < B; ++b)
                         for (int i = 0; i < n_ego; ++i) {
@@ -627,7 +644,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
         return HMVIT_OK;
     }
     HMVIT_CHECK_ARG(d->head_img_ffn && d->head_b1 && d->head_b2, "f16 mode: mlp_head image / biases are null");
-    {
+    if (!head_done) {
         FfnBatcher fb;
         memset(&fb.p, 0, sizeof(fb.p));
         fb.n = 0; fb.C = C; fb.st = st; fb.variant = FFN_HEAD_NCHW;

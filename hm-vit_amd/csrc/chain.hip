@@ -387,8 +387,9 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
 // residual stream is then read once instead of twice per stage (and not written at all for agents that the
 // pruned last stage only uses as K / V sources).  `qp` = the k_ln_qkv parameters of the next stage, job j of
 // both lists is the same agent.
-template <int C, bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW, bool QKV>
+template <int C, bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW, int TAIL>
 __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams* qp) {
+    constexpr bool QKV = TAIL == 1, HEAD = TAIL == 2;
     using Cfg = ChainCfg<C>;
     constexpr int KK = Cfg::KK, NT = Cfg::NT, NH = C / 32;   // hidden width == C
     constexpr bool STAGED = QKV && C == 256;   // coalesced Q / K' / V' stores through LDS (stage_tile / flush_tiles)
@@ -496,9 +497,10 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
 
     // ---- phase 2: per hidden tile hc: h = GELU(W_1[hc] . xn + b_1[hc]);  x'' += W_2[:, hc] . h ----
     // (N_OUT is even, so the W_1 chunk of every iteration sits in ring0 and the W_2 chunk in ring1)
+    auto ffn_pass = [&](const half_t* wfp) {
 #pragma unroll 1
     for (int hc = 0; hc < NH; ++hc) {
-        const half_t* w1c = wf + (size_t)(2 * hc) * Cfg::CHUNK_HALVES;
+        const half_t* w1c = wfp + (size_t)(2 * hc) * Cfg::CHUNK_HALVES;
         float16v hacc;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -525,6 +527,8 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
         dma_wait();
         wg_barrier();
     }
+    };
+    ffn_pass(wf);
 
     auto store_x = [&]() {
         if (valid && !(QKV && J.pad)) {   // pad = 1: x'' is not needed in memory (fused launch before the pruned stage)
@@ -569,7 +573,42 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
             }
         }
     };
-    if constexpr (!QKV) store_x();
+    if constexpr (TAIL == 0) store_x();
+
+    if constexpr (HEAD) {
+        // ---- mlp_head on the ego's x'' (bevformer_point_pillar_hetero.py:48): Linear -> GELU -> Linear, no norm, no
+        // residual; x'' itself never goes to memory, the output is the NCHW map the model returns ----
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) act[2 * t + sx][q] = (half_t)xacc[t][8 * sx + q];
+        // vec[3..4] and both ring buffers are free (last use before the barrier that ended phase 2)
+        for (int i = threadIdx.x; i < C; i += CHAIN_THREADS) {
+            vec[3][i] = p.hb_1[ty * C + i];
+            vec[4][i] = p.hb_2[ty * C + i];
+        }
+        const half_t* wh = p.w_head + (size_t)ty * 2 * NH * Cfg::CHUNK_HALVES;
+        stage_chunk<C>(wh, ring0);
+        dma_wait();
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 b2 = *reinterpret_cast<const float4*>(&vec[4][32 * t + 8 * j + 4 * hi]);
+                xacc[t][4 * j + 0] = b2.x; xacc[t][4 * j + 1] = b2.y; xacc[t][4 * j + 2] = b2.z; xacc[t][4 * j + 3] = b2.w;
+            }
+        ffn_pass(wh);
+        if (valid) {
+            float* op = J.out + (size_t)(4 * hi) * P + tok;      // (C, P) map
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) op[(size_t)(32 * t + 8 * (e >> 2) + (e & 3)) * P] = xacc[t][e];
+        }
+    }
 
     if constexpr (QKV) {
         // ---- next stage: LayerNorm(x'') -> Q / K' / V' tiles, exactly k_ln_qkv's loop ----
@@ -627,12 +666,18 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
 
 template <int C, bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW>
 __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_out_ffn(FfnParams p) {
-    out_ffn_body<C, OUTPROJ, LN, RESID, OUT_NCHW, false>(p, nullptr);
+    out_ffn_body<C, OUTPROJ, LN, RESID, OUT_NCHW, 0>(p, nullptr);
 }
 
 template <int C>
 __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_out_ffn_qkv(FfnParams p, QkvParams q) {
-    out_ffn_body<C, true, true, true, false, true>(p, &q);
+    out_ffn_body<C, true, true, true, false, 1>(p, &q);
+}
+
+// last stage of HeteroFusion: the ego's tail with mlp_head appended (FfnJob::out = the (C, P) output map)
+template <int C>
+__global__ __launch_bounds__(CHAIN_THREADS, 2) void k_out_ffn_head(FfnParams p) {
+    out_ffn_body<C, true, true, true, false, 2>(p, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -669,6 +714,15 @@ int launch_out_ffn_qkv(const FfnParams& p, const QkvParams& q, int n_jobs, int C
     HMVIT_CHECK_ARG(C == 256, "out_ffn_qkv: C=%d unsupported (256)", C);
     dim3 grid(cdiv(p.P, CHAIN_TOKENS), n_jobs), block(CHAIN_THREADS);
     hipLaunchKernelGGL((k_out_ffn_qkv<256>), grid, block, 0, st, p, q);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+int launch_out_ffn_head(const FfnParams& p, int n_jobs, int C, hipStream_t st) {
+    if (n_jobs == 0) return HMVIT_OK;
+    HMVIT_CHECK_ARG(C == 256 && p.w_head && p.hb_1 && p.hb_2, "out_ffn_head: C=%d (256) / head weights missing", C);
+    dim3 grid(cdiv(p.P, CHAIN_TOKENS), n_jobs), block(CHAIN_THREADS);
+    hipLaunchKernelGGL((k_out_ffn_head<256>), grid, block, 0, st, p);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }

@@ -77,12 +77,17 @@ struct FfnParams {
     const float* b_1;        // (T, C)
     const float* b_2;        // (T, C)
     int P;
+    const half_t* w_head;    // k_out_ffn_head only: mlp_head image (T, 2 NH chunks) and biases (T, C)
+    const float* hb_1;
+    const float* hb_2;
 };
 enum { FFN_FULL = 0, FFN_NO_ATTN = 1, FFN_HEAD_NCHW = 2 };
 int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, hipStream_t st);
 // k_out_ffn (FFN_FULL) of a stage fused with k_ln_qkv of the next one; job j of both lists = the same agent;
 // FfnJob::pad = 1 suppresses the store of the updated residual row
 int launch_out_ffn_qkv(const FfnParams& p, const QkvParams& q, int n_jobs, int C, hipStream_t st);
+// k_out_ffn (FFN_FULL) of the last stage with mlp_head appended; FfnJob::out = (C, P) output map
+int launch_out_ffn_head(const FfnParams& p, int n_jobs, int C, hipStream_t st);
 
 // ---- enc.hip (PointPillar branch) ----
 struct PfnParams {
