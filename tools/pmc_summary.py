@@ -5,8 +5,8 @@ import collections, csv, glob, json, os, sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
 out_txt = sys.argv[2] if len(sys.argv) > 2 else None
-KEYS = ["k_attention_pc", "k_ln_qkv", "k_out_ffn_qkv", "k_out_ffn<256, true", "k_out_ffn<256, false, false"]
-PHASE = {"k_attention_pc": "attention", "k_ln_qkv": "qkv_gemm", "k_out_ffn_qkv": "ffn2", "k_out_ffn<256, true": "ffn2_last", "k_out_ffn<256, false, false": "head"}
+KEYS = ["k_attention_pc", "k_ln_qkv", "k_out_ffn_qkv", "k_out_ffn_head", "k_out_ffn<256, true", "k_out_ffn<256, false, false"]
+PHASE = {"k_attention_pc": "attention", "k_ln_qkv": "qkv_gemm", "k_out_ffn_qkv": "ffn2", "k_out_ffn_head": "ffn2_last_head", "k_out_ffn<256, true": "ffn2_last", "k_out_ffn<256, false, false": "head"}
 
 def key_of(name):
     for k in KEYS:
