@@ -9,6 +9,8 @@ from .model import BevformerPointPillarHetero  # noqa: F401
 from .postprocess import VoxelPostprocessor, quad_iou, caluclate_tp_fp, calculate_ap, voc_ap  # noqa: F401
 from .voxelizer import SpVoxelPreprocessor  # noqa: F401
 from .cvt import BEVEmbedding, CrossAttention, CrossViewAttention  # noqa: F401
+from .camera import ResnetEncoder, CrossViewModule, CvtCameraEncoder  # noqa: F401
 
 __all__ = ["HeteroFusion", "HeteroFusionBlock", "PointPillar", "HeteroDecoder", "BevformerPointPillarHetero",
-           "VoxelPostprocessor", "quad_iou", "caluclate_tp_fp", "calculate_ap", "voc_ap", "SpVoxelPreprocessor", "BEVEmbedding", "CrossAttention", "CrossViewAttention"]
+           "VoxelPostprocessor", "quad_iou", "caluclate_tp_fp", "calculate_ap", "voc_ap", "SpVoxelPreprocessor", "BEVEmbedding", "CrossAttention", "CrossViewAttention",
+           "ResnetEncoder", "CrossViewModule", "CvtCameraEncoder"]

@@ -796,6 +796,7 @@ int hmvit_conv2d(const void* x, const void* w, const float* bias, void* y, int N
     p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = p.KW = ksize; p.stride = stride; p.pad = pad;
     p.relu = relu; p.y_ctot = y_ctot; p.y_coff = y_coff; p.deconv_s = deconv_stride; p.out_f32 = out_f32;
+    p.res = nullptr; p.up2 = 0;
     if (deconv_stride) {
         p.Ho = H; p.Wo = W;
     } else {
@@ -804,6 +805,27 @@ int hmvit_conv2d(const void* x, const void* w, const float* bias, void* y, int N
     }
     HMVIT_CHECK_ARG(y_ctot >= y_coff + Cout, "conv2d: output channel window [%d, %d) exceeds %d", y_coff, y_coff + Cout, y_ctot);
     return launch_conv(p, precision, reinterpret_cast<hipStream_t>(stream));
+}
+
+/* Conv2d + folded BatchNorm with the two extras a ResNet / the up-sampling decoder need. */
+int hmvit_conv2d_ex(const void* x, const void* w, const float* bias, const void* residual, void* y, int N, int H, int W, int Cin,
+                    int Cout, int ksize, int stride, int pad, int relu, int upsample2, int out_f32, int precision, void* stream) {
+    HMVIT_CHECK_ARG(x && w && y, "conv2d_ex: null pointer");
+    HMVIT_CHECK_ARG(!upsample2 || (H % 2 == 0 && W % 2 == 0), "conv2d_ex: upsampled size %dx%d must be even", H, W);
+    HMVIT_CHECK_ARG(!(residual && out_f32 && precision != HMVIT_PREC_F32), "conv2d_ex: residual needs the precision's element type");
+    ConvParams p;
+    p.x = x; p.w = w; p.bias = bias; p.y = y;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = p.KW = ksize; p.stride = stride; p.pad = pad;
+    p.relu = relu; p.y_ctot = Cout; p.y_coff = 0; p.deconv_s = 0; p.out_f32 = out_f32;
+    p.res = residual; p.up2 = upsample2;
+    p.Ho = (H + 2 * pad - ksize) / stride + 1;
+    p.Wo = (W + 2 * pad - ksize) / stride + 1;
+    return launch_conv(p, precision, reinterpret_cast<hipStream_t>(stream));
+}
+
+int hmvit_maxpool2d(const void* x, void* y, int N, int H, int W, int C, int ksize, int stride, int pad, int precision, void* stream) {
+    HMVIT_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0, "maxpool2d: bad argument");
+    return launch_maxpool(x, y, N, H, W, C, ksize, stride, pad, precision, reinterpret_cast<hipStream_t>(stream));
 }
 
 /* ---- detection post-processing (post.hip) ---- */

@@ -158,7 +158,12 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
             const int iy = roy[i] * p.stride + ky - p.pad, ix = rox[i] * p.stride + kx - p.pad;
             const bool ok = rvalid[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             ra[i] = (Vec)(T)0;
-            if (ok) ra[i] = *reinterpret_cast<const Vec*>(x + (((size_t)rn[i] * p.H + iy) * p.W + ix) * p.Cin + ci0 + kc);
+            if (ok) {
+                // up2: logical pixel (iy, ix) of the upsampled map is physical pixel (iy / 2, ix / 2)
+                const size_t pix = p.up2 ? ((size_t)rn[i] * (p.H >> 1) + (iy >> 1)) * (p.W >> 1) + (ix >> 1)
+                                         : ((size_t)rn[i] * p.H + iy) * p.W + ix;
+                ra[i] = *reinterpret_cast<const Vec*>(x + pix * p.Cin + ci0 + kc);
+            }
         }
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
@@ -262,6 +267,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[e] = acc[i][j][4 * q + e] + ((p.bias && col + e < Ncols) ? p.bias[co + e] : 0.f);
+                    if (p.res && col + e < Ncols) v[e] += (float)reinterpret_cast<const T*>(p.res)[pix * p.Cout + co + e];
                     if (p.relu) v[e] = fmaxf(v[e], 0.f);
                 }
                 if (vec_ok && col + 3 < Ncols) {
@@ -287,6 +293,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
                         const size_t pixe = s ? ((size_t)n * p.Ho * s + oy * s + dye) * (p.Wo * s) + ox * s + dxe : (size_t)m;
                         const size_t oe = pixe * p.y_ctot + p.y_coff + coe;
                         float ve = acc[i][j][4 * q + e] + (p.bias ? p.bias[coe] : 0.f);
+                        if (p.res) ve += (float)reinterpret_cast<const T*>(p.res)[pixe * p.Cout + coe];
                         if (p.relu) ve = fmaxf(ve, 0.f);
                         if (p.out_f32) reinterpret_cast<float*>(p.y)[oe] = ve;
                         else reinterpret_cast<T*>(p.y)[oe] = (T)ve;
@@ -294,6 +301,49 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
                 }
             }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// max pooling, NHWC, 8 channels per thread (padding never wins: torch pads with -inf)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_maxpool(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo,
+                                                 int ks, int stride, int pad) {
+    const int cg = C / 8;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * Ho * Wo * cg) return;
+    const int c8 = (int)(idx % cg) * 8;
+    size_t r = idx / cg;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float best[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) best[e] = -INFINITY;
+    for (int ky = 0; ky < ks; ++ky)
+        for (int kx = 0; kx < ks; ++kx) {
+            const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+            const T* src = x + (((size_t)n * H + iy) * W + ix) * C + c8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], (float)src[e]);
+        }
+    T* dst = y + (((size_t)n * Ho + oy) * Wo + ox) * C + c8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[e] = (T)best[e];
+}
+
+int launch_maxpool(const void* x, void* y, int N, int H, int W, int C, int ksize, int stride, int pad, int precision, hipStream_t st) {
+    HMVIT_CHECK_ARG(C % 8 == 0 && ksize > 0 && stride > 0, "maxpool: C=%d must be a multiple of 8", C);
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const size_t n = (size_t)N * Ho * Wo * (C / 8);
+    if (n == 0) return HMVIT_OK;
+    if (precision == HMVIT_PREC_F32)
+        hipLaunchKernelGGL((k_maxpool<float>), dim3((unsigned)cdiv((long long)n, 256)), dim3(256), 0, st, (const float*)x, (float*)y, N, H, W, C, Ho, Wo, ksize, stride, pad);
+    else
+        hipLaunchKernelGGL((k_maxpool<half_t>), dim3((unsigned)cdiv((long long)n, 256)), dim3(256), 0, st, (const half_t*)x, (half_t*)y, N, H, W, C, Ho, Wo, ksize, stride, pad);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
 }
 
 int launch_conv(const ConvParams& p, int precision, hipStream_t st) {

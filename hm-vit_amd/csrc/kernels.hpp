@@ -112,8 +112,12 @@ struct ConvParams {
     int y_ctot, y_coff;
     int deconv_s;             // > 0: ConvTranspose2d with kernel = stride = s (Ncols = s*s*Cout, Ho = H, Wo = W)
     int out_f32;
+    const void* res;          // optional residual (N, Ho, Wo, Cout) in the precision's element type, added before the ReLU
+    int up2;                  // 1: the input is the nearest-neighbour x2 upsampling of x (N, H/2, W/2, Cin); H, W are the upsampled sizes
 };
 int launch_conv(const ConvParams& p, int precision, hipStream_t st);
+// max pooling on NHWC maps (the 3x3 / stride 2 / pad 1 stage of a ResNet stem)
+int launch_maxpool(const void* x, void* y, int N, int H, int W, int C, int ksize, int stride, int pad, int precision, hipStream_t st);
 
 // ---- split.hip (architect_mode == 'parallel') ----
 struct SplitSlots {

@@ -246,6 +246,18 @@ int hmvit_conv2d(const void* x, const void* w, const float* bias, void* y, int N
                  int ksize, int stride, int pad, int relu, int y_ctot, int y_coff, int deconv_stride, int out_f32,
                  int precision, void* stream);
 
+/* hmvit_conv2d with a residual operand and an up-sampled input (camera branch):
+ *   residual (N, Ho, Wo, Cout) in the precision's element type or NULL: y = act(conv(x) + bias + residual), the tail of a
+ *   torchvision BasicBlock / Bottleneck (`out += identity; out = relu(out)`, used by resnet_ms.py:27-38 and
+ *   cvt_modules.py:13,303-305);
+ *   upsample2 = 1: x is (N, H/2, W/2, Cin) and stands for its nearest-neighbour x2 upsampling (N, H, W, Cin)
+ *   (NaiveDecoder.upsample, naive_decoder.py:56-61), which is never materialised. */
+int hmvit_conv2d_ex(const void* x, const void* w, const float* bias, const void* residual, void* y, int N, int H, int W, int Cin,
+                    int Cout, int ksize, int stride, int pad, int relu, int upsample2, int out_f32, int precision, void* stream);
+
+/* nn.MaxPool2d on NHWC maps (C a multiple of 8): the 3x3 / stride 2 / pad 1 pooling of the ResNet stem. */
+int hmvit_maxpool2d(const void* x, void* y, int N, int H, int W, int C, int ksize, int stride, int pad, int precision, void* stream);
+
 /* ---- detection post-processing ---- */
 
 /* VoxelPostprocessor.post_process up to the candidate list, for one agent's head outputs

@@ -106,3 +106,60 @@ def test_ap_replay_hip_vs_cpu_pipeline():
     assert res["detections"]["hip"] == res["detections"]["cpu"] > 0
     for t in ("AP@0.3", "AP@0.5", "AP@0.7"):
         assert res[t]["delta_points"] < 0.2
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 5e-4), ("f16", 1e-2)])
+def test_hetero_model_camera_and_lidar_agents(precision, tol):
+    """configs[2]-style batch (camera and LiDAR agents in one scene, camera ego): CvtCameraEncoder in the model's camera slot,
+    PointPillar in the LiDAR slot, against the CPU restatements composed the same way (the reference's own camera encoder,
+    BEVFormer / mmdet3d, is out of scope; its slot contract is what is exercised here)."""
+    import numpy as np
+    import hmvit_amd
+    from hmvit_amd.camera import CvtCameraEncoder
+    from model_fixture import model_batch, model_config, model_state_dict
+    from oracle import camera_oracle as CAM
+    from oracle import decoder_oracle as DO
+    from oracle import hmvit_oracle as O
+    from oracle import pointpillar_oracle as PO
+    cfg = model_config()
+    ccfg = CAM.make_config(image=64, num_layers=18)
+    ccfg["cvm"]["bev_embedding"].update(bev_height=24, bev_width=32)          # 3 x 4 queries -> (12, 16) after the decoder
+    sd = model_state_dict(cfg, 91)
+    csd = CAM.random_state_dict(ccfg, seed=97)
+    net = hmvit_amd.BevformerPointPillarHetero(cfg, camera_encoder=CvtCameraEncoder(ccfg, precision=precision), precision=precision)
+    full = dict(sd)
+    full.update({f"camera_encoder.{k}": v for k, v in csd.items()})
+    missing, unexpected = net.load_state_dict(full, strict=False)
+    assert not unexpected and all("num_batches_tracked" in k for k in missing), (missing[:5], unexpected[:5])
+    net = net.cuda().eval()
+    batch = model_batch(cfg, 95)                                               # B = 2, record_len [3, 2], 5 agents of pillars
+    mode = torch.tensor([[0.0, 1.0, 0.0], [1.0, 0.0, 0.0]], dtype=torch.float64)   # flat agents: cam, lidar, cam | lidar, cam
+    batch["mode"] = mode
+    cams = CAM.synthetic_batch(5, ccfg, seed=98)
+    batch.update({"camera": cams["camera"], "intrinsic": cams["intrinsic"], "extrinsic": cams["extrinsic"],
+                  "cav2cam_extrinsic": cams["extrinsic"].clone()})
+    out = net(_to(batch, "cuda"))
+
+    # CPU composition
+    flat = torch.tensor([0, 1, 0, 1, 0])
+    lid = batch["processed_lidar"]
+    agent = lid["voxel_coords"][:, 0].long()
+    keep = flat[agent] == 1
+    renum = torch.cumsum(flat, 0) - 1
+    coords = lid["voxel_coords"][keep].clone()
+    coords[:, 0] = renum[agent[keep]].int()
+    lsd = {k[len("lidar_encoder."):]: v for k, v in sd.items() if k.startswith("lidar_encoder.")}
+    lf = PO.point_pillar_features(lid["voxel_features"][keep], coords, lid["voxel_num_points"][keep], lsd, cfg["lidar"], 2)
+    cf = CAM.camera_encoder({k: v[flat == 0] for k, v in cams.items()}, csd, ccfg)
+    x = torch.zeros(5, *lf.shape[1:])
+    x[flat == 1] = lf
+    x[flat == 0] = cf
+    xr = torch.zeros(2, 3, *lf.shape[1:])
+    xr[0], xr[1, :2] = x[:3], x[3:]
+    mask = torch.tensor([[1, 1, 1], [1, 1, 0]])
+    fsd = {k[len("fusion_net."):]: v for k, v in sd.items() if k.startswith("fusion_net.")}
+    fused = O.hetero_fusion(xr, batch["pairwise_t_matrix"], mode.int(), batch["record_len"], mask, fsd, cfg["hetero_fusion"])
+    dsd = {k: v for k, v in sd.items() if k.startswith("decoder.")}
+    psm, rm = DO.hetero_decoder(fused.unsqueeze(1), mode.int(), dsd, cfg["hetero_decoder"], prefix="decoder")
+    assert out["psm"].shape == psm.shape and out["rm"].shape == rm.shape
+    assert rel_max_err(out["psm"].cpu(), psm) < tol and rel_max_err(out["rm"].cpu(), rm) < tol
