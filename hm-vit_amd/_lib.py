@@ -79,7 +79,7 @@ _SIGNATURES = {
     "hmvit_voxelize": (C.c_int, [C.c_void_p, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int, C.c_void_p, C.c_size_t] + [C.c_void_p] * 5),
     "hmvit_cvt_embed": (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_int] * 5 + [C.c_float, C.c_float, C.c_void_p]),
     "hmvit_bn_relu_tokens": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
-    "hmvit_cross_attention": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]),
+    "hmvit_cross_attention": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_void_p]),
     "hmvit_conv2d_ex": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 12 + [C.c_void_p]),
     "hmvit_maxpool2d": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 8 + [C.c_void_p]),
     "hmvit_debug_tr16": (C.c_int, [C.c_void_p, C.c_void_p]),

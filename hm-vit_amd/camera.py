@@ -235,6 +235,8 @@ class CrossViewModule(nn.Module):
         prec = _PREC[self.precision]
         dt = torch.float32 if prec == _lib.PREC_F32 else torch.float16
         prep = self._prep.get(self, prec, lambda: self._build(prec, dt))
+        for cross_view in self.cross_views:
+            cross_view.cross_attend.precision = self.precision
         I_inv = batch["intrinsic"].reshape(b * l, n, 3, 3).float().inverse()      # 3x3 inverses: host-side plumbing, as the reference
         E_inv = batch["extrinsic"].reshape(b * l, n, 4, 4).float()
         x = self.bev_embedding.get_prior().detach().float()[None].repeat(b * l, 1, 1, 1).contiguous()

@@ -922,10 +922,15 @@ int hmvit_bn_relu_tokens(const float* x, const float* scale, const float* shift,
     return launch_bn_relu_tokens(x, scale, shift, y, n, C, P, reinterpret_cast<hipStream_t>(stream));
 }
 
-int hmvit_cross_attention(const float* q, const float* k, const float* v, float* out, int n_agents, int n_cam, int Q, int K,
-                          int heads, int dim_head, void* stream) {
+int hmvit_cross_attention(const void* q, const void* k, const void* v, float* out, int n_agents, int n_cam, int Q, int K,
+                          int heads, int dim_head, int precision, void* stream) {
     HMVIT_CHECK_ARG(q && k && v && out && n_agents > 0 && n_cam > 0 && Q > 0 && K > 0 && heads > 0, "cross_attention: bad argument");
-    return launch_cross_attention(q, k, v, out, n_agents, n_cam, Q, K, heads, dim_head, reinterpret_cast<hipStream_t>(stream));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (precision == HMVIT_PREC_F16)
+        return launch_cross_attention_f16(reinterpret_cast<const half_t*>(q), reinterpret_cast<const half_t*>(k),
+                                          reinterpret_cast<const half_t*>(v), out, n_agents, n_cam, Q, K, heads, dim_head, st);
+    return launch_cross_attention(reinterpret_cast<const float*>(q), reinterpret_cast<const float*>(k),
+                                  reinterpret_cast<const float*>(v), out, n_agents, n_cam, Q, K, heads, dim_head, st);
 }
 
 int hmvit_debug_tr16(uint16_t* out, void* stream) {

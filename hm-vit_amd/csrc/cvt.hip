@@ -157,3 +157,123 @@ int launch_cross_attention(const float* q, const float* k, const float* v, float
 }
 
 }  // namespace hmvit
+
+namespace hmvit {
+
+// ------------------------------------------------------------------------------------------
+// MFMA version of the cross attention (f16 operands, f32 accumulate / softmax): one workgroup = 64 queries of one head
+// (4 waves x 16 queries), K / V tiles of 64 keys staged in LDS and shared by the waves, the next tile's rows prefetched
+// into registers while the current one is multiplied.  Same fragment scheme as the fusion's attention (attn.hip):
+// transposed logits S^T = K Q^T (v_mfma_f32_16x16x32_f16) so a lane owns one query column, exp2 with log2(e) / sqrt(d)
+// folded into the query operand, P^T straight into O^T = V^T P^T with V^T fragments from ds_read_b64_tr_b16, the softmax
+// denominator from an all-ones tile.  Q and K must be multiples of 64 (the f32 kernel above handles the rest).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cross_attention_mfma(const half_t* __restrict__ q, const half_t* __restrict__ k,
+                                                              const half_t* __restrict__ v, float* __restrict__ out, int n_cam,
+                                                              int Q, int K, int heads, float qscale) {
+    constexpr int D = 32, KS = D + 8, VS = D + 16;
+    __shared__ __attribute__((aligned(16))) half_t Ks[2][64 * KS];
+    __shared__ __attribute__((aligned(16))) half_t Vs[2][64 * VS];
+    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 64;
+    const int HD = heads * D;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lq = lane & 15, g = lane >> 4;
+    // staging role of this thread: key row and 8-channel piece of a 64 x 32 tile
+    const int srow = threadIdx.x >> 2, spiece = (threadIdx.x & 3) * 8;
+
+    float m_run = -INFINITY;
+    float4v o_acc[2], l_acc;
+    o_acc[0] = o_acc[1] = l_acc = (float4v)(0.f);
+    const half8 ones = (half8)(half_t)1.0f;
+    const int n_tiles = K / 64, total = n_cam * n_tiles;
+
+    auto load_tile = [&](int it, half8& rk, half8& rv) {
+        const int cam = it / n_tiles, kt = it - cam * n_tiles;
+        const size_t key = (size_t)(b * n_cam + cam) * K + (size_t)kt * 64 + srow;
+        rk = *reinterpret_cast<const half8*>(k + key * HD + head * D + spiece);
+        rv = *reinterpret_cast<const half8*>(v + key * HD + head * D + spiece);      // v is (b, n K, HD): same row index
+    };
+    auto store_tile = [&](int buf, const half8& rk, const half8& rv) {
+        *reinterpret_cast<half8*>(Ks[buf] + srow * KS + spiece) = rk;
+        *reinterpret_cast<half8*>(Vs[buf] + srow * VS + spiece) = rv;
+    };
+
+    half8 rk, rv, qh;
+    load_tile(0, rk, rv);
+    store_tile(0, rk, rv);
+    __syncthreads();
+    int cam_loaded = -1;
+    for (int it = 0; it < total; ++it) {
+        const int buf = it & 1, cam = it / n_tiles;
+        if (it + 1 < total) load_tile(it + 1, rk, rv);
+        if (cam != cam_loaded) {      // the query operand of this camera, pre-scaled by log2(e) / sqrt(d)
+            const half8 raw = *reinterpret_cast<const half8*>(q + ((size_t)(b * n_cam + cam) * Q + q0 + wave * 16 + lq) * HD + head * D + g * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qh[e] = (half_t)((float)raw[e] * qscale);
+            cam_loaded = cam;
+        }
+        const half_t* Kb = Ks[buf];
+        const half_t* Vb = Vs[buf];
+        half8 kh[4], vh[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) kh[kt] = *reinterpret_cast<const half8*>(Kb + (kt * 16 + lq) * KS + g * 8);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const half_t* base = Vb + (ks * 32 + 4 * g + (lq >> 2)) * VS + (lq & 3) * 8 + dt * 4;
+                const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base));
+                const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base + 16 * VS));
+                half8 t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { t[e] = (half_t)lo[e]; t[4 + e] = (half_t)hi[e]; }
+                vh[dt][ks] = t;
+            }
+        float4v s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[kt], qh, (float4v)(0.f), 0, 0, 0);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
+        m_run = m_new;
+        o_acc[0] *= alpha; o_acc[1] *= alpha; l_acc *= alpha;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 ph;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ph[e] = (half_t)s[2 * ks][e]; ph[4 + e] = (half_t)s[2 * ks + 1][e]; }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) o_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dt][ks], ph, o_acc[dt], 0, 0, 0);
+            l_acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, ph, l_acc, 0, 0, 0);
+        }
+        if (it + 1 < total) store_tile(buf ^ 1, rk, rv);    // that buffer was last read before the previous barrier
+        __syncthreads();
+    }
+    // lane (query lq, g) holds channels 8 g + 4 dt + r (row order of the V^T tiles)
+    const float inv = 1.f / l_acc[0];
+    float* op = out + ((size_t)b * Q + q0 + wave * 16 + lq) * HD + head * D + 8 * g;
+    *reinterpret_cast<float4*>(op) = make_float4(o_acc[0][0] * inv, o_acc[0][1] * inv, o_acc[0][2] * inv, o_acc[0][3] * inv);
+    *reinterpret_cast<float4*>(op + 4) = make_float4(o_acc[1][0] * inv, o_acc[1][1] * inv, o_acc[1][2] * inv, o_acc[1][3] * inv);
+}
+
+int launch_cross_attention_f16(const half_t* q, const half_t* k, const half_t* v, float* out, int b, int n_cam, int Q, int K,
+                               int heads, int dim_head, hipStream_t st) {
+    HMVIT_CHECK_ARG(dim_head == 32 && Q % 64 == 0 && K % 64 == 0, "cross_attention (f16): dim_head=%d (32), Q=%d, K=%d (multiples of 64)",
+                    dim_head, Q, K);
+    if (b <= 0 || Q <= 0) return HMVIT_OK;
+    const float qscale = 1.44269504088896341f / sqrtf((float)dim_head);
+    hipLaunchKernelGGL(k_cross_attention_mfma, dim3(Q / 64, heads, b), dim3(256), 0, st, q, k, v, out, n_cam, Q, K, heads, qscale);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+}  // namespace hmvit

@@ -8,7 +8,7 @@ slot of ``BevformerPointPillarHetero`` still takes any encoder honouring the slo
 
 Kernels: ``hmvit_cvt_embed`` (ray / BEV positional embeddings), ``hmvit_bn_relu_tokens`` (BN + ReLU + layout),
 ``hmvit_cross_attention`` (joint softmax over all cameras' keys); LayerNorm and every Linear / 1x1 convolution run on the
-library's LayerNorm and GEMM kernels (f32).
+library's LayerNorm and GEMM kernels (f32; the attention core and its q / k / v projections also in f16 on the matrix cores).
 """
 from __future__ import annotations
 
@@ -60,11 +60,23 @@ class BEVEmbedding(nn.Module):
         return self.learned_features
 
 
-def _layernorm(x2d, ln: nn.LayerNorm):
+def _layernorm(x2d, ln: nn.LayerNorm, prec=_F32):
     M, C = x2d.shape
-    y = torch.empty_like(x2d)
+    y = torch.empty(M, C, device=x2d.device, dtype=torch.float32 if prec == _F32 else torch.float16)
     _lib.check(_lib.lib.hmvit_layernorm(x2d.data_ptr(), y.data_ptr(), _lib.i32_array([0]), ln.weight.data_ptr(),
-                                        ln.bias.data_ptr(), 1, M, C, _F32, _stream()), "layernorm")
+                                        ln.bias.data_ptr(), 1, M, C, prec, _stream()), "layernorm")
+    return y
+
+
+def _linear_f16(x2d, weight, bias=None):
+    """f16 operands, f32 accumulate, f16 result (the q / k / v projections of the f16 mode)."""
+    M, K = x2d.shape
+    N = weight.shape[0]
+    y = torch.empty(M, N, device=x2d.device, dtype=torch.float16)
+    w2 = weight.detach().reshape(N, K).to(torch.float16).contiguous()
+    b2 = None if bias is None else bias.detach().float().contiguous()
+    _lib.check(_lib.lib.hmvit_linear(x2d.data_ptr(), w2.data_ptr(), _ptr(b2), None, y.data_ptr(), M, N, K, 0, 0, _lib.PREC_F16,
+                                     _stream()), "linear")
     return y
 
 
@@ -80,7 +92,11 @@ def _linear(x2d, weight, bias=None, residual=None, gelu=False):
 
 class CrossAttention(nn.Module):
     """cvt_modules.py:95-173.  ``forward`` takes token-major tensors here: q (b, n, Q, dim), k (b, n, K, dim), v (b, n K, dim),
-    skip (b, Q, dim) or None, and returns (b, Q, dim)."""
+    skip (b, Q, dim) or None, and returns (b, Q, dim).  ``precision`` (attribute, not a constructor argument of the reference):
+    "f32" keeps every product in f32; "f16" runs LayerNorm -> q / k / v projections -> attention with f16 operands on the
+    matrix cores (f32 accumulate and softmax) when Q and K are multiples of 64."""
+
+    precision = "f32"
 
     def __init__(self, dim, heads, dim_head, qkv_bias, norm=nn.LayerNorm):
         super().__init__()
@@ -100,12 +116,22 @@ class CrossAttention(nn.Module):
         b, n, Q, dim = q.shape
         K = k.shape[2]
         hd = self.heads * self.dim_head
-        qp = _linear(_layernorm(q.reshape(-1, dim), self.to_q[0]), self.to_q[1].weight, self.to_q[1].bias)
-        kp = _linear(_layernorm(k.reshape(-1, dim), self.to_k[0]), self.to_k[1].weight, self.to_k[1].bias)
-        vp = _linear(_layernorm(v.reshape(-1, dim), self.to_v[0]), self.to_v[1].weight, self.to_v[1].bias)
+        if self.precision not in ("f32", "f16"):
+            raise ValueError(f"CrossAttention.precision: {self.precision!r}")
+        half = self.precision == "f16" and Q % 64 == 0 and K % 64 == 0 and dim % 64 == 0
+        if half:
+            F16 = _lib.PREC_F16
+            qp = _linear_f16(_layernorm(q.reshape(-1, dim), self.to_q[0], F16), self.to_q[1].weight, self.to_q[1].bias)
+            kp = _linear_f16(_layernorm(k.reshape(-1, dim), self.to_k[0], F16), self.to_k[1].weight, self.to_k[1].bias)
+            vp = _linear_f16(_layernorm(v.reshape(-1, dim), self.to_v[0], F16), self.to_v[1].weight, self.to_v[1].bias)
+        else:
+            qp = _linear(_layernorm(q.reshape(-1, dim), self.to_q[0]), self.to_q[1].weight, self.to_q[1].bias)
+            kp = _linear(_layernorm(k.reshape(-1, dim), self.to_k[0]), self.to_k[1].weight, self.to_k[1].bias)
+            vp = _linear(_layernorm(v.reshape(-1, dim), self.to_v[0]), self.to_v[1].weight, self.to_v[1].bias)
         a = torch.empty(b * Q, hd, device=q.device, dtype=torch.float32)
         _lib.check(_lib.lib.hmvit_cross_attention(qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), a.data_ptr(), b, n, Q, K,
-                                                  self.heads, self.dim_head, _stream()), "cross_attention")
+                                                  self.heads, self.dim_head, _lib.PREC_F16 if half else _F32, _stream()),
+                   "cross_attention")
         z = _linear(a, self.proj.weight, self.proj.bias, residual=None if skip is None else skip.reshape(-1, dim).contiguous())
         z = _layernorm(z, self.prenorm)
         hdn = _linear(z, self.mlp[0].weight, self.mlp[0].bias, gelu=True)

@@ -318,10 +318,11 @@ int hmvit_cvt_embed(int mode, const float* I_inv, const float* E_inv, const floa
 int hmvit_bn_relu_tokens(const float* x, const float* scale, const float* shift, float* y, int n, int C, int P, void* stream);
 
 /* CrossAttention core (cvt_modules.py:148-158): q (n_agents, n_cam, Q, heads * 32), k (n_agents, n_cam, K, heads * 32),
- * v (n_agents, n_cam * K, heads * 32) f32 -> out (n_agents, Q, heads * 32); logits q_cam . k_cam / sqrt(32), one softmax over
- * the keys of all cameras. */
-int hmvit_cross_attention(const float* q, const float* k, const float* v, float* out, int n_agents, int n_cam, int Q, int K,
-                          int heads, int dim_head, void* stream);
+ * v (n_agents, n_cam * K, heads * 32) in the precision's element type -> out (n_agents, Q, heads * 32) f32; logits
+ * q_cam . k_cam / sqrt(32), one softmax over the keys of all cameras.  HMVIT_PREC_F16 runs on the matrix cores and needs
+ * Q and K to be multiples of 64. */
+int hmvit_cross_attention(const void* q, const void* k, const void* v, float* out, int n_agents, int n_cam, int Q, int K,
+                          int heads, int dim_head, int precision, void* stream);
 
 /* debug: lane mapping of ds_read_b64_tr_b16 (used once to pin the V-operand layout) */
 int hmvit_debug_tr16(uint16_t* out, void* stream);

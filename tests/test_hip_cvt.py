@@ -36,16 +36,44 @@ def test_cross_view_attention_golden(tag, no_feat, skip):
     assert rel_max_err(y, g["y_" + tag]) < TOL
 
 
-def test_cross_view_attention_level2_size_vs_oracle():
+@pytest.mark.parametrize("precision,tol", [("f32", TOL), ("f16", 1e-2)])
+def test_cross_view_attention_level2_size_vs_oracle(precision, tol):
     """Second pyramid level of the shipped CVT config: (4, 512, 16, 16) features, 32 x 32 BEV queries, dim 128, 4 heads."""
     from hmvit_amd.cvt import BEVEmbedding
     cfg = CO.make_config()
     sd = CO.random_state_dict(512, 128, cfg, seed=5)
     net = _net(16, 512, 128, cfg, sd)
+    net.cross_attend.precision = precision
     bev = BEVEmbedding(128, 1.0, 256, 256, 100.0, 100.0, 0.0, [128, 128, 64]).cuda()
     x, feat, I_inv, E_inv = CO.synthetic_inputs(1, 4, 512, 16, 16, 128, 32, 32, seed=6)
     ref = CO.cross_view_attention(x, bev.grid.cpu(), feat, I_inv, E_inv, sd, cfg)
     y = net(x.cuda(), bev, feat.cuda(), I_inv.cuda(), E_inv.cuda()).cpu()
-    assert rel_max_err(y, ref) < TOL
+    assert rel_max_err(y, ref) < tol
     with pytest.raises(RuntimeError):
         net(x, bev, feat, I_inv, E_inv)          # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("b,n,Q,K,heads", [(1, 1, 64, 64, 1), (2, 3, 128, 192, 4), (1, 4, 1024, 1024, 4)])
+def test_cross_attention_core_f16_vs_torch(b, n, Q, K, heads):
+    """Matrix-core attention core against a torch f32 evaluation of the same f16 operands (joint softmax over the cameras'
+    keys, cvt_modules.py:148-158); logits spread over several units so the running-max rescale is exercised."""
+    import ctypes
+    from hmvit_amd import _lib
+    gen = torch.Generator().manual_seed(b * 1000 + Q + K)
+    hd = heads * 32
+    q = (torch.randn(b, n, Q, hd, generator=gen) * 1.5).half()
+    k = (torch.randn(b, n, K, hd, generator=gen) * 1.5).half()
+    v = torch.randn(b, n * K, hd, generator=gen).half()
+    qf = q.float().reshape(b, n, Q, heads, 32).permute(0, 3, 1, 2, 4)
+    kf = k.float().reshape(b, n, K, heads, 32).permute(0, 3, 1, 2, 4)
+    dot = (32 ** -0.5) * torch.einsum("bmnqd,bmnkd->bmnqk", qf, kf)
+    att = dot.permute(0, 1, 3, 2, 4).reshape(b, heads, Q, n * K).softmax(-1)
+    ref = torch.einsum("bmqk,bkmd->bqmd", att, v.float().reshape(b, n * K, heads, 32)).reshape(b, Q, hd)
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    out = torch.empty(b, Q, hd, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(_lib.lib.hmvit_cross_attention(qc.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr(), b, n, Q, K, heads, 32,
+                                              _lib.PREC_F16, st), "cross_attention")
+    assert rel_max_err(out.cpu(), ref) < 3e-3       # P and the scaled q operand are rounded to f16
+    assert _lib.lib.hmvit_cross_attention(qc.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr(), b, n, Q - 1, K, heads, 32,
+                                          _lib.PREC_F16, st) != 0     # Q not a multiple of 64: refused, no silent fallback

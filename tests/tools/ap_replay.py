@@ -2,14 +2,14 @@
 scenes through (i) the CPU restatement end to end and (ii) the HIP pipeline end to end (pillariser -> PointPillar -> regroup
 -> HeteroFusion -> HeteroDecoder -> VoxelPostprocessor), then the reference's AP arithmetic on both against the scenes'
 ground-truth boxes.  No OPV2V data and no trained checkpoint exist here, so the absolute AP is that of an untrained detector;
-what the replay shows is the DELTA between the two pipelines.  Usage: python tools/ap_replay.py [--scenes N] [--precision f32|f16]
+what the replay shows is the DELTA between the two pipelines.  Usage: python tests/tools/ap_replay.py [--scenes N] [--precision f32|f16]
 Prints one JSON line."""
 import argparse, json, math, os, sys
 
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import hmvit_amd

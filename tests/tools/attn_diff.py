@@ -1,7 +1,7 @@
 """Debug aid: persistent attention kernel vs the one-workgroup-per-window kernel on the same f16 inputs."""
 import ctypes, os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import hmvit_amd
 from hmvit_amd import _lib
 from oracle import hmvit_oracle as O

@@ -2,7 +2,7 @@
 hmvit_window_attention with the HMVIT_ATTN_DEBUG switches of csrc/attn.hip."""
 import ctypes, os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import hmvit_amd
 from hmvit_amd import _lib
 from oracle import hmvit_oracle as O

@@ -2,7 +2,7 @@
 512 x 512 grid, layer_nums [3, 5, 8] -> (5, 256, 128, 128).  Not the headline bench; a tuning aid."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import hmvit_amd
 from oracle import pointpillar_oracle as PO
 

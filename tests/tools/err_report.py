@@ -1,6 +1,6 @@
 """Prints rel-max errors of the f16 path against the oracle / goldens for a few scenes (tuning aid, not a test)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import hmvit_amd
 from oracle import hmvit_oracle as O
