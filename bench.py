@@ -125,19 +125,16 @@ def main():
 
     import hmvit_amd
     from hmvit_amd.dist import max_over_ranks
-    from oracle import hmvit_oracle as O      # only the seeded input generators + cpu_baseline
+    from hmvit_amd import synthetic as S      # seeded workload generators (the oracle is only the cpu_baseline leg)
 
     c = CONFIGS[args.config]
-    cfg = O.make_config(c["C"], c["window"], c["L"], voxel=c["voxel"], downsample=c["downsample"],
+    cfg = S.make_config(c["C"], c["window"], c["L"], voxel=c["voxel"], downsample=c["downsample"],
                         num_iters=args.num_iters)
-    sd = O.random_state_dict(cfg, seed=0)
     # every rank gets its own scene (different features, same geometry)
-    scene = [t.to(dev) for t in O.synthetic_scene(c["L"], c["C"], c["H"], c["W"], c["modes"], seed=1 + rank)]
+    scene = [t.to(dev) for t in S.synthetic_scene(c["L"], c["C"], c["H"], c["W"], c["modes"], seed=1 + rank)]
 
     def make(precision):
-        net = hmvit_amd.HeteroFusion(cfg, precision=precision)
-        net.load_state_dict(sd, strict=True)
-        return net.to(dev).eval()
+        return S.seeded_fusion(cfg, precision=precision, seed=0).to(dev).eval()
 
     def barrier():
         torch.cuda.synchronize(dev)

@@ -434,6 +434,12 @@ __device__ __forceinline__ bool pc_fetch(const AttnParams& p, int X, int Y, int 
         }
         const int wx = (tile / nty) * TH + (t >> 3), wy = (tile % nty) * 8 + (t & 7);
         if (wx < X && wy < Y) {
+            if (p.prune) {   // items the pruned last stage cannot reach (k_window_need -> bit 31 of the visibility word)
+                const unsigned* a = p.vis_mask + __builtin_amdgcn_readfirstlane(((s * p.n_ego + ego) * X + wx) * Y + wy);
+                unsigned v;
+                asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(a) : "memory");
+                if (v >> 31) continue;
+            }
             // wave-uniform: keep the fields in SGPRs so that the per-chunk metadata (affine record, agent
             // types, plane bases) is fetched with scalar loads
             it.b = __builtin_amdgcn_readfirstlane(s);
@@ -1180,7 +1186,7 @@ static int launch_attn_t(const AttnParams& p, hipStream_t st) {
 // persistent kernel skips them outright (the reference computes them densely and masks them to -inf: same result,
 // tests/test_hip_fusion.py::test_skip_masked_tiles_is_exact_f16).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tile_vis(AttnParams p, unsigned* __restrict__ vis_mask) {
+__global__ __launch_bounds__(256) void k_tile_vis(AttnParams p, unsigned* __restrict__ vis_mask, const unsigned char* __restrict__ need) {
     const int X = p.H / 8, Y = p.W / 8, n_pos = p.B * p.n_ego * X * Y;
     const int pos = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (pos >= n_pos) return;
@@ -1198,14 +1204,49 @@ __global__ __launch_bounds__(256) void k_tile_vis(AttnParams p, unsigned* __rest
         if (a[6] == 0.f) vis = vis && make_taps(a, col, row, p.H, p.W).roi != 0.f;
         if (__any(vis)) mask |= 1u << c;
     }
+    if (need && !need[pos]) mask |= 0x80000000u;      // local partition only: pos = (b, ego, window) as in k_window_need
     if (lane == 0) vis_mask[pos] = mask;
 }
 
-int launch_tile_vis(const AttnParams& p, unsigned* vis_mask, hipStream_t st) {
+// ------------------------------------------------------------------------------------------
+// Reachability of the stage before the pruned last one.  The last stage of HeteroFusion only produces ego 0's row, so
+// of the other agents' maps it reads nothing but the K' / V' rows under ego 0's bilinear taps; a window of agent j
+// without such a tap is dead code in the stage before (its attention item and its chain tail are skipped; the
+// reference computes them and discards them).  One thread per ego-0 pixel and source agent marks the windows of the
+// taps it would load (same criterion as pc_taps, without the visibility test: a superset).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_window_need(AttnParams p, unsigned char* __restrict__ need) {
+    const int H = p.H, W = p.W, X = H / 8, Y = W / 8;
+    const int pix = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, b = blockIdx.z;
+    if (pix >= H * W) return;
+    const int row = pix / W, col = pix - row * W;
+    unsigned char* base = need + (size_t)(b * p.n_ego + j) * X * Y;
+    const float* a = p.ainv + ((size_t)(b * p.L + j) * p.L + 0) * 8;     // source j sampled on ego 0's grid
+    if (j == 0 || a[6] != 0.f) { base[(row >> 3) * Y + (col >> 3)] = 1; return; }
+    if (!p.cav[b * p.L + j]) return;
+    const Taps t = make_taps(a, col, row, H, W);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (t.w[k] != 0.f) {
+            const int r = t.idx[k] / W, c = t.idx[k] - r * W;
+            base[(r >> 3) * Y + (c >> 3)] = 1;
+        }
+}
+
+int launch_window_need(const AttnParams& p, unsigned char* need, hipStream_t st) {
+    HMVIT_CHECK_ARG(p.window == 8 && p.H % 8 == 0 && p.W % 8 == 0, "window_need: window=%d (8)", p.window);
+    if (p.B <= 0 || p.n_ego <= 0) return HMVIT_OK;
+    hipLaunchKernelGGL(k_window_need, dim3(cdiv(p.H * p.W, 256), p.n_ego, p.B), dim3(256), 0, st, p, need);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+int launch_tile_vis(const AttnParams& p, unsigned* vis_mask, const unsigned char* need, hipStream_t st) {
     HMVIT_CHECK_ARG(p.n_src <= 8 && p.window == 8, "tile_vis: n_src=%d (<= 8), window=%d (8)", p.n_src, p.window);
     const int n_pos = p.B * p.n_ego * (p.H / 8) * (p.W / 8);
     if (n_pos <= 0) return HMVIT_OK;
-    hipLaunchKernelGGL(k_tile_vis, dim3(cdiv(n_pos, 4)), dim3(256), 0, st, p, vis_mask);
+    HMVIT_CHECK_ARG(!need || p.partition == HMVIT_PART_WINDOW, "tile_vis: reachability pruning is for the local partition");
+    hipLaunchKernelGGL(k_tile_vis, dim3(cdiv(n_pos, 4)), dim3(256), 0, st, p, vis_mask, need);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }

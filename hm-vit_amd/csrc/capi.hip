@@ -24,7 +24,7 @@ struct Plan {
     int B, L, C, H, W, P, mlp, n_slots, max_cav, E_max;
     size_t es;
     // byte offsets into the workspace
-    size_t off_xs, off_xn, off_q, off_kv, off_o, off_hid, off_ainv, off_ytok, off_xa, off_xb, off_gap, off_sw, off_vis, total;
+    size_t off_xs, off_xn, off_q, off_kv, off_o, off_hid, off_ainv, off_ytok, off_xa, off_xb, off_gap, off_sw, off_vis, off_need, total;
 };
 
 static int check_desc(const HmvitFusionDesc* d) {
@@ -77,6 +77,7 @@ static void make_plan(const HmvitFusionDesc* d, Plan& pl) {
     pl.off_ainv = carve((size_t)pl.n_slots * pl.L * 8 * 4);
     pl.off_ytok = carve((size_t)pl.B * pl.P * pl.C * 4);
     pl.off_vis = carve((size_t)pl.n_slots * pl.P / 64 * 4 + 256);   // visible-chunk bits of the attention windows
+    pl.off_need = carve((size_t)pl.n_slots * pl.P / 64 + 256);      // reachable windows of the stage before the pruned one
     pl.off_xa = pl.off_xb = pl.off_gap = pl.off_sw = 0;
     if (d->parallel) {
         // branch outputs of the parallel block + SplitAttn scratch
@@ -526,6 +527,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
             HMVIT_MARK(HMVIT_PHASE_QKV);
 
             // 3. fused warp + partition + attention
+            unsigned char* need = nullptr;
             {
                 AttnParams ap;
                 memset(&ap, 0, sizeof(ap));
@@ -539,11 +541,21 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                     ap.cav[i] = (int8_t)(d->cav_mask[i] != 0);
                     ap.ego_e[i] = (int8_t)(e_of_type[d->mode[i]] < 0 ? 0 : e_of_type[d->mode[i]]);
                 }
+                // The stage after this one is the pruned last stage (ego 0 only): what it cannot reach of the other
+                // agents' maps is dead code here (k_window_need); identical output, switched off with skip_masked.
+                need = nullptr;
+                if (!par && d->skip_masked && d->window == 8 && s == 0 && d->apply_head && it == d->num_iters - 1 &&
+                    n_ego > 1 && d->H % 8 == 0 && d->W % 8 == 0 && !getenv("HMVIT_NO_PRUNE")) {
+                    need = reinterpret_cast<unsigned char*>(ws + pl.off_need);
+                    HMVIT_CHECK_HIP(hipMemsetAsync(need, 0, (size_t)B * n_ego * (P / 64), st));
+                    HMVIT_TRY(launch_window_need(ap, need, st));
+                }
                 if (d->skip_masked && d->window == 8 && C > 64 && n_src <= 8 && !getenv("HMVIT_ATTN_DEBUG")) {
                     // tiles without a visible key are skipped by the persistent kernel (launch_tile_vis)
                     unsigned* vis = reinterpret_cast<unsigned*>(ws + pl.off_vis);
-                    HMVIT_TRY(launch_tile_vis(ap, vis, st));
+                    HMVIT_TRY(launch_tile_vis(ap, vis, need, st));
                     ap.vis_mask = vis;
+                    ap.prune = need != nullptr;
                 }
                 HMVIT_TRY(launch_attention(ap, HMVIT_PREC_F16, st));
             }
@@ -560,7 +572,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                 fb.p.w_o = reinterpret_cast<const half_t*>(wt.img_o); fb.p.b_o = wt.b_o;
                 fb.p.ln_g = wt.ffn_ln_gamma; fb.p.ln_b = wt.ffn_ln_beta;
                 fb.p.w_ffn = reinterpret_cast<const half_t*>(wt.img_ffn); fb.p.b_1 = wt.b_1; fb.p.b_2 = wt.b_2;
-                fb.p.P = P;
+                fb.p.P = P; fb.p.W = d->W;
                 fb.variant = FFN_FULL;
                 if (fuse) {
                     const int it2 = s == 1 ? it + 1 : it, s2 = 1 - s;
@@ -574,11 +586,13 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                         for (int i = 0; i < n_ego; ++i) {   // n_ego == max_cav here: every source agent of the next stage
                             const int slot = b * L + i;
                             FfnJob j;
+                            j.need = nullptr;
                             j.o = ob + (size_t)slot * map_elems;
                             j.x = xs + (size_t)slot * map_elems;
                             j.out = x_out + (size_t)slot * map_elems;
                             j.type = d->mode[slot];
                             j.pad = (sn.last && i >= sn.n_ego) ? 1 : 0;   // x'' of a pure K/V source of the pruned stage is never read
+                            j.need = need ? need + (size_t)(b * n_ego + i) * (P / 64) : nullptr;
                             fb.p.job[n] = j;
                             qp.job[n] = qkv_job(wn, sn, slot, i, false);
                             if (++n == kMaxChainJobs) { HMVIT_TRY(launch_out_ffn_qkv(fb.p, qp, n, C, st)); n = 0; }
@@ -592,6 +606,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                     for (int b = 0; b < B; ++b) {
                         const int slot = b * L;
                         FfnJob j;
+                            j.need = nullptr;
                         j.o = ob + (size_t)slot * map_elems;
                         j.x = xs + (size_t)slot * map_elems;
                         j.out = d->out + (size_t)b * map_elems;
@@ -606,6 +621,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                         for (int i = 0; i < n_ego; ++i) {
                             const int slot = b * L + i;
                             FfnJob j;
+                            j.need = nullptr;
                             j.o = ob + (size_t)slot * map_elems;
                             j.x = xs + (size_t)slot * map_elems;
                             j.out = x_out + (size_t)slot * map_elems;
@@ -621,6 +637,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                             const int slot = b * L + l;
                             if (d->apply_head) continue;   // never consumed by HeteroFusion
                             FfnJob j;
+                            j.need = nullptr;
                             j.o = nullptr;
                             j.x = xs + (size_t)slot * map_elems;
                             j.out = x_out + (size_t)slot * map_elems;
@@ -652,6 +669,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
         fb.p.P = P;
         for (int b = 0; b < B; ++b) {
             FfnJob j;
+                            j.need = nullptr;
             j.o = nullptr;
             j.x = xs + (size_t)(b * L) * map_elems;
             j.out = d->out + (size_t)b * map_elems;

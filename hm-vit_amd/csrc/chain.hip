@@ -400,6 +400,12 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
 
     const FfnJob& J = p.job[blockIdx.y];
     const int P = p.P;
+    if (J.need) {   // none of this workgroup's tokens is read by a later stage (k_window_need): nothing to do
+        const int t = blockIdx.x * CHAIN_TOKENS + (threadIdx.x & (CHAIN_TOKENS - 1));
+        const int r = t / p.W, c = t - r * p.W;
+        const int live = (t < P) ? J.need[(r >> 3) * (p.W >> 3) + (c >> 3)] : 0;
+        if (!__syncthreads_or(live)) return;
+    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int m = lane & 31, hi = lane >> 5;
     const int tok = blockIdx.x * CHAIN_TOKENS + wave * 32 + m;

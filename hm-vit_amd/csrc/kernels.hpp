@@ -66,6 +66,8 @@ struct FfnJob {
     float* out;              // (P, C) token-major (may alias x) or (C, P) for FFN_HEAD_NCHW
     int type;
     int pad;
+    const unsigned char* need;   // optional (H/8, W/8): windows of this agent that a later stage can reach (k_window_need);
+                                 // workgroups whose 128 tokens lie in unreachable windows return at once
 };
 struct FfnParams {
     FfnJob job[kMaxChainJobs];
@@ -77,6 +79,7 @@ struct FfnParams {
     const float* b_1;        // (T, C)
     const float* b_2;        // (T, C)
     int P;
+    int W;                   // map width (FfnJob::need only)
     const half_t* w_head;    // k_out_ffn_head only: mlp_head image (T, 2 NH chunks) and biases (T, C)
     const float* hb_1;
     const float* hb_2;
@@ -146,12 +149,16 @@ struct AttnParams {
     unsigned long long* trace; // optional s_memtime trace buffer (debug probe), else null
     int variant;              // 0: default kernel choice, 1: force the one-window-per-workgroup kernel
     const unsigned* vis_mask;        // optional (B * n_ego * H/8 * W/8): visible-chunk bits per window (launch_tile_vis)
+    int prune;                       // vis_mask bit 31 marks items no later stage can reach: skipped by the schedule
     int8_t mode[kMaxSlots];   // (B, L)
     int8_t cav[kMaxSlots];    // (B, L)
     int8_t ego_e[kMaxSlots];  // (B, L): K/V variant used by ego (b, i)
 };
 int launch_attention(const AttnParams& p, int precision, hipStream_t st);
-int launch_tile_vis(const AttnParams& p, unsigned* vis_mask, hipStream_t st);
+int launch_tile_vis(const AttnParams& p, unsigned* vis_mask, const unsigned char* need, hipStream_t st);
+// need[(b * n_ego + j) * (H/8) * (W/8) + window] = 1 when the pruned last stage (ego 0 only) reads a key / value inside that
+// 8 x 8 window of agent j's map; `need` must be zeroed by the caller
+int launch_window_need(const AttnParams& p, unsigned char* need, hipStream_t st);
 int launch_debug_tr16(uint16_t* out, hipStream_t st);
 
 // ---- post.hip (detection post-processing) ----

@@ -164,6 +164,30 @@ def test_skip_masked_tiles_is_exact_f16():
     assert rel_max_err(a.cpu(), ref) < TOL["f16"]
 
 
+def test_unreachable_windows_pruning_is_exact_f16():
+    """C = 256, f16, two samples (4 and 2 valid agents), strongly rotated / shifted poses: in the stage before the pruned
+    last one, windows of the non-ego agents that ego 0's taps cannot reach are skipped (k_window_need: attention items
+    and chain-tail workgroups).  Bit-identical to the run with the pruning switched off, and within tolerance of the oracle."""
+    import os
+    cfg = O.make_config(256, 8, 4, voxel=0.4, downsample=4)
+    sd = O.random_state_dict(cfg, seed=33)
+    x, pw, mode, rl, mask = O.synthetic_scene(4, 256, 48, 160, [1, 0, 1, 1], seed=15, B=2, yaw_step=0.45, tx_step=30.0,
+                                              ty_step=-20.0)
+    x2, pw2, mode2, rl2, mask2 = O.synthetic_scene(4, 256, 48, 160, [1, 0, 1, 1], n_valid=2, seed=16, yaw_step=-0.3)
+    x[1], pw[1], mode[1], rl[1], mask[1] = x2[0], pw2[0], mode2[0], rl2[0], mask2[0]
+    scene = _cuda(x, pw, mode, rl, mask)
+    net = _fusion(cfg, sd, "f16")
+    a = net(*scene)
+    os.environ["HMVIT_NO_PRUNE"] = "1"
+    try:
+        b = net(*scene)
+    finally:
+        del os.environ["HMVIT_NO_PRUNE"]
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    ref = O.hetero_fusion(*[t.cpu() for t in scene], sd, cfg)
+    assert rel_max_err(a.cpu(), ref) < TOL["f16"]
+
+
 def test_inputs_not_mutated_and_repeatable():
     cfg = O.make_config(64, 4, 2)
     sd = O.random_state_dict(cfg, seed=2)
