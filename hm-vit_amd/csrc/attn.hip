@@ -1209,34 +1209,39 @@ __global__ __launch_bounds__(256) void k_tile_vis(AttnParams p, unsigned* __rest
 }
 
 // ------------------------------------------------------------------------------------------
-// Reachability of the stage before the pruned last one.  The last stage of HeteroFusion only produces ego 0's row, so
+// Reachability of the stages before the pruned last one.  The last stage of HeteroFusion only produces ego 0's row, so
 // of the other agents' maps it reads nothing but the K' / V' rows under ego 0's bilinear taps; a window of agent j
-// without such a tap is dead code in the stage before (its attention item and its chain tail are skipped; the
-// reference computes them and discards them).  One thread per ego-0 pixel and source agent marks the windows of the
-// taps it would load (same criterion as pc_taps, without the visibility test: a superset).
+// without such a tap is dead code in the (local) stage before: its attention item and its chain tail are skipped (the
+// reference computes them and discards them).  One thread per ego pixel and source agent marks the windows of the taps
+// it would load (same criterion as pc_taps, without the visibility test: a superset).  from = nullptr: what ego 0
+// reads over its whole map; from = such a table: what all egos read from the windows they still compute, plus those
+// windows themselves - the tokens the chain tail of the stage before that one has to produce.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_window_need(AttnParams p, unsigned char* __restrict__ need) {
-    const int H = p.H, W = p.W, X = H / 8, Y = W / 8;
-    const int pix = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y, b = blockIdx.z;
+__global__ __launch_bounds__(256) void k_window_need(AttnParams p, const unsigned char* __restrict__ from,
+                                                     unsigned char* __restrict__ to) {
+    const int H = p.H, W = p.W, X = H / 8, Y = W / 8, XY = X * Y;
+    const int pix = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    const int n_from = from ? p.n_ego : 1, j = blockIdx.z % n_from, b = blockIdx.z / n_from;
     if (pix >= H * W) return;
-    const int row = pix / W, col = pix - row * W;
-    unsigned char* base = need + (size_t)(b * p.n_ego + j) * X * Y;
-    const float* a = p.ainv + ((size_t)(b * p.L + j) * p.L + 0) * 8;     // source j sampled on ego 0's grid
-    if (j == 0 || a[6] != 0.f) { base[(row >> 3) * Y + (col >> 3)] = 1; return; }
-    if (!p.cav[b * p.L + j]) return;
+    const int row = pix / W, col = pix - row * W, own = (row >> 3) * Y + (col >> 3);
+    if (from && !from[(size_t)(b * p.n_ego + j) * XY + own]) return;      // ego j does not compute this pixel's window
+    unsigned char* base = to + (size_t)(b * p.n_ego + k) * XY;
+    const float* a = p.ainv + ((size_t)(b * p.L + k) * p.L + j) * 8;     // source k sampled on ego j's grid
+    if (k == j || a[6] != 0.f) { base[own] = 1; return; }
+    if (!p.cav[b * p.L + k]) return;
     const Taps t = make_taps(a, col, row, H, W);
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (t.w[k] != 0.f) {
-            const int r = t.idx[k] / W, c = t.idx[k] - r * W;
+    for (int i = 0; i < 4; ++i)
+        if (t.w[i] != 0.f) {
+            const int r = t.idx[i] / W, c = t.idx[i] - r * W;
             base[(r >> 3) * Y + (c >> 3)] = 1;
         }
 }
 
-int launch_window_need(const AttnParams& p, unsigned char* need, hipStream_t st) {
+int launch_window_need(const AttnParams& p, const unsigned char* from, unsigned char* to, hipStream_t st) {
     HMVIT_CHECK_ARG(p.window == 8 && p.H % 8 == 0 && p.W % 8 == 0, "window_need: window=%d (8)", p.window);
     if (p.B <= 0 || p.n_ego <= 0) return HMVIT_OK;
-    hipLaunchKernelGGL(k_window_need, dim3(cdiv(p.H * p.W, 256), p.n_ego, p.B), dim3(256), 0, st, p, need);
+    hipLaunchKernelGGL(k_window_need, dim3(cdiv(p.H * p.W, 256), p.n_ego, p.B * (from ? p.n_ego : 1)), dim3(256), 0, st, p, from, to);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }

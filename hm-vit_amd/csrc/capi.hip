@@ -77,7 +77,7 @@ static void make_plan(const HmvitFusionDesc* d, Plan& pl) {
     pl.off_ainv = carve((size_t)pl.n_slots * pl.L * 8 * 4);
     pl.off_ytok = carve((size_t)pl.B * pl.P * pl.C * 4);
     pl.off_vis = carve((size_t)pl.n_slots * pl.P / 64 * 4 + 256);   // visible-chunk bits of the attention windows
-    pl.off_need = carve((size_t)pl.n_slots * pl.P / 64 + 256);      // reachable windows of the stage before the pruned one
+    pl.off_need = carve(2 * ((size_t)pl.n_slots * pl.P / 64) + 256);      // reachable windows of the stage before the pruned one
     pl.off_xa = pl.off_xb = pl.off_gap = pl.off_sw = 0;
     if (d->parallel) {
         // branch outputs of the parallel block + SplitAttn scratch
@@ -500,6 +500,28 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
         return j;
     };
 
+    // Reachability tables (k_window_need): HeteroFusion's last stage only computes ego 0, so in the local stage before it
+    // the windows of the other agents that ego 0's taps cannot reach are dead code (need_last: attention items and chain
+    // tail skipped), and the chain tail of the stage before that only has to produce what those surviving windows read
+    // (need_prev).  Identical output; off with skip_masked = 0.
+    unsigned char* need_last = nullptr;
+    unsigned char* need_prev = nullptr;
+    if (!par && d->apply_head && d->skip_masked && d->window == 8 && pl.max_cav > 1 && d->H % 8 == 0 && d->W % 8 == 0 &&
+        !getenv("HMVIT_NO_PRUNE")) {
+        AttnParams ap;
+        memset(&ap, 0, sizeof(ap));
+        ap.ainv = ainv; ap.B = B; ap.L = L; ap.n_ego = pl.max_cav; ap.H = d->H; ap.W = d->W; ap.window = d->window;
+        for (int i = 0; i < pl.n_slots; ++i) ap.cav[i] = (int8_t)(d->cav_mask[i] != 0);
+        const size_t nb = (size_t)B * pl.max_cav * (P / 64);
+        need_last = reinterpret_cast<unsigned char*>(ws + pl.off_need);
+        HMVIT_CHECK_HIP(hipMemsetAsync(need_last, 0, 2 * nb, st));
+        HMVIT_TRY(launch_window_need(ap, nullptr, need_last, st));
+        if (d->num_iters >= 2 && !getenv("HMVIT_NO_PRUNE_PREV")) {
+            need_prev = need_last + nb;
+            HMVIT_TRY(launch_window_need(ap, need_last, need_prev, st));
+        }
+    }
+
     bool qkv_done = false;   // this stage's Q / K' / V' were produced by the previous stage's fused tail
     bool head_done = false;  // mlp_head rode on the last stage's tail
     for (int it = 0; it < d->num_iters; ++it) {
@@ -541,15 +563,8 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                     ap.cav[i] = (int8_t)(d->cav_mask[i] != 0);
                     ap.ego_e[i] = (int8_t)(e_of_type[d->mode[i]] < 0 ? 0 : e_of_type[d->mode[i]]);
                 }
-                // The stage after this one is the pruned last stage (ego 0 only): what it cannot reach of the other
-                // agents' maps is dead code here (k_window_need); identical output, switched off with skip_masked.
-                need = nullptr;
-                if (!par && d->skip_masked && d->window == 8 && s == 0 && d->apply_head && it == d->num_iters - 1 &&
-                    n_ego > 1 && d->H % 8 == 0 && d->W % 8 == 0 && !getenv("HMVIT_NO_PRUNE")) {
-                    need = reinterpret_cast<unsigned char*>(ws + pl.off_need);
-                    HMVIT_CHECK_HIP(hipMemsetAsync(need, 0, (size_t)B * n_ego * (P / 64), st));
-                    HMVIT_TRY(launch_window_need(ap, need, st));
-                }
+                // the stage after this one is the pruned last stage (ego 0 only): unreachable windows are dead code
+                need = (it == d->num_iters - 1 && s == 0) ? need_last : nullptr;
                 if (d->skip_masked && d->window == 8 && C > 64 && n_src <= 8 && !getenv("HMVIT_ATTN_DEBUG")) {
                     // tiles without a visible key are skipped by the persistent kernel (launch_tile_vis)
                     unsigned* vis = reinterpret_cast<unsigned*>(ws + pl.off_vis);
@@ -592,7 +607,8 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                             j.out = x_out + (size_t)slot * map_elems;
                             j.type = d->mode[slot];
                             j.pad = (sn.last && i >= sn.n_ego) ? 1 : 0;   // x'' of a pure K/V source of the pruned stage is never read
-                            j.need = need ? need + (size_t)(b * n_ego + i) * (P / 64) : nullptr;
+                            const unsigned char* nd = need ? need : (it == d->num_iters - 2 && s == 1) ? need_prev : nullptr;
+                            j.need = nd ? nd + (size_t)(b * n_ego + i) * (P / 64) : nullptr;
                             fb.p.job[n] = j;
                             qp.job[n] = qkv_job(wn, sn, slot, i, false);
                             if (++n == kMaxChainJobs) { HMVIT_TRY(launch_out_ffn_qkv(fb.p, qp, n, C, st)); n = 0; }

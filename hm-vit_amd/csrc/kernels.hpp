@@ -156,9 +156,10 @@ struct AttnParams {
 };
 int launch_attention(const AttnParams& p, int precision, hipStream_t st);
 int launch_tile_vis(const AttnParams& p, unsigned* vis_mask, const unsigned char* need, hipStream_t st);
-// need[(b * n_ego + j) * (H/8) * (W/8) + window] = 1 when the pruned last stage (ego 0 only) reads a key / value inside that
-// 8 x 8 window of agent j's map; `need` must be zeroed by the caller
-int launch_window_need(const AttnParams& p, unsigned char* need, hipStream_t st);
+// to[(b * n_ego + k) * (H/8) * (W/8) + window] = 1 when an ego reads a key / value inside that 8 x 8 window of agent k's
+// map: ego 0 over its whole map (from = nullptr: the reads of the pruned last stage), or every ego j over the windows
+// marked in `from` (plus those windows themselves).  `to` must be zeroed by the caller.
+int launch_window_need(const AttnParams& p, const unsigned char* from, unsigned char* to, hipStream_t st);
 int launch_debug_tr16(uint16_t* out, hipStream_t st);
 
 // ---- post.hip (detection post-processing) ----
