@@ -475,13 +475,17 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
             }
         return si;
     };
+    // The first stage's fused tail can take its residual straight from the (C, P) input maps: k_ln_qkv then writes no
+    // token-major f32 copy of the input (721 MB at cfg2).  Needs the fused tail (sequential block, C = 256, a next stage).
+    const bool direct_x = !par && C == 256 && !getenv("HMVIT_NO_FUSE") && !getenv("HMVIT_NO_DIRECT_X");   // = `fuse` of stage 1
+
     // LayerNorm + Q / folded K', V' projections of agent `slot` for the stage (wt, si)
     auto qkv_job = [&](const HmvitStageWeights& wt, const StageInfo& si, int slot, int l, bool first) {
         const int t = d->mode[slot];
         QkvJob j;
         memset(&j, 0, sizeof(j));
         j.x = first ? d->x + (size_t)slot * map_elems : xs + (size_t)slot * map_elems;
-        j.xs_out = xs + (size_t)slot * map_elems;
+        j.xs_out = (first && direct_x) ? nullptr : xs + (size_t)slot * map_elems;
         j.type = t;
         int nm = 0;
         if (l < si.n_ego) {
@@ -601,9 +605,10 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                         for (int i = 0; i < n_ego; ++i) {   // n_ego == max_cav here: every source agent of the next stage
                             const int slot = b * L + i;
                             FfnJob j;
-                            j.need = nullptr;
+                            j.need = nullptr; j.x_nchw = 0;
                             j.o = ob + (size_t)slot * map_elems;
                             j.x = xs + (size_t)slot * map_elems;
+                            if (first && direct_x) { j.x = d->x + (size_t)slot * map_elems; j.x_nchw = 1; }
                             j.out = x_out + (size_t)slot * map_elems;
                             j.type = d->mode[slot];
                             j.pad = (sn.last && i >= sn.n_ego) ? 1 : 0;   // x'' of a pure K/V source of the pruned stage is never read
@@ -622,7 +627,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                     for (int b = 0; b < B; ++b) {
                         const int slot = b * L;
                         FfnJob j;
-                            j.need = nullptr;
+                            j.need = nullptr; j.x_nchw = 0;
                         j.o = ob + (size_t)slot * map_elems;
                         j.x = xs + (size_t)slot * map_elems;
                         j.out = d->out + (size_t)b * map_elems;
@@ -637,7 +642,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                         for (int i = 0; i < n_ego; ++i) {
                             const int slot = b * L + i;
                             FfnJob j;
-                            j.need = nullptr;
+                            j.need = nullptr; j.x_nchw = 0;
                             j.o = ob + (size_t)slot * map_elems;
                             j.x = xs + (size_t)slot * map_elems;
                             j.out = x_out + (size_t)slot * map_elems;
@@ -653,7 +658,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                             const int slot = b * L + l;
                             if (d->apply_head) continue;   // never consumed by HeteroFusion
                             FfnJob j;
-                            j.need = nullptr;
+                            j.need = nullptr; j.x_nchw = 0;
                             j.o = nullptr;
                             j.x = xs + (size_t)slot * map_elems;
                             j.out = x_out + (size_t)slot * map_elems;
@@ -685,7 +690,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
         fb.p.P = P;
         for (int b = 0; b < B; ++b) {
             FfnJob j;
-                            j.need = nullptr;
+                            j.need = nullptr; j.x_nchw = 0;
             j.o = nullptr;
             j.x = xs + (size_t)(b * L) * map_elems;
             j.out = d->out + (size_t)b * map_elems;

@@ -331,8 +331,8 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
 
     float4 v[C / 32][4];
     load_token<C>(J.x, p.in_nchw != 0, P, min(tok, P - 1), hi, v);
-    if (p.in_nchw && valid) {
-        // first stage: also emit the token-major f32 residual stream
+    if (p.in_nchw && valid && J.xs_out) {
+        // first stage: also emit the token-major f32 residual stream (unless the stage's tail reads the input map itself)
         float* xo = J.xs_out + (size_t)tok * C + 4 * hi;
 #pragma unroll
         for (int b = 0; b < C / 32; ++b)
@@ -389,7 +389,10 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
 // residual stream is then read once instead of twice per stage (and not written at all for agents that the
 // pruned last stage only uses as K / V sources).  `qp` = the k_ln_qkv parameters of the next stage, job j of
 // both lists is the same agent.
-template <int C, bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW, int TAIL>
+typedef int int4v __attribute__((ext_vector_type(4)));
+__device__ float llvm_raw_buffer_load_f32(int4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+
+template <int C, bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW, int TAIL, bool XN = false>
 __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams* qp) {
     constexpr bool QKV = TAIL == 1, HEAD = TAIL == 2;
     using Cfg = ChainCfg<C>;
@@ -434,7 +437,22 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
     float16v xacc[NT];
     half8 act[KK];
     const int tok_c = min(tok, P - 1);   // out-of-range lanes read a valid token and never store
-    {
+    if constexpr (XN) {
+        // tail of the first stage: the residual is the module's (C, P) input itself (k_ln_qkv wrote no token-major copy).
+        // Raw buffer loads: the channel offset rides in the scalar offset, one VGPR of address for all 128 loads.
+        const unsigned long long a = (unsigned long long)J.x;
+        int4v rs;
+        rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        rs.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+        rs.z = C * P * 4;
+        rs.w = 0x00020000;
+        const int voff = (4 * hi * P + tok_c) * 4;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                xacc[t][e] = llvm_raw_buffer_load_f32(rs, voff, (32 * t + 8 * (e >> 2) + (e & 3)) * P * 4, 0);
+    } else {
         const float* xp = J.x + (size_t)tok_c * C + 4 * hi;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -677,9 +695,9 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_out_ffn(FfnParams p) {
     out_ffn_body<C, OUTPROJ, LN, RESID, OUT_NCHW, 0>(p, nullptr);
 }
 
-template <int C>
+template <int C, bool XN>
 __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_out_ffn_qkv(FfnParams p, QkvParams q) {
-    out_ffn_body<C, true, true, true, false, 1>(p, &q);
+    out_ffn_body<C, true, true, true, false, 1, XN>(p, &q);
 }
 
 // last stage of HeteroFusion: the ego's tail with mlp_head appended (FfnJob::out = the (C, P) output map)
@@ -721,7 +739,9 @@ int launch_out_ffn_qkv(const FfnParams& p, const QkvParams& q, int n_jobs, int C
     if (n_jobs == 0) return HMVIT_OK;
     HMVIT_CHECK_ARG(C == 256, "out_ffn_qkv: C=%d unsupported (256)", C);
     dim3 grid(cdiv(p.P, CHAIN_TOKENS), n_jobs), block(CHAIN_THREADS);
-    hipLaunchKernelGGL((k_out_ffn_qkv<256>), grid, block, 0, st, p, q);
+    // FfnJob::x_nchw (all jobs of a launch alike): the residual is read from (C, P) maps
+    if (p.job[0].x_nchw) hipLaunchKernelGGL((k_out_ffn_qkv<256, true>), grid, block, 0, st, p, q);
+    else hipLaunchKernelGGL((k_out_ffn_qkv<256, false>), grid, block, 0, st, p, q);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }

@@ -45,7 +45,7 @@ int launch_gemm(const GemmJobs& jobs, bool a_f32, bool gelu, bool out_f32, int p
 constexpr int kMaxChainJobs = 16;
 struct QkvJob {
     const float* x;          // (P, C) token-major, or (C, P) when in_nchw
-    float* xs_out;           // token-major copy written when in_nchw
+    float* xs_out;           // token-major copy written when in_nchw (nullptr: not needed)
     const half_t* w[5];      // weight images (NT chunks each): [Q] K'(e0) V'(e0) [K'(e1) V'(e1)]
     half_t* y[5];            // output planes (P, C)
     int n_mat;
@@ -66,6 +66,7 @@ struct FfnJob {
     float* out;              // (P, C) token-major (may alias x) or (C, P) for FFN_HEAD_NCHW
     int type;
     int pad;
+    int x_nchw;              // k_out_ffn_qkv only: x is a (C, P) map (the module input) instead of the token-major stream
     const unsigned char* need;   // optional (H/8, W/8): windows of this agent that a later stage can reach (k_window_need);
                                  // workgroups whose 128 tokens lie in unreachable windows return at once
 };
