@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMVIT_LIB", os.path.join(_HERE, "libhmvit.so"))   # HMVIT_LIB: ablation builds of tools/probe
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 PREC_F32, PREC_F16 = 0, 1
 PART_WINDOW, PART_GRID = 0, 1
 NUM_TYPES = 2
@@ -81,6 +81,7 @@ _SIGNATURES = {
     "hmvit_bn_relu_tokens": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     "hmvit_cross_attention": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_void_p]),
     "hmvit_conv2d_ex": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 12 + [C.c_void_p]),
+    "hmvit_conv2d_rowpack": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 10 + [C.c_void_p]),
     "hmvit_maxpool2d": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 8 + [C.c_void_p]),
     "hmvit_debug_tr16": (C.c_int, [C.c_void_p, C.c_void_p]),
 }

@@ -8,8 +8,8 @@ cross-view attention + bottlenecks per level -> decoder -> (N, C, Hb, Wb) BEV fe
 Same constructor dicts and ``state_dict`` names (the ResNet keeps torchvision's names, so ImageNet / reference checkpoints
 load).  Eval mode only (BatchNorm folded into the convolutions), no CPU path.  Every convolution runs on the implicit-GEMM
 kernel (``hmvit_conv2d_ex``: residual add of the ResNet blocks and the decoder's nearest x2 upsampling are operands of the
-convolution, never separate passes); channel counts that the kernel's K slab does not divide (the 3-channel stem, the
-32-channel bottlenecks) are zero-padded once at weight-preparation time.
+convolution, never separate passes); channel counts that the kernel's K slab does not divide (the 32-channel bottlenecks)
+are zero-padded once at weight-preparation time, and the 3-channel 7x7 stem runs row-packed (``hmvit_conv2d_rowpack``).
 """
 from __future__ import annotations
 
@@ -67,6 +67,39 @@ class _Conv:
                                             residual.data_ptr() if residual is not None else None, y.data_ptr(), n, H, W, self.cin,
                                             self.cout, self.k, self.stride, self.pad, 1 if relu else 0, 1 if up2 else 0, 0,
                                             self.prec, _stream()), "conv2d_ex")
+        return y
+
+
+class _StemConv:
+    """The 7x7 / stride 2 / 3-channel stem on hmvit_conv2d_rowpack: the image is copied once into a zero-bordered 4-channel
+    NHWC map and every kernel row becomes one contiguous run of 8 pixels x 4 channels of the GEMM's K axis (K = 256 with
+    147 useful taps, instead of one 64-channel slab per tap)."""
+
+    def __init__(self, conv: nn.Conv2d, bn: nn.BatchNorm2d, prec: int, dt):
+        w = conv.weight.detach().float()
+        s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+        w, b = w * s[:, None, None, None], bn.bias.detach().float() - bn.running_mean.detach().float() * s
+        co, ci, k, _ = w.shape
+        assert ci <= 4 and k <= 8 and conv.bias is None
+        self.cout, self.k, self.stride, self.pad = _cpad(co, prec), k, conv.stride[0], conv.padding[0]
+        wp = torch.zeros(self.cout, 8, 8, 4, device=w.device)
+        wp[:co, :k, :k, :ci] = w.permute(0, 2, 3, 1)
+        self.w = wp.reshape(self.cout, 256).to(dt).contiguous()
+        self.b = torch.zeros(self.cout, device=w.device)
+        self.b[:co] = b
+        self.prec, self.dt = prec, dt
+
+    def __call__(self, img_nhwc):
+        n, H, W, c = img_nhwc.shape
+        Ho = (H + 2 * self.pad - self.k) // self.stride + 1
+        Wo = (W + 2 * self.pad - self.k) // self.stride + 1
+        Hp, Wp = (Ho - 1) * self.stride + 8, (Wo - 1) * self.stride + 8          # rows / pixels the kernel touches
+        Hp, Wp = max(Hp, H + self.pad), max(Wp, W + self.pad)
+        xp = torch.zeros(n, Hp, Wp, 4, device=img_nhwc.device, dtype=self.dt)
+        xp[:, self.pad:self.pad + H, self.pad:self.pad + W, :c] = img_nhwc
+        y = torch.empty(n, Ho, Wo, self.cout, device=xp.device, dtype=self.dt)
+        _lib.check(_lib.lib.hmvit_conv2d_rowpack(xp.data_ptr(), self.w.data_ptr(), self.b.data_ptr(), y.data_ptr(), n, Hp, Wp, Ho, Wo,
+                                                 self.cout, 8, self.stride, 1, self.prec, _stream()), "conv2d_rowpack")
         return y
 
 
@@ -151,7 +184,7 @@ class ResnetEncoder(nn.Module):
 
     def _build(self, prec, dt):
         e = self.encoder
-        prep = {"stem": _Conv(e.conv1, e.bn1, prec, dt), "layers": []}
+        prep = {"stem": _StemConv(e.conv1, e.bn1, prec, dt), "layers": []}
         for li in range(4):
             blocks = []
             for blk in getattr(e, f"layer{li + 1}"):
@@ -169,9 +202,7 @@ class ResnetEncoder(nn.Module):
         dt = torch.float32 if prec == _lib.PREC_F32 else torch.float16
         prep = self._prep.get(self, prec, lambda: self._build(prec, dt))
         b, l, m, h, w, c = input_images.shape
-        x = input_images.reshape(b * l * m, h, w, c).float()
-        x = torch.nn.functional.pad(x, (0, prep["stem"].cin - c)).to(dt).contiguous()        # NHWC already
-        x = prep["stem"](x)
+        x = prep["stem"](input_images.reshape(b * l * m, h, w, c))        # NHWC already
         n, H, W, C = x.shape
         Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         y = torch.empty(n, Ho, Wo, C, device=x.device, dtype=dt)

@@ -832,6 +832,7 @@ int hmvit_conv2d(const void* x, const void* w, const float* bias, void* y, int N
                  int precision, void* stream) {
     HMVIT_CHECK_ARG(x && w && y, "conv2d: null pointer");
     ConvParams p;
+    memset(&p, 0, sizeof(p));
     p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = p.KW = ksize; p.stride = stride; p.pad = pad;
     p.relu = relu; p.y_ctot = y_ctot; p.y_coff = y_coff; p.deconv_s = deconv_stride; p.out_f32 = out_f32;
@@ -853,12 +854,24 @@ int hmvit_conv2d_ex(const void* x, const void* w, const float* bias, const void*
     HMVIT_CHECK_ARG(!upsample2 || (H % 2 == 0 && W % 2 == 0), "conv2d_ex: upsampled size %dx%d must be even", H, W);
     HMVIT_CHECK_ARG(!(residual && out_f32 && precision != HMVIT_PREC_F32), "conv2d_ex: residual needs the precision's element type");
     ConvParams p;
+    memset(&p, 0, sizeof(p));
     p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = p.KW = ksize; p.stride = stride; p.pad = pad;
     p.relu = relu; p.y_ctot = Cout; p.y_coff = 0; p.deconv_s = 0; p.out_f32 = out_f32;
     p.res = residual; p.up2 = upsample2;
     p.Ho = (H + 2 * pad - ksize) / stride + 1;
     p.Wo = (W + 2 * pad - ksize) / stride + 1;
+    return launch_conv(p, precision, reinterpret_cast<hipStream_t>(stream));
+}
+
+int hmvit_conv2d_rowpack(const void* x, const void* w, const float* bias, void* y, int N, int Hp, int Wp, int Ho, int Wo, int Cout,
+                         int krows, int stride, int relu, int precision, void* stream) {
+    HMVIT_CHECK_ARG(x && w && y && N > 0 && Ho > 0 && Wo > 0 && Cout > 0 && krows > 0 && stride > 0, "conv2d_rowpack: bad argument");
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.w = w; p.bias = bias; p.y = y;
+    p.N = N; p.H = Hp; p.W = Wp; p.Cin = 4; p.Cout = Cout; p.KH = krows; p.KW = 8; p.stride = stride; p.pad = 0;
+    p.relu = relu; p.y_ctot = Cout; p.y_coff = 0; p.Ho = Ho; p.Wo = Wo; p.rowpack = 1;
     return launch_conv(p, precision, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
 
     const int M = p.N * p.Ho * p.Wo;
     const int Ncols = p.deconv_s ? p.deconv_s * p.deconv_s * p.Cout : p.Cout;
-    const int Ktot = p.KH * p.KW * p.Cin;
+    const int Ktot = p.rowpack ? p.KH * 32 : p.KH * p.KW * p.Cin;
     const int tiles_n = (Ncols + CBN - 1) / CBN;
     const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
     const int m0 = tm * CBM, n0 = tn * CBN;
@@ -149,10 +149,24 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
     constexpr int VE = 16 / sizeof(T);
     Vec ra[RPT], rw[RPW];
     auto load_slab = [&](int k0) {
+        if (p.rowpack) {
+            // few-channel stem: k = ky * 32 + px * 4 + ci over rows of 8 pixels x 4 channels, which are contiguous in the
+            // physically padded NHWC4 input (no bounds checks; pixel 7 and any row beyond the kernel carry zero weights)
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int k = k0 + ((tid + 256 * i) & 7) * VE;
+                const int ky = k >> 5, px = (k & 31) >> 2;
+                ra[i] = (Vec)(T)0;
+                if (rvalid[i]) {
+                    const size_t pix = ((size_t)rn[i] * p.H + roy[i] * p.stride + ky) * p.W + rox[i] * p.stride + px;
+                    ra[i] = *reinterpret_cast<const Vec*>(x + pix * 4);
+                }
+            }
+        }
         const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) {
+        for (int i = 0; i < RPT && !p.rowpack; ++i) {
             const int c = tid + 256 * i, kc = (c & 7) * VE;
             // A slab: im2col rows gathered from the NHWC input
             const int iy = roy[i] * p.stride + ky - p.pad, ix = rox[i] * p.stride + kx - p.pad;
@@ -348,7 +362,10 @@ int launch_maxpool(const void* x, void* y, int N, int H, int W, int C, int ksize
 
 int launch_conv(const ConvParams& p, int precision, hipStream_t st) {
     const int bk = precision == HMVIT_PREC_F32 ? ConvCfg<float>::BK : ConvCfg<half_t>::BK;
-    HMVIT_CHECK_ARG(p.Cin > 0 && p.Cin % bk == 0, "conv: Cin=%d must be a multiple of %d", p.Cin, bk);
+    HMVIT_CHECK_ARG(p.rowpack || (p.Cin > 0 && p.Cin % bk == 0), "conv: Cin=%d must be a multiple of %d", p.Cin, bk);
+    HMVIT_CHECK_ARG(!p.rowpack || (p.Cin == 4 && (p.KH * 32) % bk == 0 && !p.deconv_s && !p.up2 &&
+                                   (p.Ho - 1) * p.stride + p.KH <= p.H && (p.Wo - 1) * p.stride + 8 <= p.W),
+                    "conv (row-packed stem): needs a 4-channel input padded to cover %d rows x 8 pixels per output", p.KH);
     HMVIT_CHECK_ARG(p.N > 0 && p.Ho > 0 && p.Wo > 0 && p.Cout > 0 && p.KH > 0 && p.KW > 0 && p.stride > 0,
                     "conv: bad geometry");
     HMVIT_CHECK_ARG(!p.deconv_s || (p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0),

@@ -118,6 +118,9 @@ struct ConvParams {
     int out_f32;
     const void* res;          // optional residual (N, Ho, Wo, Cout) in the precision's element type, added before the ReLU
     int up2;                  // 1: the input is the nearest-neighbour x2 upsampling of x (N, H/2, W/2, Cin); H, W are the upsampled sizes
+    int rowpack;              // 1: few-channel stem.  x is a physically zero-padded (N, H, W, 4) map, output pixel (oy, ox) reads
+                              // rows oy*stride .. + KH - 1 and pixels ox*stride .. + 7 of it; w is (Ncols, KH * 32) with
+                              // k = ky * 32 + px * 4 + ci; Ho, Wo are given, pad / KW / Cin are not used
 };
 int launch_conv(const ConvParams& p, int precision, hipStream_t st);
 // max pooling on NHWC maps (the 3x3 / stride 2 / pad 1 stage of a ResNet stem)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HMVIT_ABI_VERSION 4
+#define HMVIT_ABI_VERSION 5
 
 #define HMVIT_OK 0
 #define HMVIT_EINVAL (-22)   /* bad argument / unsupported shape */
@@ -254,6 +254,15 @@ int hmvit_conv2d(const void* x, const void* w, const float* bias, void* y, int N
  *   (NaiveDecoder.upsample, naive_decoder.py:56-61), which is never materialised. */
 int hmvit_conv2d_ex(const void* x, const void* w, const float* bias, const void* residual, void* y, int N, int H, int W, int Cin,
                     int Cout, int ksize, int stride, int pad, int relu, int upsample2, int out_f32, int precision, void* stream);
+
+/* Few-channel stem convolution (the 7x7 / stride-2 / 3-channel conv1 of a ResNet, resnet_ms.py:27-38 through torchvision):
+ * x is a zero-padded (N, Hp, Wp, 4) NHWC map in the precision's element type whose padding already contains the
+ * convolution's border (output pixel (oy, ox) reads rows oy*stride .. oy*stride + krows - 1 and pixels ox*stride ..
+ * ox*stride + 7); w is (Cout, krows * 32) with k = ky * 32 + px * 4 + ci (zero where px, ky or ci exceed the kernel);
+ * y (N, Ho, Wo, Cout) in the precision's element type.  One 64-byte run per kernel row instead of one zero-padded K slab
+ * per tap. */
+int hmvit_conv2d_rowpack(const void* x, const void* w, const float* bias, void* y, int N, int Hp, int Wp, int Ho, int Wo, int Cout,
+                         int krows, int stride, int relu, int precision, void* stream);
 
 /* nn.MaxPool2d on NHWC maps (C a multiple of 8): the 3x3 / stride 2 / pad 1 pooling of the ResNet stem. */
 int hmvit_maxpool2d(const void* x, void* y, int N, int H, int W, int C, int ksize, int stride, int pad, int precision, void* stream);
