@@ -95,16 +95,16 @@ template <>
 struct ConvCfg<float> {
     static constexpr int BK = 32, LS = 33;
 };
-constexpr int CBM = 128;
 
 // CBN = 128 or 64 output channels per workgroup (64: the 64-channel layers of the first backbone block would leave half
 // of a 128-wide tile empty).  2 x 2 wavefronts, each 64 pixels x CBN / 2 channels.  The K slabs are double-buffered in
 // LDS: slab k + 1 travels global -> registers while slab k is multiplied, registers -> the other buffer afterwards, one
 // barrier per slab.
-template <typename T, int CBN>
+template <typename T, int CBN, int CBM>
 __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
     constexpr int BK = ConvCfg<T>::BK, LS = ConvCfg<T>::LS;
-    constexpr int RPT = 4;               // staged A rows per thread (8 chunks per row)
+    constexpr int MI = CBM / 64;         // 32-pixel MFMA tiles per wave (pixel tile of 128 or, for small maps, 64)
+    constexpr int RPT = CBM / 32;        // staged A rows per thread (8 chunks per row)
     constexpr int RPW = CBN / 32;        // staged W rows per thread
     constexpr int NJ = CBN / 64;         // 32-channel MFMA tiles per wave
     __shared__ __attribute__((aligned(16))) T As[2][CBM * LS];
@@ -136,9 +136,9 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
         rox[i] = rem - roy[i] * p.Wo;
     }
 
-    float16v acc[2][NJ];
+    float16v acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -162,21 +162,22 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
                     ra[i] = *reinterpret_cast<const Vec*>(x + pix * 4);
                 }
             }
-        }
-        const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
-        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        } else {
+            const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
 #pragma unroll
-        for (int i = 0; i < RPT && !p.rowpack; ++i) {
-            const int c = tid + 256 * i, kc = (c & 7) * VE;
-            // A slab: im2col rows gathered from the NHWC input
-            const int iy = roy[i] * p.stride + ky - p.pad, ix = rox[i] * p.stride + kx - p.pad;
-            const bool ok = rvalid[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            ra[i] = (Vec)(T)0;
-            if (ok) {
-                // up2: logical pixel (iy, ix) of the upsampled map is physical pixel (iy / 2, ix / 2)
-                const size_t pix = p.up2 ? ((size_t)rn[i] * (p.H >> 1) + (iy >> 1)) * (p.W >> 1) + (ix >> 1)
-                                         : ((size_t)rn[i] * p.H + iy) * p.W + ix;
-                ra[i] = *reinterpret_cast<const Vec*>(x + pix * p.Cin + ci0 + kc);
+            for (int i = 0; i < RPT; ++i) {
+                const int c = tid + 256 * i, kc = (c & 7) * VE;
+                // A slab: im2col rows gathered from the NHWC input
+                const int iy = roy[i] * p.stride + ky - p.pad, ix = rox[i] * p.stride + kx - p.pad;
+                const bool ok = rvalid[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                ra[i] = (Vec)(T)0;
+                if (ok) {
+                    // up2: logical pixel (iy, ix) of the upsampled map is physical pixel (iy / 2, ix / 2)
+                    const size_t pix = p.up2 ? ((size_t)rn[i] * (p.H >> 1) + (iy >> 1)) * (p.W >> 1) + (ix >> 1)
+                                             : ((size_t)rn[i] * p.H + iy) * p.W + ix;
+                    ra[i] = *reinterpret_cast<const Vec*>(x + pix * p.Cin + ci0 + kc);
+                }
             }
         }
 #pragma unroll
@@ -223,15 +224,15 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk) {
-                half8 a[2], b[NJ];
+                half8 a[MI], b[NJ];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    a[i] = *reinterpret_cast<const half8*>(As[cur] + (wm * 64 + i * 32 + r) * LS + kk * 16 + hi * 8);
+                for (int i = 0; i < MI; ++i)
+                    a[i] = *reinterpret_cast<const half8*>(As[cur] + (wm * (CBM / 2) + i * 32 + r) * LS + kk * 16 + hi * 8);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     b[j] = *reinterpret_cast<const half8*>(Ws[cur] + (wn * (CBN / 2) + j * 32 + r) * LS + kk * 16 + hi * 8);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], a[i], acc[i][j], 0, 0, 0);
@@ -241,13 +242,13 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
             const float* Wf = reinterpret_cast<const float*>(Ws[cur]);
 #pragma unroll 4
             for (int kk = 0; kk < BK / 2; ++kk) {
-                float a[2], b[NJ];
+                float a[MI], b[NJ];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = Af[(wm * 64 + i * 32 + r) * LS + kk * 2 + hi];
+                for (int i = 0; i < MI; ++i) a[i] = Af[(wm * (CBM / 2) + i * 32 + r) * LS + kk * 2 + hi];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) b[j] = Wf[(wn * (CBN / 2) + j * 32 + r) * LS + kk * 2 + hi];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
@@ -262,8 +263,8 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
     const int s = p.deconv_s;
     const bool vec_ok = (p.Cout % 4 == 0) && (p.y_coff % 4 == 0) && (p.y_ctot % 4 == 0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 64 + i * 32 + r;
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * (CBM / 2) + i * 32 + r;
         if (m >= M) continue;
         const int n = m / (p.Ho * p.Wo), rem = m - n * p.Ho * p.Wo;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
@@ -373,14 +374,18 @@ int launch_conv(const ConvParams& p, int precision, hipStream_t st) {
     const int M = p.N * p.Ho * p.Wo;
     const int Ncols = p.deconv_s ? p.deconv_s * p.deconv_s * p.Cout : p.Cout;
     const bool narrow = Ncols <= 64;
-    dim3 grid(cdiv(M, CBM) * cdiv(Ncols, narrow ? 64 : 128)), block(256);
+    // small maps (the deep ResNet layers on 16 x 16 features): 64-pixel tiles, or the launch would not cover the CUs
+    const bool small = cdiv(M, 128) * cdiv(Ncols, narrow ? 64 : 128) < 256;
+    dim3 grid(cdiv(M, small ? 64 : 128) * cdiv(Ncols, narrow ? 64 : 128)), block(256);
+#define HMVIT_CONV_CASE(T, N_, M_) hipLaunchKernelGGL((k_conv<T, N_, M_>), grid, block, 0, st, p)
     if (precision == HMVIT_PREC_F32) {
-        if (narrow) hipLaunchKernelGGL((k_conv<float, 64>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((k_conv<float, 128>), grid, block, 0, st, p);
+        if (narrow) { if (small) HMVIT_CONV_CASE(float, 64, 64); else HMVIT_CONV_CASE(float, 64, 128); }
+        else { if (small) HMVIT_CONV_CASE(float, 128, 64); else HMVIT_CONV_CASE(float, 128, 128); }
     } else {
-        if (narrow) hipLaunchKernelGGL((k_conv<half_t, 64>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((k_conv<half_t, 128>), grid, block, 0, st, p);
+        if (narrow) { if (small) HMVIT_CONV_CASE(half_t, 64, 64); else HMVIT_CONV_CASE(half_t, 64, 128); }
+        else { if (small) HMVIT_CONV_CASE(half_t, 128, 64); else HMVIT_CONV_CASE(half_t, 128, 128); }
     }
+#undef HMVIT_CONV_CASE
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }

@@ -9,7 +9,7 @@ from oracle import camera_oracle as CAM
 cfg = CAM.make_config(image=512, num_layers=34, dim=128, bev=256)
 sd = CAM.random_state_dict(cfg, seed=1)
 batch = {k: v.cuda() for k, v in CAM.synthetic_batch(5, cfg, seed=2).items()}
-for prec in ("f16", "f32"):
+for prec in (sys.argv[1:] or ["f16", "f32"]):
     net = hmvit_amd.CvtCameraEncoder(cfg, precision=prec)
     net.load_state_dict(sd, strict=False)
     net = net.cuda().eval()
