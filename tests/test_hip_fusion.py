@@ -218,3 +218,42 @@ def test_errors():
     x, pw, mode, rl, mask = _cuda(*O.synthetic_scene(2, 64, 18, 16, [1, 0], seed=4))
     with pytest.raises(ValueError):
         net(x, pw, mode, rl, mask)                      # 18 not divisible by window 4
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fusion_random_sweep_vs_oracle(seed):
+    """Randomised parity sweep: channel count, window, map size, agent count, agent types, poses (any yaw, shifts up to the
+    map size), ragged record_len with zero-padded agents, iterations and block mode drawn from a seeded stream; f32 mode at
+    1e-4 and f16 mode at 1e-3 against the oracle on the same inputs."""
+    import math
+    import random
+    rnd = random.Random(1000 + seed)
+    C, window = rnd.choice([(64, 4), (256, 8), (256, 4), (128, 8)])
+    L = rnd.choice([2, 3, 4])
+    B = rnd.choice([1, 2])
+    H, W = window * rnd.choice([2, 3, 4]), window * rnd.choice([2, 4, 5])
+    arch = "parallel" if (C != 256 and rnd.random() < 0.3) else "sequential"
+    cfg = O.make_config(C, window, L, voxel=0.4, downsample=rnd.choice([2, 4]), num_iters=rnd.choice([1, 2, 3]), arch=arch)
+    sd = O.random_state_dict(cfg, seed=50 + seed)
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, L, C, H, W, generator=gen)
+    pw = torch.eye(4).repeat(B, L, L, 1, 1)
+    mode = torch.zeros(B, L, dtype=torch.int32)
+    mask = torch.zeros(B, L, dtype=torch.int64)
+    rl = torch.zeros(B, dtype=torch.int64)
+    span = 0.4 * cfg["spatial_transform"]["downsample_rate"] * max(H, W)
+    for b in range(B):
+        n = rnd.randint(1, L)
+        rl[b], mask[b, :n] = n, 1
+        mode[b, :n] = torch.tensor([rnd.randint(0, 1) for _ in range(n)], dtype=torch.int32)
+        x[b, n:] = 0
+        poses = [O.rigid(0.0, 0.0, 0.0)] + [O.rigid(rnd.uniform(-math.pi, math.pi), rnd.uniform(-0.6, 0.6) * span,
+                                                    rnd.uniform(-0.6, 0.6) * span) for _ in range(n - 1)]
+        pw[b] = O.pairwise_from_poses(poses, L)
+    ref = O.hetero_fusion(x, pw, mode, rl, mask, sd, cfg)
+    for precision in ("f32", "f16"):
+        if precision == "f16" and cfg["hetero_fusion_block"]["mlp_dim"] != C:
+            continue
+        y = _fusion(cfg, sd, precision)(*_cuda(x, pw, mode, rl, mask)).cpu()
+        assert y.shape == ref.shape
+        assert rel_max_err(y, ref) < TOL[precision], (precision, C, window, L, B, H, W, arch, cfg["num_iters"])
