@@ -1077,8 +1077,7 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
                     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
-                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    mx = max_over_lane_groups(mx);
                     const float m_new = fmaxf(m_run[qt], mx);
                     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
                     // logits are in log2 units (log2 e folded into W_q and the bias fragments on the host)

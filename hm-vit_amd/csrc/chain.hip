@@ -149,7 +149,7 @@ __device__ __forceinline__ void mma_chunk(float16v& acc, const half_t* buf, cons
     __builtin_amdgcn_sched_barrier(0);
 }
 
-__device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ float pair_sum(float v) { return xor32_sum(v); }
 
 // LayerNorm of the token owned by lane pair (m, hi = 0/1); v[b][j] holds channels 32b+8j+4hi+(0..3)
 template <int C>

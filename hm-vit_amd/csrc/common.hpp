@@ -86,6 +86,40 @@ __device__ __forceinline__ Taps make_taps(const float* __restrict__ a, int u, in
     return t;
 }
 
+// Exchanges with lane ^ 32 / lane ^ 16 on the VALU (v_permlane32_swap / v_permlane16_swap, gfx950): with both operands
+// holding x, the swap leaves the value of the lower partner in one register and of the upper partner in the other, in
+// every lane - no LDS round trip as with ds_bpermute (__shfl_xor), whose wait sits on the critical path of every softmax
+// row maximum and LayerNorm sum.  The elements of the builtin's result go through scalar copies: a bit_cast straight
+// from a vector element is miscompiled by hipcc 7.2 (it reads element 0).
+__device__ __forceinline__ void xor32_pair(float x, float& lo, float& hi) {
+    const unsigned a = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    lo = __builtin_bit_cast(float, r0);
+    hi = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ void xor16_pair(float x, float& lo, float& hi) {
+    const unsigned a = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane16_swap(a, a, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    lo = __builtin_bit_cast(float, r0);
+    hi = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ float max_raw(float a, float b) {   // v_max_f32 without the canonicalising max(x, x) pair
+    float m;
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ float xor32_sum(float x) { float a, b; xor32_pair(x, a, b); return a + b; }
+__device__ __forceinline__ float xor16_sum(float x) { float a, b; xor16_pair(x, a, b); return a + b; }
+// maximum over the four lanes l, l ^ 16, l ^ 32, l ^ 48
+__device__ __forceinline__ float max_over_lane_groups(float x) {
+    float a, b;
+    xor16_pair(x, a, b);
+    xor32_pair(max_raw(a, b), a, b);
+    return max_raw(a, b);
+}
+
 // pixel (row, col) of token `n` (row-major inside the w x w window) of window (wx, wy)
 // for the two partitions (hetero_fusion.py:387-389 / :430-431)
 __device__ __forceinline__ void token_pixel(int partition, int window, int X, int Y, int wx, int wy,

@@ -236,8 +236,7 @@ __global__ __launch_bounds__(256) void k_cross_attention_mfma(const half_t* __re
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = max_over_lane_groups(mx);
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
 #pragma unroll
