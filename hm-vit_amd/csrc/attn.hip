@@ -417,8 +417,9 @@ struct PcItem {
 // Returns false when the list is exhausted; windows of a border tile that fall outside the map are skipped.
 __device__ __forceinline__ bool pc_fetch(const AttnParams& p, int X, int Y, int NG, bool ego_fastest, int& k, PcItem& it) {
     const int wpx = gridDim.x >> 3, x = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int TH = wpx / NG / 8;                       // tile = TH x 8 windows
-    const int ntx = (X + TH - 1) / TH, nty = (Y + 7) / 8, n_super = ntx * nty, total = p.B * p.n_ego * n_super;
+    const int TWS = (p.variant & 0x2000) ? 2 : (p.variant & 0x4000) ? 4 : 3, TW = 1 << TWS;
+    const int TH = wpx / NG / TW;                      // tile = TH x TW windows (2 x 8; probe switches 0x2000: 4 x 4, 0x4000: 1 x 16)
+    const int ntx = (X + TH - 1) / TH, nty = (Y + TW - 1) / TW, n_super = ntx * nty, total = p.B * p.n_ego * n_super;
     const int t = j / NG;
     while (true) {
         ++k;
@@ -432,7 +433,7 @@ __device__ __forceinline__ bool pc_fetch(const AttnParams& p, int X, int Y, int 
             tile = s % n_super; s /= n_super;
             ego = s % p.n_ego; s /= p.n_ego;
         }
-        const int wx = (tile / nty) * TH + (t >> 3), wy = (tile % nty) * 8 + (t & 7);
+        const int wx = (tile / nty) * TH + (t >> TWS), wy = (tile % nty) * TW + (t & (TW - 1));
         if (wx < X && wy < Y) {
             if (p.prune) {   // items the pruned last stage cannot reach (k_window_need -> bit 31 of the visibility word)
                 const unsigned* a = p.vis_mask + __builtin_amdgcn_readfirstlane(((s * p.n_ego + ego) * X + wx) * Y + wy);
@@ -1275,6 +1276,11 @@ int launch_attention(const AttnParams& p, int precision, hipStream_t st) {
         // item order: egos interleaved per window for the local partition (cross-ego cache reuse of the
         // gathered rows), ego-major for the dilated grid partition
         if (p.partition == HMVIT_PART_GRID) q.variant ^= 0x200;
+        if (const char* e = getenv("HMVIT_ATTN_TILE44")) {      // probe: 4 x 4 window tiles (1: grid stages, 2: local, 3: both)
+            const int m = atoi(e);
+            if ((p.partition == HMVIT_PART_GRID && (m & 1)) || (p.partition != HMVIT_PART_GRID && (m & 2))) q.variant |= 0x2000;
+            if ((p.partition == HMVIT_PART_GRID && (m & 4)) || (p.partition != HMVIT_PART_GRID && (m & 8))) q.variant |= 0x4000;
+        }
         if (const char* e = getenv("HMVIT_ATTN_TRACE")) q.trace = (unsigned long long*)strtoull(e, nullptr, 0);
         // wave configurations (heads per group, compute waves per head, loader waves per head):
         //   default: 4 heads, 1 + 1 -> 8 waves of <= 256 VGPRs: a loader wave keeps 4 passes = 32 tap loads
