@@ -23,9 +23,23 @@ vf, vc, vn = PO.synthetic_pillars(L, 20000, nx, ny, largs, seed=2)
 _, pw, _, _, _ = S.synthetic_scene(L, 1, 1, 1, [1] * L, seed=0)
 batch = {"mode": torch.ones(1, L, dtype=torch.float64), "record_len": torch.tensor([L]), "pairwise_t_matrix": pw.cuda(),
          "processed_lidar": {"voxel_features": vf.cuda(), "voxel_coords": vc.cuda(), "voxel_num_points": vn.cuda()}}
-for prec in (sys.argv[1:] or ["f16"]):
-    net = hmvit_amd.BevformerPointPillarHetero(cfg, precision=prec)
-    missing, unexpected = net.load_state_dict(sd, strict=False)
+from hmvit_amd.camera import CvtCameraEncoder
+from oracle import camera_oracle as CAM
+ccfg = CAM.make_config(image=512, num_layers=34, dim=128, bev=256)
+csd = CAM.random_state_dict(ccfg, seed=7)
+cams = {k: v.cuda() for k, v in CAM.synthetic_batch(L, ccfg, seed=8).items()}
+hetero = "--hetero" in sys.argv
+if hetero:   # BASELINE configs[2]: camera ego, mixed agent types; every agent carries both sensors' inputs, `mode` picks one
+    batch["mode"] = torch.tensor([[0.0, 1.0, 0.0, 1.0, 1.0]], dtype=torch.float64)
+    batch.update({"camera": cams["camera"], "intrinsic": cams["intrinsic"], "extrinsic": cams["extrinsic"],
+                  "cav2cam_extrinsic": cams["extrinsic"].clone()})
+for prec in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["f16"]):
+    cam_enc = CvtCameraEncoder(ccfg, precision=prec) if hetero else None
+    net = hmvit_amd.BevformerPointPillarHetero(cfg, camera_encoder=cam_enc, precision=prec)
+    full = dict(sd)
+    if hetero:
+        full.update({f"camera_encoder.{k}": v for k, v in csd.items()})
+    missing, unexpected = net.load_state_dict(full, strict=False)
     net = net.cuda().eval()
     out = net(batch); torch.cuda.synchronize()
     n = 10
@@ -34,4 +48,4 @@ for prec in (sys.argv[1:] or ["f16"]):
     for _ in range(n):
         out = net(batch)
     e1.record(); torch.cuda.synchronize()
-    print(f"model {prec}: {e0.elapsed_time(e1) / n:.2f} ms per 5-agent scene (pillars -> psm {tuple(out['psm'].shape)}, rm {tuple(out['rm'].shape)})")
+    print(f"model {'hetero (2 camera + 3 LiDAR agents) ' if hetero else ''}{prec}: {e0.elapsed_time(e1) / n:.2f} ms per 5-agent scene (pillars -> psm {tuple(out['psm'].shape)}, rm {tuple(out['rm'].shape)})")
