@@ -1158,6 +1158,10 @@ __global__ __launch_bounds__((HG * CW + HG * LWX) * 64) void k_attention_pc(Attn
         else
             pc_loader_loop_general<HG, CW, LWX>(p, sm, wave - SM::CWG, threadIdx.x - SM::CWG * 64);
     } else {
+        // probe 0x8000 (with 0x800): the compute waves outrank the loader instead.  Faster on the dense probe scene
+        // (tests/tools/attn_probe.py: -6 % local, -11 % grid), 9 % slower in the fused forward, where every chunk that is
+        // walked has visible keys and the loader's issue slots are the scarcer ones.
+        if (p.variant & 0x8000) __builtin_amdgcn_s_setprio(3);
         pc_compute_loop<HG, CW, LWX>(p, sm, wave, threadIdx.x & 63, fast);
     }
 }

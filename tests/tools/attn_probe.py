@@ -40,7 +40,7 @@ def bench(tag, dbg):
 VARIANTS = [("default: 8 waves (4 compute + 4 loader)", 0), ("16 waves (8 + 8)", 2), ("1 tap (all visible)", 0x10),
             ("no loads (all masked)", 0x20), ("no compute", 0x40), ("other item order", 0x200), ("no loader priority", 0x800),
             ("L2-resident region", 0x400), ("1 tap + no compute", 0x50), ("no loads + no compute", 0x60),
-            ("general loader loop", 0x1000)]
+            ("general loader loop", 0x1000), ("compute priority instead", 0x8800)]
 if os.environ.get("ONLY"):
     want = [int(v, 0) for v in os.environ["ONLY"].split(",")]
     VARIANTS = [v for v in VARIANTS if v[1] in want]
