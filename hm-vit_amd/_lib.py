@@ -5,6 +5,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch first, on purpose: PyTorch-ROCm ships its own libamdhip64.  Loaded first, it is the HIP runtime libhmvit.so's
+# DT_NEEDED entry resolves to (same SONAME), so the library and torch share one runtime - streams and device pointers
+# pass between them.  Loaded second, the process would hold two runtimes and every call on a torch stream would fail
+# with "no ROCm-capable device is detected".
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMVIT_LIB", os.path.join(_HERE, "libhmvit.so"))   # HMVIT_LIB: ablation builds of tools/probe
 
