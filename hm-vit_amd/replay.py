@@ -135,7 +135,8 @@ def inference(model, dataset, pre, post, calibrate_top: int | None = 200, log=No
             raise RuntimeError(f"anchor grid {anchors.shape[:2]} != head grid {tuple(out['psm'].shape[2:])}")
         if calibrate_top is not None:
             k = max(1, out["psm"].numel() - calibrate_top)
-            post.params["target_args"]["score_threshold"] = float(torch.sigmoid(out["psm"]).flatten().kthvalue(k).values)
+            kth = float(torch.sigmoid(out["psm"].float()).flatten().kthvalue(k).values)
+            post.params["target_args"]["score_threshold"] = float(np.nextafter(np.float32(min(kth, 1.0)), np.float32(0)))
         data = {"ego": {"anchor_box": torch.from_numpy(anchors), "transformation_matrix": torch.eye(4)}}
         boxes, scores = post.post_process(data, {"ego": {"psm": out["psm"], "rm": out["rm"]}})
         torch.cuda.synchronize(dev)
@@ -161,7 +162,9 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("--scenes", type=int, default=8)
     ap.add_argument("--agents", type=int, default=5)
-    ap.add_argument("--grid", type=int, nargs=2, default=[512, 512], metavar=("NX", "NY"), help="pillar grid (0.4 m cells)")
+    ap.add_argument("--grid", type=int, nargs=2, default=[512, 192], metavar=("NX", "NY"),
+                    help="pillar grid (0.4 m cells); boxes outside the evaluation range |y| <= 40 m (GT_RANGE) are dropped "
+                         "by the post-processor as in the reference, so the default keeps the map inside it")
     ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
     ap.add_argument("--checkpoint", default=None, help="state_dict file of the reference model (loaded strict=False)")
     ap.add_argument("--seed", type=int, default=0)
@@ -182,6 +185,7 @@ def main(argv=None):
         with torch.no_grad():
             model.reg_head.weight.mul_(0.02)
             model.reg_head.bias.zero_()
+            model.cls_head.weight.mul_(0.05)       # and the logits out of the sigmoid's saturated range (distinct scores)
     model = model.cuda().eval()
     pre = SpVoxelPreprocessor(preprocess_params(cfg), train=False)
     post = VoxelPostprocessor(postprocess_params(cfg), train=False)
