@@ -415,25 +415,37 @@ struct PcItem {
 // window-index-strided assignment those re-reads always landed in another XCD's L2 (measured: 7.5 GB fetched
 // per grid launch for 0.7 GB of K'/V').  Step k of XCD x is tile k * 8 + x of the (sample, ego, tile) list.
 // Returns false when the list is exhausted; windows of a border tile that fall outside the map are skipped.
-__device__ __forceinline__ bool pc_fetch(const AttnParams& p, int X, int Y, int NG, bool ego_fastest, int& k, PcItem& it) {
+// The walk over the list is incremental: the list position s = k * 8 + x is kept decomposed into (sample, ego, tile row,
+// tile column), and a step of 8 is a few scalar adds and compares.  (The first version divided s out on every call: three
+// integer divisions, i.e. about 100 dependent VALU instructions - roughly 1000 cycles per item on the critical role.)
+struct PcCursor {
+    int b, ego, trow, tcol;   // position in the (sample, ego, tile) list
+    int started;
+};
+
+__device__ __forceinline__ bool pc_fetch(const AttnParams& p, int X, int Y, int NG, bool ego_fastest, PcCursor& cur, PcItem& it) {
     const int wpx = gridDim.x >> 3, x = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int TWS = (p.variant & 0x2000) ? 2 : (p.variant & 0x4000) ? 4 : 3, TW = 1 << TWS;
-    const int TH = wpx / NG / TW;                      // tile = TH x TW windows (2 x 8; probe switches 0x2000: 4 x 4, 0x4000: 1 x 16)
-    const int ntx = (X + TH - 1) / TH, nty = (Y + TW - 1) / TW, n_super = ntx * nty, total = p.B * p.n_ego * n_super;
+    const int TH = wpx / NG / 8;                       // tile = TH x 8 windows
+    const int ntx = (X + TH - 1) / TH, nty = (Y + 7) / 8;
     const int t = j / NG;
     while (true) {
-        ++k;
-        int s = k * 8 + x;
-        if (s >= total) return false;
-        int tile, ego;
+        // advance by 8 list positions (by x for the first call): the fastest index first, carries into the others
+        int step = cur.started ? 8 : x;
+        cur.started = 1;
         if (ego_fastest) {
-            ego = s % p.n_ego; s /= p.n_ego;
-            tile = s % n_super; s /= n_super;
+            cur.ego += step;
+            while (cur.ego >= p.n_ego) { cur.ego -= p.n_ego; ++cur.tcol; }
+            while (cur.tcol >= nty) { cur.tcol -= nty; ++cur.trow; }
+            while (cur.trow >= ntx) { cur.trow -= ntx; ++cur.b; }
         } else {
-            tile = s % n_super; s /= n_super;
-            ego = s % p.n_ego; s /= p.n_ego;
+            cur.tcol += step;
+            while (cur.tcol >= nty) { cur.tcol -= nty; ++cur.trow; }
+            while (cur.trow >= ntx) { cur.trow -= ntx; ++cur.ego; }
+            while (cur.ego >= p.n_ego) { cur.ego -= p.n_ego; ++cur.b; }
         }
-        const int wx = (tile / nty) * TH + (t >> TWS), wy = (tile % nty) * TW + (t & (TW - 1));
+        if (cur.b >= p.B) return false;
+        const int s = cur.b, ego = cur.ego;
+        const int wx = cur.trow * TH + (t >> 3), wy = cur.tcol * 8 + (t & 7);
         if (wx < X && wy < Y) {
             if (p.prune) {   // items the pruned last stage cannot reach (k_window_need -> bit 31 of the visibility word)
                 const unsigned* a = p.vis_mask + __builtin_amdgcn_readfirstlane(((s * p.n_ego + ego) * X + wx) * Y + wy);
@@ -762,7 +774,8 @@ __device__ __forceinline__ void pc_loader_loop_general(const AttnParams& p, PcSh
         allv &= vis;
     };
 
-    int item = -1, chunk = 0, g = 0, qi = 0;
+    PcCursor item = {0, 0, 0, 0, 0};
+    int chunk = 0, g = 0, qi = 0;
     PcItem it;
     if (!pc_fetch(p, X, Y, NG, ego_fastest, item, it)) { pc_wg_barrier(); return; }
     PcGather G = pc_describe<HG, CW, LWX>(p, sm, it, 0, 0, 0, true);
@@ -876,7 +889,8 @@ __device__ __forceinline__ void pc_loader_loop_fast(const AttnParams& p, PcShare
         pc_wg_barrier();
     };
 
-    int item = -1, g = 0, qi = 0;
+    PcCursor item = {0, 0, 0, 0, 0};
+    int g = 0, qi = 0;
     PcItem it;
     if (!pc_fetch(p, X, Y, NG, ego_fastest, item, it)) { pc_wg_barrier(); return; }
     unsigned vis = pc_item_vis(p, it, X, Y, true);   // chunks of the item with at least one visible key (bit 0 = the ego)
@@ -978,7 +992,7 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
     const int X = H / 8, Y = W / 8, NG = C / (HG * 32);
     const int n_src = p.n_src;
     const int lq = lane & 15, g = lane >> 4;
-    int item = -1;
+    PcCursor item = {0, 0, 0, 0, 0};
     PcItem it;
     __syncthreads();
     if (!pc_fetch(p, X, Y, NG, (p.variant & 0x200) == 0, item, it)) return;
@@ -1115,7 +1129,7 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
                 for (int qt = 0; qt < NQW; ++qt) {
                     int row, col;
                     token_pixel(p.partition, 8, X, Y, it.wx, it.wy, (qbase + qt) * 16 + lq, row, col);
-                    const float inv = 1.f / l_acc[qt][0];
+                    const float inv = __builtin_amdgcn_rcpf(l_acc[qt][0]);     // 1 ulp; the quotient is rounded to f16 next
                     half_t* o = outp + (size_t)(row * W + col) * C + head * 32 + 8 * g;
                     half8 h;
 #pragma unroll
