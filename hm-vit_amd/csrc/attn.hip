@@ -1093,7 +1093,7 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
 #pragma unroll
                         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
                     mx = max_over_lane_groups(mx);
-                    const float m_new = fmaxf(m_run[qt], mx);
+                    const float m_new = max_raw(m_run[qt], mx);     // both operands come out of v_max: no canonicalising pair
                     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
                     // logits are in log2 units (log2 e folded into W_q and the bias fragments on the host)
                     const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_safe);
