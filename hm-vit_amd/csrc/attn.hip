@@ -1288,6 +1288,7 @@ int launch_attention(const AttnParams& p, int precision, hipStream_t st) {
     if (p.C == 64) return w8 ? launch_attn_t<half_t, 8, 2>(p, st) : launch_attn_t<half_t, 4, 2>(p, st);
     int variant = p.variant;
     if (const char* e = getenv("HMVIT_ATTN_DEBUG")) variant ^= atoi(e);   // probe switches (tools/attn_probe.py, tools/attn_diff.py)
+    if (const char* e = getenv("HMVIT_ATTN_VARIANT")) variant ^= (int)strtol(e, nullptr, 0);   // same, without switching the visibility table off
     if (w8 && (variant & 1) == 0 && p.B * p.L * p.L <= PcShared<4, 1, 1>::MAX_PAIRS) {
         AttnParams q = p;
         q.variant = variant;
