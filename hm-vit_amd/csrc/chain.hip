@@ -538,12 +538,14 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
         dma_wait();
         wg_barrier();
 
+        // W_1 tile hc + 1 is requested before the GELU: ring0 is free since the barrier, and the activation's VALU work
+        // covers the DMA's flight on top of the W_2 products
+        if (hc + 1 < NH) stage_chunk<C>(w1c + 2 * Cfg::CHUNK_HALVES, ring0);
         half8 hop[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int q = 0; q < 8; ++q) hop[s][q] = (half_t)gelu_f(hacc[8 * s + q]);
-        if (hc + 1 < NH) stage_chunk<C>(w1c + 2 * Cfg::CHUNK_HALVES, ring0);   // W_1 tile hc + 1
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
