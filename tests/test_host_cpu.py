@@ -145,3 +145,37 @@ def test_voxelizer_oracle_properties():
     # first appearance order: the first point of voxel k precedes the first point of voxel k + 1 in the input
     first = [int(np.nonzero((cloud == v[k, 0]).all(1))[0][0]) for k in range(0, 500, 23)]
     assert first == sorted(first)
+
+
+def test_product_side_workload_generator_matches_oracle_geometry(pkg):
+    """hm-vit_amd/synthetic.py (what bench.py times) builds the same config dict and the same pose / pairwise geometry as the
+    oracle's generator (what the parity tests use); only the random streams differ."""
+    from hmvit_amd import synthetic as S
+    assert S.make_config(256, 8, 5, voxel=0.4, downsample=1) == O.make_config(256, 8, 5, voxel=0.4, downsample=1)
+    xs, pws, modes, rls, masks = S.synthetic_scene(5, 8, 16, 24, [1, 0, 1, 1, 0], seed=3)
+    xo, pwo, modeo, rlo, masko = O.synthetic_scene(5, 8, 16, 24, [1, 0, 1, 1, 0], seed=3)
+    assert xs.shape == xo.shape and torch.equal(pws, pwo) and torch.equal(modes, modeo)
+    assert torch.equal(rls, rlo) and torch.equal(masks, masko)
+    net = S.seeded_fusion(S.make_config(64, 4, 2), "f16", seed=1)
+    again = S.seeded_fusion(S.make_config(64, 4, 2), "f16", seed=1)
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), again.state_dict().values()))
+
+
+def test_replay_dataset_and_configs(pkg):
+    """hm-vit_amd/replay.py host side: config dicts carry the shipped yaml's keys, frames are reproducible, every agent's
+    cloud is in its own frame (the ego's cloud contains the vehicles' surface points inside the ground-truth boxes)."""
+    import numpy as np
+    from hmvit_amd import replay as R
+    cfg = R.lidar_model_config(96, 64, max_cav=3, window=4, small=True)
+    assert cfg["lidar"]["point_pillar_scatter"]["grid_size"] == [96, 64, 1] and cfg["hetero_fusion"]["num_iters"] == 2
+    pp = R.postprocess_params(cfg)
+    assert pp["anchor_args"]["W"] == 48 and pp["anchor_args"]["H"] == 32 and pp["order"] == "hwl"
+    ds = R.SyntheticReplayDataset(cfg, 2, n_agents=3, n_obj=4, seed=5)
+    a, b = ds[1], ds[1]
+    assert all(np.array_equal(x, y) for x, y in zip(a["clouds"], b["clouds"])) and len(a["clouds"]) == 3
+    assert a["pairwise_t_matrix"].shape == (1, 3, 3, 4, 4) and a["object_bbx_corners"].shape == (4, 8, 3)
+    corners = a["object_bbx_corners"]
+    ego = a["clouds"][0][:, :3]
+    lo, hi = corners.min(1) - 1e-3, corners.max(1) + 1e-3          # axis-aligned hulls of the boxes
+    inside = ((ego[:, None, :] >= lo[None]) & (ego[:, None, :] <= hi[None])).all(-1).any(1)
+    assert inside.sum() >= 4 * 150                                  # the 150 surface points of every vehicle
