@@ -133,3 +133,31 @@ def test_hetero_decoder_matches_golden(precision):
     assert rel_max_err(rm.cpu(), g["rm"]) < TOL[precision]
     with pytest.raises(NotImplementedError):
         net(x.cuda(), g["mode"].cuda())
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_pointpillar_random_sweep_vs_oracle(seed):
+    """Random grid sizes, agent counts and pillar counts (incl. an agent without pillars): encoder features against the
+    oracle in both precisions."""
+    import numpy as np
+    import hmvit_amd
+    rs = np.random.RandomState(500 + seed)
+    nx, ny = int(rs.choice([32, 64, 96])), int(rs.choice([32, 48]))
+    args = PO.make_args(nx, ny)
+    sd = PO.random_state_dict(args, seed=600 + seed)
+    n_agents = int(rs.choice([1, 2, 3]))
+    vf, vc, vn = PO.synthetic_pillars(n_agents, int(rs.choice([20, 150, 400])), nx, ny, args, seed=700 + seed)
+    if n_agents == 3:                                   # drop every pillar of the middle agent
+        keep = vc[:, 0] != 1
+        vf, vc, vn = vf[keep], vc[keep], vn[keep]
+    ref = PO.point_pillar_features(vf, vc, vn, sd, args, n_agents)
+    batch = {"processed_lidar": {"voxel_features": vf.cuda(), "voxel_coords": vc.cuda(), "voxel_num_points": vn.cuda()},
+             "record_len": torch.tensor([n_agents])}
+    for precision in ("f32", "f16"):
+        net = hmvit_amd.PointPillar(args, precision=precision)
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda().eval()
+        net.set_return_features()
+        y = net(batch).cpu()
+        assert y.shape == ref.shape
+        assert rel_max_err(y, ref) < TOL[precision], (precision, nx, ny, n_agents)

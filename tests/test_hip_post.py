@@ -102,3 +102,28 @@ def test_post_process_edge_cases():
     # CPU tensors are refused (no CPU path)
     with pytest.raises(RuntimeError):
         pp.post_process(data, {"ego": {"psm": torch.from_numpy(psm), "rm": torch.from_numpy(rm)}})
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_post_process_random_sweep(seed):
+    """Random anchor grids, thresholds, object counts and a random agent-to-ego transform: boxes, order and scores equal
+    the oracle's."""
+    import hmvit_amd
+    rs = np.random.RandomState(300 + seed)
+    params = PPO.make_params(W=int(rs.choice([32, 48, 96])), H=int(rs.choice([16, 32, 64])))
+    params["nms_thresh"] = float(rs.choice([0.05, 0.15, 0.4]))
+    params["target_args"]["score_threshold"] = float(rs.choice([0.2, 0.27, 0.5]))
+    pp = hmvit_amd.VoxelPostprocessor(params, train=False)
+    anchors = pp.generate_anchor_box()
+    psm, rm, _, _ = PPO.synthetic_heads(params, seed=400 + seed, n_obj=int(rs.choice([1, 8, 30])))
+    yaw, tx, ty = rs.uniform(-0.3, 0.3), rs.uniform(-3, 3), rs.uniform(-3, 3)
+    T = torch.eye(4)
+    T[0, 0], T[0, 1], T[1, 0], T[1, 1], T[0, 3], T[1, 3] = np.cos(yaw), -np.sin(yaw), np.sin(yaw), np.cos(yaw), tx, ty
+    data = {"ego": {"anchor_box": torch.from_numpy(anchors), "transformation_matrix": T}}
+    boxes, scores = pp.post_process(data, {"ego": {"psm": torch.from_numpy(psm).cuda(), "rm": torch.from_numpy(rm).cuda()}})
+    ref_b, ref_s = PPO.post_process(params, [{"psm": psm, "rm": rm, "anchor_box": anchors, "transformation_matrix": T.numpy()}])
+    if ref_b is None:
+        assert boxes is None
+        return
+    assert boxes.shape == ref_b.shape
+    assert np.abs(boxes.cpu().numpy() - ref_b).max() < 2e-4 and np.abs(scores.cpu().numpy() - ref_s).max() < 1e-6

@@ -56,3 +56,20 @@ def test_collate_prepends_agent_index():
     assert batch["voxel_coords"].shape[1] == 4
     assert int(batch["voxel_coords"][:na, 0].max()) == 0 and int(batch["voxel_coords"][na:, 0].min()) == 1
     assert torch.equal(batch["voxel_coords"][na:, 1:], b["voxel_coords"])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_voxelize_random_sweep(seed):
+    """Random ranges, voxel sizes and caps, clouds with duplicates and out-of-range points: bit-exact against the sequential
+    restatement every time."""
+    rs = np.random.RandomState(100 + seed)
+    half_x, half_y = float(rs.choice([6.4, 12.8, 25.6])), float(rs.choice([4.8, 9.6, 19.2]))
+    params = {"cav_lidar_range": [-half_x, -half_y, -3, half_x, half_y, 1],
+              "args": {"voxel_size": [float(rs.choice([0.2, 0.4, 0.8]))] * 2 + [4], "max_points_per_voxel": int(rs.choice([1, 5, 32])),
+                       "max_voxel_train": int(rs.choice([50, 700, 32000])), "max_voxel_test": 70000}}
+    n = int(rs.choice([1, 37, 4000, 30000]))
+    cloud = VO.synthetic_cloud(n, params["cav_lidar_range"], seed=200 + seed)
+    cloud[rs.rand(n) < 0.1, 0] += 3 * half_x                       # a tenth of the points outside the range
+    if n > 10:
+        cloud[n // 2:n // 2 + 5] = cloud[0]                        # exact duplicates of the first point
+    _check(params, cloud, train=bool(seed % 2))
