@@ -257,3 +257,30 @@ def test_fusion_random_sweep_vs_oracle(seed):
         y = _fusion(cfg, sd, precision)(*_cuda(x, pw, mode, rl, mask)).cpu()
         assert y.shape == ref.shape
         assert rel_max_err(y, ref) < TOL[precision], (precision, C, window, L, B, H, W, arch, cfg["num_iters"])
+
+
+def test_forward_is_graph_capturable():
+    """Every launch goes to the current stream and all buffers come from torch's allocator, so the forward can be captured
+    in a HIP graph (torch.cuda.graph) and replayed: same bits as the eager call, also after the inputs change in place."""
+    cfg = O.make_config(256, 8, 3, voxel=0.4, downsample=4)
+    sd = O.random_state_dict(cfg, seed=41)
+    net = _fusion(cfg, sd, "f16")
+    scene = _cuda(*O.synthetic_scene(3, 256, 32, 48, [1, 0, 1], seed=42))
+    eager = net(*scene).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            net(*scene)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = net(*scene)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    x2 = O.synthetic_scene(3, 256, 32, 48, [1, 0, 1], seed=43)[0].cuda()
+    scene[0].copy_(x2)                       # new features, same geometry: replay reads the captured input buffer
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, net(*scene))
