@@ -284,3 +284,17 @@ def test_forward_is_graph_capturable():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, net(*scene))
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_fusion_two_five_agent_samples(precision):
+    """B = 2 samples of L = 5 agent slots (record_len 5 and 3, mixed types): 50 (source, ego) affine records in one launch."""
+    cfg = O.make_config(256, 8, 5, voxel=0.4, downsample=4)
+    sd = O.random_state_dict(cfg, seed=61)
+    x, pw, mode, rl, mask = O.synthetic_scene(5, 256, 32, 48, [1, 0, 1, 1, 0], seed=62, B=2, yaw_step=0.3, tx_step=12.0, ty_step=-7.0)
+    x2, pw2, mode2, rl2, mask2 = O.synthetic_scene(5, 256, 32, 48, [0, 1, 1, 0, 0], n_valid=3, seed=63, yaw_step=-0.25)
+    x[1], pw[1], mode[1], rl[1], mask[1] = x2[0], pw2[0], mode2[0], rl2[0], mask2[0]
+    ref = O.hetero_fusion(x, pw, mode, rl, mask, sd, cfg)
+    y = _fusion(cfg, sd, precision)(*_cuda(x, pw, mode, rl, mask)).cpu()
+    assert y.shape == ref.shape == (2, 256, 32, 48)
+    assert rel_max_err(y, ref) < TOL[precision]
