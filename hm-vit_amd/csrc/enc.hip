@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
     using Vec = typename std::conditional<sizeof(T) == 2, half8, float4v>::type;   // 16 bytes of a row
     constexpr int VE = 16 / sizeof(T);
     Vec ra[RPT], rw[RPW];
+    int s_ky = 0, s_kx = 0, s_ci0 = 0;       // tap and first channel of the next slab to be requested
     auto load_slab = [&](int k0) {
         if (p.rowpack) {
             // few-channel stem: k = ky * 32 + px * 4 + ci over rows of 8 pixels x 4 channels, which are contiguous in the
@@ -163,8 +164,10 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
                 }
             }
         } else {
-            const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
-            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            // slabs are requested in order, so (ky, kx, first channel) advance by counting instead of dividing k0 out
+            const int ky = s_ky, kx = s_kx, ci0 = s_ci0;
+            s_ci0 += BK;
+            if (s_ci0 >= p.Cin) { s_ci0 = 0; if (++s_kx == p.KW) { s_kx = 0; ++s_ky; } }
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
                 const int c = tid + 256 * i, kc = (c & 7) * VE;
