@@ -136,6 +136,15 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
         rox[i] = rem - roy[i] * p.Wo;
     }
 
+    // (not up2) per staged row: coordinates and element offset of tap (0, 0), 16-byte piece of the slab included
+    int riy0[RPT], rix0[RPT], rowoff[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        riy0[i] = roy[i] * p.stride - p.pad;
+        rix0[i] = rox[i] * p.stride - p.pad;
+        rowoff[i] = ((rn[i] * p.H + riy0[i]) * p.W + rix0[i]) * p.Cin + ((tid + 256 * i) & 7) * (int)(16 / sizeof(T));
+    }
+
     float16v acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -168,18 +177,29 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
             const int ky = s_ky, kx = s_kx, ci0 = s_ci0;
             s_ci0 += BK;
             if (s_ci0 >= p.Cin) { s_ci0 = 0; if (++s_kx == p.KW) { s_kx = 0; ++s_ky; } }
+            if (!p.up2) {
+                // the usual case: element offset of the row's tap (0, 0) + a wave-uniform tap offset (32-bit: NHWC maps
+                // stay below 2^31 elements), range test on the two coordinates
+                const int toff = (ky * p.W + kx) * p.Cin + ci0;
 #pragma unroll
-            for (int i = 0; i < RPT; ++i) {
-                const int c = tid + 256 * i, kc = (c & 7) * VE;
-                // A slab: im2col rows gathered from the NHWC input
-                const int iy = roy[i] * p.stride + ky - p.pad, ix = rox[i] * p.stride + kx - p.pad;
-                const bool ok = rvalid[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                ra[i] = (Vec)(T)0;
-                if (ok) {
-                    // up2: logical pixel (iy, ix) of the upsampled map is physical pixel (iy / 2, ix / 2)
-                    const size_t pix = p.up2 ? ((size_t)rn[i] * (p.H >> 1) + (iy >> 1)) * (p.W >> 1) + (ix >> 1)
-                                             : ((size_t)rn[i] * p.H + iy) * p.W + ix;
-                    ra[i] = *reinterpret_cast<const Vec*>(x + pix * p.Cin + ci0 + kc);
+                for (int i = 0; i < RPT; ++i) {
+                    const bool ok = rvalid[i] && (unsigned)(riy0[i] + ky) < (unsigned)p.H && (unsigned)(rix0[i] + kx) < (unsigned)p.W;
+                    ra[i] = (Vec)(T)0;
+                    if (ok) ra[i] = *reinterpret_cast<const Vec*>(x + (long)(rowoff[i] + toff));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                    const int c = tid + 256 * i, kc = (c & 7) * VE;
+                    // A slab: im2col rows gathered from the NHWC input
+                    const int iy = roy[i] * p.stride + ky - p.pad, ix = rox[i] * p.stride + kx - p.pad;
+                    const bool ok = rvalid[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                    ra[i] = (Vec)(T)0;
+                    if (ok) {
+                        // up2: logical pixel (iy, ix) of the upsampled map is physical pixel (iy / 2, ix / 2)
+                        const size_t pix = ((size_t)rn[i] * (p.H >> 1) + (iy >> 1)) * (p.W >> 1) + (ix >> 1);
+                        ra[i] = *reinterpret_cast<const Vec*>(x + pix * p.Cin + ci0 + kc);
+                    }
                 }
             }
         }
