@@ -158,6 +158,14 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
     constexpr int VE = 16 / sizeof(T);
     Vec ra[RPT], rw[RPW];
     int s_ky = 0, s_kx = 0, s_ci0 = 0;       // tap and first channel of the next slab to be requested
+    const T* wrow[RPW];                      // weight rows staged by this thread (16-byte piece of the slab included)
+    bool wvalid[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int c = tid + 256 * i, row = c >> 3;
+        wvalid[i] = n0 + row < Ncols;
+        wrow[i] = w + (size_t)(wvalid[i] ? n0 + row : 0) * Ktot + (c & 7) * VE;
+    }
     auto load_slab = [&](int k0) {
         if (p.rowpack) {
             // few-channel stem: k = ky * 32 + px * 4 + ci over rows of 8 pixels x 4 channels, which are contiguous in the
@@ -205,9 +213,8 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
         }
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * VE;
             rw[i] = (Vec)(T)0;
-            if (n0 + row < Ncols) rw[i] = *reinterpret_cast<const Vec*>(w + (size_t)(n0 + row) * Ktot + k0 + kc);
+            if (wvalid[i]) rw[i] = *reinterpret_cast<const Vec*>(wrow[i] + k0);
         }
     };
     auto store_slab = [&](int buf) {
