@@ -100,6 +100,18 @@ struct ConvCfg<float> {
 // of a 128-wide tile empty).  2 x 2 wavefronts, each 64 pixels x CBN / 2 channels.  The K slabs are double-buffered in
 // LDS: slab k + 1 travels global -> registers while slab k is multiplied, registers -> the other buffer afterwards, one
 // barrier per slab.
+typedef int int4v __attribute__((ext_vector_type(4)));
+__device__ int4v llvm_raw_buffer_load_b128(int4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
+__device__ __forceinline__ int4v conv_rsrc(const void* base, size_t bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    int4v rs;
+    rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    rs.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    rs.z = __builtin_amdgcn_readfirstlane((int)(unsigned)(bytes < 0xfffffff0ull ? bytes : 0xfffffff0ull));
+    rs.w = 0x00020000;
+    return rs;
+}
+
 template <typename T, int CBN, int CBM>
 __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
     constexpr int BK = ConvCfg<T>::BK, LS = ConvCfg<T>::LS;
@@ -158,14 +170,17 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
     constexpr int VE = 16 / sizeof(T);
     Vec ra[RPT], rw[RPW];
     int s_ky = 0, s_kx = 0, s_ci0 = 0;       // tap and first channel of the next slab to be requested
-    const T* wrow[RPW];                      // weight rows staged by this thread (16-byte piece of the slab included)
+    unsigned wrow[RPW];                      // byte offset of the weight rows staged by this thread (16-byte piece included)
     bool wvalid[RPW];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         const int c = tid + 256 * i, row = c >> 3;
         wvalid[i] = n0 + row < Ncols;
-        wrow[i] = w + (size_t)(wvalid[i] ? n0 + row : 0) * Ktot + (c & 7) * VE;
+        wrow[i] = (unsigned)(((size_t)(wvalid[i] ? n0 + row : 0) * Ktot + (c & 7) * VE) * sizeof(T));
     }
+    // raw buffer descriptors of the input map and the weight matrix (an offset >= num_records reads as zero)
+    const size_t x_bytes = (size_t)p.N * p.H * p.W * p.Cin * sizeof(T) >> (p.up2 ? 2 : 0), w_bytes = (size_t)Ncols * Ktot * sizeof(T);
+    const int4v rs_x = conv_rsrc(x, x_bytes), rs_w = conv_rsrc(w, w_bytes);
     auto load_slab = [&](int k0) {
         if (p.rowpack) {
             // few-channel stem: k = ky * 32 + px * 4 + ci over rows of 8 pixels x 4 channels, which are contiguous in the
@@ -188,12 +203,13 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
             if (!p.up2) {
                 // the usual case: element offset of the row's tap (0, 0) + a wave-uniform tap offset (32-bit: NHWC maps
                 // stay below 2^31 elements), range test on the two coordinates
+                // buffer loads: a row outside the map asks for an out-of-range offset and gets zeros - no branch per row
                 const int toff = (ky * p.W + kx) * p.Cin + ci0;
 #pragma unroll
                 for (int i = 0; i < RPT; ++i) {
                     const bool ok = rvalid[i] && (unsigned)(riy0[i] + ky) < (unsigned)p.H && (unsigned)(rix0[i] + kx) < (unsigned)p.W;
-                    ra[i] = (Vec)(T)0;
-                    if (ok) ra[i] = *reinterpret_cast<const Vec*>(x + (long)(rowoff[i] + toff));
+                    const unsigned off = ok ? (unsigned)(rowoff[i] + toff) * (unsigned)sizeof(T) : 0xffffffffu;
+                    ra[i] = __builtin_bit_cast(Vec, llvm_raw_buffer_load_b128(rs_x, (int)off, 0, 0));
                 }
             } else {
 #pragma unroll
@@ -212,10 +228,8 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            rw[i] = (Vec)(T)0;
-            if (wvalid[i]) rw[i] = *reinterpret_cast<const Vec*>(wrow[i] + k0);
-        }
+        for (int i = 0; i < RPW; ++i)
+            rw[i] = __builtin_bit_cast(Vec, llvm_raw_buffer_load_b128(rs_w, (int)(wvalid[i] ? wrow[i] + (unsigned)k0 * (unsigned)sizeof(T) : 0xffffffffu), 0, 0));
     };
     auto store_slab = [&](int buf) {
 #pragma unroll
