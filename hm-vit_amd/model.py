@@ -26,6 +26,8 @@ def regroup(features: torch.Tensor, record_len, max_len: int):
     """(sum N, C, H, W) -> (B, max_len, C, H, W) zero padded + (B, max_len) 0/1 mask (fuse_utils.py:8-61)."""
     lens = [int(v) for v in record_len]
     B = len(lens)
+    if all(n == max_len for n in lens):             # nothing to pad: a view
+        return features.reshape((B, max_len) + tuple(features.shape[1:])), torch.ones(B, max_len, dtype=torch.int64)
     out = features.new_zeros((B, max_len) + tuple(features.shape[1:]))
     mask = torch.zeros(B, max_len, dtype=torch.int64)
     start = 0
@@ -48,6 +50,7 @@ class BevformerPointPillarHetero(nn.Module):
         self.lidar_encoder.set_return_features()
         if self.camera_encoder is not None:
             self.camera_encoder.set_return_features()
+        self._host_key, self._host_val = None, None
         self.use_hetero_decoder = "hetero_decoder" in config
         if not self.use_hetero_decoder:
             raise NotImplementedError("only the hetero_decoder tail of the shipped yaml is built")
@@ -64,6 +67,11 @@ class BevformerPointPillarHetero(nn.Module):
         """extract_lidar_input (base_camera_lidar_intermediate.py:31-65) without mutating the batch:
         pillars of the LiDAR agents, agent index renumbered to the order among LiDAR agents."""
         lid = batch["processed_lidar"]
+        if bool((flat_mode == 1).all()):
+            # every agent is a LiDAR agent: nothing to filter or renumber (and no boolean-mask indexing, whose output
+            # size costs a device synchronisation per forward)
+            return {"processed_lidar": {k: lid[k] for k in ("voxel_features", "voxel_coords", "voxel_num_points")},
+                    "n_agents": int(flat_mode.numel())}
         coords = lid["voxel_coords"]
         agent = coords[:, 0].long()
         is_lidar = flat_mode.to(coords.device) == 1
@@ -74,15 +82,21 @@ class BevformerPointPillarHetero(nn.Module):
         new_coords = coords[keep].clone()
         new_coords[:, 0] = new_index[agent[keep]].to(coords.dtype)
         return {"processed_lidar": {"voxel_features": lid["voxel_features"][keep], "voxel_coords": new_coords,
-                                    "voxel_num_points": lid["voxel_num_points"][keep]}}
+                                    "voxel_num_points": lid["voxel_num_points"][keep]},
+                "n_agents": int(is_lidar.sum())}
 
     def forward(self, batch):
-        mode = batch["mode"].to(torch.int)
-        record_len = batch["record_len"]
+        # mode / record_len are needed on the host (regrouping, kernel descriptors): one read-back per distinct tensor,
+        # remembered by identity so that a loop over the same batch does not synchronise the device every forward
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device)) for t in (batch["mode"], batch["record_len"]))
+        if self._host_key != key:
+            self._host_key = key
+            self._host_val = (batch["mode"].to(torch.int).cpu(), batch["record_len"].cpu())
+        mode, record_len = self._host_val
         rl = [int(v) for v in record_len.tolist()]
         pairwise_t_matrix = batch["pairwise_t_matrix"]
         max_cav = mode.shape[1]
-        flat_mode = self._unpad(mode.cpu(), rl)
+        flat_mode = self._unpad(mode, rl)
         bad = (flat_mode != 0) & (flat_mode != 1)
         if bool(bad.any()):
             raise ValueError(f"Mode but be either 1 or 0 but received {int(flat_mode[bad][0])}")
@@ -98,11 +112,13 @@ class BevformerPointPillarHetero(nn.Module):
             camera_features = self.camera_encoder(batch_camera)
         if not bool((flat_mode == 0).all()):
             lidar_features = self.lidar_encoder(self._lidar_batch(batch, flat_mode))
-        ref = lidar_features if lidar_features is not None else camera_features
-        x = ref.new_empty((flat_mode.numel(),) + tuple(ref.shape[1:]))
-        if camera_features is not None:
+        if camera_features is None:
+            x = lidar_features                      # single-modality batches need no interleaving (and no masked writes)
+        elif lidar_features is None:
+            x = camera_features
+        else:
+            x = lidar_features.new_empty((flat_mode.numel(),) + tuple(lidar_features.shape[1:]))
             x[(flat_mode == 0).to(x.device)] = camera_features.to(x.dtype)
-        if lidar_features is not None:
             x[(flat_mode == 1).to(x.device)] = lidar_features
         x, mask = regroup(x, rl, max_cav)
         fused = self.fusion_net(x, pairwise_t_matrix, mode, record_len, mask)

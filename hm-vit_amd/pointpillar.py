@@ -174,7 +174,9 @@ class PointPillar(nn.Module):
         vf = vf.detach().float().contiguous()
         vc = vc.detach().to(torch.int32).contiguous()
         vn = vn.detach().to(torch.int32).contiguous()
-        n_agents = int(vc[:, 0].max().item()) + 1               # same host read as point_pillar_scatter.py:18
+        # point_pillar_scatter.py:18 reads the agent count back from the coordinates (a device synchronisation per call); a
+        # caller that knows it passes it along as batch['n_agents'] (the assembled model does)
+        n_agents = int(data_dict["n_agents"]) if "n_agents" in data_dict else int(vc[:, 0].max().item()) + 1
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         with torch.cuda.device(dev):
             canvas = torch.zeros(n_agents, ny, nx, 64, device=dev, dtype=dt)
