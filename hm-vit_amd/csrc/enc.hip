@@ -112,6 +112,13 @@ __device__ __forceinline__ int4v conv_rsrc(const void* base, size_t bytes) {
     return rs;
 }
 
+// channel (inside a 32-channel tile) whose weight row is staged as LDS / MFMA row rho: an accumulator lane (pixel r, half
+// hi) owns rows 8 q + 4 hi + e, which become two runs of eight consecutive channels (cf. weights.py store_row_order)
+__device__ __forceinline__ int conv_row_channel(int rho) {
+    const int q = rho >> 3, h = (rho >> 2) & 1, e = rho & 3;
+    return 16 * (q >> 1) + 8 * h + 4 * (q & 1) + e;
+}
+
 template <typename T, int CBN, int CBM>
 __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
     constexpr int BK = ConvCfg<T>::BK, LS = ConvCfg<T>::LS;
@@ -175,8 +182,9 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         const int c = tid + 256 * i, row = c >> 3;
-        wvalid[i] = n0 + row < Ncols;
-        wrow[i] = (unsigned)(((size_t)(wvalid[i] ? n0 + row : 0) * Ktot + (c & 7) * VE) * sizeof(T));
+        const int nrow = n0 + (row & ~31) + conv_row_channel(row & 31);   // output channel whose weights go to LDS row `row`
+        wvalid[i] = nrow < Ncols;
+        wrow[i] = (unsigned)(((size_t)(wvalid[i] ? nrow : 0) * Ktot + (c & 7) * VE) * sizeof(T));
     }
     // raw buffer descriptors of the input map and the weight matrix (an offset >= num_records reads as zero)
     const size_t x_bytes = (size_t)p.N * p.H * p.W * p.Cin * sizeof(T) >> (p.up2 ? 2 : 0), w_bytes = (size_t)Ncols * Ktot * sizeof(T);
@@ -302,10 +310,13 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: bias (folded BN shift), ReLU, NHWC store with channel offset / deconv scatter ----
-    // lane (r, hi) owns output pixel m0 + wm*64 + i*32 + r and, per tile j, the channels 8 q + 4 hi + (0..3)
+    // ---- epilogue: bias (folded BN shift), residual, ReLU, NHWC store with channel offset / deconv scatter ----
+    // The weight rows of a 32-channel tile sit in LDS in the order conv_row_channel (see wrow): MFMA output row
+    // 8 q + 4 hi + e of lane (r, hi) is then channel 16 (q >> 1) + 8 hi + 4 (q & 1) + e, i.e. accumulator elements
+    // 8 qq .. 8 qq + 7 are the eight consecutive channels 16 qq + 8 hi .. + 7 of pixel m0 + wm * (CBM / 2) + i * 32 + r:
+    // one 16-byte store per run (8-byte stores are issue-bound, and this kernel is short of issue slots).
     const int s = p.deconv_s;
-    const bool vec_ok = (p.Cout % 4 == 0) && (p.y_coff % 4 == 0) && (p.y_ctot % 4 == 0);
+    const bool vec_ok = (p.Cout % 8 == 0) && (p.y_coff % 8 == 0) && (p.y_ctot % 8 == 0);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * (CBM / 2) + i * 32 + r;
@@ -315,43 +326,58 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int col = n0 + wn * (CBN / 2) + j * 32 + 8 * q + 4 * hi;
+            for (int qq = 0; qq < 2; ++qq) {
+                const int col = n0 + wn * (CBN / 2) + j * 32 + 16 * qq + 8 * hi;
                 if (col >= Ncols) continue;
-                const int sub = s ? col / p.Cout : 0, co = s ? col - sub * p.Cout : col;
-                const int dy = s ? sub / s : 0, dx = s ? sub - dy * s : 0;
-                const size_t pix = s ? ((size_t)n * p.Ho * s + oy * s + dy) * (p.Wo * s) + ox * s + dx : (size_t)m;
-                const size_t o = pix * p.y_ctot + p.y_coff + co;
-                float v[4];
+                if (vec_ok && col + 7 < Ncols) {
+                    const int sub = s ? col / p.Cout : 0, co = s ? col - sub * p.Cout : col;
+                    const int dy = s ? sub / s : 0, dx = s ? sub - dy * s : 0;
+                    const size_t pix = s ? ((size_t)n * p.Ho * s + oy * s + dy) * (p.Wo * s) + ox * s + dx : (size_t)m;
+                    const size_t o = pix * p.y_ctot + p.y_coff + co;
+                    float v[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[i][j][4 * q + e] + ((p.bias && col + e < Ncols) ? p.bias[co + e] : 0.f);
-                    if (p.res && col + e < Ncols) v[e] += (float)reinterpret_cast<const T*>(p.res)[pix * p.Cout + co + e];
-                    if (p.relu) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (vec_ok && col + 3 < Ncols) {
-                    if (p.out_f32) {
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + o) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else if constexpr (sizeof(T) == 2) {
-                        half4 h;
+                    for (int e = 0; e < 8; ++e) v[e] = acc[i][j][8 * qq + e];
+                    if (p.bias) {
+                        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co), b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
+                        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                    }
+                    if (p.res) {
+                        const T* rp = reinterpret_cast<const T*>(p.res) + pix * p.Cout + co;
+                        if constexpr (sizeof(T) == 2) {
+                            const half8 rv = *reinterpret_cast<const half8*>(rp);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
-                        *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.y) + o) = h;
+                            for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += (float)rp[e];
+                        }
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (p.out_f32 || sizeof(T) == 4) {
+                        float* yp = reinterpret_cast<float*>(p.y) + o;
+                        *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
                     } else {
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + o) = make_float4(v[0], v[1], v[2], v[3]);
+                        half8 h;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) h[e] = (half_t)v[e];
+                        *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.y) + o) = h;
                     }
                 } else {
                     // ragged channel count: element stores (the channels of one `sub` block stay together only when
-                    // Cout is a multiple of 4, so recompute the scatter per element)
+                    // Cout is a multiple of 8, so recompute the scatter per element)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                    for (int e = 0; e < 8; ++e) {
                         const int ce = col + e;
                         if (ce >= Ncols) continue;
                         const int sube = s ? ce / p.Cout : 0, coe = s ? ce - sube * p.Cout : ce;
                         const int dye = s ? sube / s : 0, dxe = s ? sube - dye * s : 0;
                         const size_t pixe = s ? ((size_t)n * p.Ho * s + oy * s + dye) * (p.Wo * s) + ox * s + dxe : (size_t)m;
                         const size_t oe = pixe * p.y_ctot + p.y_coff + coe;
-                        float ve = acc[i][j][4 * q + e] + (p.bias ? p.bias[coe] : 0.f);
+                        float ve = acc[i][j][8 * qq + e] + (p.bias ? p.bias[coe] : 0.f);
                         if (p.res) ve += (float)reinterpret_cast<const T*>(p.res)[pixe * p.Cout + coe];
                         if (p.relu) ve = fmaxf(ve, 0.f);
                         if (p.out_f32) reinterpret_cast<float*>(p.y)[oe] = ve;
