@@ -68,15 +68,17 @@ def _layernorm(x2d, ln: nn.LayerNorm, prec=_F32):
     return y
 
 
-def _linear_f16(x2d, weight, bias=None):
-    """f16 operands, f32 accumulate, f16 result (the q / k / v projections of the f16 mode)."""
+def _linear_f16(x2d, weight, bias=None, residual=None, gelu=False, out_f32=False):
+    """f16 operands (an f32 input is converted first), f32 accumulate, f16 or f32 result; residual (f32) needs out_f32."""
     M, K = x2d.shape
     N = weight.shape[0]
-    y = torch.empty(M, N, device=x2d.device, dtype=torch.float16)
+    if x2d.dtype != torch.float16:
+        x2d = x2d.to(torch.float16)
+    y = torch.empty(M, N, device=x2d.device, dtype=torch.float32 if out_f32 else torch.float16)
     w2 = weight.detach().reshape(N, K).to(torch.float16).contiguous()
     b2 = None if bias is None else bias.detach().float().contiguous()
-    _lib.check(_lib.lib.hmvit_linear(x2d.data_ptr(), w2.data_ptr(), _ptr(b2), None, y.data_ptr(), M, N, K, 0, 0, _lib.PREC_F16,
-                                     _stream()), "linear")
+    _lib.check(_lib.lib.hmvit_linear(x2d.data_ptr(), w2.data_ptr(), _ptr(b2), _ptr(residual), y.data_ptr(), M, N, K,
+                                     1 if gelu else 0, 1 if out_f32 else 0, _lib.PREC_F16, _stream()), "linear")
     return y
 
 
@@ -132,10 +134,18 @@ class CrossAttention(nn.Module):
         _lib.check(_lib.lib.hmvit_cross_attention(qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), a.data_ptr(), b, n, Q, K,
                                                   self.heads, self.dim_head, _lib.PREC_F16 if half else _F32, _stream()),
                    "cross_attention")
-        z = _linear(a, self.proj.weight, self.proj.bias, residual=None if skip is None else skip.reshape(-1, dim).contiguous())
-        z = _layernorm(z, self.prenorm)
-        hdn = _linear(z, self.mlp[0].weight, self.mlp[0].bias, gelu=True)
-        z = _linear(hdn, self.mlp[2].weight, self.mlp[2].bias, residual=z)
+        res = None if skip is None else skip.reshape(-1, dim).contiguous()
+        if half and dim % 64 == 0:
+            # the rest of the block on f16 operands too (f32 accumulate; LayerNorm and both residual adds stay in f32)
+            z = _linear_f16(a, self.proj.weight, self.proj.bias, residual=res, out_f32=True)
+            z = _layernorm(z, self.prenorm)
+            hdn = _linear_f16(z, self.mlp[0].weight, self.mlp[0].bias, gelu=True)
+            z = _linear_f16(hdn, self.mlp[2].weight, self.mlp[2].bias, residual=z, out_f32=True)
+        else:
+            z = _linear(a, self.proj.weight, self.proj.bias, residual=res)
+            z = _layernorm(z, self.prenorm)
+            hdn = _linear(z, self.mlp[0].weight, self.mlp[0].bias, gelu=True)
+            z = _linear(hdn, self.mlp[2].weight, self.mlp[2].bias, residual=z)
         z = _layernorm(z, self.postnorm)
         return z.reshape(b, Q, dim)
 
@@ -170,6 +180,8 @@ class CrossViewAttention(nn.Module):
         tok = torch.empty(bn_, h * w, C, device=feature_flat.device, dtype=torch.float32)
         _lib.check(_lib.lib.hmvit_bn_relu_tokens(feature_flat.data_ptr(), scale.data_ptr(), shift.data_ptr(), tok.data_ptr(),
                                                  bn_, C, h * w, _stream()), "bn_relu_tokens")
+        if self.cross_attend.precision == "f16" and C % 64 == 0:
+            return _linear_f16(tok.reshape(-1, C), seq[2].weight, None, residual=residual, out_f32=True)
         return _linear(tok.reshape(-1, C), seq[2].weight, None, residual=residual)
 
     def forward(self, x, bev, feature, I_inv, E_inv):
