@@ -120,7 +120,7 @@ __device__ __forceinline__ int conv_row_channel(int rho) {
 }
 
 template <typename T, int CBN, int CBM>
-__global__ __launch_bounds__(256) void k_conv(ConvParams p) {
+__global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
     constexpr int BK = ConvCfg<T>::BK, LS = ConvCfg<T>::LS;
     constexpr int MI = CBM / 64;         // 32-pixel MFMA tiles per wave (pixel tile of 128 or, for small maps, 64)
     constexpr int RPT = CBM / 32;        // staged A rows per thread (8 chunks per row)
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
     // global -> registers (the next K slab is fetched while the current one is multiplied), registers -> LDS
     using Vec = typename std::conditional<sizeof(T) == 2, half8, float4v>::type;   // 16 bytes of a row
     constexpr int VE = 16 / sizeof(T);
-    Vec ra[RPT], rw[RPW];
+    Vec ra[2][RPT], rw[2][RPW];     // two slabs in flight: slab k + 2 is requested while slab k is multiplied
     int s_ky = 0, s_kx = 0, s_ci0 = 0;       // tap and first channel of the next slab to be requested
     unsigned wrow[RPW];                      // byte offset of the weight rows staged by this thread (16-byte piece included)
     bool wvalid[RPW];
@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
     // raw buffer descriptors of the input map and the weight matrix (an offset >= num_records reads as zero)
     const size_t x_bytes = (size_t)p.N * p.H * p.W * p.Cin * sizeof(T) >> (p.up2 ? 2 : 0), w_bytes = (size_t)Ncols * Ktot * sizeof(T);
     const int4v rs_x = conv_rsrc(x, x_bytes), rs_w = conv_rsrc(w, w_bytes);
-    auto load_slab = [&](int k0) {
+    auto load_slab = [&](int k0, auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
         if (p.rowpack) {
             // few-channel stem: k = ky * 32 + px * 4 + ci over rows of 8 pixels x 4 channels, which are contiguous in the
             // physically padded NHWC4 input (no bounds checks; pixel 7 and any row beyond the kernel carry zero weights)
@@ -197,10 +198,10 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
             for (int i = 0; i < RPT; ++i) {
                 const int k = k0 + ((tid + 256 * i) & 7) * VE;
                 const int ky = k >> 5, px = (k & 31) >> 2;
-                ra[i] = (Vec)(T)0;
+                ra[SET][i] = (Vec)(T)0;
                 if (rvalid[i]) {
                     const size_t pix = ((size_t)rn[i] * p.H + roy[i] * p.stride + ky) * p.W + rox[i] * p.stride + px;
-                    ra[i] = *reinterpret_cast<const Vec*>(x + pix * 4);
+                    ra[SET][i] = *reinterpret_cast<const Vec*>(x + pix * 4);
                 }
             }
         } else {
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
                 for (int i = 0; i < RPT; ++i) {
                     const bool ok = rvalid[i] && (unsigned)(riy0[i] + ky) < (unsigned)p.H && (unsigned)(rix0[i] + kx) < (unsigned)p.W;
                     const unsigned off = ok ? (unsigned)(rowoff[i] + toff) * (unsigned)sizeof(T) : 0xffffffffu;
-                    ra[i] = __builtin_bit_cast(Vec, llvm_raw_buffer_load_b128(rs_x, (int)off, 0, 0));
+                    ra[SET][i] = __builtin_bit_cast(Vec, llvm_raw_buffer_load_b128(rs_x, (int)off, 0, 0));
                 }
             } else {
 #pragma unroll
@@ -226,51 +227,61 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
                     // A slab: im2col rows gathered from the NHWC input
                     const int iy = roy[i] * p.stride + ky - p.pad, ix = rox[i] * p.stride + kx - p.pad;
                     const bool ok = rvalid[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                    ra[i] = (Vec)(T)0;
+                    ra[SET][i] = (Vec)(T)0;
                     if (ok) {
                         // up2: logical pixel (iy, ix) of the upsampled map is physical pixel (iy / 2, ix / 2)
                         const size_t pix = ((size_t)rn[i] * (p.H >> 1) + (iy >> 1)) * (p.W >> 1) + (ix >> 1);
-                        ra[i] = *reinterpret_cast<const Vec*>(x + pix * p.Cin + ci0 + kc);
+                        ra[SET][i] = *reinterpret_cast<const Vec*>(x + pix * p.Cin + ci0 + kc);
                     }
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < RPW; ++i)
-            rw[i] = __builtin_bit_cast(Vec, llvm_raw_buffer_load_b128(rs_w, (int)(wvalid[i] ? wrow[i] + (unsigned)k0 * (unsigned)sizeof(T) : 0xffffffffu), 0, 0));
+            rw[SET][i] = __builtin_bit_cast(Vec, llvm_raw_buffer_load_b128(rs_w, (int)(wvalid[i] ? wrow[i] + (unsigned)k0 * (unsigned)sizeof(T) : 0xffffffffu), 0, 0));
     };
-    auto store_slab = [&](int buf) {
+    auto store_slab = [&](int buf, auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * VE;
             if constexpr (sizeof(T) == 2) {
-                *reinterpret_cast<half8*>(As[buf] + row * LS + kc) = ra[i];
+                *reinterpret_cast<half8*>(As[buf] + row * LS + kc) = ra[SET][i];
             } else {
                 float* da = reinterpret_cast<float*>(As[buf]) + row * LS + kc;   // LS = 33 floats: rows are not 16-byte aligned
 #pragma unroll
-                for (int e = 0; e < 4; ++e) da[e] = ra[i][e];
+                for (int e = 0; e < 4; ++e) da[e] = ra[SET][i][e];
             }
         }
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * VE;
             if constexpr (sizeof(T) == 2) {
-                *reinterpret_cast<half8*>(Ws[buf] + row * LS + kc) = rw[i];
+                *reinterpret_cast<half8*>(Ws[buf] + row * LS + kc) = rw[SET][i];
             } else {
                 float* dw = reinterpret_cast<float*>(Ws[buf]) + row * LS + kc;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dw[e] = rw[i][e];
+                for (int e = 0; e < 4; ++e) dw[e] = rw[SET][i][e];
             }
         }
     };
 
-    load_slab(0);
-    store_slab(0);
+    // Software pipeline, two slabs deep in registers (the loop body is written for a fixed slab parity so that register
+    // sets and LDS buffers are static): slab k sits in LDS buffer k & 1; while it is multiplied, slab k + 2 is requested
+    // into register set k & 1 and slab k + 1 - requested one iteration earlier, so it has had a whole slab time to arrive
+    // - goes from set (k + 1) & 1 to the other LDS buffer.  (One slab of lookahead left every iteration waiting for
+    // its global loads.)
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    load_slab(0, I0{});
+    if (BK < Ktot) load_slab(BK, I1{});
+    store_slab(0, I0{});
     __syncthreads();
-    int cur = 0;
-    for (int k0 = 0; k0 < Ktot; k0 += BK, cur ^= 1) {
-        const bool more = k0 + BK < Ktot;
-        if (more) load_slab(k0 + BK);
+    auto body = [&](int k0, auto par_c) {
+        constexpr int PAR = decltype(par_c)::value;
+        using Same = std::integral_constant<int, PAR>;
+        using Other = std::integral_constant<int, 1 - PAR>;
+        if (k0 + 2 * BK < Ktot) load_slab(k0 + 2 * BK, Same{});
         // D[channel][pixel]: the weights are the A operand, so that an accumulator lane owns one output pixel and
         // runs of 4 consecutive channels (vector stores in the epilogue instead of 2-byte ones)
         if constexpr (sizeof(T) == 2) {
@@ -279,10 +290,10 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
                 half8 a[MI], b[NJ];
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
-                    a[i] = *reinterpret_cast<const half8*>(As[cur] + (wm * (CBM / 2) + i * 32 + r) * LS + kk * 16 + hi * 8);
+                    a[i] = *reinterpret_cast<const half8*>(As[PAR] + (wm * (CBM / 2) + i * 32 + r) * LS + kk * 16 + hi * 8);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    b[j] = *reinterpret_cast<const half8*>(Ws[cur] + (wn * (CBN / 2) + j * 32 + r) * LS + kk * 16 + hi * 8);
+                    b[j] = *reinterpret_cast<const half8*>(Ws[PAR] + (wn * (CBN / 2) + j * 32 + r) * LS + kk * 16 + hi * 8);
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -290,8 +301,8 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], a[i], acc[i][j], 0, 0, 0);
             }
         } else {
-            const float* Af = reinterpret_cast<const float*>(As[cur]);
-            const float* Wf = reinterpret_cast<const float*>(Ws[cur]);
+            const float* Af = reinterpret_cast<const float*>(As[PAR]);
+            const float* Wf = reinterpret_cast<const float*>(Ws[PAR]);
 #pragma unroll 4
             for (int kk = 0; kk < BK / 2; ++kk) {
                 float a[MI], b[NJ];
@@ -306,8 +317,12 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
             }
         }
-        if (more) store_slab(cur ^ 1);   // that buffer was last read before the previous barrier
+        if (k0 + BK < Ktot) store_slab(1 - PAR, Other{});   // that buffer was last read before the previous barrier
         __syncthreads();
+    };
+    for (int k0 = 0; k0 < Ktot; k0 += 2 * BK) {
+        body(k0, I0{});
+        if (k0 + BK < Ktot) body(k0 + BK, I1{});
     }
 
     // ---- epilogue: bias (folded BN shift), residual, ReLU, NHWC store with channel offset / deconv scatter ----
