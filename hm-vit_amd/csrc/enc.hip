@@ -404,6 +404,179 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_conv3: 3 x 3 / stride 1 / pad 1 convolutions in f16 (most layers of both backbones).  k_conv fetches every input
+// pixel once per tap, and the bytes it pulls through the texture addresser are what bounds it; here a workgroup owns an
+// 8 x 16 block of output pixels of one image, stages the (8 + 2) x (16 + 2) input patch of a 64-channel slab in LDS ONCE
+// and lets the nine taps read their shifted windows out of it (the MFMA B fragment of pixel (py, px) and tap (ky, kx) is
+// patch row (py + ky) * 18 + px + kx).  Per tap only the 64-deep weight slab travels (double-buffered as in k_conv, one tap
+// ahead in registers); the patch of the next channel slab is requested at tap 0 and stored after tap 8.  Same MFMA
+// tiling (2 x 2 waves, 64 pixels x CBN / 2 channels each), same permuted weight rows and 16-byte epilogue as k_conv.
+// Needs Cin % 64 == 0, Cout % 8 == 0 (vector epilogue), no deconvolution / upsampling.
+// ------------------------------------------------------------------------------------------
+template <int CBN>
+__global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
+    using T = half_t;
+    constexpr int BK = 64, LS = 72, TH = 8, TW = 16, PW = TW + 2, NPIX = (TH + 2) * PW;   // 180 patch pixels
+    constexpr int RPW = CBN / 32, NJ = CBN / 64, MI = 2;
+    constexpr int NPP = (NPIX * 8 + 255) / 256;           // 16-byte patch pieces per thread (6, the last one partial)
+    __shared__ __attribute__((aligned(16))) T Ps[NPIX * LS];
+    __shared__ __attribute__((aligned(16))) T Ws[2][CBN * LS];
+
+    const int Ktot = 9 * p.Cin;
+    const int tiles_n = (p.Cout + CBN - 1) / CBN, tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    int tm = blockIdx.x / tiles_n;
+    const int tn = blockIdx.x - tm * tiles_n, n0 = tn * CBN;
+    const int tx = tm % tiles_x; tm /= tiles_x;
+    const int ty = tm % tiles_y, n = tm / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, hi = lane >> 5;
+    const T* x = reinterpret_cast<const T*>(p.x);
+    const T* w = reinterpret_cast<const T*>(p.w);
+    const int4v rs_x = conv_rsrc(x, (size_t)p.N * p.H * p.W * p.Cin * sizeof(T)), rs_w = conv_rsrc(w, (size_t)p.Cout * Ktot * sizeof(T));
+
+    // patch pieces of this thread: byte offset of (pixel, 16-byte chunk) for channel slab 0, out-of-map pixels read zeros
+    unsigned poff[NPP];
+    int plds[NPP];
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) {
+        const int q = tid + 256 * i, pp = q >> 3, ch = q & 7;
+        const int pr = pp / PW, pc = pp - pr * PW;
+        const int iy = oy0 + pr - 1, ix = ox0 + pc - 1;
+        const bool ok = q < NPIX * 8 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        poff[i] = ok ? (unsigned)(((n * p.H + iy) * p.W + ix) * p.Cin + ch * 8) * 2u : 0xffffffffu;
+        plds[i] = q < NPIX * 8 ? pp * LS + ch * 8 : -1;
+    }
+    unsigned wrow[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int c = tid + 256 * i, row = c >> 3;
+        const int nrow = n0 + (row & ~31) + conv_row_channel(row & 31);
+        wrow[i] = nrow < p.Cout ? (unsigned)(((size_t)nrow * Ktot + (c & 7) * 8) * sizeof(T)) : 0xffffffffu;
+    }
+    // patch row (in halves) of the two 32-pixel tiles of this wave: pixel wm * 64 + i * 32 + r of the 8 x 16 block
+    int pbase[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int pix = wm * 64 + i * 32 + r;
+        pbase[i] = ((pix >> 4) * PW + (pix & 15)) * LS + hi * 8;
+    }
+
+    float16v acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    half8 rp[NPP], rw[RPW];
+    auto load_patch = [&](int ci0) {
+#pragma unroll
+        for (int i = 0; i < NPP; ++i)
+            rp[i] = __builtin_bit_cast(half8, llvm_raw_buffer_load_b128(rs_x, (int)(poff[i] == 0xffffffffu ? poff[i] : poff[i] + (unsigned)ci0 * 2u), 0, 0));
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPP; ++i)
+            if (plds[i] >= 0) *reinterpret_cast<half8*>(Ps + plds[i]) = rp[i];
+    };
+    auto load_w = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+            rw[i] = __builtin_bit_cast(half8, llvm_raw_buffer_load_b128(rs_w, (int)(wrow[i] == 0xffffffffu ? wrow[i] : wrow[i] + (unsigned)k0 * 2u), 0, 0));
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int c = tid + 256 * i;
+            *reinterpret_cast<half8*>(Ws[buf] + (c >> 3) * LS + (c & 7) * 8) = rw[i];
+        }
+    };
+
+    load_patch(0);
+    load_w(0);
+    store_patch();
+    store_w(0);
+    __syncthreads();
+    int cur = 0;
+    for (int ci0 = 0; ci0 < p.Cin; ci0 += BK) {
+        const bool more_slabs = ci0 + BK < p.Cin;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const bool more = tap < 8 || more_slabs;
+            if (tap == 0 && more_slabs) load_patch(ci0 + BK);                     // lands during the nine taps
+            if (more) load_w(tap < 8 ? (tap + 1) * p.Cin + ci0 : ci0 + BK);      // next tap's weight slab
+            const int tapoff = ((tap / 3) * PW + (tap % 3)) * LS;                 // compile-time: the loop is unrolled
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                half8 a[MI], b[NJ];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const half8*>(Ps + pbase[i] + tapoff + kk * 16);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    b[j] = *reinterpret_cast<const half8*>(Ws[cur] + (wn * (CBN / 2) + j * 32 + r) * LS + kk * 16 + hi * 8);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+            }
+            if (more) store_w(cur ^ 1);      // that buffer was last read before the previous barrier
+            __syncthreads();
+            cur ^= 1;
+            if (tap == 8 && more_slabs) {    // every wave is done with the patch: replace it
+                store_patch();
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue (k_conv's vector path): lane (r, hi) owns pixel wm * 64 + i * 32 + r and channels 16 qq + 8 hi .. + 7 ----
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int pix = wm * 64 + i * 32 + r;
+        const int oy = oy0 + (pix >> 4), ox = ox0 + (pix & 15);
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        const size_t opix = ((size_t)n * p.Ho + oy) * p.Wo + ox;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int co = n0 + wn * (CBN / 2) + j * 32 + 16 * qq + 8 * hi;
+                if (co >= p.Cout) continue;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[i][j][8 * qq + e];
+                if (p.bias) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co), b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                }
+                if (p.res) {
+                    const half8 rv = *reinterpret_cast<const half8*>(reinterpret_cast<const T*>(p.res) + opix * p.Cout + co);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                const size_t o = opix * p.y_ctot + p.y_coff + co;
+                if (p.out_f32) {
+                    float* yp = reinterpret_cast<float*>(p.y) + o;
+                    *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+                    half8 h;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = (half_t)v[e];
+                    *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.y) + o) = h;
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // max pooling, NHWC, 8 channels per thread (padding never wins: torch pads with -inf)
 // ------------------------------------------------------------------------------------------
 template <typename T>
@@ -459,6 +632,19 @@ int launch_conv(const ConvParams& p, int precision, hipStream_t st) {
     const int M = p.N * p.Ho * p.Wo;
     const int Ncols = p.deconv_s ? p.deconv_s * p.deconv_s * p.Cout : p.Cout;
     const bool narrow = Ncols <= 64;
+    // 3 x 3 / stride 1 / pad 1 in f16: the patch-in-LDS kernel (one fetch per input pixel and channel slab instead of nine)
+    if (precision != HMVIT_PREC_F32 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && !p.deconv_s && !p.up2 && !p.rowpack &&
+        p.Cin % 64 == 0 && p.Cout % 8 == 0 && p.y_coff % 8 == 0 && p.y_ctot % 8 == 0 && p.Ho == p.H && p.Wo == p.W &&
+        !getenv("HMVIT_CONV_NO_PATCH")) {
+        const int tiles = p.N * cdiv(p.Ho, 8) * cdiv(p.Wo, 16);
+        if (tiles * cdiv(p.Cout, narrow ? 64 : 128) >= 256) {       // enough workgroups to cover the CUs
+            dim3 grid3(tiles * cdiv(p.Cout, narrow ? 64 : 128));
+            if (narrow) hipLaunchKernelGGL((k_conv3<64>), grid3, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((k_conv3<128>), grid3, dim3(256), 0, st, p);
+            HMVIT_CHECK_LAUNCH();
+            return HMVIT_OK;
+        }
+    }
     // small maps (the deep ResNet layers on 16 x 16 features): 64-pixel tiles, or the launch would not cover the CUs
     const bool small = cdiv(M, 128) * cdiv(Ncols, narrow ? 64 : 128) < 256;
     dim3 grid(cdiv(M, small ? 64 : 128) * cdiv(Ncols, narrow ? 64 : 128)), block(256);

@@ -161,3 +161,39 @@ def test_pointpillar_random_sweep_vs_oracle(seed):
         y = net(batch).cpu()
         assert y.shape == ref.shape
         assert rel_max_err(y, ref) < TOL[precision], (precision, nx, ny, n_agents)
+
+
+@pytest.mark.parametrize("N,cin,cout,H,W,res,out_f32", [(5, 128, 256, 44, 75, True, False), (8, 64, 64, 64, 66, False, False),
+                                                        (6, 192, 136, 40, 48, False, True), (6, 192, 136, 40, 48, True, False)])
+def test_conv3x3_patch_kernel(N, cin, cout, H, W, res, out_f32):
+    """The 3 x 3 / stride 1 / pad 1 f16 path (k_conv3: input patch staged in LDS once per channel slab) at sizes with ragged
+    tiles (H, W not multiples of 8 / 16, Cout not a multiple of the channel tile), with and without the residual operand and
+    the f32 output, against torch on the same f16 operands; and identical to the generic kernel's result."""
+    import os
+    from hmvit_amd import _lib
+    torch.manual_seed(N * cin + cout)
+    x = torch.randn(N, cin, H, W, device="cuda").half()
+    w = (torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5).half()
+    b = torch.randn(cout, device="cuda")
+    r = torch.randn(N, cout, H, W, device="cuda").half() if res else None
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    if res:
+        ref = ref + r.double()
+    ref = F.relu(ref)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    wn = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    rn = r.permute(0, 2, 3, 1).contiguous() if res else None
+
+    def run():
+        y = torch.empty(N, H, W, cout, device="cuda", dtype=torch.float32 if out_f32 else torch.float16)
+        _lib.check(_lib.lib.hmvit_conv2d_ex(xn.data_ptr(), wn.data_ptr(), b.data_ptr(), rn.data_ptr() if res else None, y.data_ptr(), N, H, W,
+                                            cin, cout, 3, 1, 1, 1, 0, 1 if out_f32 else 0, _lib.PREC_F16, _stream()), "conv2d_ex")
+        return y
+    y = run()
+    assert rel_max_err(y.permute(0, 3, 1, 2).double(), ref) < (2e-4 if out_f32 else 1.5e-3)
+    os.environ["HMVIT_CONV_NO_PATCH"] = "1"
+    try:
+        y_generic = run()
+    finally:
+        del os.environ["HMVIT_CONV_NO_PATCH"]
+    assert rel_max_err(y.double(), y_generic.double()) < 1e-3      # same products, different summation order per tap
