@@ -411,7 +411,8 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
 // patch row (py + ky) * 18 + px + kx).  Per tap only the 64-deep weight slab travels (double-buffered as in k_conv, one tap
 // ahead in registers); the patch of the next channel slab is requested at tap 0 and stored after tap 8.  Same MFMA
 // tiling (2 x 2 waves, 64 pixels x CBN / 2 channels each), same permuted weight rows and 16-byte epilogue as k_conv.
-// Needs Cin % 64 == 0, Cout % 8 == 0 (vector epilogue), no deconvolution / upsampling.
+// Needs Cin % 64 == 0, Cout % 8 == 0 (vector epilogue), no deconvolution; the decoder's nearest x2 upsampling of the input
+// is an addressing mode of the patch gather.
 // ------------------------------------------------------------------------------------------
 template <int CBN>
 __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, hi = lane >> 5;
     const T* x = reinterpret_cast<const T*>(p.x);
     const T* w = reinterpret_cast<const T*>(p.w);
-    const int4v rs_x = conv_rsrc(x, (size_t)p.N * p.H * p.W * p.Cin * sizeof(T)), rs_w = conv_rsrc(w, (size_t)p.Cout * Ktot * sizeof(T));
+    const int4v rs_x = conv_rsrc(x, (size_t)p.N * p.H * p.W * p.Cin * sizeof(T) >> (p.up2 ? 2 : 0)), rs_w = conv_rsrc(w, (size_t)p.Cout * Ktot * sizeof(T));
 
     // patch pieces of this thread: byte offset of (pixel, 16-byte chunk) for channel slab 0, out-of-map pixels read zeros
     unsigned poff[NPP];
@@ -444,7 +445,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
         const int pr = pp / PW, pc = pp - pr * PW;
         const int iy = oy0 + pr - 1, ix = ox0 + pc - 1;
         const bool ok = q < NPIX * 8 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        poff[i] = ok ? (unsigned)(((n * p.H + iy) * p.W + ix) * p.Cin + ch * 8) * 2u : 0xffffffffu;
+        // up2: logical pixel (iy, ix) of the nearest-upsampled map is physical pixel (iy / 2, ix / 2) of the half-size input
+        const int pixel = p.up2 ? (n * (p.H >> 1) + (iy >> 1)) * (p.W >> 1) + (ix >> 1) : (n * p.H + iy) * p.W + ix;
+        poff[i] = ok ? (unsigned)(pixel * p.Cin + ch * 8) * 2u : 0xffffffffu;
         plds[i] = q < NPIX * 8 ? pp * LS + ch * 8 : -1;
     }
     unsigned wrow[RPW];
@@ -633,7 +636,7 @@ int launch_conv(const ConvParams& p, int precision, hipStream_t st) {
     const int Ncols = p.deconv_s ? p.deconv_s * p.deconv_s * p.Cout : p.Cout;
     const bool narrow = Ncols <= 64;
     // 3 x 3 / stride 1 / pad 1 in f16: the patch-in-LDS kernel (one fetch per input pixel and channel slab instead of nine)
-    if (precision != HMVIT_PREC_F32 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && !p.deconv_s && !p.up2 && !p.rowpack &&
+    if (precision != HMVIT_PREC_F32 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && !p.deconv_s && !p.rowpack &&
         p.Cin % 64 == 0 && p.Cout % 8 == 0 && p.y_coff % 8 == 0 && p.y_ctot % 8 == 0 && p.Ho == p.H && p.Wo == p.W &&
         !getenv("HMVIT_CONV_NO_PATCH")) {
         const int tiles = p.N * cdiv(p.Ho, 8) * cdiv(p.Wo, 16);

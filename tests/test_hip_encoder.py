@@ -197,3 +197,31 @@ def test_conv3x3_patch_kernel(N, cin, cout, H, W, res, out_f32):
     finally:
         del os.environ["HMVIT_CONV_NO_PATCH"]
     assert rel_max_err(y.double(), y_generic.double()) < 1e-3      # same products, different summation order per tap
+
+
+def test_conv3x3_patch_kernel_upsampled_input():
+    """Same kernel with the decoder's operand mode: the input is the nearest x2 upsampling of a half-size map."""
+    import os
+    from hmvit_amd import _lib
+    torch.manual_seed(5)
+    N, cin, cout, h, w_ = 6, 128, 128, 21, 40                     # logical (upsampled) size 42 x 80
+    x = torch.randn(N, cin, h, w_, device="cuda").half()
+    w = (torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5).half()
+    b = torch.randn(cout, device="cuda")
+    ref = F.relu(F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w.double(), b.double(), 1, 1))
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    wn = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+
+    def run():
+        y = torch.empty(N, 2 * h, 2 * w_, cout, device="cuda", dtype=torch.float16)
+        _lib.check(_lib.lib.hmvit_conv2d_ex(xn.data_ptr(), wn.data_ptr(), b.data_ptr(), None, y.data_ptr(), N, 2 * h, 2 * w_, cin, cout, 3, 1, 1,
+                                            1, 1, 0, _lib.PREC_F16, _stream()), "conv2d_ex")
+        return y
+    y = run()
+    assert rel_max_err(y.permute(0, 3, 1, 2).double(), ref) < 1.5e-3
+    os.environ["HMVIT_CONV_NO_PATCH"] = "1"
+    try:
+        y_generic = run()
+    finally:
+        del os.environ["HMVIT_CONV_NO_PATCH"]
+    assert rel_max_err(y.double(), y_generic.double()) < 1e-3
