@@ -635,6 +635,12 @@ int launch_conv(const ConvParams& p, int precision, hipStream_t st) {
     const int M = p.N * p.Ho * p.Wo;
     const int Ncols = p.deconv_s ? p.deconv_s * p.deconv_s * p.Cout : p.Cout;
     const bool narrow = Ncols <= 64;
+    {   // the gathers address the input and the weights with 32-bit byte offsets (buffer loads)
+        const size_t es = precision == HMVIT_PREC_F32 ? 4 : 2;
+        const size_t xb = (size_t)p.N * p.H * p.W * p.Cin * es, wb = (size_t)Ncols * (p.rowpack ? p.KH * 32 : p.KH * p.KW * p.Cin) * es;
+        HMVIT_CHECK_ARG(xb < 0xfffffff0ull && wb < 0xfffffff0ull, "conv: input (%zu bytes) or weights (%zu bytes) exceed the 4 GB a launch can address",
+                        xb, wb);
+    }
     // 3 x 3 / stride 1 / pad 1 in f16: the patch-in-LDS kernel (one fetch per input pixel and channel slab instead of nine)
     if (precision != HMVIT_PREC_F32 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && !p.deconv_s && !p.rowpack &&
         p.Cin % 64 == 0 && p.Cout % 8 == 0 && p.y_coff % 8 == 0 && p.y_ctot % 8 == 0 && p.Ho == p.H && p.Wo == p.W &&
