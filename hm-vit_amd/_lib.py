@@ -14,7 +14,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMVIT_LIB", os.path.join(_HERE, "libhmvit.so"))   # HMVIT_LIB: ablation builds of tools/probe
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 PREC_F32, PREC_F16 = 0, 1
 PART_WINDOW, PART_GRID = 0, 1
 NUM_TYPES = 2
@@ -73,7 +73,8 @@ _SIGNATURES = {
                                     C.c_int, C.c_int, C.c_void_p]),
     "hmvit_window_attention": (C.c_int, [C.c_void_p] * 6 + [c_i32p, c_i32p, c_i32p, C.c_void_p] +
                                [C.c_int] * 12 + [C.c_void_p]),
-    "hmvit_pfn_scatter": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, C.c_void_p]),
+    "hmvit_pfn_scatter": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, c_f32p, c_f32p, C.c_int,
+                                    C.c_void_p]),
     "hmvit_conv2d": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 14 + [C.c_void_p]),
     "hmvit_box_decode": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int] + [C.c_void_p] * 4 +
                          [C.c_int, C.c_void_p]),

@@ -812,14 +812,15 @@ int hmvit_window_attention(const void* q, const void* kv, const float* b_q, cons
 }
 
 int hmvit_pfn_scatter(const float* voxels, const int32_t* coords, const int32_t* num_points, const float* w,
-                      const float* shift, void* canvas, float* pillar_out, int n_pillars, int nx, int ny,
-                      const float* voxel_size, const float* lidar_range, int precision, void* stream) {
+                      const float* shift, void* canvas, float* pillar_out, int n_pillars, int nx, int ny, int n_agents,
+                      int32_t* oob_count, const float* voxel_size, const float* lidar_range, int precision, void* stream) {
     HMVIT_CHECK_ARG(voxels && coords && num_points && w && shift && (canvas || pillar_out) && voxel_size && lidar_range,
                     "pfn_scatter: null pointer");
-    HMVIT_CHECK_ARG(n_pillars >= 0 && nx > 0 && ny > 0, "pfn_scatter: bad sizes");
+    HMVIT_CHECK_ARG(n_pillars >= 0 && nx > 0 && ny > 0 && n_agents > 0, "pfn_scatter: bad sizes");
     PfnParams p;
     p.voxels = voxels; p.coords = coords; p.num_points = num_points; p.w = w; p.shift = shift;
     p.canvas = canvas; p.pillar_out = pillar_out; p.n_pillars = n_pillars; p.nx = nx; p.ny = ny;
+    p.n_agents = n_agents; p.oob_count = oob_count;
     p.vx = voxel_size[0]; p.vy = voxel_size[1]; p.vz = voxel_size[2];
     p.x_off = voxel_size[0] / 2 + lidar_range[0];
     p.y_off = voxel_size[1] / 2 + lidar_range[1];

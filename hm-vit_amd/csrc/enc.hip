@@ -65,7 +65,12 @@ __global__ __launch_bounds__(256) void k_pfn_scatter(PfnParams p) {
         best = fmaxf(best, acc + shift);
     }
     if (p.pillar_out) p.pillar_out[(size_t)v * 64 + lane] = best;
-    if (p.canvas) {
+    // the reference's indexed scatter raises on an index outside the canvas (point_pillar_scatter.py:30-40); here such a
+    // pillar is dropped and counted (a stale agent index or a coordinate outside the grid must not write out of bounds)
+    const bool inside = (unsigned)co.x < (unsigned)p.n_agents && (unsigned)co.z < (unsigned)p.ny &&
+                        (unsigned)co.w < (unsigned)p.nx && co.y == 0;
+    if (!inside && p.oob_count && lane == 0) atomicAdd(p.oob_count, 1);
+    if (p.canvas && inside) {
         const size_t cell = ((size_t)co.x * p.ny + co.z) * p.nx + co.w + co.y;   // index z + y * nx + x
         reinterpret_cast<TO*>(p.canvas)[cell * 64 + lane] = (TO)best;
     }

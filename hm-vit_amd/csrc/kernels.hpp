@@ -103,6 +103,8 @@ struct PfnParams {
     void* canvas;             // (n_agents, ny, nx, 64) NHWC, zero-filled by the caller; may be null
     float* pillar_out;        // (Nv, 64) f32 or null
     int n_pillars, nx, ny;
+    int n_agents;             // canvas planes: pillars whose agent / y / x index is out of range are dropped
+    int* oob_count;           // device counter of dropped pillars, may be null
     float vx, vy, vz, x_off, y_off, z_off;
 };
 int launch_pfn_scatter(const PfnParams& p, int precision, hipStream_t st);

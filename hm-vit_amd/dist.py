@@ -21,7 +21,15 @@ def max_over_ranks(seconds: float, device=None) -> float:
     return float(t.item())
 
 
-def aggregate_throughput(units_per_rank: int, seconds: float, device=None) -> float:
-    """Whole-job units/s = units processed by all ranks / slowest rank's time."""
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-    return world * units_per_rank / max_over_ranks(seconds, device)
+def sum_over_ranks(value: float, device=None) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def aggregate_throughput(units_this_rank: int, seconds: float, device=None) -> float:
+    """Whole-job units/s = units processed by ALL ranks (summed: round-robin shards are unequal when the scene count is not
+    a multiple of the world size) / the slowest rank's time."""
+    return sum_over_ranks(float(units_this_rank), device) / max_over_ranks(seconds, device)

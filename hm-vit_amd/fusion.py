@@ -108,19 +108,23 @@ class _FusionBase(nn.Module):
         self._folded = None
         self._folded_key = None
         self._workspace = None
-        self._host_cache: Dict[str, tuple] = {}
 
-    # -- host copies of the small integer inputs (one sync unless cached / already on CPU) --
-    def _host_ints(self, name: str, t: torch.Tensor):
-        if t.device.type == "cpu":
-            return [int(v) for v in t.reshape(-1).tolist()]
-        key = (t.data_ptr(), t._version, tuple(t.shape))
-        hit = self._host_cache.get(name)
-        if hit is not None and hit[0] == key:
-            return hit[1]
-        vals = [int(v) for v in t.reshape(-1).tolist()]
-        self._host_cache[name] = (key, vals)
-        return vals
+    # -- host copies of the small integer inputs --
+    @staticmethod
+    def _host_small(mode, record_len, mask):
+        """mode / record_len / mask as Python ints.  They drive the launch plan (weight pointers per agent type, loop
+        bounds), so they are needed on the host: CPU tensors / lists cost nothing, device tensors are read back with ONE
+        combined copy per forward (the reference reads them back element by element, hetero_fusion.py:127-131).  Nothing is
+        cached across calls: a data loader hands over a fresh tensor per frame and the caching allocator reuses addresses,
+        so identity is not content."""
+        ts = [t if torch.is_tensor(t) else torch.as_tensor(t) for t in (mode, record_len, mask)]
+        if any(t.device.type != "cpu" for t in ts):
+            dev = next(t.device for t in ts if t.device.type != "cpu")
+            flat = torch.cat([t.to(dev).reshape(-1).to(torch.int64) for t in ts]).cpu().tolist()
+        else:
+            flat = torch.cat([t.reshape(-1).to(torch.int64) for t in ts]).tolist()
+        n0, n1 = ts[0].numel(), ts[1].numel()
+        return [int(v) for v in flat[:n0]], [int(v) for v in flat[n0:n0 + n1]], [int(v) for v in flat[n0 + n1:]]
 
     def _weights(self, device, prec: int):
         params = list(self.parameters()) + list(self.buffers())
@@ -151,15 +155,17 @@ class _FusionBase(nn.Module):
             raise RuntimeError("hm-vit_amd runs on the GPU only (HIP kernels, no CPU fallback)")
         if x.dim() != 5:
             raise ValueError("x must be (B, L, C, H, W)")
+        if self.training or (torch.is_grad_enabled() and x.requires_grad):
+            # no silent detach: a training loop must not get a frozen fusion net without an error
+            raise RuntimeError("hmvit_amd.HeteroFusion: this call needs gradients / training-mode dropout, which the fused "
+                               "inference launch does not provide; call .eval() and run under torch.no_grad()")
         B, L, Cc, H, W = x.shape
         prec = _PRECISIONS[self.precision]
         x = x.detach().to(torch.float32).contiguous()
         pw = pairwise_t_matrix.detach().to(device=x.device, dtype=torch.float32).contiguous()
         if tuple(pw.shape) != (B, L, L, 4, 4):
             raise ValueError(f"pairwise_t_matrix must be {(B, L, L, 4, 4)}, got {tuple(pw.shape)}")
-        mode_h = self._host_ints("mode", mode)
-        rl_h = self._host_ints("record_len", record_len)
-        mask_h = self._host_ints("mask", mask)
+        mode_h, rl_h, mask_h = self._host_small(mode, record_len, mask)
         if len(mode_h) != B * L or len(mask_h) != B * L or len(rl_h) != B:
             raise ValueError("mode / mask must be (B, L) and record_len (B,)")
 

@@ -50,7 +50,6 @@ class BevformerPointPillarHetero(nn.Module):
         self.lidar_encoder.set_return_features()
         if self.camera_encoder is not None:
             self.camera_encoder.set_return_features()
-        self._host_key, self._host_val = None, None
         self.use_hetero_decoder = "hetero_decoder" in config
         if not self.use_hetero_decoder:
             raise NotImplementedError("only the hetero_decoder tail of the shipped yaml is built")
@@ -86,13 +85,17 @@ class BevformerPointPillarHetero(nn.Module):
                 "n_agents": int(is_lidar.sum())}
 
     def forward(self, batch):
-        # mode / record_len are needed on the host (regrouping, kernel descriptors): one read-back per distinct tensor,
-        # remembered by identity so that a loop over the same batch does not synchronise the device every forward
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device)) for t in (batch["mode"], batch["record_len"]))
-        if self._host_key != key:
-            self._host_key = key
-            self._host_val = (batch["mode"].to(torch.int).cpu(), batch["record_len"].cpu())
-        mode, record_len = self._host_val
+        # mode / record_len are needed on the host (regrouping, kernel descriptors): ONE combined read-back per forward (the
+        # reference synchronises per agent, bevformer_point_pillar_hetero.py:97-112); no caching by tensor identity -- a
+        # loader's fresh tensors reuse addresses.  The host copies are handed down, so the fusion does not read back again.
+        m_t, r_t = batch["mode"], batch["record_len"]
+        if m_t.device.type != "cpu" or r_t.device.type != "cpu":
+            dev = m_t.device if m_t.device.type != "cpu" else r_t.device
+            flat = torch.cat([m_t.to(dev).reshape(-1).to(torch.int64), r_t.to(dev).reshape(-1).to(torch.int64)]).cpu()
+            mode = flat[:m_t.numel()].reshape(m_t.shape).to(torch.int)
+            record_len = flat[m_t.numel():].reshape(r_t.shape)
+        else:
+            mode, record_len = m_t.to(torch.int), r_t.to(torch.int64)
         rl = [int(v) for v in record_len.tolist()]
         pairwise_t_matrix = batch["pairwise_t_matrix"]
         max_cav = mode.shape[1]

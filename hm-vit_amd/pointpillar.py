@@ -94,6 +94,7 @@ class PointPillar(nn.Module):
         self.precision = precision
         self._prep = None
         self._prep_key = None
+        self.oob_count = None      # device counter of pillars dropped because their indices fall outside the canvas
 
     def set_return_features(self):
         self.return_features = True
@@ -171,6 +172,9 @@ class PointPillar(nn.Module):
         prep = self._prepare(dev, prec)
         nx, ny, nz = [int(v) for v in self.scatter_cfg["grid_size"]]
         assert nz == 1
+        if vf.dim() != 3 or tuple(vf.shape[1:]) != (32, 4) or vc.dim() != 2 or vc.shape[1] != 4 or vn.shape[0] != vf.shape[0]:
+            raise ValueError(f"voxel_features must be (Nv, 32, 4), voxel_coords (Nv, 4) [agent, z, y, x] and voxel_num_points "
+                             f"(Nv,); got {tuple(vf.shape)}, {tuple(vc.shape)}, {tuple(vn.shape)}")
         vf = vf.detach().float().contiguous()
         vc = vc.detach().to(torch.int32).contiguous()
         vn = vn.detach().to(torch.int32).contiguous()
@@ -180,11 +184,16 @@ class PointPillar(nn.Module):
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         with torch.cuda.device(dev):
             canvas = torch.zeros(n_agents, ny, nx, 64, device=dev, dtype=dt)
+            # pillars outside the canvas (bad agent index / coordinates) are dropped and counted here instead of raising like
+            # the reference's indexed scatter (reading the counter is a device synchronisation: the caller's choice)
+            if self.oob_count is None or self.oob_count.device != dev:
+                self.oob_count = torch.zeros(1, dtype=torch.int32, device=dev)
             vs = (ctypes.c_float * 3)(*[float(v) for v in self.args["voxel_size"]])
             rng = (ctypes.c_float * 6)(*[float(v) for v in self.args["lidar_range"]])
             _lib.check(_lib.lib.hmvit_pfn_scatter(vf.data_ptr(), vc.data_ptr(), vn.data_ptr(), prep["pfn_w"].data_ptr(),
                                                   prep["pfn_shift"].data_ptr(), canvas.data_ptr(), None, vf.shape[0], nx,
-                                                  ny, vs, rng, prec, stream), "hmvit_pfn_scatter")
+                                                  ny, n_agents, self.oob_count.data_ptr(), vs, rng, prec, stream),
+                       "hmvit_pfn_scatter")
             x, H, W = canvas, ny, nx
             cat = None
             ctot = sum(d["cout"] for d in prep["deblocks"])

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HMVIT_ABI_VERSION 5
+#define HMVIT_ABI_VERSION 6
 
 #define HMVIT_OK 0
 #define HMVIT_EINVAL (-22)   /* bad argument / unsupported shape */
@@ -228,10 +228,13 @@ int hmvit_window_attention(const void* q, const void* kv, const float* b_q, cons
  *   (eval-mode BatchNorm1d, eps 1e-3);
  *   canvas (n_agents, ny, nx, 64) NHWC in the precision's element type, ZERO-FILLED by the caller
  *   (index z + y * nx + x), may be NULL; pillar_out (Nv, 64) f32, may be NULL;
- *   voxel_size / lidar_range: host arrays of 3 / 6 floats. */
+ *   voxel_size / lidar_range: host arrays of 3 / 6 floats.  The voxel layout is fixed at 32 points x 4 features
+ *   (max_points_per_voxel of the shipped yaml).  A pillar whose agent index is not in [0, n_agents), whose y / x lies
+ *   outside the grid or whose z is not 0 is dropped (the reference's indexed scatter raises there) and counted in the
+ *   device counter oob_count (may be NULL). */
 int hmvit_pfn_scatter(const float* voxels, const int32_t* coords, const int32_t* num_points, const float* w,
-                      const float* shift, void* canvas, float* pillar_out, int n_pillars, int nx, int ny,
-                      const float* voxel_size, const float* lidar_range, int precision, void* stream);
+                      const float* shift, void* canvas, float* pillar_out, int n_pillars, int nx, int ny, int n_agents,
+                      int32_t* oob_count, const float* voxel_size, const float* lidar_range, int precision, void* stream);
 
 /* nn.Conv2d (square kernel) or nn.ConvTranspose2d (kernel = stride = deconv_stride) + bias + ReLU on
  * NHWC maps as an MFMA implicit GEMM: the layers of BaseBEVBackbone with eval-mode BatchNorm2d

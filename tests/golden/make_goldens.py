@@ -15,6 +15,11 @@ What is frozen:
   g5_fusion_ragged.npz  HeteroFusion, B=2, record_len=[3,2], C=64, 16x16, window 4.
   g6_fusion_cfg1.npz    HeteroFusion at BASELINE configs[0]: 2 LiDAR agents, 100x352, C=64,
                         window 4 -- output sub-sampled (every 5th row / 11th col) + moments.
+  g12_fusion_cfg2.npz   HeteroFusion at BASELINE configs[1] FULL SIZE: 5 LiDAR agents (modes 11111), 200x704, C=256,
+                        window 8, 2 iters, 0.4 m/px, poses of SURVEY 8(d) -- output sub-sampled (every 8th row + row
+                        offset 3 / every 16th col + col offset 5) + the first and last full rows + per-channel moments.
+                        ~2.5 min and ~16 GB on 8 cores.
+  g13_fusion_cfg3.npz   same at configs[2]'s type pattern 10110 (mixed camera / LiDAR agent types).
   g7_pointpillar.npz    PointPillar.forward (features only, eval BN): 2 agents x 400 pillars on a
                         64x48 canvas; PFN output + (2, 256, 12, 16) BEV features.
   g8_decoder.npz        HeteroDecoder.forward (no upsample), 3 samples with ego types 1,0,1, 12x10.
@@ -200,6 +205,31 @@ def g6_fusion_cfg1():
          abs_max=y64.abs().max())
 
 
+def _fusion_full_size(name, modes, seed_w, seed_x):
+    """HeteroFusion of the reference at the headline size (BASELINE configs[1] / [2])."""
+    import time
+    cfg = O.make_config(256, 8, 5, voxel=0.4, downsample=1)
+    sd = O.random_state_dict(cfg, seed=seed_w)
+    kw = dict(L=5, C=256, H=200, W=704, modes=modes, seed=seed_x)
+    net, (x, pw, mode, rl, mask) = _run_fusion(cfg, sd, kw)
+    t0 = time.time()
+    y = net(x, pw, mode, rl, mask)
+    print(f"{name}: reference forward {time.time() - t0:.1f} s on {torch.get_num_threads()} threads")
+    y64 = y.double()
+    save(name, cfg=cfg, seed_weights=seed_w, scene=kw,
+         out_sub=y[:, :, 3::8, 5::16].contiguous(), out_rows=y[:, :, [0, 199], :].contiguous(),
+         chan_mean=y64.mean((0, 2, 3)), chan_absmean=y64.abs().mean((0, 2, 3)),
+         chan_sqmean=(y64 * y64).mean((0, 2, 3)), abs_max=y64.abs().max())
+
+
+def g12_fusion_cfg2():
+    _fusion_full_size("g12_fusion_cfg2.npz", [1, 1, 1, 1, 1], 121, 1)
+
+
+def g13_fusion_cfg3():
+    _fusion_full_size("g13_fusion_cfg3.npz", [1, 0, 1, 1, 0], 131, 2)
+
+
 def g7_pointpillar():
     """PointPillar.forward (return_features), eval-mode BN with non-trivial running stats:
     2 agents x 400 pillars on a 64 x 48 canvas -> (2, 256, 12, 16); also the PFN output."""
@@ -327,6 +357,12 @@ def g11_cross_view():
 if __name__ == "__main__":
     if "g11" in sys.argv[1:]:
         g11_cross_view()
+        sys.exit(0)
+    if "g12" in sys.argv[1:]:
+        g12_fusion_cfg2()
+        sys.exit(0)
+    if "g13" in sys.argv[1:]:
+        g13_fusion_cfg3()
         sys.exit(0)
     if "g10" in sys.argv[1:]:
         g10_postprocess()

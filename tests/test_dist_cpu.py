@@ -27,7 +27,7 @@ def _worker(rank, world, port, out):
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
     t = d.max_over_ranks(1.0 + rank)              # rank 1 is the slow one
-    thr = d.aggregate_throughput(10, 1.0 + rank)
+    thr = d.aggregate_throughput(len(mine), 1.0 + rank)   # 4 + 3 scenes
     dist.barrier()
     if rank == 0:
         out.put((gathered, t, thr))
@@ -48,4 +48,41 @@ def test_two_rank_sharding_and_max_time():
     assert sorted(gathered[0] + gathered[1]) == list(range(7))
     assert not set(gathered[0]) & set(gathered[1])
     assert t == 2.0
-    assert abs(thr - 2 * 10 / 2.0) < 1e-12
+    assert abs(thr - 7 / 2.0) < 1e-12
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher must start both ranks itself (fresh child processes) and print ONE
+    JSON line from rank 0 with n_gpus = 2 -- the command the round-end driver may use.  CPU stand-in workload over gloo:
+    this exercises bench.py's own spawn / rendezvous / barrier / max-over-ranks path, not the kernels."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--backend", "gloo", "--stub"], env=env, capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["scaling"] == "weak"
+    assert r["value"] > 0 and abs(r["value"] - 2 * 3 / (r["ms_per_step"] * 3e-3)) / r["value"] < 1e-6
+
+
+def test_bench_under_a_launcher_environment():
+    """The torch.distributed.run contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, no self-spawn."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                                       "--backend", "gloo", "--stub"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][1].decode()[-2000:]
+    assert json.loads(outs[0][0].decode().strip().splitlines()[-1])["n_gpus"] == 2
+    assert not [l for l in outs[1][0].decode().splitlines() if l.startswith("{")]   # only rank 0 reports

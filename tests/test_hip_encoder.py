@@ -40,10 +40,56 @@ def test_pfn_matches_golden():
     vs = (ctypes.c_float * 3)(*args["voxel_size"])
     rng = (ctypes.c_float * 6)(*args["lidar_range"])
     _lib.check(_lib.lib.hmvit_pfn_scatter(vf.data_ptr(), vc.data_ptr(), vn.data_ptr(), w.data_ptr(), shift.data_ptr(),
-                                          canvas.data_ptr(), out.data_ptr(), vf.shape[0], nx, ny, vs, rng, 0, _stream()), "pfn")
+                                          canvas.data_ptr(), out.data_ptr(), vf.shape[0], nx, ny, 2, None, vs, rng, 0, _stream()),
+               "pfn")
     assert rel_max_err(out.cpu(), g["pillar_features"]) < 1e-5
     ref = PO.scatter(g["pillar_features"], vc.cpu(), 2, ny, nx)                 # (2, 64, ny, nx)
     assert rel_max_err(canvas.permute(0, 3, 1, 2).cpu(), ref) < 1e-5
+
+
+def test_pfn_scatter_drops_out_of_range_pillars():
+    """an agent index >= n_agents or a coordinate outside the grid must not write out of bounds; such pillars
+    are dropped and counted (the reference's indexed scatter raises, point_pillar_scatter.py:30-40)."""
+    from hmvit_amd import _lib
+    g, args, sd, (vf, vc, vn) = _golden_inputs()
+    nx, ny = [int(v) for v in g["grid"]]
+    vc = vc.clone()
+    bad = [3, 17, 101, 250]
+    vc[bad[0], 0] = 2          # agent index beyond the canvas planes
+    vc[bad[1], 2] = ny         # y outside
+    vc[bad[2], 3] = -1         # x outside
+    vc[bad[3], 0] = 1 << 20
+    w = torch.randn(64, 10).cuda()
+    shift = torch.randn(64).cuda()
+    # guard planes around the canvas: any out-of-bounds write of a near miss lands in them
+    buf = torch.zeros(4, ny, nx, 64, device="cuda")
+    canvas = buf[1:3]
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    vs = (ctypes.c_float * 3)(*args["voxel_size"])
+    rng = (ctypes.c_float * 6)(*args["lidar_range"])
+    vf, vcd, vn = vf.cuda(), vc.cuda(), vn.cuda()
+    _lib.check(_lib.lib.hmvit_pfn_scatter(vf.data_ptr(), vcd.data_ptr(), vn.data_ptr(), w.data_ptr(), shift.data_ptr(),
+                                          canvas.data_ptr(), None, vf.shape[0], nx, ny, 2, cnt.data_ptr(), vs, rng, 0,
+                                          _stream()), "pfn")
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == len(bad)
+    assert float(buf[0].abs().max()) == 0.0 and float(buf[3].abs().max()) == 0.0
+    good = torch.ones(vc.shape[0], dtype=torch.bool)
+    good[bad] = False
+    occupied = torch.zeros(2, ny, nx, dtype=torch.bool)
+    occupied[vc[good, 0].long(), vc[good, 2].long(), vc[good, 3].long()] = True
+    assert bool(((canvas.abs().sum(-1) > 0).cpu() <= occupied).all())
+
+
+def test_pointpillar_rejects_wrong_voxel_layout():
+    import hmvit_amd
+    args = PO.make_args(64, 48)
+    net = hmvit_amd.PointPillar(args, precision="f32").cuda().eval()
+    net.set_return_features()
+    batch = {"processed_lidar": {"voxel_features": torch.zeros(10, 16, 4).cuda(), "voxel_coords": torch.zeros(10, 4, dtype=torch.int32).cuda(),
+                                 "voxel_num_points": torch.ones(10, dtype=torch.int32).cuda()}}
+    with pytest.raises(ValueError):
+        net(batch)
 
 
 @pytest.mark.parametrize("prec", [0, 1])

@@ -73,6 +73,35 @@ def test_fusion_g6_cfg1_full_size(precision):
     assert float((y.double().mean((0, 2, 3)) - g["chan_mean"]).abs().max()) / scale < TOL[precision]
 
 
+def _check_full_size(g, y, tol):
+    scale = float(g["abs_max"])
+    assert float((y[:, :, 3::8, 5::16] - g["out_sub"]).abs().max()) / scale < tol
+    assert float((y[:, :, [0, 199], :] - g["out_rows"]).abs().max()) / scale < tol
+    y64 = y.double()
+    assert float((y64.mean((0, 2, 3)) - g["chan_mean"]).abs().max()) / scale < tol
+    assert float(((y64 * y64).mean((0, 2, 3)) - g["chan_sqmean"]).abs().max() / g["chan_sqmean"].max()) < 2 * tol
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+@pytest.mark.parametrize("name", ["g12_fusion_cfg2.npz", "g13_fusion_cfg3.npz"])
+def test_fusion_full_size_goldens(precision, name):
+    """BASELINE configs[1] / configs[2] at the HEADLINE size (5 agents, 200x704, C=256, window 8, 0.4 m/px): the
+    reference's own forward (tests/golden/make_goldens.py g12 / g13), sub-sampled + two full rows + channel moments.
+    This is the only place the persistent schedule, the reachability tables and the 32-bit plane offsets are checked
+    at the size bench.py runs."""
+    g = load_golden(name)
+    sd = O.random_state_dict(g["cfg"], g["seed_weights"])
+    net = _fusion(g["cfg"], sd, precision)
+    scene = _cuda(*O.synthetic_scene(**g["scene"]))
+    y = net(*scene).cpu()
+    _check_full_size(g, y, TOL[precision])
+    if precision == "f16":
+        # dead-work elimination (masked key tiles, unreachable windows) is exact at full size too
+        net.skip_masked = False
+        y_dense = net(*scene).cpu()
+        assert torch.equal(y, y_dense)
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16"])
 @pytest.mark.parametrize("modes,n_valid", [([1, 1, 1, 1, 1], 5), ([0, 0, 0, 0, 0], 5), ([0, 1, 1, 0, 1], 4),
                                            ([1, 0, 0, 0, 0], 1)])

@@ -1,6 +1,8 @@
 """The CPU oracle (oracle/hmvit_oracle.py) replayed against golden vectors frozen from the
 imported reference (tests/golden/make_goldens.py).  CPU-only; pins the oracle."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -72,6 +74,19 @@ def test_g6_fusion_cfg1_full_size():
     y64 = y.double()
     assert float((y64.mean((0, 2, 3)) - g["chan_mean"]).abs().max()) < 1e-5
     assert float((y64.abs().mean((0, 2, 3)) - g["chan_absmean"]).abs().max()) < 1e-5
+
+
+@pytest.mark.skipif(not os.environ.get("HMVIT_SLOW"), reason="full-size oracle run: ~3 min and ~20 GB; set HMVIT_SLOW=1")
+@pytest.mark.parametrize("name", ["g12_fusion_cfg2.npz", "g13_fusion_cfg3.npz"])
+def test_full_size_goldens(name):
+    """The oracle against the reference's forward at the headline size (BASELINE configs[1] / [2])."""
+    g = load_golden(name)
+    sd = O.random_state_dict(g["cfg"], g["seed_weights"])
+    y = O.hetero_fusion(*O.synthetic_scene(**g["scene"]), sd, g["cfg"])
+    scale = float(g["abs_max"])
+    assert float((y[:, :, 3::8, 5::16] - g["out_sub"]).abs().max()) / scale < TOL
+    assert float((y[:, :, [0, 199], :] - g["out_rows"]).abs().max()) / scale < TOL
+    assert float((y.double().mean((0, 2, 3)) - g["chan_mean"]).abs().max()) < 1e-5
 
 
 def test_bad_architect_mode_raises():
