@@ -51,6 +51,17 @@ class FusionDesc(C.Structure):
     ]
 
 
+class StageGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "ln_gamma", "ln_beta", "w_q", "b_q", "w_kv", "b_kv", "bias_frag", "w_o", "b_o",
+        "ffn_ln_gamma", "ffn_ln_beta", "w_1", "b_1", "w_2", "b_2")]
+
+
+class FusionTrainDesc(C.Structure):
+    _fields_ = [("fwd", FusionDesc), ("drop_p", C.c_float), ("seed", C.c_uint64), ("saved", C.c_void_p),
+                ("saved_bytes", C.c_size_t), ("bias_frag_neg", C.c_void_p * 2)]
+
+
 class HmvitError(RuntimeError):
     pass
 
@@ -61,6 +72,12 @@ _SIGNATURES = {
     "hmvit_fusion_workspace_bytes": (C.c_size_t, [C.POINTER(FusionDesc)]),
     "hmvit_fusion_forward": (C.c_int, [C.POINTER(FusionDesc), C.c_void_p]),
     "hmvit_fusion_profile": (C.c_int, [C.POINTER(FusionDesc), C.c_void_p, c_f32p, c_i32p]),
+    "hmvit_fusion_train_saved_bytes": (C.c_size_t, [C.POINTER(FusionTrainDesc)]),
+    "hmvit_fusion_backward_workspace_bytes": (C.c_size_t, [C.POINTER(FusionTrainDesc)]),
+    "hmvit_fusion_train_forward": (C.c_int, [C.POINTER(FusionTrainDesc), C.c_void_p]),
+    "hmvit_fusion_backward": (C.c_int, [C.POINTER(FusionTrainDesc), C.c_void_p, C.c_void_p, C.POINTER(StageGrads)] +
+                              [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]),
+    "hmvit_dropout_mask": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_float, C.c_void_p]),
     "hmvit_nchw_to_tokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hmvit_tokens_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hmvit_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p, C.c_void_p, C.c_void_p, C.c_int,

@@ -375,6 +375,11 @@ __global__ __launch_bounds__(HG * 64, (sizeof(T) == 2 ? 2 : 1)) void k_attention
         int row, col;
         token_pixel(p.partition, WIN, X, Y, wx, wy, qt * 16 + lq, row, col);
         const float inv = 1.f / l_run[qt];
+        if constexpr (!F16) {
+            // training: the row's log-sum-exp lets the backward pass rebuild the probabilities (train.hip)
+            if (p.lse && g == 0)
+                p.lse[((size_t)(b * L + ego) * P + row * W + col) * (C / 32) + head] = m_run[qt] + logf(l_run[qt]);
+        }
         T* o = outp + (size_t)(row * W + col) * C + head * 32 + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {

@@ -27,7 +27,7 @@ struct Plan {
     size_t off_xs, off_xn, off_q, off_kv, off_o, off_hid, off_ainv, off_ytok, off_xa, off_xb, off_gap, off_sw, off_vis, off_need, total;
 };
 
-static int check_desc(const HmvitFusionDesc* d) {
+int check_desc(const HmvitFusionDesc* d) {
     HMVIT_CHECK_ARG(d != nullptr, "desc is null");
     HMVIT_CHECK_ARG(d->B > 0 && d->L > 0 && d->L <= HMVIT_MAX_AGENTS, "B=%d L=%d out of range (L <= %d)", d->B,
                     d->L, HMVIT_MAX_AGENTS);

@@ -1,0 +1,586 @@
+// Training entry points of libhmvit: HeteroFusion forward that keeps its activations, and the backward pass
+// (bevformer_point_pillar_hetero.py:39-49 under torch.autograd in the reference's train loop, train_camera.py:163-199).
+//
+// Exact-f32 arithmetic (v_mfma_f32_32x32x2_f32 / 16x16x4_f32), sequential block, apply_head = 1.  The forward runs the
+// f32 pipeline of capi.hip stage by stage into per-stage buffers of the caller's `saved` area; Dropout
+// (hetero_fusion.py:65-66, base_transformer.py:186-192) is a pure function of (seed, salt, element) and is regenerated
+// by the backward pass.  HeteroFusion's last stage computes ego 0 only (its other rows never reach the loss), exactly
+// as the inference path does; the K'/V' of all sources still receive gradients there.
+#include <string.h>
+
+#include <vector>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace hmvit {
+
+#define HMVIT_TRY(expr)                  \
+    do {                                 \
+        int _rc = (expr);                \
+        if (_rc != HMVIT_OK) return _rc; \
+    } while (0)
+
+namespace {
+
+struct StageInfo {
+    bool last;
+    int n_ego, E;
+    int e_of_type[HMVIT_NUM_TYPES], e_type[HMVIT_NUM_TYPES];
+};
+
+struct TrainPlan {
+    int B, L, C, H, W, P, mlp, heads, n_slots, max_cav, E_max, n_stages;
+    size_t A;            // floats of one (n_slots, P, C) activation
+    size_t stage_floats; // floats saved per stage
+    // offsets (floats) inside one stage's record
+    size_t o_x, o_xn, o_q, o_kv, o_o, o_lse, o_x1, o_xn2, o_pre, o_h;
+    // offsets (floats) of the tail of the saved area
+    size_t o_xfin, o_hpre, o_hh, o_ainv, total_floats;
+};
+
+int make_train_plan(const HmvitFusionTrainDesc* t, TrainPlan& pl) {
+    const HmvitFusionDesc* d = &t->fwd;
+    HMVIT_TRY(check_desc(d));
+    HMVIT_CHECK_ARG(d->precision == HMVIT_PREC_F32, "training runs in the exact-f32 mode (precision=%d)", d->precision);
+    HMVIT_CHECK_ARG(!d->parallel, "training: architect_mode 'parallel' is not built (the shipped yaml is sequential)");
+    HMVIT_CHECK_ARG(d->apply_head == 1, "training: only HeteroFusion (apply_head = 1) is built");
+    HMVIT_CHECK_ARG(t->drop_p >= 0.f && t->drop_p < 1.f, "drop_p=%f out of [0, 1)", t->drop_p);
+    pl.B = d->B; pl.L = d->L; pl.C = d->C; pl.H = d->H; pl.W = d->W; pl.P = d->H * d->W; pl.mlp = d->mlp_dim;
+    pl.heads = d->heads; pl.n_slots = d->B * d->L; pl.n_stages = 2 * d->num_iters;
+    HMVIT_CHECK_ARG(pl.n_slots <= kMaxSlots, "B*L=%d exceeds %d agent slots per call", pl.n_slots, kMaxSlots);
+    pl.max_cav = 0;
+    for (int b = 0; b < d->B; ++b) pl.max_cav = d->record_len[b] > pl.max_cav ? d->record_len[b] : pl.max_cav;
+    bool seen[HMVIT_NUM_TYPES] = {false, false};
+    for (int b = 0; b < d->B; ++b)
+        for (int i = 0; i < pl.max_cav; ++i) seen[d->mode[b * d->L + i]] = true;
+    pl.E_max = (int)seen[0] + (int)seen[1];
+    const size_t tok = (size_t)pl.n_slots * pl.P;
+    pl.A = tok * pl.C;
+    size_t off = 0;
+    auto carve = [&](size_t n) { size_t o = off; off = (off + n + 63) / 64 * 64; return o; };
+    pl.o_x = carve(pl.A); pl.o_xn = carve(pl.A); pl.o_q = carve(pl.A);
+    pl.o_kv = carve(tok * pl.E_max * 2 * pl.C); pl.o_o = carve(pl.A); pl.o_lse = carve(tok * pl.heads);
+    pl.o_x1 = carve(pl.A); pl.o_xn2 = carve(pl.A); pl.o_pre = carve(tok * pl.mlp); pl.o_h = carve(tok * pl.mlp);
+    pl.stage_floats = off;
+    off = pl.stage_floats * pl.n_stages;
+    pl.o_xfin = carve(pl.A);
+    pl.o_hpre = carve((size_t)pl.B * pl.P * pl.C);
+    pl.o_hh = carve((size_t)pl.B * pl.P * pl.C);
+    pl.o_ainv = carve((size_t)pl.n_slots * pl.L * 8);
+    pl.total_floats = off;
+    return HMVIT_OK;
+}
+
+StageInfo stage_info(const HmvitFusionDesc* d, const TrainPlan& pl, int st) {
+    StageInfo si;
+    si.last = st == pl.n_stages - 1;
+    si.n_ego = si.last ? 1 : pl.max_cav;
+    si.E = 0;
+    for (int t = 0; t < HMVIT_NUM_TYPES; ++t) { si.e_of_type[t] = -1; si.e_type[t] = 0; }
+    for (int b = 0; b < d->B; ++b)
+        for (int i = 0; i < si.n_ego; ++i) {
+            const int t = d->mode[b * d->L + i];
+            if (si.e_of_type[t] < 0) { si.e_of_type[t] = si.E; si.e_type[si.E] = t; ++si.E; }
+        }
+    return si;
+}
+
+struct Jobs {
+    GemmJobs jobs;
+    bool a_f32, gelu, out_f32;
+    hipStream_t st;
+    Jobs(hipStream_t s) : a_f32(false), gelu(false), out_f32(true), st(s) { jobs.n = 0; }
+    int flush() {
+        if (jobs.n == 0) return HMVIT_OK;
+        int rc = launch_gemm(jobs, a_f32, gelu, out_f32, HMVIT_PREC_F32, st);
+        jobs.n = 0;
+        return rc;
+    }
+    // y (M, N) = a (M, K) w^T (+ bias) (+ residual)
+    int add(const float* a, const float* w, const float* bias, const float* residual, float* y, int M, int N, int K) {
+        GemmJob j;
+        j.a = a; j.w = w; j.bias = bias; j.residual = residual; j.y = y;
+        j.M = M; j.N = N; j.K = K; j.n_per_plane = N; j.plane_stride = 0;
+        jobs.j[jobs.n++] = j;
+        if (jobs.n == kMaxJobs) return flush();
+        return HMVIT_OK;
+    }
+};
+
+struct TnJobs {
+    GemmTnJobs jobs;
+    hipStream_t st;
+    TnJobs(hipStream_t s) : st(s) { jobs.n = 0; }
+    int flush() {
+        if (jobs.n == 0) return HMVIT_OK;
+        int rc = launch_gemm_tn(jobs, st);
+        jobs.n = 0;
+        return rc;
+    }
+    // dw (N, K) += dy^T a;  dbias (N) += colsum(dy)
+    int add(const float* dy, const float* a, float* dw, float* dbias, int M, int N, int K) {
+        GemmTnJob j;
+        j.dy = dy; j.a = a; j.dw = dw; j.dbias = dbias; j.M = M; j.N = N; j.K = K; j.ld_dy = N; j.ld_a = K;
+        jobs.j[jobs.n++] = j;
+        // jobs of one launch may target the same dw (atomics), so no ordering constraint
+        if (jobs.n == kMaxJobs) return flush();
+        return HMVIT_OK;
+    }
+};
+
+void fill_attn(const HmvitFusionDesc* d, const TrainPlan& pl, const StageInfo& si, int s, const float* q, const float* kv,
+               float* o, float* lse, const float* ainv, AttnParams& ap) {
+    const HmvitStageWeights& wt = d->stage[s];
+    memset(&ap, 0, sizeof(ap));
+    ap.q = q; ap.kv = kv; ap.b_q = wt.b_q; ap.b_kv = wt.b_kv; ap.bias_frag = wt.bias_frag;
+    ap.ainv = ainv; ap.out = o; ap.lse = lse;
+    ap.B = d->B; ap.L = d->L; ap.n_ego = si.n_ego; ap.n_src = pl.max_cav; ap.E = si.E; ap.C = d->C; ap.H = d->H; ap.W = d->W;
+    ap.window = d->window; ap.partition = s == 0 ? HMVIT_PART_WINDOW : HMVIT_PART_GRID;
+    ap.skip_masked = d->skip_masked;
+    for (int i = 0; i < pl.n_slots; ++i) {
+        ap.mode[i] = (int8_t)d->mode[i];
+        ap.cav[i] = (int8_t)(d->cav_mask[i] != 0);
+        ap.ego_e[i] = (int8_t)(si.e_of_type[d->mode[i]] < 0 ? 0 : si.e_of_type[d->mode[i]]);
+    }
+}
+
+// LayerNorm of slots [0, n) of every sample (contiguous per sample)
+int ln_slots(const float* x, float* y, const float* g, const float* be, const HmvitFusionDesc* d, const TrainPlan& pl, int n,
+             hipStream_t st) {
+    const size_t me = (size_t)pl.P * pl.C;
+    for (int b = 0; b < d->B; ++b) {
+        AgentTypes ty;
+        memset(&ty, 0, sizeof(ty));
+        for (int i = 0; i < n; ++i) ty.t[i] = (int8_t)d->mode[b * d->L + i];
+        HMVIT_TRY(launch_layernorm(x + (size_t)b * d->L * me, y + (size_t)b * d->L * me, g, be, ty, n, pl.P, pl.C,
+                                   HMVIT_PREC_F32, st));
+    }
+    return HMVIT_OK;
+}
+
+int ln_bwd_slots(const float* x, const float* dy, const float* g, const float* dres, float* dx, float* dg, float* db,
+                 const HmvitFusionDesc* d, const TrainPlan& pl, int n, hipStream_t st) {
+    const size_t me = (size_t)pl.P * pl.C;
+    for (int b = 0; b < d->B; ++b) {
+        AgentTypes ty;
+        memset(&ty, 0, sizeof(ty));
+        for (int i = 0; i < n; ++i) ty.t[i] = (int8_t)d->mode[b * d->L + i];
+        const size_t o = (size_t)b * d->L * me;
+        HMVIT_TRY(launch_layernorm_bwd(x + o, dy + o, g, ty, n, dres ? dres + o : nullptr, dx + o, dg, db, pl.P, pl.C, st));
+    }
+    return HMVIT_OK;
+}
+
+DropCfg drop_cfg(const HmvitFusionTrainDesc* t, int st, int which) {
+    DropCfg c;
+    c.seed = t->seed; c.salt = (unsigned)(st * 4 + which); c.p = t->drop_p;
+    return c;
+}
+
+}  // namespace
+
+static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
+    const HmvitFusionDesc* d = &t->fwd;
+    TrainPlan pl;
+    HMVIT_TRY(make_train_plan(t, pl));
+    HMVIT_CHECK_ARG(d->x && d->pairwise_t && d->out && t->saved, "x / pairwise_t / out / saved is null");
+    if (t->saved_bytes < pl.total_floats * 4) {
+        set_error("saved area too small: %zu < %zu bytes", t->saved_bytes, pl.total_floats * 4);
+        return HMVIT_ENOMEM;
+    }
+    const size_t scratch = (size_t)(pl.A > (size_t)pl.n_slots * pl.P * pl.mlp ? pl.A : (size_t)pl.n_slots * pl.P * pl.mlp) * 4;
+    if (!d->workspace || d->workspace_bytes < scratch) {
+        set_error("workspace too small: %zu < %zu bytes", d->workspace_bytes, scratch);
+        return HMVIT_ENOMEM;
+    }
+    HMVIT_CHECK_ARG(d->head_w1 && d->head_b1 && d->head_w2 && d->head_b2, "mlp_head weights are null");
+    const int B = d->B, L = d->L, C = d->C, P = pl.P, mlp = pl.mlp;
+    const size_t me = (size_t)P * C;
+    float* S = reinterpret_cast<float*>(t->saved);
+    float* tmp = reinterpret_cast<float*>(d->workspace);
+    float* ainv = S + pl.o_ainv;
+
+    HMVIT_TRY(launch_transpose(d->x, S + pl.o_x, pl.n_slots, C, P, st));
+    HMVIT_TRY(launch_pair_affines(d->pairwise_t, ainv, pl.n_slots * L, d->H, d->W, d->discrete_ratio, d->downsample_rate, st));
+
+    for (int sidx = 0; sidx < pl.n_stages; ++sidx) {
+        const int s = sidx & 1;
+        const HmvitStageWeights& wt = d->stage[s];
+        const StageInfo si = stage_info(d, pl, sidx);
+        float* R = S + (size_t)sidx * pl.stage_floats;
+        float* x_in = R + pl.o_x;
+        float* x_out = (sidx + 1 < pl.n_stages) ? S + (size_t)(sidx + 1) * pl.stage_floats + pl.o_x : S + pl.o_xfin;
+        float *xn = R + pl.o_xn, *q = R + pl.o_q, *kv = R + pl.o_kv, *o = R + pl.o_o, *lse = R + pl.o_lse, *x1 = R + pl.o_x1,
+              *xn2 = R + pl.o_xn2, *pre = R + pl.o_pre, *h = R + pl.o_h;
+        const int n_ego = si.n_ego;
+
+        HMVIT_TRY(ln_slots(x_in, xn, wt.ln_gamma, wt.ln_beta, d, pl, pl.max_cav, st));
+        {
+            Jobs jb(st);
+            for (int b = 0; b < B; ++b)
+                for (int l = 0; l < pl.max_cav; ++l) {
+                    const int slot = b * L + l, ty = d->mode[slot];
+                    if (l < n_ego)
+                        HMVIT_TRY(jb.add(xn + slot * me, reinterpret_cast<const float*>(wt.w_q) + (size_t)ty * C * C, nullptr, nullptr,
+                                         q + slot * me, P, C, C));
+                    for (int e = 0; e < si.E; ++e) {
+                        const float* w = reinterpret_cast<const float*>(wt.w_kv) + (size_t)(si.e_type[e] * HMVIT_NUM_TYPES + ty) * 2 * C * C;
+                        float* y = kv + (size_t)(slot * si.E + e) * 2 * me;
+                        HMVIT_TRY(jb.add(xn + slot * me, w, nullptr, nullptr, y, P, C, C));                       // K'
+                        HMVIT_TRY(jb.add(xn + slot * me, w + (size_t)C * C, nullptr, nullptr, y + me, P, C, C));  // V'
+                    }
+                }
+            HMVIT_TRY(jb.flush());
+        }
+        {
+            AttnParams ap;
+            fill_attn(d, pl, si, s, q, kv, o, lse, ainv, ap);
+            HMVIT_TRY(launch_attention(ap, HMVIT_PREC_F32, st));
+        }
+        // x' = x + Dropout(a_linears(O)) on the ego slots
+        for (int b = 0; b < B; ++b) {
+            Jobs jb(st);
+            for (int i = 0; i < n_ego; ++i) {
+                const int slot = b * L + i, ty = d->mode[slot];
+                HMVIT_TRY(jb.add(o + slot * me, reinterpret_cast<const float*>(wt.w_o) + (size_t)ty * C * C, wt.b_o + ty * C, nullptr,
+                                 tmp + slot * me, P, C, C));
+            }
+            HMVIT_TRY(jb.flush());
+            DropCfg dc = drop_cfg(t, sidx, 0);
+            // element index of the dropout stream = offset inside the (n_slots, P, C) activation
+            for (int i = 0; i < n_ego; ++i) {
+                const size_t off = (size_t)(b * L + i) * me;
+                DropCfg di = dc;
+                di.seed = dc.seed + 0x51ED270B1ull * (unsigned long long)(b * L + i + 1);
+                HMVIT_TRY(launch_add_drop(x_in + off, tmp + off, x1 + off, me, di, st));
+            }
+        }
+        HMVIT_TRY(ln_slots(x1, xn2, wt.ffn_ln_gamma, wt.ffn_ln_beta, d, pl, n_ego, st));
+        for (int b = 0; b < B; ++b) {
+            Jobs j1(st);
+            for (int i = 0; i < n_ego; ++i) {
+                const int slot = b * L + i, ty = d->mode[slot];
+                HMVIT_TRY(j1.add(xn2 + slot * me, reinterpret_cast<const float*>(wt.w_1) + (size_t)ty * mlp * C, wt.b_1 + ty * mlp, nullptr,
+                                 pre + (size_t)slot * P * mlp, P, mlp, C));
+            }
+            HMVIT_TRY(j1.flush());
+            for (int i = 0; i < n_ego; ++i) {
+                const int slot = b * L + i;
+                DropCfg di = drop_cfg(t, sidx, 1);
+                di.seed += 0x51ED270B1ull * (unsigned long long)(slot + 1);
+                HMVIT_TRY(launch_gelu_drop(pre + (size_t)slot * P * mlp, h + (size_t)slot * P * mlp, (size_t)P * mlp, di, st));
+            }
+            Jobs j2(st);
+            for (int i = 0; i < n_ego; ++i) {
+                const int slot = b * L + i, ty = d->mode[slot];
+                HMVIT_TRY(j2.add(h + (size_t)slot * P * mlp, reinterpret_cast<const float*>(wt.w_2) + (size_t)ty * C * mlp, wt.b_2 + ty * C,
+                                 nullptr, tmp + slot * me, P, C, mlp));
+            }
+            HMVIT_TRY(j2.flush());
+            for (int i = 0; i < n_ego; ++i) {
+                const int slot = b * L + i;
+                DropCfg di = drop_cfg(t, sidx, 2);
+                di.seed += 0x51ED270B1ull * (unsigned long long)(slot + 1);
+                HMVIT_TRY(launch_add_drop(x1 + slot * me, tmp + slot * me, x_out + slot * me, me, di, st));
+            }
+        }
+    }
+    // mlp_head on the ego map (no norm, no residual, dropout 0; bevformer_point_pillar_hetero.py:37,47-48)
+    {
+        float* xf = S + pl.o_xfin;
+        float* hpre = S + pl.o_hpre;
+        float* hh = S + pl.o_hh;
+        Jobs j1(st);
+        for (int b = 0; b < B; ++b) {
+            const int slot = b * L, ty = d->mode[slot];
+            HMVIT_TRY(j1.add(xf + slot * me, reinterpret_cast<const float*>(d->head_w1) + (size_t)ty * C * C, d->head_b1 + ty * C, nullptr,
+                             hpre + (size_t)b * me, P, C, C));
+        }
+        HMVIT_TRY(j1.flush());
+        DropCfg none = {0ull, 0u, 0.f};
+        HMVIT_TRY(launch_gelu_drop(hpre, hh, (size_t)B * me, none, st));
+        Jobs j2(st);
+        for (int b = 0; b < B; ++b) {
+            const int ty = d->mode[b * L];
+            HMVIT_TRY(j2.add(hh + (size_t)b * me, reinterpret_cast<const float*>(d->head_w2) + (size_t)ty * C * C, d->head_b2 + ty * C, nullptr,
+                             tmp + (size_t)b * me, P, C, C));
+        }
+        HMVIT_TRY(j2.flush());
+        HMVIT_TRY(launch_transpose(tmp, d->out, B, P, C, st));
+    }
+    return HMVIT_OK;
+}
+
+// ---- backward workspace layout (floats) ----
+struct BwdPlan {
+    size_t o_G, o_T1, o_T2, o_T3, o_T4, o_dkg, o_dkv, o_wt, total;
+    // transposed weights inside o_wt, per stage s: q (T,C,C), kv (T,T,2,C,C), o (T,C,C), w1t (T,C,mlp), w2t (T,mlp,C); head: w1t, w2t
+    size_t wt_stage, wt_q, wt_kv, wt_o, wt_1, wt_2, wt_h1, wt_h2;
+};
+
+static void make_bwd_plan(const TrainPlan& pl, BwdPlan& bp) {
+    const size_t tok = (size_t)pl.n_slots * pl.P;
+    const size_t big = pl.A > tok * pl.mlp ? pl.A : tok * pl.mlp;
+    size_t off = 0;
+    auto carve = [&](size_t n) { size_t o = off; off = (off + n + 63) / 64 * 64; return o; };
+    bp.o_G = carve(pl.A); bp.o_T1 = carve(big); bp.o_T2 = carve(big); bp.o_T3 = carve(pl.A); bp.o_T4 = carve(pl.A);
+    bp.o_dkg = carve((size_t)pl.B * pl.max_cav * pl.max_cav * 2 * pl.P * pl.C);
+    bp.o_dkv = carve(tok * pl.E_max * 2 * pl.C);
+    const size_t T = HMVIT_NUM_TYPES, C = pl.C, mlp = pl.mlp;
+    size_t w = 0;
+    bp.wt_q = w; w += T * C * C;
+    bp.wt_kv = w; w += T * T * 2 * C * C;
+    bp.wt_o = w; w += T * C * C;
+    bp.wt_1 = w; w += T * C * mlp;
+    bp.wt_2 = w; w += T * mlp * C;
+    bp.wt_stage = w;
+    bp.wt_h1 = 2 * w; bp.wt_h2 = 2 * w + T * C * C;
+    bp.o_wt = carve(2 * w + 2 * T * C * C);
+    bp.total = off;
+}
+
+static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, float* d_x, const HmvitStageGrads* grads,
+                          float* d_head_w1, float* d_head_b1, float* d_head_w2, float* d_head_b2, void* workspace,
+                          size_t workspace_bytes, hipStream_t st) {
+    const HmvitFusionDesc* d = &t->fwd;
+    TrainPlan pl;
+    HMVIT_TRY(make_train_plan(t, pl));
+    BwdPlan bp;
+    make_bwd_plan(pl, bp);
+    HMVIT_CHECK_ARG(d_out && d_x && grads && workspace && t->saved, "backward: null pointer");
+    HMVIT_CHECK_ARG(t->bias_frag_neg[0] && t->bias_frag_neg[1], "backward: bias_frag_neg is null");
+    HMVIT_CHECK_ARG(d_head_w1 && d_head_b1 && d_head_w2 && d_head_b2, "backward: mlp_head gradient buffers are null");
+    if (workspace_bytes < bp.total * 4) {
+        set_error("backward workspace too small: %zu < %zu bytes", workspace_bytes, bp.total * 4);
+        return HMVIT_ENOMEM;
+    }
+    const int B = d->B, L = d->L, C = d->C, P = pl.P, mlp = pl.mlp, T = HMVIT_NUM_TYPES;
+    const size_t me = (size_t)P * C;
+    float* S = reinterpret_cast<float*>(t->saved);
+    float* Wk = reinterpret_cast<float*>(workspace);
+    float *G = Wk + bp.o_G, *T1 = Wk + bp.o_T1, *T2 = Wk + bp.o_T2, *T3 = Wk + bp.o_T3, *T4 = Wk + bp.o_T4, *dkg = Wk + bp.o_dkg,
+          *dkv = Wk + bp.o_dkv, *WT = Wk + bp.o_wt;
+    const float* ainv = S + pl.o_ainv;
+    const DropCfg none = {0ull, 0u, 0.f};
+
+    // transposed weights: dA = dY W  is  k_gemm(dY, W^T)
+    for (int s = 0; s < 2; ++s) {
+        const HmvitStageWeights& wt = d->stage[s];
+        float* base = WT + (size_t)s * bp.wt_stage;
+        HMVIT_TRY(launch_transpose(reinterpret_cast<const float*>(wt.w_q), base + bp.wt_q, T, C, C, st));
+        HMVIT_TRY(launch_transpose(reinterpret_cast<const float*>(wt.w_kv), base + bp.wt_kv, T * T * 2, C, C, st));
+        HMVIT_TRY(launch_transpose(reinterpret_cast<const float*>(wt.w_o), base + bp.wt_o, T, C, C, st));
+        HMVIT_TRY(launch_transpose(reinterpret_cast<const float*>(wt.w_1), base + bp.wt_1, T, mlp, C, st));   // (mlp, C) -> (C, mlp)
+        HMVIT_TRY(launch_transpose(reinterpret_cast<const float*>(wt.w_2), base + bp.wt_2, T, C, mlp, st));   // (C, mlp) -> (mlp, C)
+    }
+    HMVIT_TRY(launch_transpose(reinterpret_cast<const float*>(d->head_w1), WT + bp.wt_h1, T, C, C, st));
+    HMVIT_TRY(launch_transpose(reinterpret_cast<const float*>(d->head_w2), WT + bp.wt_h2, T, C, C, st));
+
+    // ---- mlp_head ----
+    HMVIT_CHECK_HIP(hipMemsetAsync(G, 0, pl.A * 4, st));
+    {
+        float* dy = T1;                 // (B, P, C)
+        float* dh = T2;
+        const float* xf = S + pl.o_xfin;
+        const float* hpre = S + pl.o_hpre;
+        const float* hh = S + pl.o_hh;
+        HMVIT_TRY(launch_transpose(d_out, dy, B, C, P, st));
+        Jobs j1(st);
+        TnJobs tn(st);
+        for (int b = 0; b < B; ++b) {
+            const int ty = d->mode[b * L];
+            HMVIT_TRY(j1.add(dy + (size_t)b * me, WT + bp.wt_h2 + (size_t)ty * C * C, nullptr, nullptr, dh + (size_t)b * me, P, C, C));
+            HMVIT_TRY(tn.add(dy + (size_t)b * me, hh + (size_t)b * me, d_head_w2 + (size_t)ty * C * C, d_head_b2 + ty * C, P, C, C));
+        }
+        HMVIT_TRY(j1.flush());
+        HMVIT_TRY(tn.flush());
+        HMVIT_TRY(launch_gelu_bwd(hpre, dh, dh, (size_t)B * me, none, st));
+        Jobs j2(st);
+        for (int b = 0; b < B; ++b) {
+            const int slot = b * L, ty = d->mode[slot];
+            HMVIT_TRY(j2.add(dh + (size_t)b * me, WT + bp.wt_h1 + (size_t)ty * C * C, nullptr, nullptr, G + slot * me, P, C, C));
+            HMVIT_TRY(tn.add(dh + (size_t)b * me, xf + slot * me, d_head_w1 + (size_t)ty * C * C, d_head_b1 + ty * C, P, C, C));
+        }
+        HMVIT_TRY(j2.flush());
+        HMVIT_TRY(tn.flush());
+    }
+
+    for (int sidx = pl.n_stages - 1; sidx >= 0; --sidx) {
+        const int s = sidx & 1;
+        const HmvitStageWeights& wt = d->stage[s];
+        const HmvitStageGrads& gr = grads[s];
+        const StageInfo si = stage_info(d, pl, sidx);
+        const float* R = S + (size_t)sidx * pl.stage_floats;
+        const float *x_in = R + pl.o_x, *xn = R + pl.o_xn, *q = R + pl.o_q, *kv = R + pl.o_kv, *o = R + pl.o_o, *lse = R + pl.o_lse,
+                    *x1 = R + pl.o_x1, *xn2 = R + pl.o_xn2, *pre = R + pl.o_pre, *h = R + pl.o_h;
+        const float* wts = WT + (size_t)s * bp.wt_stage;
+        const int n_ego = si.n_ego;
+
+        // G = dL/dx'' (zero on slots the loss does not reach).  FFN: x'' = x' + drop(W_2 drop(gelu(W_1 LN(x') + b_1)) + b_2)
+        for (int b = 0; b < B; ++b) {
+            for (int i = 0; i < n_ego; ++i) {
+                const int slot = b * L + i;
+                DropCfg di = drop_cfg(t, sidx, 2);
+                di.seed += 0x51ED270B1ull * (unsigned long long)(slot + 1);
+                HMVIT_TRY(launch_add_drop(nullptr, G + slot * me, T1 + slot * me, me, di, st));            // df
+            }
+            Jobs j1(st);
+            TnJobs tn(st);
+            for (int i = 0; i < n_ego; ++i) {
+                const int slot = b * L + i, ty = d->mode[slot];
+                HMVIT_TRY(j1.add(T1 + slot * me, wts + bp.wt_2 + (size_t)ty * mlp * C, nullptr, nullptr, T2 + (size_t)slot * P * mlp, P, mlp, C));
+                HMVIT_TRY(tn.add(T1 + slot * me, h + (size_t)slot * P * mlp, gr.w_2 + (size_t)ty * C * mlp, gr.b_2 + ty * C, P, C, mlp));
+            }
+            HMVIT_TRY(j1.flush());
+            HMVIT_TRY(tn.flush());
+            for (int i = 0; i < n_ego; ++i) {
+                const int slot = b * L + i;
+                DropCfg di = drop_cfg(t, sidx, 1);
+                di.seed += 0x51ED270B1ull * (unsigned long long)(slot + 1);
+                float* dpre = T2 + (size_t)slot * P * mlp;
+                HMVIT_TRY(launch_gelu_bwd(pre + (size_t)slot * P * mlp, dpre, dpre, (size_t)P * mlp, di, st));
+            }
+            Jobs j2(st);
+            for (int i = 0; i < n_ego; ++i) {
+                const int slot = b * L + i, ty = d->mode[slot];
+                HMVIT_TRY(j2.add(T2 + (size_t)slot * P * mlp, wts + bp.wt_1 + (size_t)ty * C * mlp, nullptr, nullptr, T1 + slot * me, P, C, mlp));
+                HMVIT_TRY(tn.add(T2 + (size_t)slot * P * mlp, xn2 + slot * me, gr.w_1 + (size_t)ty * mlp * C, gr.b_1 + ty * mlp, P, mlp, C));
+            }
+            HMVIT_TRY(j2.flush());
+            HMVIT_TRY(tn.flush());
+        }
+        // G <- G + LN2-backward(dxn2 = T1)   (= dL/dx')
+        HMVIT_TRY(ln_bwd_slots(x1, T1, wt.ffn_ln_gamma, G, G, gr.ffn_ln_gamma, gr.ffn_ln_beta, d, pl, n_ego, st));
+
+        // x' = x + drop(O W_o^T + b_o): dO = drop'(G) W_o
+        for (int b = 0; b < B; ++b) {
+            for (int i = 0; i < n_ego; ++i) {
+                const int slot = b * L + i;
+                DropCfg di = drop_cfg(t, sidx, 0);
+                di.seed += 0x51ED270B1ull * (unsigned long long)(slot + 1);
+                HMVIT_TRY(launch_add_drop(nullptr, G + slot * me, T1 + slot * me, me, di, st));            // da
+            }
+            Jobs j1(st);
+            TnJobs tn(st);
+            for (int i = 0; i < n_ego; ++i) {
+                const int slot = b * L + i, ty = d->mode[slot];
+                HMVIT_TRY(j1.add(T1 + slot * me, wts + bp.wt_o + (size_t)ty * C * C, nullptr, nullptr, T3 + slot * me, P, C, C));
+                HMVIT_TRY(tn.add(T1 + slot * me, o + slot * me, gr.w_o + (size_t)ty * C * C, gr.b_o + ty * C, P, C, C));
+            }
+            HMVIT_TRY(j1.flush());
+            HMVIT_TRY(tn.flush());
+        }
+
+        // attention backward: dq (T4), gradients of the gathered keys (dkg), bias fragments
+        {
+            AttnBwdParams ab;
+            fill_attn(d, pl, si, s, q, kv, const_cast<float*>(o), const_cast<float*>(lse), ainv, ab.f);
+            ab.bias_frag_neg = reinterpret_cast<const float*>(t->bias_frag_neg[s]);
+            ab.d_out = T3; ab.dq = T4; ab.dkg = dkg; ab.d_bias_frag = gr.bias_frag;
+            HMVIT_CHECK_HIP(hipMemsetAsync(dkg, 0, (size_t)B * n_ego * pl.max_cav * 2 * me * 4, st));
+            HMVIT_TRY(launch_attention_bwd(ab, st));
+            // biases are added after the gather: their gradients are column sums over the EGO pixels
+            for (int b = 0; b < B; ++b)
+                for (int i = 0; i < n_ego; ++i) {
+                    const int te = d->mode[b * L + i];
+                    HMVIT_TRY(launch_colsum(T4 + (size_t)(b * L + i) * me, P, C, C, gr.b_q + te * C, st));
+                    for (int j = 0; j < pl.max_cav; ++j) {
+                        const int ts = d->mode[b * L + j];
+                        const float* g2 = dkg + ((size_t)((b * n_ego + i) * pl.max_cav + j) * 2) * me;
+                        float* db = gr.b_kv + (size_t)(te * T + ts) * 2 * C;
+                        HMVIT_TRY(launch_colsum(g2, P, C, C, db, st));
+                        HMVIT_TRY(launch_colsum(g2 + me, P, C, C, db + C, st));
+                    }
+                }
+            WarpAdjParams wa;
+            memset(&wa, 0, sizeof(wa));
+            wa.dkg = dkg; wa.ainv = ainv; wa.dkv = dkv;
+            wa.B = B; wa.L = L; wa.n_ego = n_ego; wa.n_src = pl.max_cav; wa.E = si.E; wa.C = C; wa.H = d->H; wa.W = d->W;
+            for (int i = 0; i < pl.n_slots; ++i) wa.ego_e[i] = ab.f.ego_e[i];
+            HMVIT_TRY(launch_warp_adjoint(wa, st));
+        }
+
+        // dxn (T1) = dq W_q + sum_e (dK'_e W_k,e + dV'_e W_v,e);  weight gradients against xn
+        {
+            TnJobs tn(st);
+            // pass 0: first term of every slot (no accumulate), later passes accumulate through the residual input
+            const int n_terms = 1 + 2 * si.E;
+            for (int term = 0; term < n_terms; ++term) {
+                Jobs jb(st);
+                for (int b = 0; b < B; ++b)
+                    for (int l = 0; l < pl.max_cav; ++l) {
+                        const int slot = b * L + l, ty = d->mode[slot];
+                        float* y = T1 + slot * me;
+                        const bool has_q = l < n_ego;
+                        // the first term actually present for this slot writes, the others accumulate
+                        const int first_term = has_q ? 0 : 1;
+                        const float* res = term == first_term ? nullptr : y;
+                        if (term == 0) {
+                            if (!has_q) continue;
+                            HMVIT_TRY(jb.add(T4 + slot * me, wts + bp.wt_q + (size_t)ty * C * C, nullptr, res, y, P, C, C));
+                            HMVIT_TRY(tn.add(T4 + slot * me, xn + slot * me, gr.w_q + (size_t)ty * C * C, nullptr, P, C, C));
+                        } else {
+                            const int e = (term - 1) >> 1, pln = (term - 1) & 1;
+                            const size_t widx = (size_t)((si.e_type[e] * T + ty) * 2 + pln) * C * C;
+                            const float* g2 = dkv + ((size_t)(slot * si.E + e) * 2 + pln) * me;
+                            HMVIT_TRY(jb.add(g2, wts + bp.wt_kv + widx, nullptr, res, y, P, C, C));
+                            HMVIT_TRY(tn.add(g2, xn + slot * me, gr.w_kv + widx, nullptr, P, C, C));
+                        }
+                    }
+                HMVIT_TRY(jb.flush());
+            }
+            HMVIT_TRY(tn.flush());
+        }
+        // dL/dx = (dL/dx' on the ego slots) + LN-backward(dxn)
+        HMVIT_TRY(ln_bwd_slots(x_in, T1, wt.ln_gamma, G, G, gr.ln_gamma, gr.ln_beta, d, pl, pl.max_cav, st));
+    }
+
+    // token-major -> (B, L, C, H, W); padded agents receive no gradient
+    HMVIT_CHECK_HIP(hipMemsetAsync(d_x, 0, pl.A * 4, st));
+    for (int b = 0; b < B; ++b)
+        HMVIT_TRY(launch_transpose(G + (size_t)b * L * me, d_x + (size_t)b * L * me, pl.max_cav, P, C, st));
+    return HMVIT_OK;
+}
+
+}  // namespace hmvit
+
+using namespace hmvit;
+
+extern "C" {
+
+size_t hmvit_fusion_train_saved_bytes(const HmvitFusionTrainDesc* desc) {
+    TrainPlan pl;
+    if (!desc || make_train_plan(desc, pl) != HMVIT_OK) return 0;
+    return pl.total_floats * 4;
+}
+
+size_t hmvit_fusion_backward_workspace_bytes(const HmvitFusionTrainDesc* desc) {
+    TrainPlan pl;
+    if (!desc || make_train_plan(desc, pl) != HMVIT_OK) return 0;
+    BwdPlan bp;
+    make_bwd_plan(pl, bp);
+    return bp.total * 4;
+}
+
+int hmvit_fusion_train_forward(const HmvitFusionTrainDesc* desc, void* stream) {
+    HMVIT_CHECK_ARG(desc != nullptr, "desc is null");
+    return train_forward(desc, reinterpret_cast<hipStream_t>(stream));
+}
+
+int hmvit_fusion_backward(const HmvitFusionTrainDesc* desc, const float* d_out, float* d_x, const HmvitStageGrads* grads,
+                          float* d_head_w1, float* d_head_b1, float* d_head_w2, float* d_head_b2, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    HMVIT_CHECK_ARG(desc != nullptr, "desc is null");
+    return train_backward(desc, d_out, d_x, grads, d_head_w1, d_head_b1, d_head_w2, d_head_b2, workspace, workspace_bytes,
+                          reinterpret_cast<hipStream_t>(stream));
+}
+
+int hmvit_dropout_mask(float* mask, size_t n, uint64_t seed, uint32_t salt, float p, void* stream) {
+    HMVIT_CHECK_ARG(mask != nullptr, "dropout_mask: null pointer");
+    DropCfg c;
+    c.seed = seed; c.salt = salt; c.p = p;
+    return launch_dropout_mask(mask, n, c, reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

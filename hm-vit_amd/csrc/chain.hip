@@ -32,13 +32,19 @@ namespace hmvit {
 // group's HBM load / store phases overlap the other's MFMA phase
 constexpr int CHAIN_THREADS_C = 256;
 
-template <int C>
+// SP ("split" precision mode): every fp32 product runs on the f16 matrix pipe as x = hi + lo (hi = f16(x), lo = f16(x - hi)),
+// three MFMAs per product (w_hi a_hi + w_hi a_lo + w_lo a_hi, f32 accumulate; the lo x lo term is below 2^-22 relative).  A
+// weight chunk then holds, per k-step, the hi fragment followed by the lo fragment (weights.py weight_image(split=True)), the
+// activations live in registers as hi / lo operand pairs, and everything that goes to memory between kernels (Q, K', V', O,
+// the residual stream) is f32.  The register budget doubles, so these instantiations run one workgroup per CU.
+template <int C, bool SP = false>
 struct ChainCfg {
     static constexpr int NB = C / 32;             // 32-channel blocks
     static constexpr int KK = C / 16;             // MFMA k-steps over C
     static constexpr int NT = C / 32;             // 32-row output tiles
-    static constexpr int CHUNK_HALVES = KK * 512; // one chunk: KK fragments of 64 lanes x 8 halves
-    static constexpr int PIECES = KK * 64;        // 16-byte pieces per chunk
+    static constexpr int FR = SP ? 2 : 1;         // weight fragments per k-step
+    static constexpr int CHUNK_HALVES = KK * 512 * FR; // one chunk: KK (x 2) fragments of 64 lanes x 8 halves
+    static constexpr int PIECES = KK * 64 * FR;   // 16-byte pieces per chunk
     static constexpr int PPT = (PIECES + CHAIN_THREADS_C - 1) / CHAIN_THREADS_C;
 };
 
@@ -51,7 +57,7 @@ constexpr int CHAIN_TOKENS = CHAIN_WAVES * 32;
 // [(i*8 + w) * 64, +64) with one global_load_lds_dwordx4 each (LDS destination = wave-uniform
 // base + lane * 16).  Completion: the __syncthreads() that ends the iteration (hipcc drains
 // vmcnt(0) before a barrier while an LDS-DMA is in flight).
-template <int C>
+template <int C, bool SP = false>
 __device__ __forceinline__ void stage_chunk(const half_t* __restrict__ chunk, half_t* lds_buf) {
     // Inline asm on purpose: hipcc must not count this DMA (it would drain vmcnt(0), i.e. also the
     // output stores in flight, before every ds_read of the ring).  Completion is waited for by
@@ -59,9 +65,9 @@ __device__ __forceinline__ void stage_chunk(const half_t* __restrict__ chunk, ha
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_buf;
 #pragma unroll
-    for (int i = 0; i < ChainCfg<C>::PPT; ++i) {
+    for (int i = 0; i < ChainCfg<C, SP>::PPT; ++i) {
         const int piece0 = (i * CHAIN_WAVES + wave) * 64;
-        if (piece0 < ChainCfg<C>::PIECES) {
+        if (piece0 < ChainCfg<C, SP>::PIECES) {
             const uint4* gsrc = reinterpret_cast<const uint4*>(chunk) + piece0 + lane;
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + piece0 * 16);
             unsigned keep;
@@ -129,6 +135,27 @@ struct MmaSteps {
         if constexpr (kk + 1 < KK) MmaSteps<KK, DEPTH, kk + 1>::run(acc, addr, act, w);
     }
 };
+// split mode: 2 KK fragments (hi, lo per k-step); the hi fragment feeds two MFMAs (x a_hi, x a_lo), the lo fragment one
+template <int KK, int DEPTH, int f = 0>
+struct MmaStepsSplit {
+    static constexpr int F = 2 * KK;
+    static __device__ __forceinline__ void run(float16v& acc, unsigned addr, const half8 (&ah)[KK], const half8 (&al)[KK],
+                                               half8 (&w)[DEPTH]) {
+        constexpr int outstanding = (F - f - 1) < (DEPTH - 1) ? (F - f - 1) : (DEPTH - 1);
+        lgkm_wait<outstanding>();
+        if constexpr ((f & 1) == 0) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[f % DEPTH], al[f / 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[f % DEPTH], ah[f / 2], acc, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[f % DEPTH], ah[f / 2], acc, 0, 0, 0);
+        }
+        if constexpr (f + DEPTH < F) {
+            __builtin_amdgcn_sched_barrier(0);
+            lds_read_frag<(f + DEPTH) * 1024>(w[f % DEPTH], addr);
+        }
+        if constexpr (f + 1 < F) MmaStepsSplit<KK, DEPTH, f + 1>::run(acc, addr, ah, al, w);
+    }
+};
 template <int DEPTH, int i = 0>
 struct MmaPrologue {
     static __device__ __forceinline__ void run(unsigned addr, half8 (&w)[DEPTH]) {
@@ -147,6 +174,33 @@ __device__ __forceinline__ void mma_chunk(float16v& acc, const half_t* buf, cons
     MmaPrologue<DEPTH>::run(addr, w);
     MmaSteps<KK, DEPTH>::run(acc, addr, act, w);
     __builtin_amdgcn_sched_barrier(0);
+}
+template <int KK, int DEPTH>
+__device__ __forceinline__ void mma_chunk_split(float16v& acc, const half_t* buf, const half8 (&ah)[KK], const half8 (&al)[KK], int lane) {
+    static_assert((2 * KK) % DEPTH == 0 && DEPTH <= 15, "");
+    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)(buf + lane * 8);
+    half8 w[DEPTH];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    MmaPrologue<DEPTH>::run(addr, w);
+    MmaStepsSplit<KK, DEPTH>::run(acc, addr, ah, al, w);
+    __builtin_amdgcn_sched_barrier(0);
+}
+// operand pair of the current precision mode: hi always, lo only in split mode
+template <int KK, bool SP>
+struct Operands {
+    half8 hi[KK];
+    half8 lo[SP ? KK : 1];
+};
+template <int KK, int DEPTH, bool SP>
+__device__ __forceinline__ void mma_chunk_op(float16v& acc, const half_t* buf, const Operands<KK, SP>& a, int lane) {
+    if constexpr (SP) mma_chunk_split<KK, DEPTH>(acc, buf, a.hi, a.lo, lane);
+    else mma_chunk<KK, DEPTH>(acc, buf, a.hi, lane);
+}
+// x -> (hi, lo) f16 pair
+__device__ __forceinline__ void split_h(float x, half_t& hi, half_t& lo) {
+    hi = (half_t)x;
+    lo = (half_t)(x - (float)hi);
 }
 
 __device__ __forceinline__ float pair_sum(float v) { return xor32_sum(v); }

@@ -10,6 +10,9 @@ struct AgentTypes {
     int8_t t[kMaxSlots];
 };
 
+// ---- capi.hip ----
+int check_desc(const HmvitFusionDesc* d);   // argument validation shared by the inference and training entry points
+
 // ---- tok.hip ----
 int launch_transpose(const float* x, float* y, int n, int R, int S, hipStream_t st);
 int launch_layernorm(const float* x, void* y, const float* gamma, const float* beta,
@@ -156,6 +159,7 @@ struct AttnParams {
     int variant;              // 0: default kernel choice, 1: force the one-window-per-workgroup kernel
     const unsigned* vis_mask;        // optional (B * n_ego * H/8 * W/8): visible-chunk bits per window (launch_tile_vis)
     int prune;                       // vis_mask bit 31 marks items no later stage can reach: skipped by the schedule
+    float* lse;               // optional (B, L, P, heads) f32: log-sum-exp of every query row (f32 kernel; kept for the backward pass)
     int8_t mode[kMaxSlots];   // (B, L)
     int8_t cav[kMaxSlots];    // (B, L)
     int8_t ego_e[kMaxSlots];  // (B, L): K/V variant used by ego (b, i)
@@ -167,6 +171,56 @@ int launch_tile_vis(const AttnParams& p, unsigned* vis_mask, const unsigned char
 // marked in `from` (plus those windows themselves).  `to` must be zeroed by the caller.
 int launch_window_need(const AttnParams& p, const unsigned char* from, unsigned char* to, hipStream_t st);
 int launch_debug_tr16(uint16_t* out, hipStream_t st);
+
+// ---- train.hip (backward pass of the fusion, exact-f32 MFMA; SURVEY 8b "autograd must flow") ----
+// dw[n][k] += sum_m dy[m][n] a[m][k]  (weight gradient of y = a w^T), dbias[n] += sum_m dy[m][n]; f32 atomics
+struct GemmTnJob {
+    const float* dy;        // (M, N) row stride ld_dy
+    const float* a;         // (M, K) row stride ld_a
+    float* dw;              // (N, K) row-major, accumulated into
+    float* dbias;           // (N) accumulated into, or null
+    int M, N, K, ld_dy, ld_a;
+};
+struct GemmTnJobs {
+    GemmTnJob j[kMaxJobs];
+    int n;
+};
+int launch_gemm_tn(const GemmTnJobs& jobs, hipStream_t st);
+// dx = dres + LayerNorm-backward(dy; x, gamma[type]); dgamma / dbeta (T, C) accumulated with atomics
+int launch_layernorm_bwd(const float* x, const float* dy, const float* gamma, const AgentTypes& types, int n_agents,
+                         const float* dres, float* dx, float* dgamma, float* dbeta, int P, int C, hipStream_t st);
+// counter-based dropout: keep(seed, salt, i) is a pure function, so the backward pass regenerates the forward's mask
+struct DropCfg {
+    unsigned long long seed;
+    unsigned salt;
+    float p;                // drop probability, 0 = identity
+};
+int launch_add_drop(const float* x, const float* a, float* y, size_t n, DropCfg d, hipStream_t st);      // y = x + drop(a); x may be null
+int launch_gelu_drop(const float* pre, float* h, size_t n, DropCfg d, hipStream_t st);                   // h = drop(gelu(pre))
+int launch_gelu_bwd(const float* pre, const float* dh, float* dpre, size_t n, DropCfg d, hipStream_t st); // dpre = drop'(dh) gelu'(pre)
+int launch_dropout_mask(float* mask, size_t n, DropCfg d, hipStream_t st);                               // mask[i] = 0 or 1 / (1 - p)
+struct AttnBwdParams {
+    AttnParams f;             // the forward launch (q, kv, biases, bias_frag, ainv, out = O, lse, geometry)
+    const float* bias_frag_neg;   // bias fragments of the negated offset table: the S (not S^T) tiles' bias
+    const float* d_out;       // (B, L, P, C) gradient of O
+    float* dq;                // (B, L, P, C) gradient of the (un-biased) q planes, ego slots
+    float* dkg;               // (B, n_ego, n_src, 2, P, C): gradient of the gathered K / V keys of every (ego, source) pair,
+                              // indexed by EGO pixel; zero-filled by the caller
+    float* d_bias_frag;       // (heads, NB, 64, 4) accumulated into
+};
+int launch_attention_bwd(const AttnBwdParams& p, hipStream_t st);
+// adjoint of the bilinear key gather: dkv[(b, src), e, plane, s, :] = sum over egos of variant e and ego pixels u whose taps
+// touch source pixel s of weight(u -> s) dkg[(b, ego, src), plane, u, :]   (gather form, no atomics)
+struct WarpAdjParams {
+    const float* dkg;         // as AttnBwdParams::dkg
+    const float* ainv;        // (B, L_src, L_ego, 8)
+    float* dkv;               // (B, L, E, 2, P, C)
+    int B, L, n_ego, n_src, E, C, H, W;
+    int8_t ego_e[kMaxSlots];
+};
+int launch_warp_adjoint(const WarpAdjParams& p, hipStream_t st);
+// out[n] += sum_m y[m][n]  (bias gradients), y (M, N) with row stride ld
+int launch_colsum(const float* y, int M, int N, int ld, float* out, hipStream_t st);
 
 // ---- post.hip (detection post-processing) ----
 struct BoxDecodeParams {

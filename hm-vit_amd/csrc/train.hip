@@ -1,0 +1,644 @@
+// Backward pass of the fusion hot path (training, exact-f32 MFMA): the adjoints of the f32-mode forward kernels.
+//
+// The reference trains HeteroFusion through torch.autograd (train_camera.py:163-199); here every forward kernel of
+// the f32 pipeline has a hand-written adjoint:
+//
+//   k_gemm_tn          weight / bias gradients of the typed Linears (dW = dY^T A, reduction over the tokens of an
+//                      agent map), v_mfma_f32_32x32x2_f32
+//   k_layernorm_bwd    HeteroLayerNorm backward (base_transformer.py:172-177), per-type dgamma / dbeta
+//   k_add_drop, k_gelu_drop, k_gelu_bwd    residual + Dropout, GELU + Dropout and their adjoints
+//                      (hetero_fusion.py:65-66, base_transformer.py:186-192); the dropout mask is a pure function of
+//                      (seed, salt, element index), so the backward pass regenerates it instead of storing it
+//   k_attention_bwd    adjoint of k_attention (attn.hip): the probabilities are rebuilt from the saved row
+//                      log-sum-exp, dS = P o (dP - rowsum(dO o O)); dQ, the gradients of the GATHERED keys / values
+//                      and the gradient of the relative-position bias fragments (hetero_fusion.py:216-267)
+//   k_warp_adjoint     adjoint of the bilinear key gather (warp_features, hetero_fusion.py:338-361): scatter written
+//                      as a gather over the few ego pixels whose taps can touch a source pixel -> no atomics
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace hmvit {
+
+// ------------------------------------------------------------------------------------------
+// dropout
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float drop_scale(const DropCfg& d, unsigned long long idx, float inv_keep) {
+    // splitmix64 finaliser over (seed, salt, idx): 24 uniform bits
+    unsigned long long z = d.seed + 0x9E3779B97F4A7C15ull * (idx + ((unsigned long long)d.salt << 40) + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(unsigned)(z >> 40) * (1.f / 16777216.f);
+    return u < d.p ? 0.f : inv_keep;
+}
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+
+// MODE 0: y = x + drop(a) (x may be null); 1: y = drop(gelu(a)); 2: y = drop'(x) * gelu'(a) (x = dh, a = pre); 3: mask
+template <int MODE>
+__global__ __launch_bounds__(256) void k_elementwise(const float* __restrict__ x, const float* __restrict__ a,
+                                                      float* __restrict__ y, size_t n4, DropCfg d) {
+    const float inv_keep = d.p > 0.f ? 1.f / (1.f - d.p) : 1.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 av = make_float4(0.f, 0.f, 0.f, 0.f), xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE != 3) av = reinterpret_cast<const float4*>(a)[i];
+        if ((MODE == 0 && x) || MODE == 2) xv = reinterpret_cast<const float4*>(x)[i];
+        float s[4] = {1.f, 1.f, 1.f, 1.f};
+        if (d.p > 0.f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] = drop_scale(d, 4 * i + e, inv_keep);
+        }
+        float4 r;
+        if (MODE == 0) {
+            r = make_float4(xv.x + s[0] * av.x, xv.y + s[1] * av.y, xv.z + s[2] * av.z, xv.w + s[3] * av.w);
+        } else if (MODE == 1) {
+            r = make_float4(s[0] * gelu_exact(av.x), s[1] * gelu_exact(av.y), s[2] * gelu_exact(av.z), s[3] * gelu_exact(av.w));
+        } else if (MODE == 2) {
+            r = make_float4(s[0] * xv.x * gelu_grad(av.x), s[1] * xv.y * gelu_grad(av.y), s[2] * xv.z * gelu_grad(av.z),
+                            s[3] * xv.w * gelu_grad(av.w));
+        } else {
+            r = make_float4(s[0], s[1], s[2], s[3]);
+        }
+        reinterpret_cast<float4*>(y)[i] = r;
+    }
+}
+
+template <int MODE>
+static int launch_ew(const float* x, const float* a, float* y, size_t n, DropCfg d, hipStream_t st) {
+    if (n == 0) return HMVIT_OK;
+    HMVIT_CHECK_ARG(n % 4 == 0, "elementwise: n=%zu must be a multiple of 4", n);
+    HMVIT_CHECK_ARG(d.p >= 0.f && d.p < 1.f, "dropout p=%f out of [0, 1)", d.p);
+    const size_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 16384 ? (n4 + 255) / 256 : 16384);
+    hipLaunchKernelGGL((k_elementwise<MODE>), dim3(blocks), dim3(256), 0, st, x, a, y, n4, d);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+int launch_add_drop(const float* x, const float* a, float* y, size_t n, DropCfg d, hipStream_t st) { return launch_ew<0>(x, a, y, n, d, st); }
+int launch_gelu_drop(const float* pre, float* h, size_t n, DropCfg d, hipStream_t st) { return launch_ew<1>(nullptr, pre, h, n, d, st); }
+int launch_gelu_bwd(const float* pre, const float* dh, float* dpre, size_t n, DropCfg d, hipStream_t st) { return launch_ew<2>(dh, pre, dpre, n, d, st); }
+int launch_dropout_mask(float* mask, size_t n, DropCfg d, hipStream_t st) { return launch_ew<3>(nullptr, nullptr, mask, n, d, st); }
+
+// ------------------------------------------------------------------------------------------
+// dW += dY^T A  (and dbias += column sums of dY)
+// ------------------------------------------------------------------------------------------
+// Tile: 128 (n) x 128 (k) of dW per workgroup over a slice of TN_ROWS tokens; 2 x 2 wavefronts of 64 x 64.  The slabs
+// are staged as they lie in memory (row = token): the MFMA contraction index is the token, so both operands are read
+// down LDS columns (consecutive lanes = consecutive columns: conflict-free).
+constexpr int TN_BM = 32;         // tokens per slab
+constexpr int TN_ROWS = 1024;     // tokens per workgroup
+constexpr int TN_LS = 128;
+
+__global__ __launch_bounds__(256) void k_gemm_tn(GemmTnJobs jobs) {
+    __shared__ __attribute__((aligned(16))) float Ds[TN_BM * TN_LS];
+    __shared__ __attribute__((aligned(16))) float As[TN_BM * TN_LS];
+    const GemmTnJob& J = jobs.j[blockIdx.z];
+    const int tiles_k = (J.K + 127) / 128, tiles_n = (J.N + 127) / 128;
+    if ((int)blockIdx.x >= tiles_k * tiles_n) return;
+    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
+    const int n0 = tn * 128, k0 = tk * 128;
+    const int m_begin = blockIdx.y * TN_ROWS;
+    if (m_begin >= J.M) return;
+    const int m_end = min(J.M, m_begin + TN_ROWS);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wn = wave >> 1, wk = wave & 1, r = lane & 31, hi = lane >> 5;
+
+    float16v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float colsum = 0.f;
+    const bool do_bias = J.dbias != nullptr && tk == 0;
+
+    for (int m0 = m_begin; m0 < m_end; m0 += TN_BM) {
+        // 32 rows x 128 columns of each operand: 1024 float4, 4 per thread
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = c >> 5, col = (c & 31) * 4;
+            float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), av = dv;
+            if (m0 + row < m_end) {
+                if (n0 + col < J.N) dv = *reinterpret_cast<const float4*>(J.dy + (size_t)(m0 + row) * J.ld_dy + n0 + col);
+                if (k0 + col < J.K) av = *reinterpret_cast<const float4*>(J.a + (size_t)(m0 + row) * J.ld_a + k0 + col);
+            }
+            *reinterpret_cast<float4*>(Ds + row * TN_LS + col) = dv;
+            *reinterpret_cast<float4*>(As + row * TN_LS + col) = av;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < TN_BM / 2; ++kk) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = Ds[(2 * kk + hi) * TN_LS + wn * 64 + i * 32 + r];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = As[(2 * kk + hi) * TN_LS + wk * 64 + j * 32 + r];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (do_bias && tid < 128) {
+#pragma unroll 8
+            for (int row = 0; row < TN_BM; ++row) colsum += Ds[row * TN_LS + tid];
+        }
+        __syncthreads();
+    }
+    // acc[i][j][e]: row n = (e & 3) + 8 (e >> 2) + 4 hi of block i, column k = r of block j
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = k0 + wk * 64 + j * 32 + r;
+            if (k >= J.K) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wn * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                if (n < J.N) unsafeAtomicAdd(J.dw + (size_t)n * J.K + k, acc[i][j][e]);
+            }
+        }
+    if (do_bias && tid < 128 && n0 + tid < J.N) unsafeAtomicAdd(J.dbias + n0 + tid, colsum);
+}
+
+int launch_gemm_tn(const GemmTnJobs& jobs, hipStream_t st) {
+    if (jobs.n == 0) return HMVIT_OK;
+    int max_tiles = 0, max_slices = 0;
+    for (int i = 0; i < jobs.n; ++i) {
+        const GemmTnJob& j = jobs.j[i];
+        HMVIT_CHECK_ARG(j.N % 4 == 0 && j.K % 4 == 0 && j.ld_dy % 4 == 0 && j.ld_a % 4 == 0, "gemm_tn: N=%d K=%d ld=%d/%d must be multiples of 4",
+                        j.N, j.K, j.ld_dy, j.ld_a);
+        max_tiles = max(max_tiles, cdiv(j.N, 128) * cdiv(j.K, 128));
+        max_slices = max(max_slices, cdiv(j.M, TN_ROWS));
+    }
+    if (max_tiles == 0 || max_slices == 0) return HMVIT_OK;
+    hipLaunchKernelGGL(k_gemm_tn, dim3(max_tiles, max_slices, jobs.n), dim3(256), 0, st, jobs);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// column sums (bias gradients)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ y, int M, int N, int ld, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * 1024, m1 = min(M, m0 + 1024);
+    float s = 0.f;
+    if (c < N)
+        for (int m = m0 + rg; m < m1; m += 4) s += y[(size_t)m * ld + c];
+    red[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rg == 0 && c < N) unsafeAtomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+int launch_colsum(const float* y, int M, int N, int ld, float* out, hipStream_t st) {
+    if (M <= 0 || N <= 0) return HMVIT_OK;
+    hipLaunchKernelGGL(k_colsum, dim3(cdiv(N, 64), cdiv(M, 1024)), dim3(256), 0, st, y, M, N, ld, out);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm backward
+// ------------------------------------------------------------------------------------------
+constexpr int LNB_TOK = 16;   // tokens per wavefront
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ gamma, AgentTypes types,
+                                                        const float* dres, float* dx, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, int P) {
+    constexpr int C = VPL * 64;
+    __shared__ float red[2][4][C];
+    const int agent = blockIdx.y, t = types.t[agent];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float g[VPL], dg[VPL], db[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        g[i] = gamma[t * C + lane * VPL + i];
+        dg[i] = db[i] = 0.f;
+    }
+    const int tok0 = (blockIdx.x * 4 + wave) * LNB_TOK;
+    for (int tt = 0; tt < LNB_TOK; ++tt) {
+        const int tok = tok0 + tt;
+        if (tok >= P) break;
+        const size_t base = ((size_t)agent * P + tok) * C + lane * VPL;
+        float v[VPL], d[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) { v[i] = x[base + i]; d[i] = dy[base + i]; }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) s += v[i];
+        const float mean = wave_sum64(s) * (1.f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) { v[i] -= mean; q += v[i] * v[i]; }
+        const float rstd = rsqrtf(wave_sum64(q) * (1.f / C) + 1e-5f);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            v[i] *= rstd;                       // xhat
+            const float gd = g[i] * d[i];
+            s1 += gd;
+            s2 += gd * v[i];
+            dg[i] += d[i] * v[i];
+            db[i] += d[i];
+        }
+        s1 = wave_sum64(s1) * (1.f / C);
+        s2 = wave_sum64(s2) * (1.f / C);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            float o = rstd * (g[i] * d[i] - s1 - v[i] * s2);
+            if (dres) o += dres[base + i];
+            dx[base + i] = o;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        red[0][wave][lane * VPL + i] = dg[i];
+        red[1][wave][lane * VPL + i] = db[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        unsafeAtomicAdd(dgamma + t * C + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        unsafeAtomicAdd(dbeta + t * C + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
+}
+
+int launch_layernorm_bwd(const float* x, const float* dy, const float* gamma, const AgentTypes& types, int n_agents,
+                         const float* dres, float* dx, float* dgamma, float* dbeta, int P, int C, hipStream_t st) {
+    if (n_agents <= 0) return HMVIT_OK;
+    dim3 grid(cdiv(P, 4 * LNB_TOK), n_agents);
+    switch (C) {
+        case 64: hipLaunchKernelGGL((k_layernorm_bwd<1>), grid, dim3(256), 0, st, x, dy, gamma, types, dres, dx, dgamma, dbeta, P); break;
+        case 128: hipLaunchKernelGGL((k_layernorm_bwd<2>), grid, dim3(256), 0, st, x, dy, gamma, types, dres, dx, dgamma, dbeta, P); break;
+        case 256: hipLaunchKernelGGL((k_layernorm_bwd<4>), grid, dim3(256), 0, st, x, dy, gamma, types, dres, dx, dgamma, dbeta, P); break;
+        default: set_error("layernorm_bwd: C=%d unsupported (64, 128, 256)", C); return HMVIT_EINVAL;
+    }
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// attention backward
+// ------------------------------------------------------------------------------------------
+// Same decomposition as k_attention<float>: one workgroup per (sample, ego, window, group of HG heads), one wavefront
+// per head, keys in chunks of 64, K / V tiles re-gathered into LDS.  MFMA tile algebra (v_mfma_f32_16x16x4_f32: a lane
+// (l = lane & 15, g = lane >> 4) supplies A[row l][k g] and B[k g][col l] and receives D[row 4g + r][col l]): an
+// accumulator tile can only be contracted over its ROW index, so both orientations of the logits are formed:
+//   T tiles  S^T[key][query]   -> contraction over keys:    dQ^T = K^T dS^T
+//   N tiles  S[query][key]     -> contraction over queries: dV = P^T dO, dK = dS^T Q
+// The probabilities come from the saved log-sum-exp: P = exp(S + mask - lse), dS = P o (dP - D), D = rowsum(dO o O).
+template <int WIN, int HG>
+__global__ __launch_bounds__(HG * 64, 1) void k_attention_bwd(AttnBwdParams bp) {
+    const AttnParams& p = bp.f;
+    constexpr int N = WIN * WIN, NQT = N / 16, SPC = 64 / N, NB = (WIN == 8) ? 7 : 1;
+    constexpr int CH = HG * 32, QS = CH + 2, KS = CH + 2;
+    constexpr int TPK = CH / 8, KPP = HG * 64 / TPK;
+    __shared__ __attribute__((aligned(16))) float Qs[N * QS];
+    __shared__ __attribute__((aligned(16))) float dOs[N * QS];
+    __shared__ __attribute__((aligned(16))) float Ks[64 * KS];
+    __shared__ __attribute__((aligned(16))) float Vs[64 * KS];
+    __shared__ float maskadd[64];
+    __shared__ float Dl[N][HG], Lse[N][HG];
+
+    const int C = p.C, H = p.H, W = p.W, L = p.L, P = H * W;
+    const int X = H / WIN, Y = W / WIN, NG = C / CH, heads = C / 32;
+    const int win = blockIdx.x / NG, hg = blockIdx.x - win * NG;
+    const int ego = blockIdx.y, b = blockIdx.z;
+    const int wx = win / Y, wy = win - wx * Y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lq = lane & 15, g = lane >> 4;
+    const int head = hg * HG + wave;
+    const int te = p.mode[b * L + ego], ev = p.ego_e[b * L + ego];
+    const int ch0 = hg * CH;
+    const float* qplane = reinterpret_cast<const float*>(p.q) + (size_t)(b * L + ego) * P * C;
+    const float* oplane = reinterpret_cast<const float*>(p.out) + (size_t)(b * L + ego) * P * C;
+    const float* doplane = bp.d_out + (size_t)(b * L + ego) * P * C;
+    const float* kvplanes = reinterpret_cast<const float*>(p.kv);
+
+    // ---- query tile (+ bias), dO tile, D and lse ----
+    {
+        const float* bq = p.b_q + te * C + ch0;
+        const int cl = (tid % TPK) * 8;
+        for (int n = tid / TPK; n < N; n += KPP) {
+            int row, col;
+            token_pixel(p.partition, WIN, X, Y, wx, wy, n, row, col);
+            const size_t o = (size_t)(row * W + col) * C + ch0 + cl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                Qs[n * QS + cl + e] = qplane[o + e] + bq[cl + e];
+                dOs[n * QS + cl + e] = doplane[o + e];
+            }
+        }
+        for (int i = tid; i < N * HG; i += HG * 64) {
+            const int n = i / HG, hh = i - n * HG;
+            int row, col;
+            token_pixel(p.partition, WIN, X, Y, wx, wy, n, row, col);
+            const size_t o = (size_t)(row * W + col) * C + ch0 + hh * 32;
+            float d = 0.f;
+#pragma unroll 8
+            for (int e = 0; e < 32; ++e) d = fmaf(doplane[o + e], oplane[o + e], d);
+            Dl[n][hh] = d;
+            Lse[n][hh] = p.lse[((size_t)(b * L + ego) * P + row * W + col) * heads + hg * HG + hh];
+        }
+    }
+    float4v biasT[NB], biasN[NB], dbias[NB];
+#pragma unroll
+    for (int v = 0; v < NB; ++v) {
+        biasT[v] = *reinterpret_cast<const float4v*>(p.bias_frag + ((size_t)(head * NB + v) * 64 + lane) * 4);
+        biasN[v] = *reinterpret_cast<const float4v*>(bp.bias_frag_neg + ((size_t)(head * NB + v) * 64 + lane) * 4);
+        dbias[v] = (float4v)(0.f);
+    }
+    float4v dq_acc[NQT][2];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) dq_acc[qt][dt] = (float4v)(0.f);
+    __syncthreads();
+
+    const int hoff = wave * 32;
+    const int n_chunks = (p.n_src + SPC - 1) / SPC;
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        // ---- gather 64 keys x CH channels of K and V (as the forward does) ----
+        int any_visible = 0;
+        {
+            const int cl = (tid % TPK) * 8;
+#pragma unroll 1
+            for (int pass = 0; pass < 64 / KPP; ++pass) {
+                const int kk = pass * KPP + tid / TPK;
+                const int src = chunk * SPC + kk / N;
+                const int n = kk % N;
+                float kvv[2][8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) kvv[0][e] = kvv[1][e] = 0.f;
+                bool visible = false;
+                if (src < p.n_src) {
+                    int row, col;
+                    token_pixel(p.partition, WIN, X, Y, wx, wy, n, row, col);
+                    const float* a = p.ainv + ((size_t)(b * L + src) * L + ego) * 8;
+                    const bool ident = a[6] != 0.f;
+                    Taps t;
+                    if (ident) {
+                        t.roi = 1.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { t.idx[k] = row * W + col; t.w[k] = k == 0 ? 1.f : 0.f; }
+                    } else {
+                        t = make_taps(a, col, row, H, W);
+                    }
+                    visible = (t.roi != 0.f) && (p.cav[b * L + src] != 0);
+                    if (visible) {
+                        const int ts = p.mode[b * L + src];
+                        const float* kpl = kvplanes + ((size_t)((b * L + src) * p.E + ev) * 2) * P * C + ch0 + cl;
+                        const float* bk = p.b_kv + (size_t)(te * HMVIT_NUM_TYPES + ts) * 2 * C + ch0 + cl;
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                float acc = 0.f;
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+                                    acc = fmaf(t.w[k], kpl[(size_t)pl * P * C + (size_t)t.idx[k] * C + e], acc);
+                                kvv[pl][e] = acc + bk[pl * C + e];
+                            }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    Ks[kk * KS + cl + e] = kvv[0][e];
+                    Vs[kk * KS + cl + e] = kvv[1][e];
+                }
+                if (cl == 0) maskadd[kk] = visible ? 0.f : -INFINITY;
+                any_visible |= visible ? 1 : 0;
+            }
+        }
+        any_visible = __syncthreads_or(any_visible);
+
+        if (any_visible) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                // operands of key tile kt: rows (kt*16 + lq) x k (4 ks + g), and the "row 4g + r, column lq" form of K
+                float kf[8], vf[8], kfd[4][2];
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    kf[ks] = Ks[(kt * 16 + lq) * KS + hoff + ks * 4 + g];
+                    vf[ks] = Vs[(kt * 16 + lq) * KS + hoff + ks * 4 + g];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) kfd[r][dt] = Ks[(kt * 16 + 4 * g + r) * KS + hoff + dt * 16 + lq];
+                const float4v maddT = *reinterpret_cast<const float4v*>(maskadd + kt * 16 + 4 * g);
+                const float maddN = maskadd[kt * 16 + lq];
+                float4v dk_acc[2], dv_acc[2];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) dk_acc[dt] = dv_acc[dt] = (float4v)(0.f);
+
+#pragma unroll
+                for (int qt = 0; qt < NQT; ++qt) {
+                    float qf[8], dof[8], qfd[4][2], dofd[4][2];
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        qf[ks] = Qs[(qt * 16 + lq) * QS + hoff + ks * 4 + g];
+                        dof[ks] = dOs[(qt * 16 + lq) * QS + hoff + ks * 4 + g];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) {
+                            qfd[r][dt] = Qs[(qt * 16 + 4 * g + r) * QS + hoff + dt * 16 + lq];
+                            dofd[r][dt] = dOs[(qt * 16 + 4 * g + r) * QS + hoff + dt * 16 + lq];
+                        }
+                    const int bvT = (WIN == 8) ? (qt - kt + 3) : 0, bvN = (WIN == 8) ? (kt - qt + 3) : 0;
+                    // ---- T orientation: rows = keys 4g + r, column = query lq ----
+                    float4v sT = biasT[bvT], dpT = (float4v)(0.f);
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        sT = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[ks], qf[ks], sT, 0, 0, 0);
+                        dpT = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[ks], dof[ks], dpT, 0, 0, 0);
+                    }
+                    const float lseT = Lse[qt * 16 + lq][wave], dT = Dl[qt * 16 + lq][wave];
+                    float4v dsT;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dsT[r] = expf(sT[r] + maddT[r] - lseT) * (dpT[r] - dT);
+                    dbias[bvT] += dsT;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt)
+                            dq_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kfd[r][dt], dsT[r], dq_acc[qt][dt], 0, 0, 0);
+                    // ---- N orientation: rows = queries 4g + r, column = key lq ----
+                    float4v sN = biasN[bvN], dpN = (float4v)(0.f);
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        sN = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[ks], kf[ks], sN, 0, 0, 0);
+                        dpN = __builtin_amdgcn_mfma_f32_16x16x4f32(dof[ks], vf[ks], dpN, 0, 0, 0);
+                    }
+                    float4v pN, dsN;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pN[r] = expf(sN[r] + maddN - Lse[qt * 16 + 4 * g + r][wave]);
+                        dsN[r] = pN[r] * (dpN[r] - Dl[qt * 16 + 4 * g + r][wave]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) {
+                            dv_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pN[r], dofd[r][dt], dv_acc[dt], 0, 0, 0);
+                            dk_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsN[r], qfd[r][dt], dk_acc[dt], 0, 0, 0);
+                        }
+                }
+                // ---- store: lane holds keys kt*16 + 4g + r, channel head*32 + dt*16 + lq ----
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kk = kt * 16 + 4 * g + r;
+                    const int src = chunk * SPC + kk / N, n = kk % N;
+                    if (src < p.n_src) {
+                        int row, col;
+                        token_pixel(p.partition, WIN, X, Y, wx, wy, n, row, col);
+                        float* dst = bp.dkg + (((size_t)(b * p.n_ego + ego) * p.n_src + src) * 2) * P * C +
+                                     (size_t)(row * W + col) * C + head * 32 + lq;
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) {
+                            dst[dt * 16] = dk_acc[dt][r];
+                            dst[(size_t)P * C + dt * 16] = dv_acc[dt][r];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // dQ^T tiles: lane holds channels dt*16 + 4g + (0..3) of query qt*16 + lq
+    float* dqp = bp.dq + (size_t)(b * L + ego) * P * C;
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        int row, col;
+        token_pixel(p.partition, WIN, X, Y, wx, wy, qt * 16 + lq, row, col);
+        float* o = dqp + (size_t)(row * W + col) * C + head * 32 + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+            *reinterpret_cast<float4*>(o + dt * 16) = make_float4(dq_acc[qt][dt][0], dq_acc[qt][dt][1], dq_acc[qt][dt][2], dq_acc[qt][dt][3]);
+    }
+#pragma unroll
+    for (int v = 0; v < NB; ++v)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (dbias[v][r] != 0.f) unsafeAtomicAdd(bp.d_bias_frag + ((size_t)(head * NB + v) * 64 + lane) * 4 + r, dbias[v][r]);
+}
+
+template <int WIN, int HG>
+static int launch_attn_bwd_t(const AttnBwdParams& p, hipStream_t st) {
+    const int NG = p.f.C / (HG * 32);
+    dim3 grid((p.f.H / WIN) * (p.f.W / WIN) * NG, p.f.n_ego, p.f.B);
+    hipLaunchKernelGGL((k_attention_bwd<WIN, HG>), grid, dim3(HG * 64), 0, st, p);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+int launch_attention_bwd(const AttnBwdParams& p, hipStream_t st) {
+    HMVIT_CHECK_ARG(p.f.window == 4 || p.f.window == 8, "attention_bwd: window=%d unsupported (4 or 8)", p.f.window);
+    HMVIT_CHECK_ARG(p.f.C == 64 || p.f.C == 128 || p.f.C == 256, "attention_bwd: C=%d unsupported", p.f.C);
+    HMVIT_CHECK_ARG(p.f.lse && p.f.out && p.d_out && p.dq && p.dkg && p.d_bias_frag && p.bias_frag_neg, "attention_bwd: null pointer");
+    if (p.f.n_ego <= 0 || p.f.B <= 0) return HMVIT_OK;
+    return p.f.window == 8 ? launch_attn_bwd_t<8, 2>(p, st) : launch_attn_bwd_t<4, 2>(p, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// adjoint of the bilinear gather
+// ------------------------------------------------------------------------------------------
+// One wavefront per source pixel s.  For an ego whose keys were sampled from this source, the ego pixels u with a tap on s
+// satisfy |Ainv u - s|_inf < 1, i.e. u lies within (|A00| + |A01|, |A10| + |A11|) of A s (A = inverse of the sampling
+// map): the candidates are the integer points of that box around round(A s), one per lane; lanes with a non-zero weight
+// are then visited in turn by the whole wave (4 channels per lane and plane).
+constexpr int WADJ_R = 3;   // supported candidate radius: 2 covers every rigid transform (radius < sqrt(2) + 0.5)
+
+template <int VPL>
+__global__ __launch_bounds__(256) void k_warp_adjoint(WarpAdjParams p) {
+    constexpr int C = VPL * 64;
+    const int P = p.H * p.W;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= P) return;
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.y;                 // b * L + src
+    const int b = slot / p.L, src = slot - b * p.L;
+    if (src >= p.n_src) return;
+    const int e = blockIdx.z;
+    const int sy = s / p.W, sx = s - sy * p.W;
+    float acc[2][VPL];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) acc[pl][i] = 0.f;
+
+    for (int ego = 0; ego < p.n_ego; ++ego) {
+        if (p.ego_e[b * p.L + ego] != e) continue;
+        const float* a = p.ainv + ((size_t)(b * p.L + src) * p.L + ego) * 8;
+        const float* g = p.dkg + (((size_t)(b * p.n_ego + ego) * p.n_src + src) * 2) * P * C;
+        if (a[6] != 0.f) {   // identity: key u reads source pixel u
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) acc[pl][i] += g[(size_t)pl * P * C + (size_t)s * C + lane * VPL + i];
+            continue;
+        }
+        // forward map A = Ainv^-1 (2 x 3)
+        const float det = a[0] * a[4] - a[1] * a[3], id = 1.f / det;
+        const float f00 = a[4] * id, f01 = -a[1] * id, f10 = -a[3] * id, f11 = a[0] * id;
+        const float f02 = -(f00 * a[2] + f01 * a[5]), f12 = -(f10 * a[2] + f11 * a[5]);
+        const float ux = f00 * sx + f01 * sy + f02, uy = f10 * sx + f11 * sy + f12;
+        const int cx = (int)rintf(fminf(fmaxf(ux, -1.0e6f), 1.0e6f)), cy = (int)rintf(fminf(fmaxf(uy, -1.0e6f), 1.0e6f));
+        // lane -> candidate offset in a 7 x 7 box (49 of 64 lanes)
+        const int oy = lane / (2 * WADJ_R + 1) - WADJ_R, ox = lane % (2 * WADJ_R + 1) - WADJ_R;
+        const int u = cx + ox, v = cy + oy;
+        float w = 0.f;
+        if (lane < (2 * WADJ_R + 1) * (2 * WADJ_R + 1) && u >= 0 && u < p.W && v >= 0 && v < p.H) {
+            const Taps t = make_taps(a, u, v, p.H, p.W);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w += (t.idx[k] == s) ? t.w[k] : 0.f;
+        }
+        unsigned long long live = __ballot(w != 0.f);
+        while (live) {
+            const int i = __ffsll((long long)live) - 1;
+            live &= live - 1;
+            const float wi = __shfl(w, i, 64);
+            const int ui = __shfl(v * p.W + u, i, 64);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int c = 0; c < VPL; ++c)
+                    acc[pl][c] = fmaf(wi, g[(size_t)pl * P * C + (size_t)ui * C + lane * VPL + c], acc[pl][c]);
+        }
+    }
+    float* o = p.dkv + ((size_t)(slot * p.E + e) * 2) * P * C + (size_t)s * C + lane * VPL;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) o[(size_t)pl * P * C + i] = acc[pl][i];
+}
+
+int launch_warp_adjoint(const WarpAdjParams& p, hipStream_t st) {
+    if (p.B <= 0 || p.n_src <= 0 || p.E <= 0) return HMVIT_OK;
+    dim3 grid(cdiv(p.H * p.W, 4), p.B * p.L, p.E);
+    switch (p.C) {
+        case 64: hipLaunchKernelGGL((k_warp_adjoint<1>), grid, dim3(256), 0, st, p); break;
+        case 128: hipLaunchKernelGGL((k_warp_adjoint<2>), grid, dim3(256), 0, st, p); break;
+        case 256: hipLaunchKernelGGL((k_warp_adjoint<4>), grid, dim3(256), 0, st, p); break;
+        default: set_error("warp_adjoint: C=%d unsupported", p.C); return HMVIT_EINVAL;
+    }
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+}  // namespace hmvit

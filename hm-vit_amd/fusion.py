@@ -156,20 +156,21 @@ class _FusionBase(nn.Module):
         if x.dim() != 5:
             raise ValueError("x must be (B, L, C, H, W)")
         if self.training or (torch.is_grad_enabled() and x.requires_grad):
-            # no silent detach: a training loop must not get a frozen fusion net without an error
-            raise RuntimeError("hmvit_amd.HeteroFusion: this call needs gradients / training-mode dropout, which the fused "
-                               "inference launch does not provide; call .eval() and run under torch.no_grad()")
+            # no silent detach: the fused inference launch carries no autograd history (HeteroFusion routes such calls to
+            # the training path before getting here; HeteroFusionBlock on its own has no backward)
+            raise RuntimeError("hmvit_amd: this call needs gradients / training-mode dropout, which the fused inference "
+                               "launch does not provide; call .eval() and run under torch.no_grad()")
         B, L, Cc, H, W = x.shape
         prec = _PRECISIONS[self.precision]
         x = x.detach().to(torch.float32).contiguous()
         pw = pairwise_t_matrix.detach().to(device=x.device, dtype=torch.float32).contiguous()
         if tuple(pw.shape) != (B, L, L, 4, 4):
             raise ValueError(f"pairwise_t_matrix must be {(B, L, L, 4, 4)}, got {tuple(pw.shape)}")
-        mode_h, rl_h, mask_h = self._host_small(mode, record_len, mask)
-        if len(mode_h) != B * L or len(mask_h) != B * L or len(rl_h) != B:
-            raise ValueError("mode / mask must be (B, L) and record_len (B,)")
-
+        # everything that does not depend on the small integer inputs first: the read-back below waits for the device, and
+        # whatever host work precedes it overlaps the previous forward still running on the GPU
         w = self._weights(x.device, prec)
+        out = torch.empty((B, Cc, H, W) if apply_head else (B, L, Cc, H, W), device=x.device,
+                          dtype=torch.float32)
         d = _lib.FusionDesc()
         d.B, d.L, d.C, d.H, d.W = B, L, Cc, H, W
         d.heads, d.dim_head = Cc // blk["dim_head"], blk["dim_head"]
@@ -177,10 +178,6 @@ class _FusionBase(nn.Module):
         d.precision, d.apply_head, d.skip_masked = prec, int(apply_head), int(self.skip_masked)
         d.discrete_ratio = float(self.discrete_ratio)
         d.downsample_rate = float(self.downsample_rate)
-        keep = (_lib.i32_array(mode_h), _lib.i32_array(rl_h), _lib.i32_array(mask_h))
-        d.mode, d.record_len, d.cav_mask = keep
-        out = torch.empty((B, Cc, H, W) if apply_head else (B, L, Cc, H, W), device=x.device,
-                          dtype=torch.float32)
         d.x, d.pairwise_t, d.out = x.data_ptr(), pw.data_ptr(), out.data_ptr()
         for s in range(2):
             for name, _ in _lib.StageWeights._fields_:
@@ -192,6 +189,11 @@ class _FusionBase(nn.Module):
             d.parallel = 1
             for name, t in w["split"].items():
                 setattr(d, name, t.data_ptr())
+        mode_h, rl_h, mask_h = self._host_small(mode, record_len, mask)
+        if len(mode_h) != B * L or len(mask_h) != B * L or len(rl_h) != B:
+            raise ValueError("mode / mask must be (B, L) and record_len (B,)")
+        keep = (_lib.i32_array(mode_h), _lib.i32_array(rl_h), _lib.i32_array(mask_h))
+        d.mode, d.record_len, d.cav_mask = keep
         need = _lib.lib.hmvit_fusion_workspace_bytes(ctypes.byref(d))
         if need == 0:
             _lib.check(-22, "hmvit_fusion_workspace_bytes")
@@ -279,7 +281,23 @@ class HeteroFusion(_FusionBase):
         self.downsample_rate = self.hetero_fusion_block.downsample_rate
         self.discrete_ratio = self.hetero_fusion_block.discrete_ratio
 
+    def needs_autograd(self, x) -> bool:
+        """Training mode (dropout active) or an input on the autograd tape: the call goes through the exact-f32 training
+        kernels (hm-vit_amd/train.py), whatever ``precision`` the module infers with.  An eval-mode call whose input does not
+        require grad is inference, as under ``torch.no_grad()`` -- also when parameters have ``requires_grad`` set (their
+        default state); set ``force_autograd = True`` to record such a call."""
+        if not torch.is_grad_enabled():
+            return False
+        return bool(self.training or x.requires_grad or self.force_autograd)
+
+    force_autograd = False
+
     def forward(self, x, pairwise_t_matrix, mode, record_len, mask):
+        if self.needs_autograd(x):
+            from .train import fusion_forward_with_grad
+            return fusion_forward_with_grad(self, x, pairwise_t_matrix, mode, record_len, mask)
+        if self.training:   # grad mode off but dropout active: not an inference call, and there is no tape to train on
+            raise RuntimeError("hmvit_amd.HeteroFusion is in training mode under torch.no_grad(): call .eval() for inference")
         return self._run(x, pairwise_t_matrix, mode, record_len, mask, apply_head=True,
                          num_iters=self.num_iters)
 

@@ -22,7 +22,7 @@ from . import _lib
 NUM_TYPES = _lib.NUM_TYPES
 
 
-def bias_fragments(table: torch.Tensor, window: int) -> torch.Tensor:
+def bias_fragments(table: torch.Tensor, window: int, keep_graph: bool = False) -> torch.Tensor:
     """table ((2w-1)^2, heads) -> (heads, NB, 64, 4) f32; NB = 7 for window 8 (one fragment per
     query-tile minus key-tile offset -3..3), 1 for window 4."""
     w = window
@@ -39,7 +39,7 @@ def bias_fragments(table: torch.Tensor, window: int) -> torch.Tensor:
     else:
         raise ValueError(f"window_size={w} unsupported (4 or 8)")
     idx = (drow + w - 1) * (2 * w - 1) + (dcol + w - 1)          # (NB, 64, 4)
-    frag = table.detach().float()[idx.to(table.device)]           # (NB, 64, 4, heads)
+    frag = (table if keep_graph else table.detach()).float()[idx.to(table.device)]   # (NB, 64, 4, heads)
     return frag.permute(3, 0, 1, 2).contiguous()
 
 
@@ -90,12 +90,14 @@ def ffn_image(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
 
 
 def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: int, window: int,
-               dtype: torch.dtype) -> Dict[str, torch.Tensor]:
+               dtype: torch.dtype, keep_graph: bool = False) -> Dict[str, torch.Tensor]:
     """Folded tensors of one stage (which = 'window' | 'grid') in the layout of
-    HmvitStageWeights (include/hmvit.h).  Matrices in `dtype`, vectors in f32."""
+    HmvitStageWeights (include/hmvit.h).  Matrices in `dtype`, vectors in f32.  ``keep_graph`` (training, f32): `sd` holds
+    the live parameters and the folds stay on the autograd tape, so the gradients the backward kernels return for the folded
+    tensors flow back to relation_att / relation_msg / the typed Linears / the bias table through this very algebra."""
     prefix = f"{prefix}." if prefix else ""
     att = f"{prefix}{which}_attention"
-    f = lambda k: sd[k].detach().float()
+    f = (lambda k: sd[k].float()) if keep_graph else (lambda k: sd[k].detach().float())
     C = f(f"{att}.q_linears.0.weight").shape[0]
     M = C // dim_head
     f16 = dtype == torch.float16
@@ -135,7 +137,11 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
     else:
         out["w_kv"] = w_kv
     out["b_kv"] = b_kv
-    out["bias_frag"] = bias_fragments(sd[f"{att}.relative_position_bias_table.weight"], window) * (LOG2E if f16 else 1.0)
+    out["bias_frag"] = bias_fragments(sd[f"{att}.relative_position_bias_table.weight"], window, keep_graph) * (LOG2E if f16 else 1.0)
+    if keep_graph:
+        # the backward kernel also forms the un-transposed logit tiles: their bias is the fragment set of the table with
+        # negated offsets, i.e. the table flipped along its first axis (index (dr + w - 1)(2w - 1) + dc + w - 1)
+        out["bias_frag_neg"] = bias_fragments(sd[f"{att}.relative_position_bias_table.weight"].detach().flip(0), window)
     w_o = stack(f"{att}.a_linears.{{t}}.0.weight")
     if f16:
         out["img_o"] = per_type(w_o, lambda m: weight_image(m, linear_k=True))
@@ -155,8 +161,8 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
     return {k: v.contiguous() for k, v in out.items()}
 
 
-def fold_head(sd: Dict[str, torch.Tensor], prefix: str, dtype: torch.dtype) -> Dict[str, torch.Tensor]:
-    f = lambda k: sd[k].detach().float()
+def fold_head(sd: Dict[str, torch.Tensor], prefix: str, dtype: torch.dtype, keep_graph: bool = False) -> Dict[str, torch.Tensor]:
+    f = (lambda k: sd[k].float()) if keep_graph else (lambda k: sd[k].detach().float())
     stack = lambda fmt: torch.stack([f(fmt.format(t=t)) for t in range(NUM_TYPES)])
     w1, w2 = stack(f"{prefix}.net.{{t}}.0.weight"), stack(f"{prefix}.net.{{t}}.3.weight")
     out = {"head_b1": stack(f"{prefix}.net.{{t}}.0.bias").contiguous(),

@@ -167,6 +167,57 @@ int hmvit_fusion_forward(const HmvitFusionDesc* desc, void* stream);
 int hmvit_fusion_profile(const HmvitFusionDesc* desc, void* stream, float* phase_ms,
                          int32_t* phase_launches);
 
+/* ---- training: forward that keeps its activations + backward ("autograd must flow to x and all used
+ * parameters").  The reference trains this path through torch.autograd (opencood/tools/train_camera.py:163-199, Dropout 0.1
+ * after the out-projection and inside the FFN, hetero_fusion.py:65-66, base_transformer.py:186-192).  Exact-f32 arithmetic,
+ * sequential block, apply_head = 1; gradients are with respect to the FOLDED weights of HmvitStageWeights (the host maps them
+ * back to the reference's parameters through the fold, hm-vit_amd/weights.py + autograd).  Every gradient buffer is
+ * ACCUMULATED into (the two iterations share the block weights) and must be zero-filled by the caller, f32, same shapes as
+ * the corresponding HmvitStageWeights field in HMVIT_PREC_F32 layout.
+ *
+ * Dropout: element i of the activation of agent slot s = b * L + l in stage k (k = 2 * iteration + {0 window, 1 grid}) is
+ * kept iff u(seed + 0x51ED270B1 * (s + 1), salt = 4 k + which, i) >= drop_p, which = 0 out-projection, 1 FFN hidden,
+ * 2 FFN output; hmvit_dropout_mask writes exactly that mask (0 or 1 / (1 - p)) so a checker can replay it. */
+typedef struct HmvitStageGrads {
+    float* ln_gamma;
+    float* ln_beta;
+    float* w_q;
+    float* b_q;
+    float* w_kv;
+    float* b_kv;
+    float* bias_frag;
+    float* w_o;
+    float* b_o;
+    float* ffn_ln_gamma;
+    float* ffn_ln_beta;
+    float* w_1;
+    float* b_1;
+    float* w_2;
+    float* b_2;
+} HmvitStageGrads;
+
+typedef struct HmvitFusionTrainDesc {
+    HmvitFusionDesc fwd;             /* precision = HMVIT_PREC_F32, apply_head = 1, parallel = 0; fwd.workspace: scratch of
+                                        max(B L P C, B L P mlp) floats; pairwise_t[b, i, i] must be the identity            */
+    float drop_p;                    /* hetero_fusion_block.drop_out in training, 0 in eval                                */
+    uint64_t seed;                   /* dropout stream of this step                                                        */
+    void* saved;                     /* device: activations kept for the backward pass                                     */
+    size_t saved_bytes;              /* >= hmvit_fusion_train_saved_bytes                                                  */
+    const void* bias_frag_neg[2];    /* per stage, device (heads, NB, 64, 4) f32: bias_frag of the table with negated
+                                        offsets (table flipped along its first axis); read by the backward pass only       */
+} HmvitFusionTrainDesc;
+
+size_t hmvit_fusion_train_saved_bytes(const HmvitFusionTrainDesc* desc);
+size_t hmvit_fusion_backward_workspace_bytes(const HmvitFusionTrainDesc* desc);
+/* HeteroFusion.forward in training mode: fwd.out (B, C, H, W) */
+int hmvit_fusion_train_forward(const HmvitFusionTrainDesc* desc, void* stream);
+/* d_out (B, C, H, W) -> d_x (B, L, C, H, W) (padded agents: 0), grads[2] (window, grid), mlp_head gradients (T, C, C) / (T, C).
+ * `desc` must be the descriptor of the matching hmvit_fusion_train_forward call (same saved area, seed, weights). */
+int hmvit_fusion_backward(const HmvitFusionTrainDesc* desc, const float* d_out, float* d_x, const HmvitStageGrads* grads,
+                          float* d_head_w1, float* d_head_b1, float* d_head_w2, float* d_head_b2, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int hmvit_dropout_mask(float* mask, size_t n, uint64_t seed, uint32_t salt, float p, void* stream);
+
 /* ---- single operators (used by the parity tests; same kernels as the fused forward) ---- */
 
 /* (n_agents, C, P) f32 -> (n_agents, P, C) f32 and back: the layout change between the

@@ -49,9 +49,11 @@ def hetero_layer_norm(x: Tensor, mode: Tensor, sd: Dict[str, Tensor], prefix: st
     return out
 
 
-def hetero_feed_forward(x: Tensor, mode: Tensor, sd: Dict[str, Tensor], prefix: str) -> Tensor:
-    """HeteroFeedForward in eval mode (base_transformer.py:180-192): Linear -> GELU(erf) ->
-    Linear, weights picked by agent type.  x: (B, L, ..., C)."""
+def hetero_feed_forward(x: Tensor, mode: Tensor, sd: Dict[str, Tensor], prefix: str,
+                        mask_hidden: Tensor | None = None, mask_out: Tensor | None = None) -> Tensor:
+    """HeteroFeedForward (base_transformer.py:180-192): Linear -> GELU(erf) -> Dropout -> Linear -> Dropout, weights
+    picked by agent type.  x: (B, L, ..., C).  Eval mode by default; a training-mode run is replayed by passing the two
+    Dropout masks (0 or 1/(1-p), shaped like the hidden / output activations)."""
     out = None
     for t in range(NUM_TYPES):
         sel = mode == t
@@ -59,7 +61,11 @@ def hetero_feed_forward(x: Tensor, mode: Tensor, sd: Dict[str, Tensor], prefix: 
             continue
         h = F.linear(x[sel], sd[f"{prefix}.net.{t}.0.weight"], sd[f"{prefix}.net.{t}.0.bias"])
         h = F.gelu(h)
+        if mask_hidden is not None:
+            h = h * mask_hidden[sel]
         h = F.linear(h, sd[f"{prefix}.net.{t}.3.weight"], sd[f"{prefix}.net.{t}.3.bias"])
+        if mask_out is not None:
+            h = h * mask_out[sel]
         if out is None:
             out = torch.zeros(x.shape[:-1] + (h.shape[-1],), dtype=x.dtype)
         out[sel] = h
@@ -242,9 +248,11 @@ def _unpartition(t: Tensor, grid: bool) -> Tensor:
 
 def fusion_stage(x: Tensor, pairwise_t: Tensor, mask: Tensor, mode: Tensor,
                  record_len: Tensor, sd: Dict[str, Tensor], prefix: str, which: str,
-                 cfg: dict) -> Tensor:
+                 cfg: dict, drop=None) -> Tensor:
     """local_/global_spatial_multi_agent_attention (hetero_fusion.py:363-444).
-    which = 'window' (local) or 'grid' (global)."""
+    which = 'window' (local) or 'grid' (global).  drop: None (eval) or the three Dropout masks of a training-mode run,
+    (B, L, H, W, C) each: [0] after the attention out-projection (hetero_fusion.py:65-66), [1] FFN hidden, [2] FFN output
+    (base_transformer.py:186-192)."""
     B, L, C, H, W = x.shape
     w = cfg["window_size"]
     dr = cfg["spatial_transform"]["voxel_size"][0]
@@ -272,11 +280,14 @@ def fusion_stage(x: Tensor, pairwise_t: Tensor, mask: Tensor, mode: Tensor,
                                cfg["dim_head"], w)
         updates.append(_unpartition(upd, grid))
     upd = torch.cat(updates, dim=1)
+    if drop is not None:
+        upd = upd * drop[0][:, :max_cav].permute(0, 1, 4, 2, 3)
     upd = F.pad(upd, (0, 0, 0, 0, 0, 0, 0, L - max_cav))
     x = upd + x                                                            # (:399,439)
     xt = x.permute(0, 1, 3, 4, 2)
     y = hetero_feed_forward(hetero_layer_norm(xt, mode, sd, f"{prefix}.{which}_ffd.norm"),
-                            mode, sd, f"{prefix}.{which}_ffd.fn") + xt      # (:401,441)
+                            mode, sd, f"{prefix}.{which}_ffd.fn",
+                            None if drop is None else drop[1], None if drop is None else drop[2]) + xt      # (:401,441)
     return y.permute(0, 1, 4, 2, 3)
 
 
@@ -295,12 +306,12 @@ def split_attn(branches, sd: Dict[str, Tensor], prefix: str) -> Tensor:
 
 
 def hetero_fusion_block(x: Tensor, pairwise_t: Tensor, mode: Tensor, record_len: Tensor,
-                        mask: Tensor, sd: Dict[str, Tensor], prefix: str, cfg: dict) -> Tensor:
-    """HeteroFusionBlock.forward (hetero_fusion.py:446-474)."""
+                        mask: Tensor, sd: Dict[str, Tensor], prefix: str, cfg: dict, drop=None) -> Tensor:
+    """HeteroFusionBlock.forward (hetero_fusion.py:446-474).  drop: None or [window masks, grid masks] (fusion_stage)."""
     arch = cfg["architect_mode"]
     if arch == "sequential":
-        x = fusion_stage(x, pairwise_t, mask, mode, record_len, sd, prefix, "window", cfg)
-        x = fusion_stage(x, pairwise_t, mask, mode, record_len, sd, prefix, "grid", cfg)
+        x = fusion_stage(x, pairwise_t, mask, mode, record_len, sd, prefix, "window", cfg, None if drop is None else drop[0])
+        x = fusion_stage(x, pairwise_t, mask, mode, record_len, sd, prefix, "grid", cfg, None if drop is None else drop[1])
         return x
     if arch == "parallel":
         a = fusion_stage(x, pairwise_t, mask, mode, record_len, sd, prefix, "window", cfg)
@@ -312,8 +323,10 @@ def hetero_fusion_block(x: Tensor, pairwise_t: Tensor, mode: Tensor, record_len:
 
 
 def hetero_fusion(x: Tensor, pairwise_t: Tensor, mode: Tensor, record_len: Tensor,
-                  mask: Tensor, sd: Dict[str, Tensor], cfg: dict) -> Tensor:
-    """HeteroFusion.forward (bevformer_point_pillar_hetero.py:39-49).
+                  mask: Tensor, sd: Dict[str, Tensor], cfg: dict, drop_masks=None) -> Tensor:
+    """HeteroFusion.forward (bevformer_point_pillar_hetero.py:39-49).  Plain torch, so torch.autograd differentiates it:
+    the gradient checker of the HIP backward pass.  drop_masks: None (eval) or, per iteration, [window, grid] triples of
+    Dropout masks replaying a training-mode run (fusion_stage).
 
     x (B, L, C, H, W) f32; pairwise_t (B, L, L, 4, 4), [b, i, j] maps agent i -> agent j;
     mode (B, L) int 1 = lidar / 0 = camera (padding 0); record_len (B,); mask (B, L) 1/0.
@@ -322,9 +335,10 @@ def hetero_fusion(x: Tensor, pairwise_t: Tensor, mode: Tensor, record_len: Tenso
     mode = mode.to(torch.int64)
     pairwise_t = pairwise_t.to(torch.float32)
     x = x.to(torch.float32)
-    for _ in range(cfg["num_iters"]):
+    for it in range(cfg["num_iters"]):
         x = hetero_fusion_block(x, pairwise_t, mode, record_len, mask, sd,
-                                "hetero_fusion_block", cfg["hetero_fusion_block"])
+                                "hetero_fusion_block", cfg["hetero_fusion_block"],
+                                None if drop_masks is None else drop_masks[it])
     ego = x[:, :1].permute(0, 1, 3, 4, 2)                      # (B, 1, H, W, C)
     y = hetero_feed_forward(ego, mode[:, :1], sd, "mlp_head")
     return y[:, 0].permute(0, 3, 1, 2)

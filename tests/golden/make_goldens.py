@@ -20,6 +20,9 @@ What is frozen:
                         offset 3 / every 16th col + col offset 5) + the first and last full rows + per-channel moments.
                         ~2.5 min and ~16 GB on 8 cores.
   g13_fusion_cfg3.npz   same at configs[2]'s type pattern 10110 (mixed camera / LiDAR agent types).
+  g14_loss.npz          PointPillarLoss.forward (loss/point_pillar_loss.py:68-142; cls_weight 1, reg 2) on seeded head outputs /
+                        targets (B=2, 2 anchors, 8x12, a few positives, one NaN target): total / reg / conf loss and the
+                        gradients with respect to psm and rm.
   g7_pointpillar.npz    PointPillar.forward (features only, eval BN): 2 agents x 400 pillars on a
                         64x48 canvas; PFN output + (2, 256, 12, 16) BEV features.
   g8_decoder.npz        HeteroDecoder.forward (no upsample), 3 samples with ego types 1,0,1, 12x10.
@@ -73,6 +76,7 @@ from oracle import hmvit_oracle as O  # noqa: E402  (only for the seeded input g
 from oracle import pointpillar_oracle as PO  # noqa: E402  (seeded pillars / weights)
 from oracle import decoder_oracle as DO  # noqa: E402  (seeded weights)
 from model_fixture import model_batch, model_config, model_state_dict  # noqa: E402
+from make_goldens_inputs import loss_inputs  # noqa: E402
 
 torch.set_grad_enabled(False)
 
@@ -230,6 +234,20 @@ def g13_fusion_cfg3():
     _fusion_full_size("g13_fusion_cfg3.npz", [1, 0, 1, 1, 0], 131, 2)
 
 
+def g14_loss():
+    from opencood.loss.point_pillar_loss import PointPillarLoss
+    torch.set_grad_enabled(True)
+    psm, rm, tgt = loss_inputs()
+    psm.requires_grad_(True)
+    rm.requires_grad_(True)
+    crit = PointPillarLoss({"cls_weight": 1.0, "reg": 2.0})
+    total = crit({"psm": psm, "rm": rm}, tgt)
+    total.backward()
+    save("g14_loss.npz", total=total.detach(), reg=crit.loss_dict["reg_loss"].detach(), conf=crit.loss_dict["conf_loss"].detach(),
+         d_psm=psm.grad, d_rm=rm.grad)
+    torch.set_grad_enabled(False)
+
+
 def g7_pointpillar():
     """PointPillar.forward (return_features), eval-mode BN with non-trivial running stats:
     2 agents x 400 pillars on a 64 x 48 canvas -> (2, 256, 12, 16); also the PFN output."""
@@ -357,6 +375,9 @@ def g11_cross_view():
 if __name__ == "__main__":
     if "g11" in sys.argv[1:]:
         g11_cross_view()
+        sys.exit(0)
+    if "g14" in sys.argv[1:]:
+        g14_loss()
         sys.exit(0)
     if "g12" in sys.argv[1:]:
         g12_fusion_cfg2()
