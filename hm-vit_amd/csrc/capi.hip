@@ -18,7 +18,7 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-static size_t elem_size(int precision) { return precision == HMVIT_PREC_F32 ? 4 : 2; }
+static size_t elem_size(int precision) { return precision == HMVIT_PREC_F16 ? 2 : 4; }   // Q / K' / V' / O planes
 
 struct Plan {
     int B, L, C, H, W, P, mlp, n_slots, max_cav, E_max;
@@ -39,7 +39,8 @@ int check_desc(const HmvitFusionDesc* d) {
                     "BEV %dx%d must be divisible by window_size %d", d->H, d->W, d->window);
     HMVIT_CHECK_ARG(d->mlp_dim > 0 && d->mlp_dim % 64 == 0, "mlp_dim=%d must be a multiple of 64", d->mlp_dim);
     HMVIT_CHECK_ARG(d->num_iters >= 1, "num_iters=%d", d->num_iters);
-    HMVIT_CHECK_ARG(d->precision == HMVIT_PREC_F32 || d->precision == HMVIT_PREC_F16, "precision=%d", d->precision);
+    HMVIT_CHECK_ARG(d->precision == HMVIT_PREC_F32 || d->precision == HMVIT_PREC_F16 || d->precision == HMVIT_PREC_SPLIT,
+                    "precision=%d", d->precision);
     HMVIT_CHECK_ARG(d->mode && d->record_len && d->cav_mask, "mode / record_len / cav_mask must be host arrays");
     HMVIT_CHECK_ARG(d->discrete_ratio * d->downsample_rate != 0.f, "discrete_ratio * downsample_rate is 0");
     HMVIT_CHECK_ARG(!d->parallel || (d->split_fc1 && d->split_ln_g && d->split_ln_b && d->split_fc2),
@@ -170,7 +171,7 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st, PhaseTimer* 
         return HMVIT_ENOMEM;
     }
     HMVIT_CHECK_ARG(pl.n_slots <= kMaxSlots, "B*L=%d exceeds %d agent slots per call", pl.n_slots, kMaxSlots);
-    if (d->precision == HMVIT_PREC_F16) return fusion_forward_f16(d, pl, st, timer);
+    if (d->precision != HMVIT_PREC_F32) return fusion_forward_f16(d, pl, st, timer);   // fused chains: f16 or split operands
 
     const int B = pl.B, L = pl.L, C = pl.C, P = pl.P, mlp = pl.mlp, prec = d->precision;
     const size_t es = pl.es;
@@ -394,15 +395,17 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st, PhaseTimer* 
 }
 
 // ------------------------------------------------------------------------------------------
-// f16-operand mode: three launches per stage (chain.hip + attn.hip), no layout kernels
+// fused modes (f16 operands, or split hi / lo f16 operands = fp32-class products): three launches per stage
+// (chain.hip + attn.hip), no layout kernels
 // ------------------------------------------------------------------------------------------
 struct QkvBatcher {
     QkvParams p;
     int n, C;
+    bool split;
     hipStream_t st;
     int flush() {
         if (n == 0) return HMVIT_OK;
-        int rc = launch_ln_qkv(p, n, C, st);
+        int rc = launch_ln_qkv(p, n, C, split, st);
         n = 0;
         return rc;
     }
@@ -415,10 +418,11 @@ struct QkvBatcher {
 struct FfnBatcher {
     FfnParams p;
     int n, C, variant;
+    bool split;
     hipStream_t st;
     int flush() {
         if (n == 0) return HMVIT_OK;
-        int rc = launch_out_ffn(p, n, C, variant, st);
+        int rc = launch_out_ffn(p, n, C, variant, split, st);
         n = 0;
         return rc;
     }
@@ -430,19 +434,22 @@ struct FfnBatcher {
 };
 
 static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStream_t st, PhaseTimer* timer) {
-    HMVIT_CHECK_ARG(d->mlp_dim == d->C, "f16 mode: mlp_dim=%d must equal input_dim=%d (fused FFN kernel)", d->mlp_dim, d->C);
+    HMVIT_CHECK_ARG(d->mlp_dim == d->C, "fused modes: mlp_dim=%d must equal input_dim=%d (fused FFN kernel)", d->mlp_dim, d->C);
     for (int s = 0; s < 2; ++s)
         HMVIT_CHECK_ARG(d->stage[s].img_q && d->stage[s].img_kv && d->stage[s].img_o && d->stage[s].img_ffn,
-                        "f16 mode: stage %d weight images are null", s);
+                        "fused modes: stage %d weight images are null", s);
     const int B = pl.B, L = pl.L, C = pl.C, P = pl.P;
+    const bool split = d->precision == HMVIT_PREC_SPLIT;   // hi / lo images (twice the halves), f32 Q / K' / V' / O planes
+    const size_t es = pl.es;
     char* ws = reinterpret_cast<char*>(d->workspace);
     float* xs = reinterpret_cast<float*>(ws + pl.off_xs);
-    half_t* qb = reinterpret_cast<half_t*>(ws + pl.off_q);
-    half_t* kvb = reinterpret_cast<half_t*>(ws + pl.off_kv);
-    half_t* ob = reinterpret_cast<half_t*>(ws + pl.off_o);
+    char* qb = ws + pl.off_q;
+    char* kvb = ws + pl.off_kv;
+    char* ob = ws + pl.off_o;
     float* ainv = reinterpret_cast<float*>(ws + pl.off_ainv);
     const size_t map_elems = (size_t)P * C;
-    const size_t img_elems = (size_t)C * C;   // one (C, C) matrix image
+    const size_t map_bytes = map_elems * es;    // one projected (P, C) plane
+    const size_t img_elems = (size_t)C * C * (split ? 2 : 1);   // halves of one (C, C) matrix image
 
     HMVIT_MARK(-1);
     HMVIT_TRY(launch_pair_affines(d->pairwise_t, ainv, pl.n_slots * L, d->H, d->W, d->discrete_ratio,
@@ -490,15 +497,15 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
         int nm = 0;
         if (l < si.n_ego) {
             j.w[nm] = reinterpret_cast<const half_t*>(wt.img_q) + (size_t)t * img_elems;
-            j.y[nm] = qb + (size_t)slot * map_elems;
+            j.y[nm] = qb + (size_t)slot * map_bytes;
             ++nm;
         }
         for (int e = 0; e < si.E; ++e) {
             const half_t* wkv = reinterpret_cast<const half_t*>(wt.img_kv) +
                                 (size_t)(si.e_type[e] * HMVIT_NUM_TYPES + t) * 2 * img_elems;
-            half_t* ykv = kvb + (size_t)(slot * si.E + e) * 2 * map_elems;
+            char* ykv = kvb + (size_t)(slot * si.E + e) * 2 * map_bytes;
             j.w[nm] = wkv;             j.y[nm] = ykv;             ++nm;
-            j.w[nm] = wkv + img_elems; j.y[nm] = ykv + map_elems; ++nm;
+            j.w[nm] = wkv + img_elems; j.y[nm] = ykv + map_bytes; ++nm;
         }
         j.n_mat = nm;
         return j;
@@ -543,7 +550,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
             if (!qkv_done) {
                 QkvBatcher qb_;
                 memset(&qb_.p, 0, sizeof(qb_.p));
-                qb_.n = 0; qb_.C = C; qb_.st = st;
+                qb_.n = 0; qb_.C = C; qb_.st = st; qb_.split = split;
                 qb_.p.gamma = wt.ln_gamma; qb_.p.beta = wt.ln_beta; qb_.p.P = P; qb_.p.in_nchw = first ? 1 : 0;
                 for (int b = 0; b < B; ++b)
                     for (int l = 0; l < pl.max_cav; ++l) HMVIT_TRY(qb_.add(qkv_job(wt, si, b * L + l, l, first)));
@@ -569,14 +576,15 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                 }
                 // the stage after this one is the pruned last stage (ego 0 only): unreachable windows are dead code
                 need = (it == d->num_iters - 1 && s == 0) ? need_last : nullptr;
-                if (d->skip_masked && d->window == 8 && C > 64 && n_src <= 8 && !getenv("HMVIT_ATTN_DEBUG")) {
+                if (!split && d->skip_masked && d->window == 8 && C > 64 && n_src <= 8 && !getenv("HMVIT_ATTN_DEBUG")) {
                     // tiles without a visible key are skipped by the persistent kernel (launch_tile_vis)
                     unsigned* vis = reinterpret_cast<unsigned*>(ws + pl.off_vis);
                     HMVIT_TRY(launch_tile_vis(ap, vis, need, st));
                     ap.vis_mask = vis;
                     ap.prune = need != nullptr;
                 }
-                HMVIT_TRY(launch_attention(ap, HMVIT_PREC_F16, st));
+                // split mode: the exact-f32 attention kernel on the f32 planes (attn.hip k_attention<float>)
+                HMVIT_TRY(launch_attention(ap, split ? HMVIT_PREC_F32 : HMVIT_PREC_F16, st));
             }
             HMVIT_MARK(HMVIT_PHASE_ATTENTION);
 
@@ -587,7 +595,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                 const bool fuse = !par && has_next && !last && C == 256 && !getenv("HMVIT_NO_FUSE");
                 FfnBatcher fb;
                 memset(&fb.p, 0, sizeof(fb.p));
-                fb.n = 0; fb.C = C; fb.st = st;
+                fb.n = 0; fb.C = C; fb.st = st; fb.split = split;
                 fb.p.w_o = reinterpret_cast<const half_t*>(wt.img_o); fb.p.b_o = wt.b_o;
                 fb.p.ln_g = wt.ffn_ln_gamma; fb.p.ln_b = wt.ffn_ln_beta;
                 fb.p.w_ffn = reinterpret_cast<const half_t*>(wt.img_ffn); fb.p.b_1 = wt.b_1; fb.p.b_2 = wt.b_2;
@@ -606,7 +614,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                             const int slot = b * L + i;
                             FfnJob j;
                             j.need = nullptr; j.x_nchw = 0;
-                            j.o = ob + (size_t)slot * map_elems;
+                            j.o = ob + (size_t)slot * map_bytes;
                             j.x = xs + (size_t)slot * map_elems;
                             if (first && direct_x) { j.x = d->x + (size_t)slot * map_elems; j.x_nchw = 1; }
                             j.out = x_out + (size_t)slot * map_elems;
@@ -616,9 +624,9 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                             j.need = nd ? nd + (size_t)(b * n_ego + i) * (P / 64) : nullptr;
                             fb.p.job[n] = j;
                             qp.job[n] = qkv_job(wn, sn, slot, i, false);
-                            if (++n == kMaxChainJobs) { HMVIT_TRY(launch_out_ffn_qkv(fb.p, qp, n, C, st)); n = 0; }
+                            if (++n == kMaxChainJobs) { HMVIT_TRY(launch_out_ffn_qkv(fb.p, qp, n, C, split, st)); n = 0; }
                         }
-                    HMVIT_TRY(launch_out_ffn_qkv(fb.p, qp, n, C, st));
+                    HMVIT_TRY(launch_out_ffn_qkv(fb.p, qp, n, C, split, st));
                     qkv_done = true;
                 } else if (last && !par && C == 256 && d->head_img_ffn && !getenv("HMVIT_NO_FUSE")) {
                     // last stage: only the ego row is alive and mlp_head follows immediately (k_out_ffn_head)
@@ -628,14 +636,14 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                         const int slot = b * L;
                         FfnJob j;
                             j.need = nullptr; j.x_nchw = 0;
-                        j.o = ob + (size_t)slot * map_elems;
+                        j.o = ob + (size_t)slot * map_bytes;
                         j.x = xs + (size_t)slot * map_elems;
                         j.out = d->out + (size_t)b * map_elems;
                         j.type = d->mode[slot]; j.pad = 0;
                         fb.p.job[n] = j;
-                        if (++n == kMaxChainJobs) { HMVIT_TRY(launch_out_ffn_head(fb.p, n, C, st)); n = 0; }
+                        if (++n == kMaxChainJobs) { HMVIT_TRY(launch_out_ffn_head(fb.p, n, C, split, st)); n = 0; }
                     }
-                    HMVIT_TRY(launch_out_ffn_head(fb.p, n, C, st));
+                    HMVIT_TRY(launch_out_ffn_head(fb.p, n, C, split, st));
                     head_done = true;
                 } else {
                     for (int b = 0; b < B; ++b)
@@ -643,7 +651,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                             const int slot = b * L + i;
                             FfnJob j;
                             j.need = nullptr; j.x_nchw = 0;
-                            j.o = ob + (size_t)slot * map_elems;
+                            j.o = ob + (size_t)slot * map_bytes;
                             j.x = xs + (size_t)slot * map_elems;
                             j.out = x_out + (size_t)slot * map_elems;
                             j.type = d->mode[slot]; j.pad = 0;
@@ -685,7 +693,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
     if (!head_done) {
         FfnBatcher fb;
         memset(&fb.p, 0, sizeof(fb.p));
-        fb.n = 0; fb.C = C; fb.st = st; fb.variant = FFN_HEAD_NCHW;
+        fb.n = 0; fb.C = C; fb.st = st; fb.variant = FFN_HEAD_NCHW; fb.split = split;
         fb.p.w_ffn = reinterpret_cast<const half_t*>(d->head_img_ffn); fb.p.b_1 = d->head_b1; fb.p.b_2 = d->head_b2;
         fb.p.P = P;
         for (int b = 0; b < B; ++b) {

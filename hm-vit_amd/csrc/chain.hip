@@ -197,11 +197,14 @@ __device__ __forceinline__ void mma_chunk_op(float16v& acc, const half_t* buf, c
     if constexpr (SP) mma_chunk_split<KK, DEPTH>(acc, buf, a.hi, a.lo, lane);
     else mma_chunk<KK, DEPTH>(acc, buf, a.hi, lane);
 }
-// x -> (hi, lo) f16 pair
-__device__ __forceinline__ void split_h(float x, half_t& hi, half_t& lo) {
-    hi = (half_t)x;
-    lo = (half_t)(x - (float)hi);
-}
+// x -> (hi, lo) f16 pair (a macro: vector elements cannot bind to references)
+#define split_h(x, H, L)                     \
+    do {                                     \
+        const float _x = (x);                \
+        const half_t _h = (half_t)_x;        \
+        (H) = _h;                            \
+        (L) = (half_t)(_x - (float)_h);      \
+    } while (0)
 
 __device__ __forceinline__ float pair_sum(float v) { return xor32_sum(v); }
 
@@ -240,27 +243,33 @@ __device__ __forceinline__ void layer_norm_regs(float4 (&v)[C / 32][4], const fl
 }
 
 // f32 activations -> MFMA B operands
-template <int C>
-__device__ __forceinline__ void to_operands(const float4 (&v)[C / 32][4], half8 (&act)[C / 16]) {
+template <int C, bool SP>
+__device__ __forceinline__ void to_operands(const float4 (&v)[C / 32][4], Operands<C / 16, SP>& act) {
 #pragma unroll
     for (int b = 0; b < C / 32; ++b)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            half8 h;
+            half8 h, l;
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const float4 f = v[b][2 * s + jj];
-                h[4 * jj + 0] = (half_t)f.x; h[4 * jj + 1] = (half_t)f.y;
-                h[4 * jj + 2] = (half_t)f.z; h[4 * jj + 3] = (half_t)f.w;
+                if constexpr (SP) {
+                    split_h(f.x, h[4 * jj + 0], l[4 * jj + 0]); split_h(f.y, h[4 * jj + 1], l[4 * jj + 1]);
+                    split_h(f.z, h[4 * jj + 2], l[4 * jj + 2]); split_h(f.w, h[4 * jj + 3], l[4 * jj + 3]);
+                } else {
+                    h[4 * jj + 0] = (half_t)f.x; h[4 * jj + 1] = (half_t)f.y;
+                    h[4 * jj + 2] = (half_t)f.z; h[4 * jj + 3] = (half_t)f.w;
+                }
             }
-            act[2 * b + s] = h;
+            act.hi[2 * b + s] = h;
+            if constexpr (SP) act.lo[2 * b + s] = l;
         }
 }
 
 // LayerNorm straight from the accumulator layout into MFMA B operands (no f32 copy is kept)
-template <int C>
+template <int C, bool SP>
 __device__ __forceinline__ void ln_acc_to_operands(const float16v (&xa)[C / 32], const float* __restrict__ lg,
-                                                   const float* __restrict__ lb, int hi, half8 (&act)[C / 16]) {
+                                                   const float* __restrict__ lb, int hi, Operands<C / 16, SP>& act) {
     constexpr int NT = C / 32;
     float s = 0.f;
 #pragma unroll
@@ -283,7 +292,7 @@ __device__ __forceinline__ void ln_acc_to_operands(const float16v (&xa)[C / 32],
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx) {
             __builtin_amdgcn_sched_barrier(0);
-            half8 h;
+            half8 h, l;
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = 2 * sx + jj, c = 32 * t + 8 * j + 4 * hi;
@@ -291,13 +300,24 @@ __device__ __forceinline__ void ln_acc_to_operands(const float16v (&xa)[C / 32],
                 const float4 be = *reinterpret_cast<const float4*>(lb + c);
                 // x * rstd + shift, not (x - mean) * rstd: the latter shares (x - mean) with the variance pass and
                 // hipcc then keeps all C centred values alive next to the accumulators (32 spilled registers)
-                h[4 * jj + 0] = (half_t)(fmaf(xa[t][4 * j + 0], rstd, shift) * g.x + be.x);
-                h[4 * jj + 1] = (half_t)(fmaf(xa[t][4 * j + 1], rstd, shift) * g.y + be.y);
-                h[4 * jj + 2] = (half_t)(fmaf(xa[t][4 * j + 2], rstd, shift) * g.z + be.z);
-                h[4 * jj + 3] = (half_t)(fmaf(xa[t][4 * j + 3], rstd, shift) * g.w + be.w);
+                const float n0 = fmaf(xa[t][4 * j + 0], rstd, shift) * g.x + be.x;
+                const float n1 = fmaf(xa[t][4 * j + 1], rstd, shift) * g.y + be.y;
+                const float n2 = fmaf(xa[t][4 * j + 2], rstd, shift) * g.z + be.z;
+                const float n3 = fmaf(xa[t][4 * j + 3], rstd, shift) * g.w + be.w;
+                if constexpr (SP) {
+                    split_h(n0, h[4 * jj + 0], l[4 * jj + 0]); split_h(n1, h[4 * jj + 1], l[4 * jj + 1]);
+                    split_h(n2, h[4 * jj + 2], l[4 * jj + 2]); split_h(n3, h[4 * jj + 3], l[4 * jj + 3]);
+                } else {
+                    h[4 * jj + 0] = (half_t)n0; h[4 * jj + 1] = (half_t)n1;
+                    h[4 * jj + 2] = (half_t)n2; h[4 * jj + 3] = (half_t)n3;
+                }
             }
             asm volatile("" : "+v"(h));   // pin: the optimizer otherwise sinks the normalisation to the first use
-            act[2 * t + sx] = h;
+            act.hi[2 * t + sx] = h;
+            if constexpr (SP) {
+                asm volatile("" : "+v"(l));
+                act.lo[2 * t + sx] = l;
+            }
         }
     // (the fences below keep hipcc from hoisting all 64 gamma / beta reads ahead of the arithmetic)
 }
@@ -345,6 +365,27 @@ __device__ __forceinline__ void stage_tile(half_t* stg, int m, int hi, int t4, c
     }
 }
 
+// split mode: the projected tiles go to memory as f32.  Two consecutive tiles (64 channels = 256 bytes per token) share the same
+// per-wave buffer: rows of 64 floats + 4 floats of padding (= STG_ROW halves), rows in store order as above.
+__device__ __forceinline__ void stage_tile_f32(half_t* stg_h, int m, int hi, int t2, const float16v& acc) {
+    float* d = reinterpret_cast<float*>(stg_h) + m * (STG_ROW / 2) + 32 * t2 + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        *reinterpret_cast<float4*>(d + 16 * s) = make_float4(acc[8 * s], acc[8 * s + 1], acc[8 * s + 2], acc[8 * s + 3]);
+        *reinterpret_cast<float4*>(d + 16 * s + 4) = make_float4(acc[8 * s + 4], acc[8 * s + 5], acc[8 * s + 6], acc[8 * s + 7]);
+    }
+}
+// y: first token row of the wave in the output plane, already offset to the 64-channel group
+__device__ __forceinline__ void flush_tiles_f32(const half_t* stg_h, float* y, int lane, int n_tok, int C) {
+    const float* stg = reinterpret_cast<const float*>(stg_h);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int token = 4 * k + (lane >> 4), piece = lane & 15;
+        const float4 v = *reinterpret_cast<const float4*>(stg + token * (STG_ROW / 2) + piece * 4);
+        if (token < n_tok) *reinterpret_cast<float4*>(y + (size_t)token * C + piece * 4) = v;
+    }
+}
+
 // y: first token row of the wave in the output plane, already offset to the 128-channel group
 __device__ __forceinline__ void flush_tiles(const half_t* stg, half_t* y, int lane, int n_tok, int C) {
 #pragma unroll
@@ -355,12 +396,46 @@ __device__ __forceinline__ void flush_tiles(const half_t* stg, half_t* y, int la
     }
 }
 
+// One projected 32-channel tile `t` of matrix output `y` (f16 plane, or f32 plane in split mode) for the wave's 32 tokens.
+template <int C, bool SP, bool STAGED>
+__device__ __forceinline__ void store_proj_tile(half_t* stg, void* y, int t, const float16v& acc, int m, int hi, int lane, int tok,
+                                                bool valid, int tok_w, int P) {
+    if constexpr (STAGED && SP) {
+        stage_tile_f32(stg, m, hi, t & 1, acc);
+        if ((t & 1) == 1) flush_tiles_f32(stg, reinterpret_cast<float*>(y) + (size_t)tok_w * C + 64 * (t >> 1), lane, P - tok_w, C);
+    } else if constexpr (STAGED) {
+        stage_tile(stg, m, hi, t & 3, acc);
+        if ((t & 3) == 3) flush_tiles(stg, reinterpret_cast<half_t*>(y) + (size_t)tok_w * C + 128 * (t >> 2), lane, P - tok_w, C);
+    } else if (valid) {
+        // the images of these kernels order the rows of a tile so that the lane's 16 results are two runs
+        // of 8 consecutive channels (weights.py store_row_order): 2 x 16-byte stores (f16), adjacent for the
+        // lane pair of a token, instead of 4 x 8 (the store path is issue-bound)
+        if constexpr (SP) {
+            float* o = reinterpret_cast<float*>(y) + ((size_t)tok * C + 32 * t + 8 * hi);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                *reinterpret_cast<float4*>(o + 16 * s) = make_float4(acc[8 * s], acc[8 * s + 1], acc[8 * s + 2], acc[8 * s + 3]);
+                *reinterpret_cast<float4*>(o + 16 * s + 4) = make_float4(acc[8 * s + 4], acc[8 * s + 5], acc[8 * s + 6], acc[8 * s + 7]);
+            }
+        } else {
+            half_t* o = reinterpret_cast<half_t*>(y) + ((size_t)tok * C + 32 * t + 8 * hi);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                half8 h;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) h[i] = (half_t)acc[8 * s + i];
+                *reinterpret_cast<half8*>(o + 16 * s) = h;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // k_ln_qkv
 // ------------------------------------------------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
-    using Cfg = ChainCfg<C>;
+template <int C, bool SP>
+__global__ __launch_bounds__(CHAIN_THREADS, SP ? 1 : 2) void k_ln_qkv(QkvParams p) {
+    using Cfg = ChainCfg<C, SP>;
     constexpr int KK = Cfg::KK, NT = Cfg::NT;
     // ONE LDS object (a second one would make hipcc wait for the DMA before every ds_read)
     constexpr bool STAGED = C == 256;   // coalesced stores through LDS (stage_tile / flush_tiles)
@@ -381,7 +456,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
         lnp[C + i] = p.beta[J.type * C + i];
     }
     const int n_chunks = J.n_mat * NT;
-    stage_chunk<C>(J.w[0], ring0);
+    stage_chunk<C, SP>(J.w[0], ring0);
 
     float4 v[C / 32][4];
     load_token<C>(J.x, p.in_nchw != 0, P, min(tok, P - 1), hi, v);
@@ -396,41 +471,24 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
     dma_wait();
     __syncthreads();
     layer_norm_regs<C>(v, lnp, lnp + C, hi);
-    half8 act[KK];
-    to_operands<C>(v, act);
+    Operands<KK, SP> act;
+    to_operands<C, SP>(v, act);
+    half_t* stg = smem + 2 * Cfg::CHUNK_HALVES + 4 * C + wave * STG_WAVE;
+    const int tok_w = blockIdx.x * CHAIN_TOKENS + wave * 32;
 
     for (int c = 0; c < n_chunks; ++c) {
         const int mat = c / NT, t = c - mat * NT;
         const half_t* buf = (c & 1) ? ring1 : ring0;
         if (c + 1 < n_chunks) {
             const int c1 = c + 1, mat1 = c1 / NT, t1 = c1 - mat1 * NT;
-            stage_chunk<C>(J.w[mat1] + (size_t)t1 * Cfg::CHUNK_HALVES, (c & 1) ? ring0 : ring1);
+            stage_chunk<C, SP>(J.w[mat1] + (size_t)t1 * Cfg::CHUNK_HALVES, (c & 1) ? ring0 : ring1);
         }
         float16v acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        mma_chunk<KK, (KK < 8 ? KK : 8)>(acc, buf, act, lane);
+        mma_chunk_op<KK, (KK < 8 ? KK : 8), SP>(acc, buf, act, lane);
         dma_wait();
-        if constexpr (STAGED) {
-            half_t* stg = smem + 2 * Cfg::CHUNK_HALVES + 4 * C + wave * STG_WAVE;
-            stage_tile(stg, m, hi, t & 3, acc);
-            if ((t & 3) == 3) {
-                const int tok_w = blockIdx.x * CHAIN_TOKENS + wave * 32;
-                flush_tiles(stg, J.y[mat] + (size_t)tok_w * C + 128 * (t >> 2), lane, P - tok_w, C);
-            }
-        } else if (valid) {
-            // the images of this kernel order the rows of a tile so that the lane's 16 results are two runs
-            // of 8 consecutive channels (weights.py store_row_order): 2 x 16-byte stores, adjacent for the
-            // lane pair of a token, instead of 4 x 8 (the store path is issue-bound)
-            half_t* o = J.y[mat] + ((size_t)tok * C + 32 * t + 8 * hi);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                half8 h;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) h[i] = (half_t)acc[8 * s + i];
-                *reinterpret_cast<half8*>(o + 16 * s) = h;
-            }
-        }
+        store_proj_tile<C, SP, STAGED>(stg, J.y[mat], t, acc, m, hi, lane, tok, valid, tok_w, P);
         wg_barrier();
     }
 }
@@ -446,10 +504,10 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void k_ln_qkv(QkvParams p) {
 typedef int int4v __attribute__((ext_vector_type(4)));
 __device__ float llvm_raw_buffer_load_f32(int4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 
-template <int C, bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW, int TAIL, bool XN = false>
+template <int C, bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW, int TAIL, bool XN = false, bool SP = false>
 __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams* qp) {
     constexpr bool QKV = TAIL == 1, HEAD = TAIL == 2;
-    using Cfg = ChainCfg<C>;
+    using Cfg = ChainCfg<C, SP>;
     constexpr int KK = Cfg::KK, NT = Cfg::NT, NH = C / 32;   // hidden width == C
     constexpr bool STAGED = QKV && C == 256;   // coalesced Q / K' / V' stores through LDS (stage_tile / flush_tiles)
     __shared__ __attribute__((aligned(16))) half_t smem[2 * Cfg::CHUNK_HALVES + 10 * C + (STAGED ? CHAIN_WAVES * STG_WAVE : 0)];
@@ -485,11 +543,11 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
     auto chunk_ptr = [&](int c) -> const half_t* {
         return (c < N_OUT) ? wo + (size_t)c * Cfg::CHUNK_HALVES : wf + (size_t)(c - N_OUT) * Cfg::CHUNK_HALVES;
     };
-    stage_chunk<C>(chunk_ptr(0), ring0);
+    stage_chunk<C, SP>(chunk_ptr(0), ring0);
 
     // residual stream (f32) in accumulator layout: xacc[t][4j+i] = channel 32t + 8j + 4hi + i
     float16v xacc[NT];
-    half8 act[KK];
+    Operands<KK, SP> act;
     const int tok_c = min(tok, P - 1);   // out-of-range lanes read a valid token and never store
     if constexpr (XN) {
         // tail of the first stage: the residual is the module's (C, P) input itself (k_ln_qkv wrote no token-major copy).
@@ -516,21 +574,37 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
                 xacc[t][4 * j + 0] = f.x; xacc[t][4 * j + 1] = f.y; xacc[t][4 * j + 2] = f.z; xacc[t][4 * j + 3] = f.w;
             }
     }
-    if constexpr (!OUTPROJ && !LN) {
-        // mlp_head: x itself is the operand
+    // accumulator-layout f32 rows -> operands (x itself as the operand of mlp_head)
+    auto acc_to_operands = [&]() {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int sx = 0; sx < 2; ++sx)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) act[2 * t + sx][q] = (half_t)xacc[t][8 * sx + q];
-    }
+                for (int q = 0; q < 8; ++q) {
+                    if constexpr (SP) split_h(xacc[t][8 * sx + q], act.hi[2 * t + sx][q], act.lo[2 * t + sx][q]);
+                    else act.hi[2 * t + sx][q] = (half_t)xacc[t][8 * sx + q];
+                }
+    };
+    if constexpr (!OUTPROJ && !LN) acc_to_operands();   // mlp_head: x itself is the operand
     if constexpr (OUTPROJ) {
         // attention output of this token as B operands: img_o is built with the linear K order (weights.py
         // weight_image(linear_k)), so fragment kk of lane (m, hi) is the 8 channels 16 kk + 8 hi + (0..7)
-        const half_t* op = J.o + (size_t)tok_c * C + 8 * hi;
+        if constexpr (SP) {
+            const float* op = reinterpret_cast<const float*>(J.o) + (size_t)tok_c * C + 8 * hi;
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) act[kk] = *reinterpret_cast<const half8*>(op + 16 * kk);
+            for (int kk = 0; kk < KK; ++kk) {
+                const float4 a = *reinterpret_cast<const float4*>(op + 16 * kk);
+                const float4 b = *reinterpret_cast<const float4*>(op + 16 * kk + 4);
+                const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) split_h(f[q], act.hi[kk][q], act.lo[kk][q]);
+            }
+        } else {
+            const half_t* op = reinterpret_cast<const half_t*>(J.o) + (size_t)tok_c * C + 8 * hi;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) act.hi[kk] = *reinterpret_cast<const half8*>(op + 16 * kk);
+        }
     }
     dma_wait();
     __syncthreads();
@@ -542,14 +616,14 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
 #pragma unroll 1
         for (int c = 0; c < N_OUT; ++c) {
             const half_t* buf = (c & 1) ? ring1 : ring0;
-            stage_chunk<C>(chunk_ptr(c + 1), (c & 1) ? ring0 : ring1);   // there is always a next chunk
+            stage_chunk<C, SP>(chunk_ptr(c + 1), (c & 1) ? ring0 : ring1);   // there is always a next chunk
             float16v acc;   // starts from the out-projection bias of the tile
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float4 bo = *reinterpret_cast<const float4*>(&vec[0][32 * c + 8 * j + 4 * hi]);
                 acc[4 * j + 0] = bo.x; acc[4 * j + 1] = bo.y; acc[4 * j + 2] = bo.z; acc[4 * j + 3] = bo.w;
             }
-            mma_chunk<KK, 4>(acc, buf, act, lane);
+            mma_chunk_op<KK, 4, SP>(acc, buf, act, lane);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 if (t == c) xacc[t] += acc;
@@ -557,7 +631,7 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
             wg_barrier();
         }
     }
-    if constexpr (LN) ln_acc_to_operands<C>(xacc, vec[1], vec[2], hi, act);
+    if constexpr (LN) ln_acc_to_operands<C, SP>(xacc, vec[1], vec[2], hi, act);
 
     // accumulator of the second Linear starts from (residual +) b_2
 #pragma unroll
@@ -587,24 +661,35 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
             const float4 b1 = *reinterpret_cast<const float4*>(&vec[3][32 * hc + 8 * j + 4 * hi]);
             hacc[4 * j + 0] = b1.x; hacc[4 * j + 1] = b1.y; hacc[4 * j + 2] = b1.z; hacc[4 * j + 3] = b1.w;
         }
-        stage_chunk<C>(w1c + Cfg::CHUNK_HALVES, ring1);          // W_2 slice hc
-        mma_chunk<KK, 4>(hacc, ring0, act, lane);
+        stage_chunk<C, SP>(w1c + Cfg::CHUNK_HALVES, ring1);          // W_2 slice hc
+        mma_chunk_op<KK, 4, SP>(hacc, ring0, act, lane);
         dma_wait();
         wg_barrier();
 
         // W_1 tile hc + 1 is requested before the GELU: ring0 is free since the barrier, and the activation's VALU work
         // covers the DMA's flight on top of the W_2 products
-        if (hc + 1 < NH) stage_chunk<C>(w1c + 2 * Cfg::CHUNK_HALVES, ring0);
-        half8 hop[2];
+        if (hc + 1 < NH) stage_chunk<C, SP>(w1c + 2 * Cfg::CHUNK_HALVES, ring0);
+        half8 hop[2], hopl[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) hop[s][q] = (half_t)gelu_f(hacc[8 * s + q]);
+            for (int q = 0; q < 8; ++q) {
+                if constexpr (SP) split_h(gelu_f(hacc[8 * s + q]), hop[s][q], hopl[s][q]);
+                else hop[s][q] = (half_t)gelu_f(hacc[8 * s + q]);
+            }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-                xacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(ring1, t * 2 + s, lane), hop[s], xacc[t], 0, 0, 0);
+            for (int s = 0; s < 2; ++s) {
+                if constexpr (SP) {
+                    const half8 wh = lds_frag(ring1, (t * 2 + s) * 2, lane), wl = lds_frag(ring1, (t * 2 + s) * 2 + 1, lane);
+                    xacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hopl[s], xacc[t], 0, 0, 0);
+                    xacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hop[s], xacc[t], 0, 0, 0);
+                    xacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hop[s], xacc[t], 0, 0, 0);
+                } else {
+                    xacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(ring1, t * 2 + s, lane), hop[s], xacc[t], 0, 0, 0);
+                }
+            }
         }
         dma_wait();
         wg_barrier();
@@ -660,19 +745,14 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
     if constexpr (HEAD) {
         // ---- mlp_head on the ego's x'' (bevformer_point_pillar_hetero.py:48): Linear -> GELU -> Linear, no norm, no
         // residual; x'' itself never goes to memory, the output is the NCHW map the model returns ----
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) act[2 * t + sx][q] = (half_t)xacc[t][8 * sx + q];
+        acc_to_operands();
         // vec[3..4] and both ring buffers are free (last use before the barrier that ended phase 2)
         for (int i = threadIdx.x; i < C; i += CHAIN_THREADS) {
             vec[3][i] = p.hb_1[ty * C + i];
             vec[4][i] = p.hb_2[ty * C + i];
         }
         const half_t* wh = p.w_head + (size_t)ty * 2 * NH * Cfg::CHUNK_HALVES;
-        stage_chunk<C>(wh, ring0);
+        stage_chunk<C, SP>(wh, ring0);
         dma_wait();
         __syncthreads();
 #pragma unroll
@@ -702,42 +782,28 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
                 vec[1][i] = qp->gamma[ty * C + i];
                 vec[2][i] = qp->beta[ty * C + i];
             }
-            stage_chunk<C>(Q.w[0], ring0);
+            stage_chunk<C, SP>(Q.w[0], ring0);
             dma_wait();
             __syncthreads();
-            ln_acc_to_operands<C>(xacc, vec[1], vec[2], hi, act);
+            ln_acc_to_operands<C, SP>(xacc, vec[1], vec[2], hi, act);
             // x'' leaves while the first tiles are computed (the stores are not waited for here)
             if constexpr (STAGED) store_x_staged(smem + 2 * Cfg::CHUNK_HALVES + 10 * C + wave * STG_WAVE);
             else store_x();
+            half_t* stg = smem + 2 * Cfg::CHUNK_HALVES + 10 * C + wave * STG_WAVE;
+            const int tok_w = blockIdx.x * CHAIN_TOKENS + wave * 32;
             for (int c = 0; c < n_chunks; ++c) {
                 const int mat = c / NT, t = c - mat * NT;
                 const half_t* buf = (c & 1) ? ring1 : ring0;
                 if (c + 1 < n_chunks) {
                     const int c1 = c + 1, mat1 = c1 / NT, t1 = c1 - mat1 * NT;
-                    stage_chunk<C>(Q.w[mat1] + (size_t)t1 * Cfg::CHUNK_HALVES, (c & 1) ? ring0 : ring1);
+                    stage_chunk<C, SP>(Q.w[mat1] + (size_t)t1 * Cfg::CHUNK_HALVES, (c & 1) ? ring0 : ring1);
                 }
                 float16v acc;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-                mma_chunk<KK, 4>(acc, buf, act, lane);
+                mma_chunk_op<KK, 4, SP>(acc, buf, act, lane);
                 dma_wait();
-                if constexpr (STAGED) {
-                    half_t* stg = smem + 2 * Cfg::CHUNK_HALVES + 10 * C + wave * STG_WAVE;
-                    stage_tile(stg, m, hi, t & 3, acc);
-                    if ((t & 3) == 3) {
-                        const int tok_w = blockIdx.x * CHAIN_TOKENS + wave * 32;
-                        flush_tiles(stg, Q.y[mat] + (size_t)tok_w * C + 128 * (t >> 2), lane, P - tok_w, C);
-                    }
-                } else if (valid) {
-                    half_t* o = Q.y[mat] + ((size_t)tok * C + 32 * t + 8 * hi);   // rows in store order (weights.py)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        half8 h;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) h[i] = (half_t)acc[8 * s2 + i];
-                        *reinterpret_cast<half8*>(o + 16 * s2) = h;
-                    }
-                }
+                store_proj_tile<C, SP, STAGED>(stg, Q.y[mat], t, acc, m, hi, lane, tok, valid, tok_w, P);
                 wg_barrier();
             }
         } else {
@@ -746,77 +812,87 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
     }
 }
 
-template <int C, bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW>
-__global__ __launch_bounds__(CHAIN_THREADS, 2) void k_out_ffn(FfnParams p) {
-    out_ffn_body<C, OUTPROJ, LN, RESID, OUT_NCHW, 0>(p, nullptr);
+template <int C, bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW, bool SP>
+__global__ __launch_bounds__(CHAIN_THREADS, SP ? 1 : 2) void k_out_ffn(FfnParams p) {
+    out_ffn_body<C, OUTPROJ, LN, RESID, OUT_NCHW, 0, false, SP>(p, nullptr);
 }
 
-template <int C, bool XN>
-__global__ __launch_bounds__(CHAIN_THREADS, 2) void k_out_ffn_qkv(FfnParams p, QkvParams q) {
-    out_ffn_body<C, true, true, true, false, 1, XN>(p, &q);
+template <int C, bool XN, bool SP>
+__global__ __launch_bounds__(CHAIN_THREADS, SP ? 1 : 2) void k_out_ffn_qkv(FfnParams p, QkvParams q) {
+    out_ffn_body<C, true, true, true, false, 1, XN, SP>(p, &q);
 }
 
 // last stage of HeteroFusion: the ego's tail with mlp_head appended (FfnJob::out = the (C, P) output map)
-template <int C>
-__global__ __launch_bounds__(CHAIN_THREADS, 2) void k_out_ffn_head(FfnParams p) {
-    out_ffn_body<C, true, true, true, false, 2>(p, nullptr);
+template <int C, bool SP>
+__global__ __launch_bounds__(CHAIN_THREADS, SP ? 1 : 2) void k_out_ffn_head(FfnParams p) {
+    out_ffn_body<C, true, true, true, false, 2, false, SP>(p, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
-// launchers
+// launchers (split = the "split" precision mode: hi / lo weight images, f32 Q / K' / V' / O planes)
 // ------------------------------------------------------------------------------------------
-int launch_ln_qkv(const QkvParams& p, int n_jobs, int C, hipStream_t st) {
-    if (n_jobs == 0) return HMVIT_OK;
+template <bool SP>
+static int launch_ln_qkv_t(const QkvParams& p, int n_jobs, int C, hipStream_t st) {
     dim3 grid(cdiv(p.P, CHAIN_TOKENS), n_jobs), block(CHAIN_THREADS);
     switch (C) {
-        case 64: hipLaunchKernelGGL((k_ln_qkv<64>), grid, block, 0, st, p); break;
-        case 128: hipLaunchKernelGGL((k_ln_qkv<128>), grid, block, 0, st, p); break;
-        case 256: hipLaunchKernelGGL((k_ln_qkv<256>), grid, block, 0, st, p); break;
+        case 64: hipLaunchKernelGGL((k_ln_qkv<64, SP>), grid, block, 0, st, p); break;
+        case 128: hipLaunchKernelGGL((k_ln_qkv<128, SP>), grid, block, 0, st, p); break;
+        case 256: hipLaunchKernelGGL((k_ln_qkv<256, SP>), grid, block, 0, st, p); break;
         default: set_error("ln_qkv: C=%d unsupported", C); return HMVIT_EINVAL;
     }
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }
+int launch_ln_qkv(const QkvParams& p, int n_jobs, int C, bool split, hipStream_t st) {
+    if (n_jobs == 0) return HMVIT_OK;
+    return split ? launch_ln_qkv_t<true>(p, n_jobs, C, st) : launch_ln_qkv_t<false>(p, n_jobs, C, st);
+}
 
-template <int C>
+template <int C, bool SP>
 static int launch_out_ffn_c(const FfnParams& p, int n_jobs, int variant, hipStream_t st) {
     dim3 grid(cdiv(p.P, CHAIN_TOKENS), n_jobs), block(CHAIN_THREADS);
     switch (variant) {
-        case FFN_FULL: hipLaunchKernelGGL((k_out_ffn<C, true, true, true, false>), grid, block, 0, st, p); break;
-        case FFN_NO_ATTN: hipLaunchKernelGGL((k_out_ffn<C, false, true, true, false>), grid, block, 0, st, p); break;
-        case FFN_HEAD_NCHW: hipLaunchKernelGGL((k_out_ffn<C, false, false, false, true>), grid, block, 0, st, p); break;
+        case FFN_FULL: hipLaunchKernelGGL((k_out_ffn<C, true, true, true, false, SP>), grid, block, 0, st, p); break;
+        case FFN_NO_ATTN: hipLaunchKernelGGL((k_out_ffn<C, false, true, true, false, SP>), grid, block, 0, st, p); break;
+        case FFN_HEAD_NCHW: hipLaunchKernelGGL((k_out_ffn<C, false, false, false, true, SP>), grid, block, 0, st, p); break;
         default: set_error("out_ffn: bad variant %d", variant); return HMVIT_EINVAL;
     }
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }
 
-int launch_out_ffn_qkv(const FfnParams& p, const QkvParams& q, int n_jobs, int C, hipStream_t st) {
+int launch_out_ffn_qkv(const FfnParams& p, const QkvParams& q, int n_jobs, int C, bool split, hipStream_t st) {
     if (n_jobs == 0) return HMVIT_OK;
     HMVIT_CHECK_ARG(C == 256, "out_ffn_qkv: C=%d unsupported (256)", C);
     dim3 grid(cdiv(p.P, CHAIN_TOKENS), n_jobs), block(CHAIN_THREADS);
     // FfnJob::x_nchw (all jobs of a launch alike): the residual is read from (C, P) maps
-    if (p.job[0].x_nchw) hipLaunchKernelGGL((k_out_ffn_qkv<256, true>), grid, block, 0, st, p, q);
-    else hipLaunchKernelGGL((k_out_ffn_qkv<256, false>), grid, block, 0, st, p, q);
+    if (split) {
+        if (p.job[0].x_nchw) hipLaunchKernelGGL((k_out_ffn_qkv<256, true, true>), grid, block, 0, st, p, q);
+        else hipLaunchKernelGGL((k_out_ffn_qkv<256, false, true>), grid, block, 0, st, p, q);
+    } else {
+        if (p.job[0].x_nchw) hipLaunchKernelGGL((k_out_ffn_qkv<256, true, false>), grid, block, 0, st, p, q);
+        else hipLaunchKernelGGL((k_out_ffn_qkv<256, false, false>), grid, block, 0, st, p, q);
+    }
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }
 
-int launch_out_ffn_head(const FfnParams& p, int n_jobs, int C, hipStream_t st) {
+int launch_out_ffn_head(const FfnParams& p, int n_jobs, int C, bool split, hipStream_t st) {
     if (n_jobs == 0) return HMVIT_OK;
     HMVIT_CHECK_ARG(C == 256 && p.w_head && p.hb_1 && p.hb_2, "out_ffn_head: C=%d (256) / head weights missing", C);
     dim3 grid(cdiv(p.P, CHAIN_TOKENS), n_jobs), block(CHAIN_THREADS);
-    hipLaunchKernelGGL((k_out_ffn_head<256>), grid, block, 0, st, p);
+    if (split) hipLaunchKernelGGL((k_out_ffn_head<256, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((k_out_ffn_head<256, false>), grid, block, 0, st, p);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }
 
-int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, hipStream_t st) {
+int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, bool split, hipStream_t st) {
     if (n_jobs == 0) return HMVIT_OK;
     switch (C) {
-        case 64: return launch_out_ffn_c<64>(p, n_jobs, variant, st);
-        case 128: return launch_out_ffn_c<128>(p, n_jobs, variant, st);
-        case 256: return launch_out_ffn_c<256>(p, n_jobs, variant, st);
+        case 64: return split ? launch_out_ffn_c<64, true>(p, n_jobs, variant, st) : launch_out_ffn_c<64, false>(p, n_jobs, variant, st);
+        case 128: return split ? launch_out_ffn_c<128, true>(p, n_jobs, variant, st) : launch_out_ffn_c<128, false>(p, n_jobs, variant, st);
+        case 256: return split ? launch_out_ffn_c<256, true>(p, n_jobs, variant, st) : launch_out_ffn_c<256, false>(p, n_jobs, variant, st);
         default: set_error("out_ffn: C=%d unsupported", C); return HMVIT_EINVAL;
     }
 }

@@ -50,7 +50,7 @@ struct QkvJob {
     const float* x;          // (P, C) token-major, or (C, P) when in_nchw
     float* xs_out;           // token-major copy written when in_nchw (nullptr: not needed)
     const half_t* w[5];      // weight images (NT chunks each): [Q] K'(e0) V'(e0) [K'(e1) V'(e1)]
-    half_t* y[5];            // output planes (P, C)
+    void* y[5];              // output planes (P, C): f16, or f32 in split mode
     int n_mat;
     int type;
 };
@@ -61,10 +61,10 @@ struct QkvParams {
     int P;
     int in_nchw;
 };
-int launch_ln_qkv(const QkvParams& p, int n_jobs, int C, hipStream_t st);
+int launch_ln_qkv(const QkvParams& p, int n_jobs, int C, bool split, hipStream_t st);
 
 struct FfnJob {
-    const half_t* o;         // (P, C) attention output (FFN_FULL)
+    const void* o;           // (P, C) attention output (FFN_FULL): f16, or f32 in split mode
     const float* x;          // (P, C) residual stream in
     float* out;              // (P, C) token-major (may alias x) or (C, P) for FFN_HEAD_NCHW
     int type;
@@ -89,12 +89,12 @@ struct FfnParams {
     const float* hb_2;
 };
 enum { FFN_FULL = 0, FFN_NO_ATTN = 1, FFN_HEAD_NCHW = 2 };
-int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, hipStream_t st);
+int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, bool split, hipStream_t st);
 // k_out_ffn (FFN_FULL) of a stage fused with k_ln_qkv of the next one; job j of both lists = the same agent;
 // FfnJob::pad = 1 suppresses the store of the updated residual row
-int launch_out_ffn_qkv(const FfnParams& p, const QkvParams& q, int n_jobs, int C, hipStream_t st);
+int launch_out_ffn_qkv(const FfnParams& p, const QkvParams& q, int n_jobs, int C, bool split, hipStream_t st);
 // k_out_ffn (FFN_FULL) of the last stage with mlp_head appended; FfnJob::out = (C, P) output map
-int launch_out_ffn_head(const FfnParams& p, int n_jobs, int C, hipStream_t st);
+int launch_out_ffn_head(const FfnParams& p, int n_jobs, int C, bool split, hipStream_t st);
 
 // ---- enc.hip (PointPillar branch) ----
 struct PfnParams {

@@ -25,7 +25,9 @@ from . import _lib, weights
 
 NUM_TYPES = _lib.NUM_TYPES
 _PRECISIONS = {"f32": _lib.PREC_F32, "fp32": _lib.PREC_F32, "strict": _lib.PREC_F32,
-               "f16": _lib.PREC_F16, "fp16": _lib.PREC_F16, "fast": _lib.PREC_F16}
+               "f16": _lib.PREC_F16, "fp16": _lib.PREC_F16, "fast": _lib.PREC_F16,
+               # fp32-class products on the f16 matrix pipes (operands split into hi + lo halves, 3 MFMAs per product)
+               "split": _lib.PREC_SPLIT}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -131,14 +133,15 @@ class _FusionBase(nn.Module):
         key = (prec, str(device)) + tuple((p.data_ptr(), p._version) for p in params)
         if self._folded_key != key:
             dtype = torch.float32 if prec == _lib.PREC_F32 else torch.float16
+            split = prec == _lib.PREC_SPLIT
             sd = {k: v.to(device) for k, v in self.state_dict().items()}
             blk = self._block_cfg
             folded = {}
             for s, which in enumerate(("window", "grid")):
                 folded[s] = weights.fold_stage(sd, self._block_prefix, which, blk["dim_head"],
-                                               blk["window_size"], dtype)
+                                               blk["window_size"], dtype, split=split)
             if self._head_prefix is not None:
-                folded["head"] = weights.fold_head(sd, self._head_prefix, dtype)
+                folded["head"] = weights.fold_head(sd, self._head_prefix, dtype, split=split)
             if blk["architect_mode"] == "parallel":
                 pre = f"{self._block_prefix}." if self._block_prefix else ""
                 folded["split"] = {k: sd[f"{pre}split_attn.{n}"].detach().float().contiguous()

@@ -52,12 +52,24 @@ def store_row_order(r):
     return 16 * (j >> 1) + 8 * hi + 4 * (j & 1) + i
 
 
-def weight_image(w: torch.Tensor, store_rows: bool = False, linear_k: bool = False) -> torch.Tensor:
+def split_halves(w: torch.Tensor):
+    """x = hi + lo with hi = f16(x), lo = f16(x - hi): the operand pair of the split precision mode (22+ mantissa bits)."""
+    hi = w.to(torch.float16)
+    lo = (w - hi.to(w.dtype)).to(torch.float16)
+    return hi, lo
+
+
+def weight_image(w: torch.Tensor, store_rows: bool = False, linear_k: bool = False, split: bool = False) -> torch.Tensor:
     """(N, K) matrix -> (N/32, K/16, 64, 8) f16 fragment image (include/hmvit.h):
     img[t][kk][lane][4 jj + i] = W[32 t + row(lane & 31)][16 kk + 8 jj + 4 (lane >> 5) + i],
     row(r) = r, or store_row_order(r) for the images of k_ln_qkv.  ``linear_k`` (img_o, whose operand is
     loaded from memory rather than taken from an accumulator) uses the K index
     16 kk + 8 (lane >> 5) + 4 jj + i instead: 8 consecutive input channels per lane = one 16-byte load."""
+    if split:
+        # (N/32, K/16, 2, 64, 8): per k-step the fragment of the hi half followed by the fragment of the lo half
+        hi, lo = split_halves(w.float())
+        return torch.stack([weight_image(hi.float(), store_rows, linear_k), weight_image(lo.float(), store_rows, linear_k)],
+                           dim=2).contiguous()
     N, K = w.shape
     if N % 32 or K % 16:
         raise ValueError(f"weight_image: ({N}, {K}) must be multiples of (32, 16)")
@@ -75,22 +87,25 @@ def weight_image(w: torch.Tensor, store_rows: bool = False, linear_k: bool = Fal
     return w[n.expand(-1, K // 16, -1, 8), k.expand(N // 32, -1, -1, -1)].to(torch.float16).contiguous()
 
 
-def ffn_image(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+def ffn_image(w1: torch.Tensor, w2: torch.Tensor, split: bool = False) -> torch.Tensor:
     """Interleaved weight stream of Linear(C, C) -> GELU -> Linear(C, C) for k_out_ffn:
     (C/32, 2, C/16, 64, 8): [hc][0] = image of W_1 rows of hidden tile hc, [hc][1] = fragments
-    (t, 2 hc + s) of the image of W_2."""
+    (t, 2 hc + s) of the image of W_2.  split: every fragment becomes a (hi, lo) pair, (C/32, 2, C/16, 2, 64, 8)."""
     C = w1.shape[1]
     if tuple(w1.shape) != (C, C) or tuple(w2.shape) != (C, C):
         raise ValueError("the fused FFN kernel needs mlp_dim == input_dim")
-    i1 = weight_image(w1)
-    i2 = weight_image(w2)
+    i1 = weight_image(w1, split=split)
+    i2 = weight_image(w2, split=split)
     nt, kk = C // 32, C // 16
-    i2 = i2.view(nt, nt, 2, 64, 8).permute(1, 0, 2, 3, 4).reshape(nt, kk, 64, 8)
+    if split:
+        i2 = i2.view(nt, nt, 2, 2, 64, 8).permute(1, 0, 2, 3, 4, 5).reshape(nt, kk, 2, 64, 8)
+    else:
+        i2 = i2.view(nt, nt, 2, 64, 8).permute(1, 0, 2, 3, 4).reshape(nt, kk, 64, 8)
     return torch.stack([i1, i2], dim=1).contiguous()
 
 
 def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: int, window: int,
-               dtype: torch.dtype, keep_graph: bool = False) -> Dict[str, torch.Tensor]:
+               dtype: torch.dtype, keep_graph: bool = False, split: bool = False, log2e: bool | None = None) -> Dict[str, torch.Tensor]:
     """Folded tensors of one stage (which = 'window' | 'grid') in the layout of
     HmvitStageWeights (include/hmvit.h).  Matrices in `dtype`, vectors in f32.  ``keep_graph`` (training, f32): `sd` holds
     the live parameters and the folds stay on the autograd tape, so the gradients the backward kernels return for the folded
@@ -100,10 +115,12 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
     f = (lambda k: sd[k].float()) if keep_graph else (lambda k: sd[k].detach().float())
     C = f(f"{att}.q_linears.0.weight").shape[0]
     M = C // dim_head
-    f16 = dtype == torch.float16
-    # f16 kernels evaluate the softmax with exp2: log2(e) rides on the q scale and on the position bias
+    f16 = dtype == torch.float16       # fragment images (f16 mode, or split mode with hi / lo pairs)
+    # the persistent attention kernel evaluates the softmax with exp2: log2(e) rides on the q scale and on the position bias
     LOG2E = 1.4426950408889634
-    scale = dim_head ** -0.5 * (LOG2E if f16 else 1.0)
+    if log2e is None:
+        log2e = f16 and not split
+    scale = dim_head ** -0.5 * (LOG2E if log2e else 1.0)
     rel_att = f(f"{att}.relation_att")     # (4, M, d, d) [e, h, p, q]
     rel_msg = f(f"{att}.relation_msg")
 
@@ -114,7 +131,7 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
     per_type = lambda m, fn: torch.stack([fn(m[t]) for t in range(NUM_TYPES)])
     w_q = stack(f"{att}.q_linears.{{t}}.weight") * scale
     if f16:
-        out["img_q"] = per_type(w_q, lambda m: weight_image(m, store_rows=True))
+        out["img_q"] = per_type(w_q, lambda m: weight_image(m, store_rows=True, split=split))
     else:
         out["w_q"] = w_q
     out["b_q"] = stack(f"{att}.q_linears.{{t}}.bias") * scale
@@ -133,18 +150,18 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
             w_kv[te, ts, C:] = torch.einsum("hpq,hpc->hqc", rel_msg[e], wv).reshape(C, C)
             b_kv[te, ts, C:] = torch.einsum("hpq,hp->hq", rel_msg[e], bv).reshape(C)
     if f16:
-        out["img_kv"] = torch.stack([per_type(w_kv[te], lambda m: weight_image(m, store_rows=True)) for te in range(NUM_TYPES)])
+        out["img_kv"] = torch.stack([per_type(w_kv[te], lambda m: weight_image(m, store_rows=True, split=split)) for te in range(NUM_TYPES)])
     else:
         out["w_kv"] = w_kv
     out["b_kv"] = b_kv
-    out["bias_frag"] = bias_fragments(sd[f"{att}.relative_position_bias_table.weight"], window, keep_graph) * (LOG2E if f16 else 1.0)
+    out["bias_frag"] = bias_fragments(sd[f"{att}.relative_position_bias_table.weight"], window, keep_graph) * (LOG2E if log2e else 1.0)
     if keep_graph:
         # the backward kernel also forms the un-transposed logit tiles: their bias is the fragment set of the table with
         # negated offsets, i.e. the table flipped along its first axis (index (dr + w - 1)(2w - 1) + dc + w - 1)
         out["bias_frag_neg"] = bias_fragments(sd[f"{att}.relative_position_bias_table.weight"].detach().flip(0), window)
     w_o = stack(f"{att}.a_linears.{{t}}.0.weight")
     if f16:
-        out["img_o"] = per_type(w_o, lambda m: weight_image(m, linear_k=True))
+        out["img_o"] = per_type(w_o, lambda m: weight_image(m, linear_k=True, split=split))
     else:
         out["w_o"] = w_o
     out["b_o"] = stack(f"{att}.a_linears.{{t}}.0.bias")
@@ -153,7 +170,7 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
     w_1 = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.0.weight")
     w_2 = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.3.weight")
     if f16:
-        out["img_ffn"] = torch.stack([ffn_image(w_1[t], w_2[t]) for t in range(NUM_TYPES)])
+        out["img_ffn"] = torch.stack([ffn_image(w_1[t], w_2[t], split=split) for t in range(NUM_TYPES)])
     else:
         out["w_1"], out["w_2"] = w_1, w_2
     out["b_1"] = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.0.bias")
@@ -161,14 +178,14 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
     return {k: v.contiguous() for k, v in out.items()}
 
 
-def fold_head(sd: Dict[str, torch.Tensor], prefix: str, dtype: torch.dtype, keep_graph: bool = False) -> Dict[str, torch.Tensor]:
+def fold_head(sd: Dict[str, torch.Tensor], prefix: str, dtype: torch.dtype, keep_graph: bool = False, split: bool = False) -> Dict[str, torch.Tensor]:
     f = (lambda k: sd[k].float()) if keep_graph else (lambda k: sd[k].detach().float())
     stack = lambda fmt: torch.stack([f(fmt.format(t=t)) for t in range(NUM_TYPES)])
     w1, w2 = stack(f"{prefix}.net.{{t}}.0.weight"), stack(f"{prefix}.net.{{t}}.3.weight")
     out = {"head_b1": stack(f"{prefix}.net.{{t}}.0.bias").contiguous(),
            "head_b2": stack(f"{prefix}.net.{{t}}.3.bias").contiguous()}
     if dtype == torch.float16:
-        out["head_img_ffn"] = torch.stack([ffn_image(w1[t], w2[t]) for t in range(NUM_TYPES)])
+        out["head_img_ffn"] = torch.stack([ffn_image(w1[t], w2[t], split=split) for t in range(NUM_TYPES)])
     else:
         out["head_w1"], out["head_w2"] = w1.contiguous(), w2.contiguous()
     return out

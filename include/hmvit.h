@@ -36,6 +36,11 @@ extern "C" {
 /* arithmetic modes */
 #define HMVIT_PREC_F32 0     /* f32 MFMA everywhere: strict parity mode */
 #define HMVIT_PREC_F16 1     /* f16 operands, f32 accumulate, f32 LN/softmax/residual */
+#define HMVIT_PREC_SPLIT 2   /* fp32-class products on the f16 matrix pipes: every operand x = hi + lo (two f16 halves),
+                                three MFMAs per product, f32 accumulate; Q / K' / V' / O planes are f32.  Reads the
+                                fragment images of HMVIT_PREC_F16 with, per k-step, the hi fragment followed by the lo
+                                fragment (twice the size; weights.py weight_image(split=True)); w_q / b_q / bias_frag carry
+                                no log2(e) factor.  Held to the f32 tolerance (1e-4) by the parity tests. */
 
 /* partition of one attention stage (hetero_fusion.py:387-389 vs :430-431) */
 #define HMVIT_PART_WINDOW 0  /* 'b m d (x w1) (y w2)': contiguous w x w windows */

@@ -150,18 +150,21 @@ def test_adamw_steps_reduce_the_loss():
     cfg = O.make_config(64, 4, 3, voxel=0.4, downsample=4)
     sd = O.random_state_dict(cfg, seed=21)
     scene = [t.cuda() for t in O.synthetic_scene(3, 64, 16, 16, [1, 0, 1], seed=22, tx_step=3.0, ty_step=-2.0)]
-    target = torch.randn(1, 64, 16, 16, generator=torch.Generator().manual_seed(23)).cuda()
-    net = _net(cfg, sd).train()
-    opt = make_optimizer(net.parameters(), {"lr": 2e-3})
+    # a reachable target: the output of the same architecture with other weights (teacher / student)
+    with torch.no_grad():
+        target = _net(cfg, O.random_state_dict(cfg, seed=24)).eval()(*scene)
+    net = _net(cfg, sd).eval()
+    net.force_autograd = True            # eval mode: no dropout noise in the loss curve, still on the tape
+    opt = make_optimizer(net.parameters(), {"lr": 1e-3})
     losses = []
-    torch.manual_seed(0)
-    for _ in range(12):
+    for _ in range(15):
         opt.zero_grad()
         loss = torch.nn.functional.mse_loss(net(*scene), target)
         loss.backward()
         opt.step()
         losses.append(float(loss))
-    assert losses[-1] < 0.8 * losses[0], losses
+    assert losses[-1] < 0.7 * losses[0], losses
+    assert sum(b < a for a, b in zip(losses, losses[1:])) >= 12, losses
 
 
 def test_ddp_wraps_the_module_over_rccl():
@@ -192,7 +195,7 @@ def test_ddp_wraps_the_module_over_rccl():
         torch.manual_seed(5)
         ref(*scene).square().mean().backward()
         for (n, a), (_, b) in zip(net.named_parameters(), ref.named_parameters()):
-            if b.grad is None:
+            if b.grad is None or float(b.grad.abs().max()) == 0.0:      # unused (aggregate_fc) / the absent agent type
                 assert a.grad is None or float(a.grad.abs().max()) == 0.0, n
             else:
                 assert rel_max_err(a.grad, b.grad) < 1e-4, n     # f32 atomics: summation order differs run to run
