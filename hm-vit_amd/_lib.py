@@ -14,7 +14,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMVIT_LIB", os.path.join(_HERE, "libhmvit.so"))   # HMVIT_LIB: ablation builds of tools/probe
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 PREC_F32, PREC_F16, PREC_SPLIT = 0, 1, 2
 PART_WINDOW, PART_GRID = 0, 1
 NUM_TYPES = 2
@@ -48,6 +48,7 @@ class FusionDesc(C.Structure):
         ("parallel", C.c_int32),
         ("split_fc1", C.c_void_p), ("split_ln_g", C.c_void_p), ("split_ln_b", C.c_void_p),
         ("split_fc2", C.c_void_p),
+        ("self_identity", C.c_int32),
     ]
 
 

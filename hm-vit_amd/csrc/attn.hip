@@ -475,7 +475,7 @@ __device__ __forceinline__ bool pc_fetch(const AttnParams& p, int X, int Y, int 
 // would drain the loader's in-flight taps once per item.
 __device__ __forceinline__ unsigned pc_item_vis(const AttnParams& p, const PcItem& it, int X, int Y, bool enabled) {
     if (!enabled || !p.vis_mask) return 0xffffffffu;
-    const int pos = ((it.b * p.n_ego + it.ego) * X + it.wx) * Y + it.wy;
+    const int pos = __builtin_amdgcn_readfirstlane(((it.b * p.n_ego + it.ego) * X + it.wx) * Y + it.wy);
     const unsigned* a = p.vis_mask + pos;
     unsigned v;
     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(a) : "memory");
@@ -1193,6 +1193,522 @@ static int launch_attn_pc(const AttnParams& p, hipStream_t st, int wg_per_cu) {
     return HMVIT_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Split-precision persistent kernel (HMVIT_PREC_SPLIT): k_attention_pcs.
+//
+// Same producer / consumer structure, schedule and tap tables as k_attention_pc<4, 1, 1>, for f32 planes and fp32-class
+// products on the f16 matrix pipe: every MFMA operand is a (hi, lo) pair of f16 halves (x = hi + lo, |lo| <= 2^-11 |hi|) and
+// every product is three MFMAs (lo x hi, hi x lo, hi x hi; f32 accumulate).  What changes against the f16 kernel:
+//   * Q / K' / V' are f32 in memory: a loader lane owns 4 channels (one 16-byte tap load), a key row takes 32 lanes;
+//   * the bilinear blend is f32 FMAs on the loaded words, the sum is split into hi / lo and stored to two LDS tiles;
+//   * a gather is a HALF chunk of 32 keys (same 32 tap loads per lane in flight, same LDS bytes per buffer), the
+//     compute wave's online softmax advances by 32 keys; the query tile (64 rows) is fetched with the first half chunk;
+//   * the visibility word carries a bit per half chunk (k_tile_vis), walked by both roles alike;
+//   * logits are in natural units (the folded weights are shared with the exact-f32 kernel): exp(x) = exp2(x log2 e);
+//   * O is stored as f32.
+// Requires identity self transforms (pairwise_t[b, i, i] = I, HmvitFusionDesc::self_identity).
+// ------------------------------------------------------------------------------------------
+struct PcSharedS {
+    static constexpr int HG = 4, CH = 128, KEYS = 32;
+    static constexpr int QS = CH + 8, KS = CH + 8, VS = CH + 16;   // halves per LDS row
+    static constexpr int TPK = CH / 4;             // loader lanes per key row (4 f32 channels each)
+    static constexpr int KPW = 64 / TPK;           // keys per loader wave and pass (2)
+    static constexpr int LWG = 4, CWG = 4;
+    static constexpr int KPP = LWG * KPW;          // keys per pass (8)
+    static constexpr int NP = KEYS / KPP;          // passes per half chunk (4)
+    static constexpr int NK = NP * KPW;            // keys owned by one loader wave (8)
+    static constexpr int TGH = 4;                  // half chunks whose taps sit in the tables (= 2 sources)
+    static constexpr int MAX_PAIRS = 128;
+    half_t Qh[2][64 * QS], Ql[2][64 * QS];
+    half_t Kh[2][KEYS * KS], Kl[2][KEYS * KS];
+    half_t Vh[2][KEYS * VS], Vl[2][KEYS * VS];
+    float maskadd[2][KEYS];
+    int vis[2][LWG];
+    float ainv[MAX_PAIRS * 8];
+    float bkv[HMVIT_NUM_TYPES * HMVIT_NUM_TYPES][2][CH];
+    float bq[HMVIT_NUM_TYPES][CH];
+    int mode[kMaxSlots], cav[kMaxSlots], ego_e[kMaxSlots];
+    int tidx[LWG][TGH][NK][4];
+    float tw[LWG][TGH][NK][4];
+    int tvis[LWG][TGH][NK];
+};
+
+__device__ __forceinline__ uint4v tok_load4f(int4v rs, int token, int off_bytes, int soff) {
+    return llvm_struct_buffer_load_b128(rs, token, off_bytes, soff, 0);
+}
+
+struct PcGatherS {
+    PcItem it;
+    int4v rs_kv, rs_q;
+    int half, slot, kvbuf, qbuf, te, tsel;
+    bool valid, self_vis;
+};
+
+__device__ __forceinline__ PcGatherS pcs_describe(const AttnParams& p, const PcSharedS& sm, const PcItem& it, int chunk, int half,
+                                                  int slot, int g, int qi, bool valid) {
+    const int L = p.L, P = p.H * p.W, C = p.C;
+    PcGatherS G;
+    G.it = it; G.half = half; G.slot = slot; G.kvbuf = g & 1; G.qbuf = qi; G.valid = valid;
+    const int src = pc_src(chunk, it.ego);
+    const int te = __builtin_amdgcn_readfirstlane(sm.mode[it.b * L + it.ego]);
+    const int ts = __builtin_amdgcn_readfirstlane(sm.mode[it.b * L + src]);
+    const int ev = __builtin_amdgcn_readfirstlane(sm.ego_e[it.b * L + it.ego]);
+    G.te = te; G.tsel = te * HMVIT_NUM_TYPES + ts;
+    const float* kpl = reinterpret_cast<const float*>(p.kv) + ((size_t)((it.b * L + src) * p.E + ev) * 2) * P * C + it.hg * PcSharedS::CH;
+    const float* qpl = reinterpret_cast<const float*>(p.q) + (size_t)(it.b * L + it.ego) * P * C + it.hg * PcSharedS::CH;
+    G.rs_kv = token_rsrc(kpl, C * 4, P);
+    G.rs_q = token_rsrc(qpl, C * 4, P);
+    G.self_vis = __builtin_amdgcn_readfirstlane(sm.cav[it.b * L + it.ego]) != 0;
+    return G;
+}
+
+// taps of this loader wave's keys for the TGH half chunks starting at half chunk hc0 of the item's general chunks
+// (half chunk h = 2 (chunk - 1) + half)
+__device__ __forceinline__ void pcs_taps(const AttnParams& p, PcSharedS& sm, const PcItem& it, int hc0, int lw, int lane) {
+    using SM = PcSharedS;
+    constexpr int KPW = SM::KPW, NK = SM::NK, KPP = SM::KPP, TGH = SM::TGH;
+    const int H = p.H, W = p.W, L = p.L, X = H / 8, Y = W / 8;
+    const int e = lane, c = e / NK, j = e % NK;
+    const int hc = hc0 + c, chunk = 1 + (hc >> 1), half = hc & 1;
+    if (e < TGH * NK && chunk < p.n_src) {
+        const int src = pc_src(chunk, it.ego);
+        const float* a = sm.ainv + ((it.b * L + src) * L + it.ego) * 8;
+        const int n = half * 32 + (j / KPW) * KPP + KPW * lw + (j % KPW);
+        int row, col;
+        token_pixel(p.partition, 8, X, Y, it.wx, it.wy, n, row, col);
+        const bool cav = sm.cav[it.b * L + src] != 0;
+        int ix[4];
+        float w[4];
+        bool vis;
+        if (a[6] != 0.f) {   // identity map: the key's own pixel
+            ix[0] = row * W + col; ix[1] = ix[2] = ix[3] = -1;
+            w[0] = 1.f; w[1] = w[2] = w[3] = 0.f;
+            vis = cav;
+        } else {
+            const Taps t = make_taps(a, col, row, H, W);
+            vis = cav && t.roi != 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ix[k] = (t.w[k] != 0.f) ? t.idx[k] : -1;
+                w[k] = t.w[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (!vis) ix[k] = -1;
+        *reinterpret_cast<int4*>(sm.tidx[lw][c][j]) = make_int4(ix[0], ix[1], ix[2], ix[3]);
+        *reinterpret_cast<float4*>(sm.tw[lw][c][j]) = make_float4(w[0], w[1], w[2], w[3]);
+        sm.tvis[lw][c][j] = vis ? 1 : 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read ordering
+}
+
+// 4 f32 values -> hi / lo halves, stored to two LDS rows
+__device__ __forceinline__ void store_split4(half_t* dh, half_t* dl, const float (&v)[4]) {
+    half4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const half_t hh = (half_t)v[e];
+        h[e] = hh;
+        l[e] = (half_t)(v[e] - (float)hh);
+    }
+    *reinterpret_cast<half4*>(dh) = h;
+    *reinterpret_cast<half4*>(dl) = l;
+}
+
+__device__ __forceinline__ void pcs_loader_loop(const AttnParams& p, PcSharedS& sm, int lw, int ltid) {
+    using SM = PcSharedS;
+    constexpr int QS = SM::QS, KS = SM::KS, VS = SM::VS, TPK = SM::TPK, KPW = SM::KPW, NP = SM::NP, KPP = SM::KPP, TGH = SM::TGH;
+    const int X = p.H / 8, Y = p.W / 8, NG = p.C / SM::CH;
+    const int n_src = p.n_src;
+    const int plane_bytes = p.H * p.W * p.C * 4;
+    const int lane = ltid & 63;
+    const int cl = (ltid % TPK) * 4, cl_bytes = cl * 4;
+    const int kin = ltid / TPK;                  // key row of this lane inside a KPP-key pass
+    const int kj = kin % KPW;
+    const bool ego_fastest = (p.variant & 0x200) == 0;
+
+    uint4v R[NP][2][4];
+    float4 Wt[NP];
+    int vflag[NP];
+    bool any = false, allv = true;
+
+    auto issueG = [&](int pass, const PcGatherS& G) {
+        const int j = pass * KPW + kj;
+        const int4 ix = *reinterpret_cast<const int4*>(sm.tidx[lw][G.slot][j]);
+        Wt[pass] = *reinterpret_cast<const float4*>(sm.tw[lw][G.slot][j]);
+        vflag[pass] = sm.tvis[lw][G.slot][j];
+        const int ixa[4] = {ix.x, ix.y, ix.z, ix.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            R[pass][0][k] = tok_load4f(G.rs_kv, G.valid ? ixa[k] : -1, cl_bytes, 0);
+            R[pass][1][k] = tok_load4f(G.rs_kv, G.valid ? ixa[k] : -1, cl_bytes, plane_bytes);
+        }
+    };
+    // identity half chunk: the ego's own rows; the first half also brings the whole 64-row query tile
+    auto issueI = [&](int pass, const PcGatherS& G) {
+        int row, col;
+        token_pixel(p.partition, 8, X, Y, G.it.wx, G.it.wy, G.half * 32 + pass * KPP + kin, row, col);
+        const int tok = row * p.W + col;
+        const int tk = (G.valid && G.self_vis) ? tok : -1;
+        R[pass][0][0] = tok_load4f(G.rs_kv, tk, cl_bytes, 0);
+        R[pass][1][0] = tok_load4f(G.rs_kv, tk, cl_bytes, plane_bytes);
+        if (G.half == 0) {
+            token_pixel(p.partition, 8, X, Y, G.it.wx, G.it.wy, 32 + pass * KPP + kin, row, col);
+            R[pass][0][1] = tok_load4f(G.rs_q, G.valid ? tok : -1, cl_bytes, 0);
+            R[pass][0][2] = tok_load4f(G.rs_q, G.valid ? row * p.W + col : -1, cl_bytes, 0);
+        }
+    };
+    float4 bias_k, bias_v;
+    auto load_bias = [&](const PcGatherS& G) {
+        bias_k = *reinterpret_cast<const float4*>(&sm.bkv[G.tsel][0][cl]);
+        bias_v = *reinterpret_cast<const float4*>(&sm.bkv[G.tsel][1][cl]);
+    };
+    auto blend4 = [&](const uint4v (&t)[4], const float4 w, const float4 b, float (&o)[4]) {
+        const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned t0 = t[0][e], t1 = t[1][e], t2 = t[2][e], t3 = t[3][e];
+            float acc = fmaf(w.x, __builtin_bit_cast(float, t0), bb[e]);
+            acc = fmaf(w.y, __builtin_bit_cast(float, t1), acc);
+            acc = fmaf(w.z, __builtin_bit_cast(float, t2), acc);
+            o[e] = fmaf(w.w, __builtin_bit_cast(float, t3), acc);
+        }
+    };
+    auto add4 = [&](const uint4v t, const float4 b, float (&o)[4]) {
+        const unsigned t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+        o[0] = __builtin_bit_cast(float, t0) + b.x; o[1] = __builtin_bit_cast(float, t1) + b.y;
+        o[2] = __builtin_bit_cast(float, t2) + b.z; o[3] = __builtin_bit_cast(float, t3) + b.w;
+    };
+    auto blendG = [&](int pass, const PcGatherS& G) {
+        const int kk = pass * KPP + kin;
+        float k4[4], v4[4];
+        blend4(R[pass][0], Wt[pass], bias_k, k4);
+        blend4(R[pass][1], Wt[pass], bias_v, v4);
+        store_split4(sm.Kh[G.kvbuf] + kk * KS + cl, sm.Kl[G.kvbuf] + kk * KS + cl, k4);
+        store_split4(sm.Vh[G.kvbuf] + kk * VS + cl, sm.Vl[G.kvbuf] + kk * VS + cl, v4);
+        const bool vis = vflag[pass] != 0;
+        if ((ltid % TPK) == 0) sm.maskadd[G.kvbuf][kk] = vis ? 0.f : -INFINITY;
+        any |= vis;
+        allv &= vis;
+    };
+    auto blendI = [&](int pass, const PcGatherS& G) {
+        const int kk = pass * KPP + kin;
+        float k4[4], v4[4];
+        add4(R[pass][0][0], bias_k, k4);
+        add4(R[pass][1][0], bias_v, v4);
+        store_split4(sm.Kh[G.kvbuf] + kk * KS + cl, sm.Kl[G.kvbuf] + kk * KS + cl, k4);
+        store_split4(sm.Vh[G.kvbuf] + kk * VS + cl, sm.Vl[G.kvbuf] + kk * VS + cl, v4);
+        if (G.half == 0) {
+            const float4 bq = *reinterpret_cast<const float4*>(&sm.bq[G.te][cl]);
+            float q4[4];
+            add4(R[pass][0][1], bq, q4);
+            store_split4(sm.Qh[G.qbuf] + kk * QS + cl, sm.Ql[G.qbuf] + kk * QS + cl, q4);
+            add4(R[pass][0][2], bq, q4);
+            store_split4(sm.Qh[G.qbuf] + (32 + kk) * QS + cl, sm.Ql[G.qbuf] + (32 + kk) * QS + cl, q4);
+        }
+        if ((ltid % TPK) == 0) sm.maskadd[G.kvbuf][kk] = G.self_vis ? 0.f : -INFINITY;
+    };
+    auto publish = [&](const PcGatherS& G, bool some, bool every) {
+        __builtin_amdgcn_sched_barrier(0);
+        const bool wave_any = __any(some), wave_all = __all(every);
+        if (lane == 0) sm.vis[G.kvbuf][lw] = (wave_any ? 1 : 0) | (wave_all ? 2 : 0);
+        pc_wg_barrier();
+    };
+
+    PcCursor item = {0, 0, 0, 0, 0};
+    int g = 0, qi = 0;
+    PcItem it;
+    if (!pc_fetch(p, X, Y, NG, ego_fastest, item, it)) { pc_wg_barrier(); return; }
+    unsigned vis = pc_item_vis(p, it, X, Y, true);
+    PcGatherS G = pcs_describe(p, sm, it, 0, 0, 0, 0, 0, true);
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) issueI(pass, G);
+
+    // Per item: identity halves I0, I1, then the visible general half chunks, then on to the next item; every body is
+    // "blend the gather whose loads are in the registers, pass by pass, while the next gather's loads are issued".
+    const unsigned half_bits = ((1u << (2 * n_src)) - 1u) << 8;
+#pragma unroll 1
+    while (true) {
+        // I0 -> I1
+        PcGatherS N = pcs_describe(p, sm, it, 0, 1, 0, g + 1, qi, true);
+        load_bias(G);
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
+            __builtin_amdgcn_sched_barrier(0);
+            blendI(pass, G);
+            __builtin_amdgcn_sched_barrier(0);
+            issueI(pass, N);
+        }
+        publish(G, G.self_vis, G.self_vis);
+        G = N; ++g;
+        // visible general half chunks: bit 8 + h' of the word, h' = 2 chunk + half (chunk >= 1)
+        unsigned rest = (vis & half_bits) >> 10;            // bit h = half chunk h = 2 (chunk - 1) + half
+        bool blend_is_identity = true;
+        int tap_group = -1;
+#pragma unroll 1
+        while (rest) {
+            const int h = __builtin_ctz(rest);
+            rest &= rest - 1;
+            if (h / TGH != tap_group) {
+                tap_group = h / TGH;
+                pcs_taps(p, sm, it, tap_group * TGH, lw, lane);
+            }
+            N = pcs_describe(p, sm, it, 1 + (h >> 1), h & 1, h % TGH, g + 1, qi, true);
+            load_bias(G);
+            if (blend_is_identity) {
+#pragma unroll
+                for (int pass = 0; pass < NP; ++pass) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    blendI(pass, G);
+                    __builtin_amdgcn_sched_barrier(0);
+                    issueG(pass, N);
+                }
+                publish(G, G.self_vis, G.self_vis);
+                blend_is_identity = false;
+            } else {
+                any = false; allv = true;
+#pragma unroll
+                for (int pass = 0; pass < NP; ++pass) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    blendG(pass, G);
+                    __builtin_amdgcn_sched_barrier(0);
+                    issueG(pass, N);
+                }
+                publish(G, any, allv);
+            }
+            G = N; ++g;
+        }
+        // last gather of the item while the first identity half of the next item is requested
+        const bool nvalid = pc_fetch(p, X, Y, NG, ego_fastest, item, it);
+        if (nvalid) vis = pc_item_vis(p, it, X, Y, true);
+        qi ^= 1;
+        N = pcs_describe(p, sm, it, 0, 0, 0, g + 1, qi, nvalid);
+        load_bias(G);
+        if (blend_is_identity) {
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                __builtin_amdgcn_sched_barrier(0);
+                blendI(pass, G);
+                __builtin_amdgcn_sched_barrier(0);
+                issueI(pass, N);
+            }
+            publish(G, G.self_vis, G.self_vis);
+        } else {
+            any = false; allv = true;
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                __builtin_amdgcn_sched_barrier(0);
+                blendG(pass, G);
+                __builtin_amdgcn_sched_barrier(0);
+                issueI(pass, N);
+            }
+            publish(G, any, allv);
+        }
+        if (!nvalid) break;
+        G = N; ++g;
+    }
+    pc_wg_barrier();   // the interval in which the compute waves consume the last gather
+}
+
+__device__ __forceinline__ void pcs_compute_loop(const AttnParams& p, PcSharedS& sm, int wave, int lane) {
+    using SM = PcSharedS;
+    constexpr int QS = SM::QS, KS = SM::KS, VS = SM::VS, LWG = SM::LWG;
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int hl = wave;
+    const int C = p.C, H = p.H, W = p.W, L = p.L, P = H * W;
+    const int X = H / 8, Y = W / 8, NG = C / SM::CH;
+    const int n_src = p.n_src;
+    const int lq = lane & 15, g = lane >> 4;
+    PcCursor item = {0, 0, 0, 0, 0};
+    PcItem it;
+    __syncthreads();
+    if (!pc_fetch(p, X, Y, NG, (p.variant & 0x200) == 0, item, it)) return;
+
+    float4v biasf[7];
+    int bias_head = -1;
+    half8 qhh[4], qhl[4];
+    float m_run[4];
+    float4v o_acc[4][2], l_acc[4];
+    const half8 ones = (half8)(half_t)1.0f;
+    int gstep = 0, qi = 0;
+    const unsigned half_bits = ((1u << (2 * n_src)) - 1u) << 8;
+    while (true) {
+        const int head = it.hg * SM::HG + hl;
+        // half chunks to walk: both identity halves, then the visible general ones (the loader walks the same list)
+        unsigned todo = ((pc_item_vis(p, it, X, Y, true) & half_bits) >> 8) | 3u;
+        const int h_last = 31 - __builtin_clz(todo);
+        if (head != bias_head) {
+#pragma unroll
+            for (int v = 0; v < 7; ++v)
+                biasf[v] = *reinterpret_cast<const float4v*>(p.bias_frag + ((size_t)(head * 7 + v) * 64 + lane) * 4);
+            bias_head = head;
+        }
+        bool first = true;
+        while (todo) {
+            const int h = __builtin_ctz(todo);
+            todo &= todo - 1;
+            const int buf = gstep & 1;
+            if (first) {
+                first = false;
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) {
+                    qhh[qt] = *reinterpret_cast<const half8*>(sm.Qh[qi] + (qt * 16 + lq) * QS + hl * 32 + g * 8);
+                    qhl[qt] = *reinterpret_cast<const half8*>(sm.Ql[qi] + (qt * 16 + lq) * QS + hl * 32 + g * 8);
+                    m_run[qt] = -INFINITY;
+                    l_acc[qt] = (float4v)(0.f);
+                    o_acc[qt][0] = (float4v)(0.f);
+                    o_acc[qt][1] = (float4v)(0.f);
+                }
+            }
+            int vis_or = 0, vis_and = 3;
+#pragma unroll
+            for (int w = 0; w < LWG; ++w) {
+                vis_or |= sm.vis[buf][w];
+                vis_and &= sm.vis[buf][w];
+            }
+            const bool any_visible = (vis_or & 1) != 0;
+            const bool all_visible = (vis_and & 2) != 0;
+            if (any_visible || !p.skip_masked) {
+                float4v madd[2];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) madd[kt] = (float4v)(0.f);
+                if (!all_visible) {
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) madd[kt] = *reinterpret_cast<const float4v*>(sm.maskadd[buf] + kt * 16 + 4 * g);
+                }
+                half8 khh[2], khl[2], vhh[2], vhl[2];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    khh[kt] = *reinterpret_cast<const half8*>(sm.Kh[buf] + (kt * 16 + lq) * KS + hl * 32 + g * 8);
+                    khl[kt] = *reinterpret_cast<const half8*>(sm.Kl[buf] + (kt * 16 + lq) * KS + hl * 32 + g * 8);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    // V^T tile dt takes the head's channels 8 q4 + 4 dt + r (q4 = lq & 3) as its rows 4 q4 + r, so that an
+                    // accumulator lane ends up with 8 consecutive channels over the two tiles (as in k_attention_pc)
+                    const int off = (4 * g + (lq >> 2)) * VS + hl * 32 + (lq & 3) * 8 + dt * 4;
+#pragma unroll
+                    for (int hlx = 0; hlx < 2; ++hlx) {
+                        const half_t* base = (hlx ? sm.Vl[buf] : sm.Vh[buf]) + off;
+                        const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base));
+                        const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base + 16 * VS));
+                        half8 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = (half_t)lo[e];
+                            v[4 + e] = (half_t)hi[e];
+                        }
+                        if (hlx) vhl[dt] = v; else vhh[dt] = v;
+                    }
+                }
+                const int hk = h & 1;                        // which half of the 64 key positions: bias tiles 2 hk + kt
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) {
+                    float4v s[2];
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) {
+                        // bias fragment of (query tile qt, key tile 2 hk + kt): index qt - kt - 2 hk + 3, selected without
+                        // dynamic register indexing
+                        const float4v b0 = biasf[qt - kt + 3], b1 = biasf[qt - kt + 1 >= 0 ? qt - kt + 1 : 0];
+                        float4v acc = hk ? b1 : b0;
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(khl[kt], qhh[qt], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(khh[kt], qhl[qt], acc, 0, 0, 0);
+                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(khh[kt], qhh[qt], acc, 0, 0, 0);
+                    }
+                    if (!all_visible) {
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt) s[kt] += madd[kt];
+                    }
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+                    mx = max_over_lane_groups(mx);
+                    const float m_new = max_raw(m_run[qt], mx);
+                    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+                    const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_safe) * LOG2E);
+                    half8 ph, pl;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float e = __builtin_amdgcn_exp2f((s[kt][r] - m_safe) * LOG2E);
+                            const half_t eh = (half_t)e;
+                            ph[4 * kt + r] = eh;
+                            pl[4 * kt + r] = (half_t)(e - (float)eh);
+                        }
+                    m_run[qt] = m_new;
+                    o_acc[qt][0] *= alpha;
+                    o_acc[qt][1] *= alpha;
+                    l_acc[qt] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        o_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhl[dt], ph, o_acc[qt][dt], 0, 0, 0);
+                        o_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhh[dt], pl, o_acc[qt][dt], 0, 0, 0);
+                        o_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhh[dt], ph, o_acc[qt][dt], 0, 0, 0);
+                    }
+                    l_acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pl, l_acc[qt], 0, 0, 0);
+                    l_acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, ph, l_acc[qt], 0, 0, 0);
+                }
+            }
+            if (h == h_last) {
+                float* outp = reinterpret_cast<float*>(p.out) + (size_t)(it.b * L + it.ego) * P * C;
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) {
+                    int row, col;
+                    token_pixel(p.partition, 8, X, Y, it.wx, it.wy, qt * 16 + lq, row, col);
+                    const float inv = 1.f / l_acc[qt][0];
+                    float* o = outp + (size_t)(row * W + col) * C + head * 32 + 8 * g;
+                    *reinterpret_cast<float4*>(o) = make_float4(o_acc[qt][0][0] * inv, o_acc[qt][0][1] * inv, o_acc[qt][0][2] * inv, o_acc[qt][0][3] * inv);
+                    *reinterpret_cast<float4*>(o + 4) = make_float4(o_acc[qt][1][0] * inv, o_acc[qt][1][1] * inv, o_acc[qt][1][2] * inv, o_acc[qt][1][3] * inv);
+                }
+            }
+            __syncthreads();
+            ++gstep;
+        }
+        if (!pc_fetch(p, X, Y, NG, (p.variant & 0x200) == 0, item, it)) break;
+        qi ^= 1;
+    }
+}
+
+__global__ __launch_bounds__(512) void k_attention_pcs(AttnParams p) {
+    using SM = PcSharedS;
+    __shared__ __attribute__((aligned(16))) SM sm;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hg = (blockIdx.x >> 3) % (p.C / SM::CH);
+    {
+        const int n_rec = p.B * p.L * p.L * 8;
+        for (int i = threadIdx.x; i < n_rec; i += blockDim.x) sm.ainv[i] = p.ainv[i];
+        for (int i = threadIdx.x; i < HMVIT_NUM_TYPES * HMVIT_NUM_TYPES * 2 * SM::CH; i += blockDim.x) {
+            const int e = i / (2 * SM::CH), pl = (i / SM::CH) & 1, c = i % SM::CH;
+            sm.bkv[e][pl][c] = p.b_kv[(size_t)e * 2 * p.C + pl * p.C + hg * SM::CH + c];
+        }
+        for (int i = threadIdx.x; i < HMVIT_NUM_TYPES * SM::CH; i += blockDim.x)
+            sm.bq[i / SM::CH][i % SM::CH] = p.b_q[(i / SM::CH) * p.C + hg * SM::CH + (i % SM::CH)];
+        if (threadIdx.x < kMaxSlots) {
+            sm.mode[threadIdx.x] = p.mode[threadIdx.x];
+            sm.cav[threadIdx.x] = p.cav[threadIdx.x];
+            sm.ego_e[threadIdx.x] = p.ego_e[threadIdx.x];
+        }
+    }
+    __syncthreads();
+    if (wave >= SM::CWG) {
+        __builtin_amdgcn_s_setprio(3);
+        pcs_loader_loop(p, sm, wave - SM::CWG, threadIdx.x - SM::CWG * 64);
+    } else {
+        pcs_compute_loop(p, sm, wave, threadIdx.x & 63);
+    }
+}
+
+static int launch_attn_pcs(const AttnParams& p, hipStream_t st) {
+    hipLaunchKernelGGL(k_attention_pcs, dim3(256), dim3(512), 0, st, p);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
 template <typename T, int WIN, int HG>
 static int launch_attn_t(const AttnParams& p, hipStream_t st) {
     const int NG = p.C / (HG * 32);
@@ -1225,7 +1741,11 @@ __global__ __launch_bounds__(256) void k_tile_vis(AttnParams p, unsigned* __rest
         const float* a = p.ainv + ((size_t)(b * p.L + src) * p.L + ego) * 8;
         bool vis = p.cav[b * p.L + src] != 0;
         if (a[6] == 0.f) vis = vis && make_taps(a, col, row, p.H, p.W).roi != 0.f;
-        if (__any(vis)) mask |= 1u << c;
+        const unsigned long long bal = __ballot(vis);
+        if (bal) mask |= 1u << c;
+        // bits 8 + 2c / 9 + 2c: keys 0..31 / 32..63 of the chunk (the split-precision kernel walks 32-key half chunks)
+        if (bal & 0xffffffffull) mask |= 1u << (8 + 2 * c);
+        if (bal >> 32) mask |= 1u << (9 + 2 * c);
     }
     if (need && !need[pos]) mask |= 0x80000000u;      // local partition only: pos = (b, ego, window) as in k_window_need
     if (lane == 0) vis_mask[pos] = mask;
@@ -1287,7 +1807,13 @@ int launch_attention(const AttnParams& p, int precision, hipStream_t st) {
     HMVIT_CHECK_ARG(p.B * p.L <= kMaxSlots, "attention: B*L=%d exceeds %d per launch", p.B * p.L, kMaxSlots);
     if (p.n_ego <= 0 || p.B <= 0) return HMVIT_OK;
     const bool w8 = p.window == 8;
-    if (precision == HMVIT_PREC_F32) {
+    if (precision == HMVIT_PREC_SPLIT && w8 && p.C >= 128 && p.self_identity && p.n_src <= 8 &&
+        p.B * p.L * p.L <= PcSharedS::MAX_PAIRS) {
+        AttnParams q = p;
+        if (p.partition == HMVIT_PART_GRID) q.variant ^= 0x200;   // item order as for k_attention_pc
+        return launch_attn_pcs(q, st);
+    }
+    if (precision == HMVIT_PREC_F32 || precision == HMVIT_PREC_SPLIT) {   // f32 planes, exact-f32 MFMA
         return w8 ? launch_attn_t<float, 8, 2>(p, st) : launch_attn_t<float, 4, 2>(p, st);
     }
     if (p.C == 64) return w8 ? launch_attn_t<half_t, 8, 2>(p, st) : launch_attn_t<half_t, 4, 2>(p, st);

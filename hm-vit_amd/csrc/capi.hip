@@ -576,15 +576,18 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                 }
                 // the stage after this one is the pruned last stage (ego 0 only): unreachable windows are dead code
                 need = (it == d->num_iters - 1 && s == 0) ? need_last : nullptr;
-                if (!split && d->skip_masked && d->window == 8 && C > 64 && n_src <= 8 && !getenv("HMVIT_ATTN_DEBUG")) {
+                ap.self_identity = d->self_identity;
+                // split mode: the persistent split kernel needs the table and identity self transforms; otherwise (and for
+                // window 4 / C = 64) the exact-f32 kernel runs on the f32 planes
+                const bool pc_split = split && d->self_identity && pl.n_slots * L <= 128;
+                if ((!split || pc_split) && d->skip_masked && d->window == 8 && C > 64 && n_src <= 8 && !getenv("HMVIT_ATTN_DEBUG")) {
                     // tiles without a visible key are skipped by the persistent kernel (launch_tile_vis)
                     unsigned* vis = reinterpret_cast<unsigned*>(ws + pl.off_vis);
                     HMVIT_TRY(launch_tile_vis(ap, vis, need, st));
                     ap.vis_mask = vis;
                     ap.prune = need != nullptr;
                 }
-                // split mode: the exact-f32 attention kernel on the f32 planes (attn.hip k_attention<float>)
-                HMVIT_TRY(launch_attention(ap, split ? HMVIT_PREC_F32 : HMVIT_PREC_F16, st));
+                HMVIT_TRY(launch_attention(ap, split ? HMVIT_PREC_SPLIT : HMVIT_PREC_F16, st));
             }
             HMVIT_MARK(HMVIT_PHASE_ATTENTION);
 

@@ -159,6 +159,8 @@ struct AttnParams {
     int variant;              // 0: default kernel choice, 1: force the one-window-per-workgroup kernel
     const unsigned* vis_mask;        // optional (B * n_ego * H/8 * W/8): visible-chunk bits per window (launch_tile_vis)
     int prune;                       // vis_mask bit 31 marks items no later stage can reach: skipped by the schedule
+    int self_identity;               // caller's guarantee that every self transform pairwise_t[b, i, i] is the identity
+                                     // (needed by the split-precision persistent kernel, which has no general-self loader)
     float* lse;               // optional (B, L, P, heads) f32: log-sum-exp of every query row (f32 kernel; kept for the backward pass)
     int8_t mode[kMaxSlots];   // (B, L)
     int8_t cav[kMaxSlots];    // (B, L)

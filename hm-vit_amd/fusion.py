@@ -113,20 +113,28 @@ class _FusionBase(nn.Module):
 
     # -- host copies of the small integer inputs --
     @staticmethod
-    def _host_small(mode, record_len, mask):
+    def _host_small(mode, record_len, mask, pairwise=None):
         """mode / record_len / mask as Python ints.  They drive the launch plan (weight pointers per agent type, loop
         bounds), so they are needed on the host: CPU tensors / lists cost nothing, device tensors are read back with ONE
         combined copy per forward (the reference reads them back element by element, hetero_fusion.py:127-131).  Nothing is
         cached across calls: a data loader hands over a fresh tensor per frame and the caching allocator reuses addresses,
         so identity is not content."""
         ts = [t if torch.is_tensor(t) else torch.as_tensor(t) for t in (mode, record_len, mask)]
-        if any(t.device.type != "cpu" for t in ts):
-            dev = next(t.device for t in ts if t.device.type != "cpu")
-            flat = torch.cat([t.to(dev).reshape(-1).to(torch.int64) for t in ts]).cpu().tolist()
+        extra = []
+        if pairwise is not None:
+            # "every self transform is the identity" (always so for the reference's datasets) rides on the same read-back:
+            # it selects the split mode's persistent attention kernel
+            L = pairwise.shape[1]
+            idx = torch.arange(L, device=pairwise.device)
+            extra = [(pairwise[:, idx, idx] == torch.eye(4, device=pairwise.device, dtype=pairwise.dtype)).all().reshape(1)]
+        if any(t.device.type != "cpu" for t in ts + extra):
+            dev = next(t.device for t in ts + extra if t.device.type != "cpu")
+            flat = torch.cat([t.to(dev).reshape(-1).to(torch.int64) for t in ts + extra]).cpu().tolist()
         else:
-            flat = torch.cat([t.reshape(-1).to(torch.int64) for t in ts]).tolist()
-        n0, n1 = ts[0].numel(), ts[1].numel()
-        return [int(v) for v in flat[:n0]], [int(v) for v in flat[n0:n0 + n1]], [int(v) for v in flat[n0 + n1:]]
+            flat = torch.cat([t.reshape(-1).to(torch.int64) for t in ts + extra]).tolist()
+        n0, n1, n2 = ts[0].numel(), ts[1].numel(), ts[2].numel()
+        out = ([int(v) for v in flat[:n0]], [int(v) for v in flat[n0:n0 + n1]], [int(v) for v in flat[n0 + n1:n0 + n1 + n2]])
+        return out + (bool(flat[-1]),) if pairwise is not None else out
 
     def _weights(self, device, prec: int):
         params = list(self.parameters()) + list(self.buffers())
@@ -192,7 +200,11 @@ class _FusionBase(nn.Module):
             d.parallel = 1
             for name, t in w["split"].items():
                 setattr(d, name, t.data_ptr())
-        mode_h, rl_h, mask_h = self._host_small(mode, record_len, mask)
+        if prec == _lib.PREC_SPLIT:
+            mode_h, rl_h, mask_h, self_ident = self._host_small(mode, record_len, mask, pw)
+            d.self_identity = int(self_ident)
+        else:
+            mode_h, rl_h, mask_h = self._host_small(mode, record_len, mask)
         if len(mode_h) != B * L or len(mask_h) != B * L or len(rl_h) != B:
             raise ValueError("mode / mask must be (B, L) and record_len (B,)")
         keep = (_lib.i32_array(mode_h), _lib.i32_array(rl_h), _lib.i32_array(mask_h))

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HMVIT_ABI_VERSION 6
+#define HMVIT_ABI_VERSION 7
 
 #define HMVIT_OK 0
 #define HMVIT_EINVAL (-22)   /* bad argument / unsupported shape */
@@ -143,6 +143,9 @@ typedef struct HmvitFusionDesc {
     const float* split_ln_g;
     const float* split_ln_b;
     const float* split_fc2;
+    int32_t self_identity;        /* 1: the caller guarantees pairwise_t[b, i, i] = I for every agent (what the reference's
+                                     datasets produce, mixed/intermediate_fusion_dataset.py:163-202); lets HMVIT_PREC_SPLIT use
+                                     its persistent attention kernel.  0: unknown (always correct, slower in split mode) */
 } HmvitFusionDesc;
 
 int hmvit_abi_version(void);
