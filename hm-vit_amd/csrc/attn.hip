@@ -1228,9 +1228,11 @@ struct PcSharedS {
     float bkv[HMVIT_NUM_TYPES * HMVIT_NUM_TYPES][2][CH];
     float bq[HMVIT_NUM_TYPES][CH];
     int mode[kMaxSlots], cav[kMaxSlots], ego_e[kMaxSlots];
-    int tidx[LWG][TGH][NK][4];
-    float tw[LWG][TGH][NK][4];
-    int tvis[LWG][TGH][NK];
+    // two sets of tap tables (group parity): a gather is blended - weights and visibility re-read from here - while the
+    // first gather of the NEXT group is already being issued from freshly written tables
+    int tidx[LWG][2 * TGH][NK][4];
+    float tw[LWG][2 * TGH][NK][4];
+    int tvis[LWG][2 * TGH][NK];
 };
 
 __device__ __forceinline__ uint4v tok_load4f(int4v rs, int token, int off_bytes, int soff) {
@@ -1268,8 +1270,9 @@ __device__ __forceinline__ void pcs_taps(const AttnParams& p, PcSharedS& sm, con
     using SM = PcSharedS;
     constexpr int KPW = SM::KPW, NK = SM::NK, KPP = SM::KPP, TGH = SM::TGH;
     const int H = p.H, W = p.W, L = p.L, X = H / 8, Y = W / 8;
-    const int e = lane, c = e / NK, j = e % NK;
-    const int hc = hc0 + c, chunk = 1 + (hc >> 1), half = hc & 1;
+    const int e = lane, cc = e / NK, j = e % NK;
+    const int hc = hc0 + cc, chunk = 1 + (hc >> 1), half = hc & 1;
+    const int c = ((hc0 / TGH) & 1) * TGH + cc;            // table slot: group parity, position in the group
     if (e < TGH * NK && chunk < p.n_src) {
         const int src = pc_src(chunk, it.ego);
         const float* a = sm.ainv + ((it.b * L + src) * L + it.ego) * 8;
@@ -1329,16 +1332,14 @@ __device__ __forceinline__ void pcs_loader_loop(const AttnParams& p, PcSharedS& 
     const int kj = kin % KPW;
     const bool ego_fastest = (p.variant & 0x200) == 0;
 
+    // the only state carried from the issue of a gather to its blend: the 32 tap loads per lane.  Tap weights, visibility
+    // and biases are re-read from LDS when the taps are blended (the register file is the scarce resource of this role)
     uint4v R[NP][2][4];
-    float4 Wt[NP];
-    int vflag[NP];
     bool any = false, allv = true;
 
     auto issueG = [&](int pass, const PcGatherS& G) {
         const int j = pass * KPW + kj;
         const int4 ix = *reinterpret_cast<const int4*>(sm.tidx[lw][G.slot][j]);
-        Wt[pass] = *reinterpret_cast<const float4*>(sm.tw[lw][G.slot][j]);
-        vflag[pass] = sm.tvis[lw][G.slot][j];
         const int ixa[4] = {ix.x, ix.y, ix.z, ix.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1360,11 +1361,7 @@ __device__ __forceinline__ void pcs_loader_loop(const AttnParams& p, PcSharedS& 
             R[pass][0][2] = tok_load4f(G.rs_q, G.valid ? row * p.W + col : -1, cl_bytes, 0);
         }
     };
-    float4 bias_k, bias_v;
-    auto load_bias = [&](const PcGatherS& G) {
-        bias_k = *reinterpret_cast<const float4*>(&sm.bkv[G.tsel][0][cl]);
-        bias_v = *reinterpret_cast<const float4*>(&sm.bkv[G.tsel][1][cl]);
-    };
+    auto load_bias = [&](const PcGatherS& G) {};
     auto blend4 = [&](const uint4v (&t)[4], const float4 w, const float4 b, float (&o)[4]) {
         const float bb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
@@ -1383,23 +1380,25 @@ __device__ __forceinline__ void pcs_loader_loop(const AttnParams& p, PcSharedS& 
     };
     auto blendG = [&](int pass, const PcGatherS& G) {
         const int kk = pass * KPP + kin;
-        float k4[4], v4[4];
-        blend4(R[pass][0], Wt[pass], bias_k, k4);
-        blend4(R[pass][1], Wt[pass], bias_v, v4);
+        const int j = pass * KPW + kj;
+        const float4 wt = *reinterpret_cast<const float4*>(sm.tw[lw][G.slot][j]);
+        float k4[4];
+        blend4(R[pass][0], wt, *reinterpret_cast<const float4*>(&sm.bkv[G.tsel][0][cl]), k4);
         store_split4(sm.Kh[G.kvbuf] + kk * KS + cl, sm.Kl[G.kvbuf] + kk * KS + cl, k4);
-        store_split4(sm.Vh[G.kvbuf] + kk * VS + cl, sm.Vl[G.kvbuf] + kk * VS + cl, v4);
-        const bool vis = vflag[pass] != 0;
+        blend4(R[pass][1], wt, *reinterpret_cast<const float4*>(&sm.bkv[G.tsel][1][cl]), k4);
+        store_split4(sm.Vh[G.kvbuf] + kk * VS + cl, sm.Vl[G.kvbuf] + kk * VS + cl, k4);
+        const bool vis = sm.tvis[lw][G.slot][j] != 0;
         if ((ltid % TPK) == 0) sm.maskadd[G.kvbuf][kk] = vis ? 0.f : -INFINITY;
         any |= vis;
         allv &= vis;
     };
     auto blendI = [&](int pass, const PcGatherS& G) {
         const int kk = pass * KPP + kin;
-        float k4[4], v4[4];
-        add4(R[pass][0][0], bias_k, k4);
-        add4(R[pass][1][0], bias_v, v4);
+        float k4[4];
+        add4(R[pass][0][0], *reinterpret_cast<const float4*>(&sm.bkv[G.tsel][0][cl]), k4);
         store_split4(sm.Kh[G.kvbuf] + kk * KS + cl, sm.Kl[G.kvbuf] + kk * KS + cl, k4);
-        store_split4(sm.Vh[G.kvbuf] + kk * VS + cl, sm.Vl[G.kvbuf] + kk * VS + cl, v4);
+        add4(R[pass][1][0], *reinterpret_cast<const float4*>(&sm.bkv[G.tsel][1][cl]), k4);
+        store_split4(sm.Vh[G.kvbuf] + kk * VS + cl, sm.Vl[G.kvbuf] + kk * VS + cl, k4);
         if (G.half == 0) {
             const float4 bq = *reinterpret_cast<const float4*>(&sm.bq[G.te][cl]);
             float q4[4];
@@ -1455,7 +1454,7 @@ __device__ __forceinline__ void pcs_loader_loop(const AttnParams& p, PcSharedS& 
                 tap_group = h / TGH;
                 pcs_taps(p, sm, it, tap_group * TGH, lw, lane);
             }
-            N = pcs_describe(p, sm, it, 1 + (h >> 1), h & 1, h % TGH, g + 1, qi, true);
+            N = pcs_describe(p, sm, it, 1 + (h >> 1), h & 1, (tap_group & 1) * TGH + h % TGH, g + 1, qi, true);
             load_bias(G);
             if (blend_is_identity) {
 #pragma unroll

@@ -5,8 +5,12 @@ import collections, csv, glob, json, os, sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
 out_txt = sys.argv[2] if len(sys.argv) > 2 else None
-KEYS = ["k_attention_pc", "k_ln_qkv", "k_out_ffn_qkv", "k_out_ffn_head", "k_out_ffn<256, true", "k_out_ffn<256, false, false"]
-PHASE = {"k_attention_pc": "attention", "k_ln_qkv": "qkv_gemm", "k_out_ffn_qkv": "ffn2", "k_out_ffn_head": "ffn2_last_head", "k_out_ffn<256, true": "ffn2_last", "k_out_ffn<256, false, false": "head"}
+prec = sys.argv[3] if len(sys.argv) > 3 else "f16"
+KEYS = ["k_attention_pcs", "k_attention_pc<", "k_attention<float", "k_ln_qkv", "k_out_ffn_qkv", "k_out_ffn_head", "k_gemm<float, false, false, false>",
+        "k_gemm<float, false, false, true>", "k_gemm<float, false, true, false>", "k_layernorm"]
+PHASE = {"k_attention_pcs": "attention", "k_attention_pc<": "attention", "k_attention<float": "attention", "k_ln_qkv": "ln_qkv",
+         "k_out_ffn_qkv": "stage_tail", "k_out_ffn_head": "stage_tail_head", "k_gemm<float, false, false, false>": "qkv_gemm",
+         "k_gemm<float, false, false, true>": "out_proj_ffn2", "k_gemm<float, false, true, false>": "ffn1", "k_layernorm": "ln"}
 
 def key_of(name):
     for k in KEYS:
@@ -56,4 +60,13 @@ for k in KEYS:
 print("\n".join(lines))
 if out_txt:
     open(out_txt, "w").write("\n".join(lines) + "\n")
-    json.dump(traffic, open(os.path.join(os.path.dirname(out_txt), "pmc_traffic.json"), "w"), indent=1)
+    # per-precision traffic table for bench.py's roofline.traffic, stamped with the hash of the kernel sources it was measured on
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    path = os.path.join(os.path.dirname(out_txt), "pmc_traffic.json")
+    allt = json.load(open(path)) if os.path.exists(path) else {}
+    h = bench.kernel_source_hash()
+    if allt.get("kernel_source_hash") != h:
+        allt = {"kernel_source_hash": h}
+    allt[prec] = traffic
+    json.dump(allt, open(path, "w"), indent=1)
