@@ -105,6 +105,7 @@ _SIGNATURES = {
     "hmvit_cvt_embed": (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_int] * 5 + [C.c_float, C.c_float, C.c_void_p]),
     "hmvit_bn_relu_tokens": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     "hmvit_cross_attention": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_void_p]),
+    "hmvit_attention_bias": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]),
     "hmvit_conv2d_ex": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 12 + [C.c_void_p]),
     "hmvit_conv2d_rowpack": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 10 + [C.c_void_p]),
     "hmvit_maxpool2d": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 8 + [C.c_void_p]),

@@ -518,11 +518,15 @@ struct PcShared {
 __device__ __forceinline__ int pc_src(int c, int ego) { return c == 0 ? ego : (c <= ego ? c - 1 : c); }
 
 // debug trace: workgroup 0, one lane of one wave per role, stamps[(iter * 8 + slot)]
+#ifdef HMVIT_PROBE
 #define PC_TRACE(cond, iter, slot)                                                              \
     do {                                                                                        \
         if (p.trace && blockIdx.x == 0 && (cond) && (iter) < 64)                                \
             p.trace[(iter) * 8 + (slot)] = __builtin_readcyclecounter();                        \
     } while (0)
+#else
+#define PC_TRACE(cond, iter, slot) do {} while (0)
+#endif
 
 // 16 bytes of a projected map through a STRUCTURED buffer descriptor (record = the C channels of
 // one token): the address base + soffset + index * stride + offset is formed by the texture
@@ -1817,20 +1821,20 @@ int launch_attention(const AttnParams& p, int precision, hipStream_t st) {
     }
     if (p.C == 64) return w8 ? launch_attn_t<half_t, 8, 2>(p, st) : launch_attn_t<half_t, 4, 2>(p, st);
     int variant = p.variant;
-    if (const char* e = getenv("HMVIT_ATTN_DEBUG")) variant ^= atoi(e);   // probe switches (tools/attn_probe.py, tools/attn_diff.py)
-    if (const char* e = getenv("HMVIT_ATTN_VARIANT")) variant ^= (int)strtol(e, nullptr, 0);   // same, without switching the visibility table off
+    if (const char* e = HMVIT_ENV("HMVIT_ATTN_DEBUG")) variant ^= atoi(e);   // probe switches (tools/attn_probe.py, tools/attn_diff.py)
+    if (const char* e = HMVIT_ENV("HMVIT_ATTN_VARIANT")) variant ^= (int)strtol(e, nullptr, 0);   // same, without switching the visibility table off
     if (w8 && (variant & 1) == 0 && p.B * p.L * p.L <= PcShared<4, 1, 1>::MAX_PAIRS) {
         AttnParams q = p;
         q.variant = variant;
         // item order: egos interleaved per window for the local partition (cross-ego cache reuse of the
         // gathered rows), ego-major for the dilated grid partition
         if (p.partition == HMVIT_PART_GRID) q.variant ^= 0x200;
-        if (const char* e = getenv("HMVIT_ATTN_TILE44")) {      // probe: 4 x 4 window tiles (1: grid stages, 2: local, 3: both)
+        if (const char* e = HMVIT_ENV("HMVIT_ATTN_TILE44")) {      // probe: 4 x 4 window tiles (1: grid stages, 2: local, 3: both)
             const int m = atoi(e);
             if ((p.partition == HMVIT_PART_GRID && (m & 1)) || (p.partition != HMVIT_PART_GRID && (m & 2))) q.variant |= 0x2000;
             if ((p.partition == HMVIT_PART_GRID && (m & 4)) || (p.partition != HMVIT_PART_GRID && (m & 8))) q.variant |= 0x4000;
         }
-        if (const char* e = getenv("HMVIT_ATTN_TRACE")) q.trace = (unsigned long long*)strtoull(e, nullptr, 0);
+        if (const char* e = HMVIT_ENV("HMVIT_ATTN_TRACE")) q.trace = (unsigned long long*)strtoull(e, nullptr, 0);
         // wave configurations (heads per group, compute waves per head, loader waves per head):
         //   default: 4 heads, 1 + 1 -> 8 waves of <= 256 VGPRs: a loader wave keeps 4 passes = 32 tap loads
         //            per lane in flight

@@ -484,7 +484,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
     };
     // The first stage's fused tail can take its residual straight from the (C, P) input maps: k_ln_qkv then writes no
     // token-major f32 copy of the input (721 MB at cfg2).  Needs the fused tail (sequential block, C = 256, a next stage).
-    const bool direct_x = !par && C == 256 && !getenv("HMVIT_NO_FUSE") && !getenv("HMVIT_NO_DIRECT_X");   // = `fuse` of stage 1
+    const bool direct_x = !par && C == 256 && !HMVIT_ENV("HMVIT_NO_FUSE") && !HMVIT_ENV("HMVIT_NO_DIRECT_X");   // = `fuse` of stage 1
 
     // LayerNorm + Q / folded K', V' projections of agent `slot` for the stage (wt, si)
     auto qkv_job = [&](const HmvitStageWeights& wt, const StageInfo& si, int slot, int l, bool first) {
@@ -517,8 +517,8 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
     // (need_prev).  Identical output; off with skip_masked = 0.
     unsigned char* need_last = nullptr;
     unsigned char* need_prev = nullptr;
-    if (!par && d->apply_head && d->skip_masked && d->window == 8 && pl.max_cav > 1 && d->H % 8 == 0 && d->W % 8 == 0 &&
-        !getenv("HMVIT_NO_PRUNE")) {
+    if (!par && d->apply_head && d->skip_masked == 1 && d->window == 8 && pl.max_cav > 1 && d->H % 8 == 0 && d->W % 8 == 0 &&
+        !HMVIT_ENV("HMVIT_NO_PRUNE")) {
         AttnParams ap;
         memset(&ap, 0, sizeof(ap));
         ap.ainv = ainv; ap.B = B; ap.L = L; ap.n_ego = pl.max_cav; ap.H = d->H; ap.W = d->W; ap.window = d->window;
@@ -527,7 +527,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
         need_last = reinterpret_cast<unsigned char*>(ws + pl.off_need);
         HMVIT_CHECK_HIP(hipMemsetAsync(need_last, 0, 2 * nb, st));
         HMVIT_TRY(launch_window_need(ap, nullptr, need_last, st));
-        if (d->num_iters >= 2 && !getenv("HMVIT_NO_PRUNE_PREV")) {
+        if (d->num_iters >= 2 && !HMVIT_ENV("HMVIT_NO_PRUNE_PREV")) {
             need_prev = need_last + nb;
             HMVIT_TRY(launch_window_need(ap, need_last, need_prev, st));
         }
@@ -580,7 +580,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                 // split mode: the persistent split kernel needs the table and identity self transforms; otherwise (and for
                 // window 4 / C = 64) the exact-f32 kernel runs on the f32 planes
                 const bool pc_split = split && d->self_identity && pl.n_slots * L <= 128;
-                if ((!split || pc_split) && d->skip_masked && d->window == 8 && C > 64 && n_src <= 8 && !getenv("HMVIT_ATTN_DEBUG")) {
+                if ((!split || pc_split) && d->skip_masked && d->window == 8 && C > 64 && n_src <= 8 && !HMVIT_ENV("HMVIT_ATTN_DEBUG")) {
                     // tiles without a visible key are skipped by the persistent kernel (launch_tile_vis)
                     unsigned* vis = reinterpret_cast<unsigned*>(ws + pl.off_vis);
                     HMVIT_TRY(launch_tile_vis(ap, vis, need, st));
@@ -595,7 +595,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
             // block the next stage's LayerNorm + projections ride on the same kernel (k_out_ffn_qkv)
             {
                 const bool has_next = !(it == d->num_iters - 1 && s == 1);
-                const bool fuse = !par && has_next && !last && C == 256 && !getenv("HMVIT_NO_FUSE");
+                const bool fuse = !par && has_next && !last && C == 256 && !HMVIT_ENV("HMVIT_NO_FUSE");
                 FfnBatcher fb;
                 memset(&fb.p, 0, sizeof(fb.p));
                 fb.n = 0; fb.C = C; fb.st = st; fb.split = split;
@@ -631,7 +631,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                         }
                     HMVIT_TRY(launch_out_ffn_qkv(fb.p, qp, n, C, split, st));
                     qkv_done = true;
-                } else if (last && !par && C == 256 && d->head_img_ffn && !getenv("HMVIT_NO_FUSE")) {
+                } else if (last && !par && C == 256 && d->head_img_ffn && !HMVIT_ENV("HMVIT_NO_FUSE")) {
                     // last stage: only the ego row is alive and mlp_head follows immediately (k_out_ffn_head)
                     fb.p.w_head = reinterpret_cast<const half_t*>(d->head_img_ffn); fb.p.hb_1 = d->head_b1; fb.p.hb_2 = d->head_b2;
                     int n = 0;
@@ -863,14 +863,14 @@ int hmvit_conv2d(const void* x, const void* w, const float* bias, void* y, int N
 int hmvit_conv2d_ex(const void* x, const void* w, const float* bias, const void* residual, void* y, int N, int H, int W, int Cin,
                     int Cout, int ksize, int stride, int pad, int relu, int upsample2, int out_f32, int precision, void* stream) {
     HMVIT_CHECK_ARG(x && w && y, "conv2d_ex: null pointer");
-    HMVIT_CHECK_ARG(!upsample2 || (H % 2 == 0 && W % 2 == 0), "conv2d_ex: upsampled size %dx%d must be even", H, W);
+    HMVIT_CHECK_ARG(!(upsample2 & 1) || (H % 2 == 0 && W % 2 == 0), "conv2d_ex: upsampled size %dx%d must be even", H, W);
     HMVIT_CHECK_ARG(!(residual && out_f32 && precision != HMVIT_PREC_F32), "conv2d_ex: residual needs the precision's element type");
     ConvParams p;
     memset(&p, 0, sizeof(p));
     p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = p.KW = ksize; p.stride = stride; p.pad = pad;
     p.relu = relu; p.y_ctot = Cout; p.y_coff = 0; p.deconv_s = 0; p.out_f32 = out_f32;
-    p.res = residual; p.up2 = upsample2;
+    p.res = residual; p.up2 = upsample2 & 1; p.no_patch = (upsample2 >> 1) & 1;
     p.Ho = (H + 2 * pad - ksize) / stride + 1;
     p.Wo = (W + 2 * pad - ksize) / stride + 1;
     return launch_conv(p, precision, reinterpret_cast<hipStream_t>(stream));
@@ -994,7 +994,13 @@ int hmvit_cross_attention(const void* q, const void* k, const void* v, float* ou
         return launch_cross_attention_f16(reinterpret_cast<const half_t*>(q), reinterpret_cast<const half_t*>(k),
                                           reinterpret_cast<const half_t*>(v), out, n_agents, n_cam, Q, K, heads, dim_head, st);
     return launch_cross_attention(reinterpret_cast<const float*>(q), reinterpret_cast<const float*>(k),
-                                  reinterpret_cast<const float*>(v), out, n_agents, n_cam, Q, K, heads, dim_head, st);
+                                  reinterpret_cast<const float*>(v), out, n_agents, n_cam, Q, K, heads, dim_head, nullptr, st);
+}
+
+int hmvit_attention_bias(const float* q, const float* k, const float* v, const float* bias, float* out, int batch, int Q, int K,
+                         int heads, int dim_head, void* stream) {
+    HMVIT_CHECK_ARG(q && k && v && bias && out && batch > 0 && Q > 0 && K > 0 && heads > 0, "attention_bias: bad argument");
+    return launch_cross_attention(q, k, v, out, batch, 1, Q, K, heads, dim_head, bias, reinterpret_cast<hipStream_t>(stream));
 }
 
 int hmvit_debug_tr16(uint16_t* out, void* stream) {

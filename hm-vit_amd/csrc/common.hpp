@@ -17,6 +17,15 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
+// Tuning / ablation switches read from the environment exist only in probe builds (`make PROBE=1` -> -DHMVIT_PROBE, used by
+// tools/probe and tests/tools): the shipped library never calls getenv and never takes a pointer out of the environment.
+#ifdef HMVIT_PROBE
+#include <stdlib.h>
+#define HMVIT_ENV(name) getenv(name)
+#else
+#define HMVIT_ENV(name) ((const char*)nullptr)
+#endif
+
 // ---- thread-local error string (hmvit_last_error) ----
 void set_error(const char* fmt, ...);
 #define HMVIT_CHECK_ARG(cond, ...)            \

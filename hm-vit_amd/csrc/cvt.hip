@@ -98,9 +98,11 @@ int launch_bn_relu_tokens(const float* x, const float* scale, const float* shift
 // q (b, n, Q, heads * 32), k (b, n, K, heads * 32), v (b, n * K, heads * 32) -> out (b, Q, heads * 32).
 // One thread per query (64 per workgroup), one head per workgroup; K / V tiles of 64 keys staged in LDS; online softmax
 // over the n cameras' keys.
+// bias: optional (heads, Q, K) additive logit bias (n_cam = 1): the relative-position bias of FAX's self-attention
+// (fax_modules.py:122-160).
 __global__ __launch_bounds__(64) void k_cross_attention(const float* __restrict__ q, const float* __restrict__ k,
                                                         const float* __restrict__ v, float* __restrict__ out, int n_cam, int Q,
-                                                        int K, int heads, float scale) {
+                                                        int K, int heads, float scale, const float* __restrict__ bias) {
     constexpr int D = 32;
     __shared__ float Ks[64][D + 1], Vs[64][D + 1];
     const int b = blockIdx.z, head = blockIdx.y, qi = blockIdx.x * 64 + threadIdx.x;
@@ -125,8 +127,9 @@ __global__ __launch_bounds__(64) void k_cross_attention(const float* __restrict_
             }
             __syncthreads();
             const int cnt = min(64, K - k0);
+            const float* brow = bias ? bias + ((size_t)head * Q + (valid ? qi : 0)) * K + k0 : nullptr;
             for (int j = 0; j < cnt; ++j) {
-                float s = 0.f;
+                float s = brow ? brow[j] : 0.f;
 #pragma unroll
                 for (int d = 0; d < D; ++d) s = fmaf(qv[d], Ks[j][d], s);
                 const float m_new = fmaxf(m_run, s);
@@ -147,11 +150,12 @@ __global__ __launch_bounds__(64) void k_cross_attention(const float* __restrict_
 }
 
 int launch_cross_attention(const float* q, const float* k, const float* v, float* out, int b, int n_cam, int Q, int K, int heads,
-                           int dim_head, hipStream_t st) {
+                           int dim_head, const float* bias, hipStream_t st) {
     HMVIT_CHECK_ARG(dim_head == 32, "cross_attention: dim_head=%d (32)", dim_head);
+    HMVIT_CHECK_ARG(!bias || n_cam == 1, "cross_attention: a logit bias needs n_cam = 1 (got %d)", n_cam);
     if (b <= 0 || Q <= 0) return HMVIT_OK;
     hipLaunchKernelGGL(k_cross_attention, dim3(cdiv(Q, 64), heads, b), dim3(64), 0, st, q, k, v, out, n_cam, Q, K, heads,
-                       1.f / sqrtf((float)dim_head));
+                       1.f / sqrtf((float)dim_head), bias);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }

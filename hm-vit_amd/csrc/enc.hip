@@ -649,7 +649,7 @@ int launch_conv(const ConvParams& p, int precision, hipStream_t st) {
     // 3 x 3 / stride 1 / pad 1 in f16: the patch-in-LDS kernel (one fetch per input pixel and channel slab instead of nine)
     if (precision != HMVIT_PREC_F32 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && !p.deconv_s && !p.rowpack &&
         p.Cin % 64 == 0 && p.Cout % 8 == 0 && p.y_coff % 8 == 0 && p.y_ctot % 8 == 0 && p.Ho == p.H && p.Wo == p.W &&
-        !getenv("HMVIT_CONV_NO_PATCH")) {
+        !p.no_patch && !HMVIT_ENV("HMVIT_CONV_NO_PATCH")) {
         const int tiles = p.N * cdiv(p.Ho, 8) * cdiv(p.Wo, 16);
         if (tiles * cdiv(p.Cout, narrow ? 64 : 128) >= 256) {       // enough workgroups to cover the CUs
             dim3 grid3(tiles * cdiv(p.Cout, narrow ? 64 : 128));

@@ -122,6 +122,7 @@ struct ConvParams {
     int deconv_s;             // > 0: ConvTranspose2d with kernel = stride = s (Ncols = s*s*Cout, Ho = H, Wo = W)
     int out_f32;
     const void* res;          // optional residual (N, Ho, Wo, Cout) in the precision's element type, added before the ReLU
+    int no_patch;             // 1: never take the patch-in-LDS 3 x 3 kernel (A/B checks of the two kernels against each other)
     int up2;                  // 1: the input is the nearest-neighbour x2 upsampling of x (N, H/2, W/2, Cin); H, W are the upsampled sizes
     int rowpack;              // 1: few-channel stem.  x is a physically zero-padded (N, H, W, 4) map, output pixel (oy, ox) reads
                               // rows oy*stride .. + KH - 1 and pixels ox*stride .. + 7 of it; w is (Ncols, KH * 32) with
@@ -283,7 +284,7 @@ struct CvtEmbedParams {
 int launch_cvt_embed(const CvtEmbedParams& p, hipStream_t st);
 int launch_bn_relu_tokens(const float* x, const float* scale, const float* shift, float* y, int n, int C, int P, hipStream_t st);
 int launch_cross_attention(const float* q, const float* k, const float* v, float* out, int b, int n_cam, int Q, int K, int heads,
-                           int dim_head, hipStream_t st);
+                           int dim_head, const float* bias, hipStream_t st);
 int launch_cross_attention_f16(const half_t* q, const half_t* k, const half_t* v, float* out, int b, int n_cam, int Q, int K,
                                int heads, int dim_head, hipStream_t st);
 

@@ -30,6 +30,43 @@ class NaiveDecoder(nn.Module):
         self.decoder = nn.ModuleList(layers)
 
 
+class NaiveCompressor(nn.Module):
+    """Channel compressor for the exchanged BEV maps (``opencood/models/sub_modules/naive_compress.py:5-28``; the model's
+    ``compression`` option, ``bevformer_point_pillar_hetero.py:69-71,116-117``): conv3x3(C -> C/r) + BN(eps 1e-3) + ReLU, then
+    conv3x3(C/r -> C) + BN + ReLU, conv3x3(C -> C) + BN + ReLU.  Same constructor and ``state_dict`` names; eval mode
+    (BatchNorm folded into the convolutions); ``forward(x (N, C, H, W)) -> (N, C, H, W)`` on the implicit-GEMM kernel."""
+
+    def __init__(self, input_dim: int, compress_raito: int, precision: str = "f16"):
+        super().__init__()
+        mid = input_dim // compress_raito
+        self.encoder = nn.Sequential(nn.Conv2d(input_dim, mid, 3, 1, 1), nn.BatchNorm2d(mid, eps=1e-3, momentum=0.01), nn.ReLU())
+        self.decoder = nn.Sequential(nn.Conv2d(mid, input_dim, 3, 1, 1), nn.BatchNorm2d(input_dim, eps=1e-3, momentum=0.01), nn.ReLU(),
+                                     nn.Conv2d(input_dim, input_dim, 3, 1, 1), nn.BatchNorm2d(input_dim, eps=1e-3, momentum=0.01),
+                                     nn.ReLU())
+        self.input_dim = input_dim
+        self.precision = precision
+        self._prep = None
+
+    def forward(self, x):
+        from .camera import _Conv, _Prepared, _to_nchw, _to_nhwc      # shared convolution plumbing (channel padding, BN fold)
+        if self.training:
+            raise RuntimeError("hmvit_amd.NaiveCompressor folds BatchNorm statistics: call .eval() (inference only)")
+        if x.device.type != "cuda":
+            raise RuntimeError("hm-vit_amd runs on the GPU only (HIP kernels, no CPU fallback)")
+        if self._prep is None:
+            self._prep = _Prepared()
+        prec = _PREC[self.precision]
+        dt = torch.float32 if prec == _lib.PREC_F32 else torch.float16
+        convs = self._prep.get(self, prec, lambda: [_Conv(self.encoder[0], self.encoder[1], prec, dt),
+                                                    _Conv(self.decoder[0], self.decoder[1], prec, dt),
+                                                    _Conv(self.decoder[3], self.decoder[4], prec, dt)])
+        with torch.cuda.device(x.device):
+            t = _to_nhwc(x.detach().float(), convs[0].cin, dt)
+            for c in convs:
+                t = c(t, relu=True)
+            return _to_nchw(t, self.input_dim)
+
+
 class HeteroDecoder(nn.Module):
     def __init__(self, params: dict, precision: str = "f16"):
         super().__init__()

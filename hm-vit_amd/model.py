@@ -17,7 +17,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from .decoder import HeteroDecoder
+from .decoder import HeteroDecoder, NaiveCompressor
 from .fusion import HeteroFusion
 from .pointpillar import PointPillar
 
@@ -42,11 +42,17 @@ class BevformerPointPillarHetero(nn.Module):
     def __init__(self, config: dict, camera_encoder: nn.Module = None, precision: str = "f16"):
         super().__init__()
         self.camera_encoder = camera_encoder
+        fusion_precision = precision
+        if precision == "split":
+            # the split (hi + lo f16 operand) kernels exist for the fusion; the convolutional encoders / decoder run their
+            # exact-f32 kernels in that mode (their f16 kernels are the 1e-3-class fast mode)
+            precision = "f32"
         self.lidar_encoder = PointPillar(config["lidar"], precision=precision)
-        if config.get("compression", 0) > 0:
-            raise NotImplementedError("NaiveCompressor (compression > 0) is not built; the shipped yaml uses 0")
         self.compression = False
-        self.fusion_net = HeteroFusion(config["hetero_fusion"], precision=precision)
+        if config.get("compression", 0) > 0:             # bevformer_point_pillar_hetero.py:69-71 (the shipped yaml uses 0)
+            self.compression = True
+            self.naive_compressor = NaiveCompressor(256, config["compression"], precision=precision)
+        self.fusion_net = HeteroFusion(config["hetero_fusion"], precision=fusion_precision)
         self.lidar_encoder.set_return_features()
         if self.camera_encoder is not None:
             self.camera_encoder.set_return_features()
@@ -123,6 +129,8 @@ class BevformerPointPillarHetero(nn.Module):
             x = lidar_features.new_empty((flat_mode.numel(),) + tuple(lidar_features.shape[1:]))
             x[(flat_mode == 0).to(x.device)] = camera_features.to(x.dtype)
             x[(flat_mode == 1).to(x.device)] = lidar_features
+        if self.compression:                              # :116-117, on the concatenated agent maps
+            x = self.naive_compressor(x)
         x, mask = regroup(x, rl, max_cav)
         fused = self.fusion_net(x, pairwise_t_matrix, mode, record_len, mask)
         psm, rm = self.decoder(fused.unsqueeze(1), mode, use_upsample=False)

@@ -116,7 +116,9 @@ typedef struct HmvitFusionDesc {
     int32_t precision;            /* HMVIT_PREC_*                                         */
     int32_t apply_head;           /* 1: ego slice + mlp_head -> out (B, C, H, W)
                                      0: out (B, L, C, H, W), all agents                   */
-    int32_t skip_masked;          /* 1: skip key tiles whose 64 keys are all masked (exact) */
+    int32_t skip_masked;          /* 0: everything computed, masked keys at -inf; 1 (default): key tiles whose 64 keys are all
+                                     masked and windows no later stage can reach are skipped (both exact: identical output);
+                                     2: masked key tiles only */
     float discrete_ratio;         /* spatial_transform.voxel_size[0]                      */
     float downsample_rate;        /* spatial_transform.downsample_rate                    */
     /* host arrays (read during the call, not retained) */
@@ -313,7 +315,8 @@ int hmvit_conv2d(const void* x, const void* w, const float* bias, void* y, int N
  *   torchvision BasicBlock / Bottleneck (`out += identity; out = relu(out)`, used by resnet_ms.py:27-38 and
  *   cvt_modules.py:13,303-305);
  *   upsample2 = 1: x is (N, H/2, W/2, Cin) and stands for its nearest-neighbour x2 upsampling (N, H, W, Cin)
- *   (NaiveDecoder.upsample, naive_decoder.py:56-61), which is never materialised. */
+ *   (NaiveDecoder.upsample, naive_decoder.py:56-61), which is never materialised.  Bit 1 of `upsample2` (value 2) selects the
+ *   generic implicit-GEMM kernel where the library would take the patch-in-LDS 3 x 3 kernel (for A/B checks). */
 int hmvit_conv2d_ex(const void* x, const void* w, const float* bias, const void* residual, void* y, int N, int H, int W, int Cin,
                     int Cout, int ksize, int stride, int pad, int relu, int upsample2, int out_f32, int precision, void* stream);
 
@@ -394,6 +397,12 @@ int hmvit_bn_relu_tokens(const float* x, const float* scale, const float* shift,
  * Q and K to be multiples of 64. */
 int hmvit_cross_attention(const void* q, const void* k, const void* v, float* out, int n_agents, int n_cam, int Q, int K,
                           int heads, int dim_head, int precision, void* stream);
+
+/* Softmax attention with an additive logit bias, f32: q (batch, Q, heads * 32), k / v (batch, K, heads * 32),
+ * bias (heads, Q, K) -> out (batch, Q, heads * 32); logits q . k / sqrt(32) + bias.  The self-attention that closes FAXModule
+ * (fax_modules.py:96-180, relative-position bias over the whole BEV map). */
+int hmvit_attention_bias(const float* q, const float* k, const float* v, const float* bias, float* out, int batch, int Q, int K,
+                         int heads, int dim_head, void* stream);
 
 /* debug: lane mapping of ds_read_b64_tr_b16 (used once to pin the V-operand layout) */
 int hmvit_debug_tr16(uint16_t* out, void* stream);

@@ -44,6 +44,35 @@ def hetero_decoder(x: Tensor, mode: Tensor, sd: Dict[str, Tensor], params: dict,
     return torch.stack(psm), torch.stack(rm)
 
 
+def naive_compressor(x: Tensor, sd: Dict[str, Tensor], prefix: str = "") -> Tensor:
+    """NaiveCompressor.forward in eval mode (naive_compress.py:5-28): three conv3x3 + BatchNorm(eps 1e-3) + ReLU."""
+    pre = f"{prefix}." if prefix else ""
+    for c, b in (("encoder.0", "encoder.1"), ("decoder.0", "decoder.1"), ("decoder.3", "decoder.4")):
+        x = F.conv2d(x, sd[f"{pre}{c}.weight"], sd[f"{pre}{c}.bias"], 1, 1)
+        x = F.relu(F.batch_norm(x, sd[f"{pre}{b}.running_mean"], sd[f"{pre}{b}.running_var"], sd[f"{pre}{b}.weight"],
+                                sd[f"{pre}{b}.bias"], False, 0.0, 1e-3))
+    return x
+
+
+def compressor_state_dict(input_dim: int, ratio: int, seed: int = 0) -> Dict[str, Tensor]:
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+    sd: Dict[str, Tensor] = {}
+    mid = input_dim // ratio
+    for c, b, co, ci in (("encoder.0", "encoder.1", mid, input_dim), ("decoder.0", "decoder.1", input_dim, mid),
+                         ("decoder.3", "decoder.4", input_dim, input_dim)):
+        bd = 1.0 / math.sqrt(ci * 9)
+        sd[f"{c}.weight"] = t(rs.uniform(-bd, bd, (co, ci, 3, 3)))
+        sd[f"{c}.bias"] = t(rs.uniform(-bd, bd, co))
+        sd[f"{b}.weight"] = t(1 + 0.2 * rs.standard_normal(co))
+        sd[f"{b}.bias"] = t(0.2 * rs.standard_normal(co))
+        sd[f"{b}.running_mean"] = t(0.3 * rs.standard_normal(co))
+        sd[f"{b}.running_var"] = t(rs.uniform(0.5, 1.5, co))
+        sd[f"{b}.num_batches_tracked"] = torch.tensor(1)
+    return sd
+
+
 def make_params(input_dim: int = 256, anchor_number: int = 2) -> dict:
     return {"input_dim": input_dim, "num_layer": 2, "num_ch_dec": [256, 256], "anchor_number": anchor_number}
 

@@ -23,6 +23,11 @@ What is frozen:
   g14_loss.npz          PointPillarLoss.forward (loss/point_pillar_loss.py:68-142; cls_weight 1, reg 2) on seeded head outputs /
                         targets (B=2, 2 anchors, 8x12, a few positives, one NaN target): total / reg / conf loss and the
                         gradients with respect to psm and rm.
+  g15_compressor.npz    NaiveCompressor.forward (naive_compress.py:5-28, eval BatchNorm), input_dim 256, ratio 4, 3 maps of 10 x 12.
+  g16_fax.npz           FAX lift (fax_modules.py, torchvision stubbed): CrossViewSwapAttention.forward for level 0 (BEV embedding,
+                        16x16 queries in 8x8 windows, 8x8 features in 4x4 windows) and level 1 (no BEV embedding, 8x8 queries in
+                        4x4 windows, 4x4 features in 2x2 windows), 2 agents x 3 cameras, dim 128; Attention.forward (self
+                        attention with relative-position bias, window 8); one down-sampling block of FAXModule.
   g7_pointpillar.npz    PointPillar.forward (features only, eval BN): 2 agents x 400 pillars on a
                         64x48 canvas; PFN output + (2, 256, 12, 16) BEV features.
   g8_decoder.npz        HeteroDecoder.forward (no upsample), 3 samples with ego types 1,0,1, 12x10.
@@ -234,6 +239,63 @@ def g13_fusion_cfg3():
     _fusion_full_size("g13_fusion_cfg3.npz", [1, 0, 1, 1, 0], 131, 2)
 
 
+def g16_fax():
+    from oracle import fax_oracle as FO
+    _stub("torchvision"); _stub("torchvision.models"); _stub("torchvision.models.resnet", Bottleneck=object)
+    from opencood.models.sub_modules.fax_modules import Attention, BEVEmbedding, CrossViewSwapAttention
+    cfg = FO.make_swap_config(64)
+    be = dict(sigma=1.0, bev_height=32, bev_width=32, h_meters=50.0, w_meters=50.0, offset=0.0, upsample_scales=[2, 4])
+    bev = BEVEmbedding(128, **be)
+    grids = FO.bev_grids(be["bev_height"], be["bev_width"], be["h_meters"], be["w_meters"], be["offset"], be["upsample_scales"])
+    assert torch.allclose(bev.grid0, grids[0]) and torch.allclose(bev.grid1, grids[1])
+    out = {}
+    cv = {k: cfg[k] for k in ("image_height", "image_width", "no_image_features", "skip", "heads", "dim_head", "qkv_bias")}
+    sw = {k: cfg[k] for k in ("rel_pos_emb", "q_win_size", "feat_win_size", "bev_embedding_flag")}
+    for index, (fh, H) in enumerate(((8, 16), (4, 8))):
+        net = CrossViewSwapAttention(fh, fh, 64, 128, index, **cv, **sw).eval()
+        sd = FO.swap_state_dict(64, 128, cfg, index, seed=161 + index)
+        own = net.state_dict()
+        missing = [k for k in own if k not in sd and "num_batches_tracked" not in k]
+        assert not missing, missing
+        net.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
+        x, feat, I_inv, E_inv = FO.synthetic_inputs(2, 3, 64, fh, fh, 128, H, H, seed=163 + index, image=64)
+        out[f"swap{index}"] = net(index, x, bev, feat, I_inv, E_inv)
+    att = Attention(128, dim_head=32, dropout=0.1, window_size=8).eval()
+    rs = np.random.RandomState(165)
+    asd = {"to_qkv.weight": torch.from_numpy(rs.uniform(-0.09, 0.09, (384, 128)).astype(np.float32)),
+           "to_out.0.weight": torch.from_numpy(rs.uniform(-0.09, 0.09, (128, 128)).astype(np.float32)),
+           "rel_pos_bias.weight": torch.from_numpy(rs.standard_normal((225, 4)).astype(np.float32))}
+    att.load_state_dict(asd, strict=True)
+    xa = torch.from_numpy(rs.standard_normal((2, 128, 8, 8)).astype(np.float32))
+    out["self_attn"] = att(xa)
+    assert torch.equal(att.rel_pos_indices, FO.rel_pos_indices(8))
+    down = torch.nn.Sequential(torch.nn.Sequential(
+        torch.nn.Conv2d(128, 32, 3, 1, 1, bias=False), torch.nn.PixelUnshuffle(2), torch.nn.Conv2d(128, 128, 3, padding=1, bias=False),
+        torch.nn.BatchNorm2d(128), torch.nn.ReLU(inplace=True), torch.nn.Conv2d(128, 128, 1, padding=0, bias=False),
+        torch.nn.BatchNorm2d(128))).eval()                       # fax_modules.py:478-492 for dim[i] = dim[i+1] = 128
+    dsd = {}
+    for k, v in down.state_dict().items():
+        if "num_batches" in k:
+            dsd[k] = v
+        elif "running_var" in k:
+            dsd[k] = torch.from_numpy(rs.uniform(0.5, 1.5, tuple(v.shape)).astype(np.float32))
+        else:
+            dsd[k] = torch.from_numpy((0.1 * rs.standard_normal(tuple(v.shape))).astype(np.float32)) + (1.0 if k.endswith((".3.weight", ".6.weight")) else 0.0)
+    down.load_state_dict(dsd, strict=True)
+    xd = torch.from_numpy(rs.standard_normal((2, 128, 8, 8)).astype(np.float32))
+    out["down"] = down(xd)
+    save("g16_fax.npz", **out, **{f"down_sd.{k}": v for k, v in dsd.items() if "num_batches" not in k}, down_x=xd, attn_x=xa,
+         **{f"attn_sd.{k}": v for k, v in asd.items()})
+
+
+def g15_compressor():
+    from opencood.models.sub_modules.naive_compress import NaiveCompressor
+    net = NaiveCompressor(256, 4).eval()
+    net.load_state_dict(DO.compressor_state_dict(256, 4, seed=151), strict=True)
+    x = torch.from_numpy(np.random.RandomState(152).standard_normal((3, 256, 10, 12)).astype(np.float32))
+    save("g15_compressor.npz", seed_weights=151, seed_x=152, out=net(x))
+
+
 def g14_loss():
     from opencood.loss.point_pillar_loss import PointPillarLoss
     torch.set_grad_enabled(True)
@@ -375,6 +437,12 @@ def g11_cross_view():
 if __name__ == "__main__":
     if "g11" in sys.argv[1:]:
         g11_cross_view()
+        sys.exit(0)
+    if "g16" in sys.argv[1:]:
+        g16_fax()
+        sys.exit(0)
+    if "g15" in sys.argv[1:]:
+        g15_compressor()
         sys.exit(0)
     if "g14" in sys.argv[1:]:
         g14_loss()

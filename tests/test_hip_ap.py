@@ -1,0 +1,26 @@
+"""AP on the synthetic replay with TRAINED weights (tests/golden/ap_checkpoint.npz): north_star's "AP@0.7 within 0.2 of the
+reference".  The reference side is the CPU oracle (pinned to the reference by the goldens) with the reference's AP arithmetic;
+the checkpoint makes the comparison non-vacuous: AP@0.7 is well above zero on both sides."""
+import importlib.util
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _replay():
+    spec = importlib.util.spec_from_file_location("ap_replay", os.path.join(ROOT, "tests", "tools", "ap_replay.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("precision", ["split", "f16"])
+def test_ap07_within_0p2_points_of_the_oracle_on_24_scenes(precision):
+    r = _replay().run(scenes=24, precision=precision)
+    assert r["gt_boxes"] >= 60
+    assert r["AP@0.7"]["cpu_oracle"] > 20.0, r                 # the fixture detects: not 0 vs 0
+    for t in ("AP@0.3", "AP@0.5", "AP@0.7"):
+        assert r[t]["delta_points"] <= 0.2, r

@@ -230,18 +230,15 @@ def test_conv3x3_patch_kernel(N, cin, cout, H, W, res, out_f32):
     wn = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
     rn = r.permute(0, 2, 3, 1).contiguous() if res else None
 
-    def run():
+    def run(generic=False):
         y = torch.empty(N, H, W, cout, device="cuda", dtype=torch.float32 if out_f32 else torch.float16)
         _lib.check(_lib.lib.hmvit_conv2d_ex(xn.data_ptr(), wn.data_ptr(), b.data_ptr(), rn.data_ptr() if res else None, y.data_ptr(), N, H, W,
-                                            cin, cout, 3, 1, 1, 1, 0, 1 if out_f32 else 0, _lib.PREC_F16, _stream()), "conv2d_ex")
+                                            cin, cout, 3, 1, 1, 1, 2 if generic else 0, 1 if out_f32 else 0, _lib.PREC_F16, _stream()),
+                   "conv2d_ex")
         return y
     y = run()
     assert rel_max_err(y.permute(0, 3, 1, 2).double(), ref) < (2e-4 if out_f32 else 1.5e-3)
-    os.environ["HMVIT_CONV_NO_PATCH"] = "1"
-    try:
-        y_generic = run()
-    finally:
-        del os.environ["HMVIT_CONV_NO_PATCH"]
+    y_generic = run(generic=True)
     assert rel_max_err(y.double(), y_generic.double()) < 1e-3      # same products, different summation order per tap
 
 
@@ -258,16 +255,27 @@ def test_conv3x3_patch_kernel_upsampled_input():
     xn = x.permute(0, 2, 3, 1).contiguous()
     wn = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
 
-    def run():
+    def run(generic=False):
         y = torch.empty(N, 2 * h, 2 * w_, cout, device="cuda", dtype=torch.float16)
         _lib.check(_lib.lib.hmvit_conv2d_ex(xn.data_ptr(), wn.data_ptr(), b.data_ptr(), None, y.data_ptr(), N, 2 * h, 2 * w_, cin, cout, 3, 1, 1,
-                                            1, 1, 0, _lib.PREC_F16, _stream()), "conv2d_ex")
+                                            1, 3 if generic else 1, 0, _lib.PREC_F16, _stream()), "conv2d_ex")
         return y
     y = run()
     assert rel_max_err(y.permute(0, 3, 1, 2).double(), ref) < 1.5e-3
-    os.environ["HMVIT_CONV_NO_PATCH"] = "1"
-    try:
-        y_generic = run()
-    finally:
-        del os.environ["HMVIT_CONV_NO_PATCH"]
+    y_generic = run(generic=True)
     assert rel_max_err(y.double(), y_generic.double()) < 1e-3
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_naive_compressor_matches_golden(precision):
+    """NaiveCompressor (naive_compress.py:5-28) against the reference's own forward (g15) and the model's `compression` option."""
+    import numpy as np
+    import hmvit_amd
+    from oracle import decoder_oracle as DO
+    g = load_golden("g15_compressor.npz")
+    net = hmvit_amd.NaiveCompressor(256, 4, precision=precision)
+    net.load_state_dict(DO.compressor_state_dict(256, 4, seed=g["seed_weights"]), strict=True)
+    net = net.cuda().eval()
+    x = torch.from_numpy(np.random.RandomState(int(g["seed_x"])).standard_normal((3, 256, 10, 12)).astype(np.float32))
+    y = net(x.cuda()).cpu()
+    assert rel_max_err(y, g["out"]) < TOL[precision]

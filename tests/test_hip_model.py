@@ -94,13 +94,14 @@ def test_full_inference_chain_on_device():
 
 
 def test_ap_replay_hip_vs_cpu_pipeline():
-    """tests/tools/ap_replay.py: procedurally generated scenes through the CPU restatement and through the HIP pipeline end to end;
-    in exact-f32 mode the two produce the same detections, hence the same AP (AP within 0.2 of the reference)."""
+    """tests/tools/ap_replay.py: procedurally generated scenes through the CPU oracle and through the HIP pipeline end to end;
+    in exact-f32 mode the two produce the same detections, hence the same AP (the trained-checkpoint comparison in the fast
+    modes is tests/test_hip_ap.py)."""
     import json
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "ap_replay.py"), "--scenes", "2"], capture_output=True,
-                         text=True, timeout=600, cwd=root)
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "ap_replay.py"), "--scenes", "3", "--precision", "f32"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert res["detections"]["hip"] == res["detections"]["cpu"] > 0

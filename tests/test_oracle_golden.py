@@ -165,3 +165,28 @@ def test_g11_cross_view_attention():
         x, feat, I_inv, E_inv = CO.synthetic_inputs(2, 4, 64, 12, 12, 128, 8, 8, seed=int(g["seed_inputs"]))
         y = CO.cross_view_attention(x, CO.bev_grid(64, 64, 100.0, 100.0, 0.0, 3), feat, I_inv, E_inv, sd, cfg)
         assert rel_max_err(y, g["y_" + tag]) < TOL
+
+
+def test_g15_naive_compressor():
+    from oracle import decoder_oracle as DO
+    g = load_golden("g15_compressor.npz")
+    x = torch.from_numpy(np.random.RandomState(int(g["seed_x"])).standard_normal((3, 256, 10, 12)).astype(np.float32))
+    y = DO.naive_compressor(x, DO.compressor_state_dict(256, 4, seed=g["seed_weights"]))
+    assert rel_max_err(y, g["out"]) < TOL
+
+
+def test_g16_fax_modules():
+    """CrossViewSwapAttention (both level kinds), Attention and the down-sampling block of the reference's FAX lift."""
+    from oracle import fax_oracle as FO
+    g = load_golden("g16_fax.npz")
+    cfg = FO.make_swap_config(64)
+    grids = FO.bev_grids(32, 32, 50.0, 50.0, 0.0, [2, 4])
+    for index, (fh, H) in enumerate(((8, 16), (4, 8))):
+        sd = FO.swap_state_dict(64, 128, cfg, index, seed=161 + index)
+        x, feat, I_inv, E_inv = FO.synthetic_inputs(2, 3, 64, fh, fh, 128, H, H, seed=163 + index, image=64)
+        y = FO.cross_view_swap_attention(x, grids[index], feat, I_inv, E_inv, sd, cfg, index)
+        assert rel_max_err(y, g[f"swap{index}"]) < TOL, index
+    asd = {k[len("attn_sd."):]: v for k, v in g.items() if k.startswith("attn_sd.")}
+    assert rel_max_err(FO.self_attention(g["attn_x"], asd, 32, 8), g["self_attn"]) < TOL
+    dsd = {f"downsample_layers.0.{k[len('down_sd.'):]}": v for k, v in g.items() if k.startswith("down_sd.")}
+    assert rel_max_err(FO.downsample_block(g["down_x"], dsd, "downsample_layers.0"), g["down"]) < TOL
