@@ -5,7 +5,9 @@ Model = the g9 LiDAR-only HM-ViT config (tests/golden/model_fixture.py: 64x48 pi
 evaluated by the CPU oracle, which is plain differentiable torch.  Everything keeps its seeded random weights except
 `mlp_head` (LiDAR type), the LiDAR cls / reg heads and the affine parameters of the LiDAR decoder's BatchNorms (~137 k floats,
 replay_scenes.is_trained) -- the frozen PointPillar + H3GAT stack acts as a random feature extractor, which is enough for the
-easy synthetic scenes (axis-aligned vehicles of the anchor size) and keeps the fixture small.  Labels come from the REFERENCE's
+easy synthetic scenes (axis-aligned vehicles of the anchor size) and keeps the fixture small.  With so few trainable floats the
+fixture MEMORISES its 64 training scenes (AP@0.7 97.5 there, 0.3 on held-out scenes); the AP replay therefore replays the fitted
+scenes -- its purpose is a detector with true positives at IoU 0.7 on both sides of the comparison, not generalisation.  Labels come from the REFERENCE's
 own VoxelPostprocessor.generate_label (voxel_postprocessor.py:74-194; its Cython bbox_overlaps restated in numpy with the same
 +1 convention, box_overlaps.pyx:17-57) and the loss is the reference's PointPillarLoss (loss/point_pillar_loss.py:68-142).
 Usage: python tests/golden/train_ap_checkpoint.py   (about 10 minutes on 8 cores)"""

@@ -6,7 +6,11 @@ against the scenes' ground-truth boxes.
 Weights: the seeded random model of tests/golden/model_fixture.py with the trained tensors of tests/golden/ap_checkpoint.npz on
 top (tests/golden/train_ap_checkpoint.py: mlp_head, the LiDAR heads and the decoder's BatchNorm affines trained on the
 synthetic scenes against the reference's own label generator and loss) -- so the detector detects, and AP@0.7 is non-zero on
-both sides.  Operating point: the yaml's score threshold 0.27 and NMS 0.15.
+both sides.  The replayed scenes are, by default, the first 24 of the 64 scenes the fixture was FITTED on (seed 1001): with
+~137 k trainable floats on frozen random features the fixture memorises rather than generalises (AP@0.7 97.5 on these scenes,
+0.3 on held-out ones: --held-out), and what the replay needs is a detector with many true positives at IoU 0.7 whose scores
+and boxes are sensitive to the arithmetic of every stage, not a good detector.  Operating point: the yaml's score threshold
+0.27 and NMS 0.15.
 
     python tests/tools/ap_replay.py [--scenes N] [--precision f32|split|f16] [--no-checkpoint]
 Prints one JSON line."""
@@ -55,7 +59,7 @@ def oracle_forward(cfg, sd, clouds, pw):
     return DO.hetero_decoder(fused.unsqueeze(1), mode, dsd, cfg["hetero_decoder"], prefix="decoder")
 
 
-def run(scenes=20, precision="f16", checkpoint=True, seed=RS.EVAL_SCENE_SEED):
+def run(scenes=24, precision="f16", checkpoint=True, seed=RS.TRAIN_SCENE_SEED):
     import hmvit_amd
     cfg = model_config()
     sd = fixture_weights(cfg, checkpoint)
@@ -106,5 +110,6 @@ if __name__ == "__main__":
     ap.add_argument("--scenes", type=int, default=24)
     ap.add_argument("--precision", default="f16")
     ap.add_argument("--no-checkpoint", action="store_true")
+    ap.add_argument("--held-out", action="store_true", help="scenes of the held-out seed instead of the fitted ones")
     a = ap.parse_args()
-    print(json.dumps(run(a.scenes, a.precision, not a.no_checkpoint)))
+    print(json.dumps(run(a.scenes, a.precision, not a.no_checkpoint, RS.EVAL_SCENE_SEED if a.held_out else RS.TRAIN_SCENE_SEED)))
