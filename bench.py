@@ -50,15 +50,17 @@ CONFIGS = {
 }
 # dense MFMA TFLOP/s (MI355X_MICROARCH.md).  The split mode runs on the f16 pipes: its roof is the f16 peak, its
 # numerator stays the ALGORITHMIC (fp32-product) flop count -- the three-fold MFMA work is overhead, not credit.
-PEAK = {"f16": 2500.0, "split": 2500.0, "f32": 157.3}
+PEAK = {"f16": 2500.0, "split": 2500.0, "mixed": 2500.0, "f32": 157.3}
 PEAK_HBM = 8000.0                          # GB/s
 DTYPE = {
     "f16": "f16 operands, f32 accumulate/softmax/LayerNorm/residual (1e-3 tolerance mode)",
     "split": "fp32 via split f16 operands (x = hi + lo, 3 MFMA products per fp32 product), f32 accumulate/softmax/LayerNorm/residual",
+    "mixed": "fp32 via split f16 operands (3 MFMA products per fp32 product) in every Linear / FFN / LayerNorm / residual; attention "
+             "operands Q / K' / V' / O stored and multiplied as f16 (f32 accumulate / softmax)",
     "f32": "f32 (exact-f32 MFMA)",
 }
-TOLERANCE = {"f16": 1e-3, "split": 1e-4, "f32": 1e-4}
-ES = {"f16": 2, "split": 4, "f32": 4}      # bytes per stored activation element (Q / K' / V' / O planes)
+TOLERANCE = {"f16": 1e-3, "split": 1e-4, "mixed": 1e-4, "f32": 1e-4}
+ES = {"f16": 2, "split": 4, "mixed": 2, "f32": 4}      # bytes per stored activation element (Q / K' / V' / O planes)
 
 
 def phase_work(c, num_iters, es):
@@ -180,7 +182,7 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
-    ap.add_argument("--precision", default=None, choices=["split", "f32", "f16"])
+    ap.add_argument("--precision", default=None, choices=["split", "mixed", "f32", "f16"])
     ap.add_argument("--num-iters", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the side figures (fast_f16, strict_f32, dense_masked_tiles)")
@@ -291,7 +293,7 @@ def main(argv=None):
         runs = [net.profile_phases(*scene) for _ in range(5)]
         es = ES[prec]
         work = phase_work(c, args.num_iters, es)
-        fused = prec in ("f16", "split")
+        fused = prec in ("f16", "split", "mixed")
         rename = {"qkv_gemm": "ln_qkv", "ffn2": "stage_tail"} if fused else {}
         phases = {}
         for name in runs[0]:

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMVIT_LIB", os.path.join(_HERE, "libhmvit.so"))   # HMVIT_LIB: ablation builds of tools/probe
 
 ABI_VERSION = 7
-PREC_F32, PREC_F16, PREC_SPLIT = 0, 1, 2
+PREC_F32, PREC_F16, PREC_SPLIT, PREC_MIXED = 0, 1, 2, 3
 PART_WINDOW, PART_GRID = 0, 1
 NUM_TYPES = 2
 MAX_AGENTS = 8

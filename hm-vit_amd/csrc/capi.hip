@@ -18,7 +18,10 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-static size_t elem_size(int precision) { return precision == HMVIT_PREC_F16 ? 2 : 4; }   // Q / K' / V' / O planes
+// bytes per element of the Q / K' / V' / O planes
+static size_t elem_size(int precision, int C) {
+    return (precision == HMVIT_PREC_F16 || (precision == HMVIT_PREC_MIXED && C == 256)) ? 2 : 4;
+}
 
 struct Plan {
     int B, L, C, H, W, P, mlp, n_slots, max_cav, E_max;
@@ -39,8 +42,8 @@ int check_desc(const HmvitFusionDesc* d) {
                     "BEV %dx%d must be divisible by window_size %d", d->H, d->W, d->window);
     HMVIT_CHECK_ARG(d->mlp_dim > 0 && d->mlp_dim % 64 == 0, "mlp_dim=%d must be a multiple of 64", d->mlp_dim);
     HMVIT_CHECK_ARG(d->num_iters >= 1, "num_iters=%d", d->num_iters);
-    HMVIT_CHECK_ARG(d->precision == HMVIT_PREC_F32 || d->precision == HMVIT_PREC_F16 || d->precision == HMVIT_PREC_SPLIT,
-                    "precision=%d", d->precision);
+    HMVIT_CHECK_ARG(d->precision == HMVIT_PREC_F32 || d->precision == HMVIT_PREC_F16 || d->precision == HMVIT_PREC_SPLIT ||
+                        d->precision == HMVIT_PREC_MIXED, "precision=%d", d->precision);
     HMVIT_CHECK_ARG(d->mode && d->record_len && d->cav_mask, "mode / record_len / cav_mask must be host arrays");
     HMVIT_CHECK_ARG(d->discrete_ratio * d->downsample_rate != 0.f, "discrete_ratio * downsample_rate is 0");
     HMVIT_CHECK_ARG(!d->parallel || (d->split_fc1 && d->split_ln_g && d->split_ln_b && d->split_fc2),
@@ -57,7 +60,7 @@ int check_desc(const HmvitFusionDesc* d) {
 static void make_plan(const HmvitFusionDesc* d, Plan& pl) {
     pl.B = d->B; pl.L = d->L; pl.C = d->C; pl.H = d->H; pl.W = d->W;
     pl.P = d->H * d->W; pl.mlp = d->mlp_dim; pl.n_slots = d->B * d->L;
-    pl.es = elem_size(d->precision);
+    pl.es = elem_size(d->precision, d->C);
     pl.max_cav = 0;
     for (int b = 0; b < d->B; ++b) pl.max_cav = d->record_len[b] > pl.max_cav ? d->record_len[b] : pl.max_cav;
     bool seen[HMVIT_NUM_TYPES] = {false, false};
@@ -401,7 +404,7 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st, PhaseTimer* 
 struct QkvBatcher {
     QkvParams p;
     int n, C;
-    bool split;
+    int split;
     hipStream_t st;
     int flush() {
         if (n == 0) return HMVIT_OK;
@@ -418,7 +421,7 @@ struct QkvBatcher {
 struct FfnBatcher {
     FfnParams p;
     int n, C, variant;
-    bool split;
+    int split;
     hipStream_t st;
     int flush() {
         if (n == 0) return HMVIT_OK;
@@ -439,7 +442,9 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
         HMVIT_CHECK_ARG(d->stage[s].img_q && d->stage[s].img_kv && d->stage[s].img_o && d->stage[s].img_ffn,
                         "fused modes: stage %d weight images are null", s);
     const int B = pl.B, L = pl.L, C = pl.C, P = pl.P;
-    const bool split = d->precision == HMVIT_PREC_SPLIT;   // hi / lo images (twice the halves), f32 Q / K' / V' / O planes
+    // 0: f16 operands; 1: split (hi + lo) operands, f32 Q / K' / V' / O planes; 2 ("mixed", C = 256): split operands in every
+    // Linear / FFN, f16 planes and the f16 attention kernels (log2(e) folded into W_q / bias as in f16 mode)
+    const int split = d->precision == HMVIT_PREC_SPLIT ? 1 : d->precision == HMVIT_PREC_MIXED ? (C == 256 ? 2 : 1) : 0;
     const size_t es = pl.es;
     char* ws = reinterpret_cast<char*>(d->workspace);
     float* xs = reinterpret_cast<float*>(ws + pl.off_xs);
@@ -579,15 +584,15 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                 ap.self_identity = d->self_identity;
                 // split mode: the persistent split kernel needs the table and identity self transforms; otherwise (and for
                 // window 4 / C = 64) the exact-f32 kernel runs on the f32 planes
-                const bool pc_split = split && d->self_identity && pl.n_slots * L <= 128;
-                if ((!split || pc_split) && d->skip_masked && d->window == 8 && C > 64 && n_src <= 8 && !HMVIT_ENV("HMVIT_ATTN_DEBUG")) {
+                const bool pc_split = split == 1 && d->self_identity && pl.n_slots * L <= 128;
+                if ((split != 1 || pc_split) && d->skip_masked && d->window == 8 && C > 64 && n_src <= 8 && !HMVIT_ENV("HMVIT_ATTN_DEBUG")) {
                     // tiles without a visible key are skipped by the persistent kernel (launch_tile_vis)
                     unsigned* vis = reinterpret_cast<unsigned*>(ws + pl.off_vis);
                     HMVIT_TRY(launch_tile_vis(ap, vis, need, st));
                     ap.vis_mask = vis;
                     ap.prune = need != nullptr;
                 }
-                HMVIT_TRY(launch_attention(ap, split ? HMVIT_PREC_SPLIT : HMVIT_PREC_F16, st));
+                HMVIT_TRY(launch_attention(ap, split == 1 ? HMVIT_PREC_SPLIT : HMVIT_PREC_F16, st));
             }
             HMVIT_MARK(HMVIT_PHASE_ATTENTION);
 

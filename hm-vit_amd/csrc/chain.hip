@@ -82,7 +82,9 @@ __device__ __forceinline__ void stage_chunk(const half_t* __restrict__ chunk, ha
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void wg_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef HMVIT_EXP_NOBAR
     __builtin_amdgcn_s_barrier();
+#endif
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -487,8 +489,12 @@ __global__ __launch_bounds__(CHAIN_THREADS, SP ? 1 : 2) void k_ln_qkv(QkvParams 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         mma_chunk_op<KK, (KK < 8 ? KK : 8), SP>(acc, buf, act, lane);
+#ifndef HMVIT_EXP_NOWAIT
         dma_wait();
+#endif
+#ifndef HMVIT_EXP_NOSTORE
         store_proj_tile<C, SP, STAGED>(stg, J.y[mat], t, acc, m, hi, lane, tok, valid, tok_w, P);
+#endif
         wg_barrier();
     }
 }
@@ -802,14 +808,526 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = 0.f;
                 mma_chunk_op<KK, 4, SP>(acc, buf, act, lane);
+#ifndef HMVIT_EXP_NOWAIT
                 dma_wait();
+#endif
+#ifndef HMVIT_EXP_NOSTORE
                 store_proj_tile<C, SP, STAGED>(stg, Q.y[mat], t, acc, m, hi, lane, tok, valid, tok_w, P);
+#endif
                 wg_barrier();
             }
         } else {
             store_x();
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Split mode, C = 256: 16 tokens per wavefront, 8 wavefronts per workgroup ("x16" kernels).
+//
+// The 32-token split kernels above hold a token's residual row, both operand halves and the accumulators of one lane pair in
+// ~470 registers: one wavefront per SIMD, so VALU work (LayerNorm, GELU, hi / lo splits), LDS staging, global loads / stores
+// and the MFMA stream of a workgroup run one after the other.  Here a token is spread over FOUR lanes
+// (v_mfma_f32_16x16x32_f16: lane (tk = lane & 15, g = lane >> 4) supplies B[k = 8 g + j][token tk] and receives
+// D[row 4 g + r][token tk]), 128 + ~60 registers per lane, two wavefronts per SIMD in one 512-thread workgroup: same 128 tokens,
+// same weight chunks (32 output rows x K = 256 x (hi, lo) = 32 KB) and ring as before, but while one wavefront of a SIMD
+// converts, stages or waits, the other one feeds the matrix pipe.
+//
+// Layout: lane (tk, g) owns channels 16 t + 4 g + r of token tk (t < 16, r < 4): xacc[t] (float4).  k-step s (channels
+// 32 s .. 32 s + 31) takes operand slot j of that lane from channel 32 s + 16 (j >> 2) + 4 g + (j & 3), i.e. from
+// xacc[2 s + (j >> 2)][j & 3]; the weight images are built in that k order (weights.py weight_image16): fragment
+// (row tile T, k-step s, half) = 64 lanes x 8 halves with lane (l, g) holding W[16 T + l][32 s + 16 (j >> 2) + 4 g + (j & 3)].
+// A chunk = row tiles (2 c, 2 c + 1) x 8 k-steps x (hi, lo); a W_2 slice chunk = 16 row tiles x k-step hc x (hi, lo).
+// ------------------------------------------------------------------------------------------
+constexpr int X16_WAVES = 8, X16_THREADS = 512, X16_TOKENS = 128;
+constexpr int X16_CHUNK = 16384;                    // halves per chunk (32 KB)
+constexpr int X16_STG_ROW = 64 + 4;                 // floats per staged token row (64 channels + padding)
+constexpr int X16_STG_WAVE = 16 * X16_STG_ROW;      // floats per wave
+
+__device__ __forceinline__ void stage_chunk16(const half_t* __restrict__ chunk, half_t* lds_buf) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_buf;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                   // 2048 pieces of 16 bytes, 512 threads
+        const int piece0 = (i * X16_WAVES + wave) * 64;
+        const uint4* gsrc = reinterpret_cast<const uint4*>(chunk) + piece0 + lane;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + piece0 * 16);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+    }
+}
+
+__device__ __forceinline__ float quad_sum(float v) { return xor32_sum(xor16_sum(v)); }   // over the 4 lanes of a token
+
+// fragment f of a chunk: hi fragments feed two MFMAs (x a_lo, x a_hi), lo fragments one (x a_hi)
+// NT16 = 2: projection chunk, fragment f = (row tile f / 16, k-step (f % 16) / 2, half f & 1), accumulators acc[2]
+template <int DEPTH, bool HAS_LO, int f = 0>
+struct MmaProj16 {
+    static __device__ __forceinline__ void run(float4v (&acc)[2], unsigned addr, const half8 (&ah)[8], const half8 (&al)[8], half8 (&w)[DEPTH]) {
+        constexpr int F = 32, T = f / 16, s = (f % 16) / 2;
+        constexpr int outstanding = (F - f - 1) < (DEPTH - 1) ? (F - f - 1) : (DEPTH - 1);
+        lgkm_wait<outstanding>();
+        if constexpr ((f & 1) == 0) {
+            if constexpr (HAS_LO) acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[f % DEPTH], al[s], acc[T], 0, 0, 0);
+            acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[f % DEPTH], ah[s], acc[T], 0, 0, 0);
+        } else {
+            acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[f % DEPTH], ah[s], acc[T], 0, 0, 0);
+        }
+        if constexpr (f + DEPTH < F) {
+            __builtin_amdgcn_sched_barrier(0);
+            lds_read_frag<(f + DEPTH) * 1024>(w[f % DEPTH], addr);
+        }
+        if constexpr (f + 1 < F) MmaProj16<DEPTH, HAS_LO, f + 1>::run(acc, addr, ah, al, w);
+    }
+};
+#ifndef HMVIT_X16_DEPTH
+#define HMVIT_X16_DEPTH 8
+#endif
+template <bool HAS_LO = true>
+__device__ __forceinline__ void mma_proj16(float4v (&acc)[2], const half_t* buf, const half8 (&ah)[8], const half8 (&al)[8], int lane) {
+#ifdef HMVIT_EXP_NOMMA
+    return;
+#endif
+    constexpr int DEPTH = HMVIT_X16_DEPTH;
+    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)(buf + lane * 8);
+    half8 w[DEPTH];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    MmaPrologue<DEPTH>::run(addr, w);
+    MmaProj16<DEPTH, HAS_LO>::run(acc, addr, ah, al, w);
+    __builtin_amdgcn_sched_barrier(0);
+}
+// W_2 slice chunk: fragment f = (row tile f / 2, half f & 1), one k-step (the hidden tile), accumulators xacc[16]
+template <int DEPTH, int f = 0>
+struct MmaSlice16 {
+    static __device__ __forceinline__ void run(float4v (&xacc)[16], unsigned addr, const half8& hh, const half8& hl, half8 (&w)[DEPTH]) {
+        constexpr int F = 32, T = f / 2;
+        constexpr int outstanding = (F - f - 1) < (DEPTH - 1) ? (F - f - 1) : (DEPTH - 1);
+        lgkm_wait<outstanding>();
+        if constexpr ((f & 1) == 0) {
+            xacc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[f % DEPTH], hl, xacc[T], 0, 0, 0);
+            xacc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[f % DEPTH], hh, xacc[T], 0, 0, 0);
+        } else {
+            xacc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[f % DEPTH], hh, xacc[T], 0, 0, 0);
+        }
+        if constexpr (f + DEPTH < F) {
+            __builtin_amdgcn_sched_barrier(0);
+            lds_read_frag<(f + DEPTH) * 1024>(w[f % DEPTH], addr);
+        }
+        if constexpr (f + 1 < F) MmaSlice16<DEPTH, f + 1>::run(xacc, addr, hh, hl, w);
+    }
+};
+__device__ __forceinline__ void mma_slice16(float4v (&xacc)[16], const half_t* buf, const half8& hh, const half8& hl, int lane) {
+#ifdef HMVIT_EXP_NOMMA
+    return;
+#endif
+    constexpr int DEPTH = HMVIT_X16_DEPTH;
+    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)(buf + lane * 8);
+    half8 w[DEPTH];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    MmaPrologue<DEPTH>::run(addr, w);
+    MmaSlice16<DEPTH>::run(xacc, addr, hh, hl, w);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// f32 rows in accumulator layout -> operand halves: slot j of k-step s <- x[2 s + (j >> 2)][j & 3]
+__device__ __forceinline__ void rows_to_operands16(const float4v (&x)[16], half8 (&ah)[8], half8 (&al)[8]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split_h(x[2 * s + (j >> 2)][j & 3], ah[s][j], al[s][j]);
+}
+// LayerNorm of the token held by 4 lanes, straight into operand halves (gamma / beta from LDS)
+__device__ __forceinline__ void ln_to_operands16(const float4v (&x)[16], const float* __restrict__ lg, const float* __restrict__ lb, int g,
+                                                 half8 (&ah)[8], half8 (&al)[8]) {
+    constexpr int C = 256;
+    float sm = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) sm += (x[t][0] + x[t][1]) + (x[t][2] + x[t][3]);
+    const float mean = quad_sum(sm) * (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = x[t][r] - mean;
+            q = fmaf(d, d, q);
+        }
+    const float rstd = rsqrtf(quad_sum(q) * (1.f / C) + 1e-5f);
+    const float shift = -mean * rstd;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int t = 2 * s + jj, c = 16 * t + 4 * g;
+            const float4 ga = *reinterpret_cast<const float4*>(lg + c);
+            const float4 be = *reinterpret_cast<const float4*>(lb + c);
+            split_h(fmaf(x[t][0], rstd, shift) * ga.x + be.x, ah[s][4 * jj + 0], al[s][4 * jj + 0]);
+            split_h(fmaf(x[t][1], rstd, shift) * ga.y + be.y, ah[s][4 * jj + 1], al[s][4 * jj + 1]);
+            split_h(fmaf(x[t][2], rstd, shift) * ga.z + be.z, ah[s][4 * jj + 2], al[s][4 * jj + 2]);
+            split_h(fmaf(x[t][3], rstd, shift) * ga.w + be.w, ah[s][4 * jj + 3], al[s][4 * jj + 3]);
+        }
+    }
+}
+
+// two projected row tiles (32 channels 32 c .. 32 c + 31) of the wave's 16 tokens -> f32 plane, through the wave's staging rows:
+// chunks (2 k, 2 k + 1) fill 64 channels = 256 bytes per token, then 4 store instructions write 4 x (4 tokens x 256 bytes)
+__device__ __forceinline__ void store_proj16(float* stg, float* y, int c, const float4v (&acc)[2], int tk, int g, int lane, int tok_w, int P) {
+    constexpr int C = 256;
+    float* d = stg + tk * X16_STG_ROW + 32 * (c & 1) + 4 * g;
+    *reinterpret_cast<float4*>(d) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+    *reinterpret_cast<float4*>(d + 16) = make_float4(acc[1][0], acc[1][1], acc[1][2], acc[1][3]);
+    if (c & 1) {
+        float* yo = y + (size_t)tok_w * C + 64 * (c >> 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int token = 4 * k + (lane >> 4), piece = lane & 15;
+            const float4 v = *reinterpret_cast<const float4*>(stg + token * X16_STG_ROW + piece * 4);
+            if (tok_w + token < P) *reinterpret_cast<float4*>(yo + (size_t)token * C + piece * 4) = v;
+        }
+    }
+}
+
+// Weight ring of the x16 kernels: THREE chunk slots.  Chunk i is requested two steps ahead (into the slot chunk i - 3 left at
+// the barrier that ended its step) and must have landed when step i - 1 ends: the LDS-DMA of a 32 KB chunk takes longer from
+// issue to landing (~1.1-1.3 us) than a step's matrix products (~0.65 us), so with a single chunk of lookahead every step
+// stalled on its successor.  ring_wait(n): all of this wave's memory operations except the newest n requests are complete.
+constexpr int X16_RING = 3;
+__device__ __forceinline__ void ring_wait_newest4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+// the same when this wave has issued the 4 global stores of a tile flush (store_proj16) between the request it waits for and
+// the newest request: loads and stores share the in-order vmcnt counter, so "newest 8" keeps those stores in flight too - a
+// store's write acknowledgement takes longer than a step, and waiting for it at every flush stalled the whole workgroup
+__device__ __forceinline__ void ring_wait_newest8() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+
+// "mixed" precision mode (A16): the projected Q / K' / V' planes are f16 (they are attention operands, rounded once; the f16
+// attention kernels consume them), 128 channels = 256 bytes per token and flush
+__device__ __forceinline__ void store_proj16_h(float* stg_f, half_t* y, int c, const float4v (&acc)[2], int tk, int g, int lane, int tok_w, int P) {
+    constexpr int C = 256, ROW = 2 * X16_STG_ROW;          // halves per staged token row (128 channels + padding)
+    half_t* stg = reinterpret_cast<half_t*>(stg_f);
+    half_t* d = stg + tk * ROW + 32 * (c & 3) + 4 * g;
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+        half4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = (half_t)acc[T][r];
+        *reinterpret_cast<half4*>(d + 16 * T) = h;
+    }
+    if ((c & 3) == 3) {
+        half_t* yo = y + (size_t)tok_w * C + 128 * (c >> 2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int token = 4 * k + (lane >> 4), piece = lane & 15;
+            const half8 v = *reinterpret_cast<const half8*>(stg + token * ROW + piece * 8);
+            if (tok_w + token < P) *reinterpret_cast<half8*>(yo + (size_t)token * C + piece * 8) = v;
+        }
+    }
+}
+
+template <bool A16>
+__global__ __launch_bounds__(X16_THREADS, 2) void k_ln_qkv16(QkvParams p) {
+    constexpr int C = 256, NCH = 8;                 // chunks (32 rows) per matrix
+    __shared__ __attribute__((aligned(16))) half_t smem[X16_RING * X16_CHUNK + 4 * C + 2 * X16_WAVES * X16_STG_WAVE];
+    float* lnp = reinterpret_cast<float*>(smem + X16_RING * X16_CHUNK);
+    const QkvJob& J = p.job[blockIdx.y];
+    const int P = p.P;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tk = lane & 15, g = lane >> 4;
+    const int tok_w = blockIdx.x * X16_TOKENS + wave * 16, tok = tok_w + tk;
+    float* stg = reinterpret_cast<float*>(smem + X16_RING * X16_CHUNK + 4 * C) + wave * X16_STG_WAVE;
+    for (int i = threadIdx.x; i < C; i += X16_THREADS) {
+        lnp[i] = p.gamma[J.type * C + i];
+        lnp[C + i] = p.beta[J.type * C + i];
+    }
+    const int n_chunks = J.n_mat * NCH;
+    auto chunk_ptr = [&](int i) -> const half_t* { return J.w[i / NCH] + (size_t)(i % NCH) * X16_CHUNK; };
+    auto slot = [&](int i) -> half_t* { return smem + (i % X16_RING) * X16_CHUNK; };
+    stage_chunk16(chunk_ptr(0), slot(0));
+    if (n_chunks > 1) stage_chunk16(chunk_ptr(1), slot(1));
+    float4v x[16];
+    const int tok_c = min(tok, P - 1);
+    if (p.in_nchw) {
+        const float* xp = J.x + (size_t)(4 * g) * P + tok_c;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[t][r] = xp[(size_t)(16 * t + r) * P];
+        if (tok < P && J.xs_out) {
+            float* xo = J.xs_out + (size_t)tok * C + 4 * g;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) *reinterpret_cast<float4*>(xo + 16 * t) = make_float4(x[t][0], x[t][1], x[t][2], x[t][3]);
+        }
+    } else {
+        const float* xp = J.x + (size_t)tok_c * C + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float4 f = *reinterpret_cast<const float4*>(xp + 16 * t);
+            x[t][0] = f.x; x[t][1] = f.y; x[t][2] = f.z; x[t][3] = f.w;
+        }
+    }
+    dma_wait();
+    __syncthreads();
+    half8 ah[8], al[8];
+    ln_to_operands16(x, lnp, lnp + C, g, ah, al);
+    for (int c = 0; c < n_chunks; ++c) {
+        const int mat = c / NCH, t = c - mat * NCH;
+        const bool ahead = c + 2 < n_chunks;
+        if (ahead) stage_chunk16(chunk_ptr(c + 2), slot(c + 2));
+        float4v acc[2] = {(float4v)(0.f), (float4v)(0.f)};
+        mma_proj16(acc, slot(c), ah, al, lane);
+        // chunk c + 1 has landed (c + 2, and the tile flush of step c - 1 if there was one, may still be in flight)
+        if (!ahead) dma_wait();
+        else if (c > 0 && (A16 ? ((c - 1) & 3) == 3 : ((c - 1) & 1))) ring_wait_newest8();
+        else ring_wait_newest4();
+#ifndef HMVIT_EXP_NOSTORE
+        if constexpr (A16) store_proj16_h(stg, reinterpret_cast<half_t*>(J.y[mat]), t, acc, tk, g, lane, tok_w, P);
+        else store_proj16(stg, reinterpret_cast<float*>(J.y[mat]), t, acc, tk, g, lane, tok_w, P);
+#endif
+        wg_barrier();
+    }
+}
+
+// TAIL: 0 = stage tail only (x'' stored), 1 = + next stage's LayerNorm / Q / K' / V', 2 = + mlp_head (output (C, P) map).
+// OUTPROJ / LN / RESID as in out_ffn_body; OUT_NCHW (TAIL 0): x'' goes to a (C, P) map (the stand-alone mlp_head launch).
+template <bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW, int TAIL, bool XN, bool A16>
+__device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams* qp) {
+    constexpr int C = 256, NCH = 8, NH = 8;
+    constexpr bool QKV = TAIL == 1, HEAD = TAIL == 2;
+    __shared__ __attribute__((aligned(16))) half_t smem[X16_RING * X16_CHUNK + 10 * C + 2 * X16_WAVES * X16_STG_WAVE];
+    float (*vec)[C] = reinterpret_cast<float (*)[C]>(smem + X16_RING * X16_CHUNK);   // b_o, ln g, ln b, b_1, b_2
+    const FfnJob& J = p.job[blockIdx.y];
+    const int P = p.P;
+    if (J.need) {   // none of this workgroup's tokens is read by a later stage (k_window_need)
+        const int t = blockIdx.x * X16_TOKENS + (threadIdx.x & (X16_TOKENS - 1));
+        const int r = t / p.W, c = t - r * p.W;
+        const int live = (t < P) ? J.need[(r >> 3) * (p.W >> 3) + (c >> 3)] : 0;
+        if (!__syncthreads_or(live)) return;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tk = lane & 15, g = lane >> 4;
+    const int tok_w = blockIdx.x * X16_TOKENS + wave * 16, tok = tok_w + tk;
+    const bool valid = tok < P;
+    const int ty = J.type;
+    float* stg = reinterpret_cast<float*>(smem + X16_RING * X16_CHUNK + 10 * C) + wave * X16_STG_WAVE;
+    for (int i = threadIdx.x; i < C; i += X16_THREADS) {
+        vec[0][i] = OUTPROJ ? p.b_o[ty * C + i] : 0.f;
+        vec[1][i] = LN ? p.ln_g[ty * C + i] : 1.f;
+        vec[2][i] = LN ? p.ln_b[ty * C + i] : 0.f;
+        vec[3][i] = p.b_1[ty * C + i];
+        vec[4][i] = p.b_2[ty * C + i];
+    }
+    // the whole launch as ONE chunk sequence: [out-projection 8] [FFN 16: W_1 tile, W_2 slice alternating] [tail: mlp_head 16 |
+    // next stage's Q / K' / V' 8 per matrix]
+    constexpr int N_OUT = OUTPROJ ? NCH : 0, N_FFN = 2 * NH;
+    const half_t* wo = OUTPROJ ? p.w_o + (size_t)ty * NCH * X16_CHUNK : nullptr;
+    const half_t* wf = p.w_ffn + (size_t)ty * N_FFN * X16_CHUNK;
+    const half_t* wh = HEAD ? p.w_head + (size_t)ty * N_FFN * X16_CHUNK : nullptr;
+    const QkvJob* Qj = QKV ? &qp->job[blockIdx.y] : nullptr;
+    const int n_tail = QKV ? Qj->n_mat * NCH : (HEAD ? N_FFN : 0);
+    const int n_total = N_OUT + N_FFN + n_tail;
+    auto chunk_ptr = [&](int i) -> const half_t* {
+        if (i < N_OUT) return wo + (size_t)i * X16_CHUNK;
+        i -= N_OUT;
+        if (i < N_FFN) return wf + (size_t)i * X16_CHUNK;
+        i -= N_FFN;
+        if constexpr (QKV) return Qj->w[i / NCH] + (size_t)(i % NCH) * X16_CHUNK;
+        else return wh + (size_t)i * X16_CHUNK;
+    };
+    auto slot = [&](int i) -> half_t* { return smem + (i % X16_RING) * X16_CHUNK; };
+    int cc = 0;                                          // chunk of the current step
+    // start of a step: request chunk cc + 2; end of a step: chunk cc + 1 has landed, then the workgroup barrier
+    auto step_begin = [&]() { if (cc + 2 < n_total) stage_chunk16(chunk_ptr(cc + 2), slot(cc + 2)); };
+    auto step_end = [&]() {
+        if (cc + 2 < n_total) ring_wait_newest4(); else dma_wait();
+        wg_barrier();
+        ++cc;
+    };
+    stage_chunk16(chunk_ptr(0), slot(0));
+    stage_chunk16(chunk_ptr(1), slot(1));
+
+    float4v xacc[16];
+    half8 ah[8], al[8];
+    const int tok_c = min(tok, P - 1);
+    if constexpr (XN) {
+        const unsigned long long a = (unsigned long long)J.x;
+        int4v rs;
+        rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        rs.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+        rs.z = C * P * 4;
+        rs.w = 0x00020000;
+        const int voff = (4 * g * P + tok_c) * 4;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xacc[t][r] = llvm_raw_buffer_load_f32(rs, voff, (16 * t + r) * P * 4, 0);
+    } else {
+        const float* xp = J.x + (size_t)tok_c * C + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float4 f = *reinterpret_cast<const float4*>(xp + 16 * t);
+            xacc[t][0] = f.x; xacc[t][1] = f.y; xacc[t][2] = f.z; xacc[t][3] = f.w;
+        }
+    }
+    if constexpr (!OUTPROJ && !LN) rows_to_operands16(xacc, ah, al);   // mlp_head: x itself is the operand
+    if constexpr (OUTPROJ && A16) {
+        // attention output (f16, exact operand: no lo half) of this token
+        const half_t* op = reinterpret_cast<const half_t*>(J.o) + (size_t)tok_c * C + 4 * g;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const half4 a = *reinterpret_cast<const half4*>(op + 32 * s);
+            const half4 b = *reinterpret_cast<const half4*>(op + 32 * s + 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ah[s][j] = a[j]; ah[s][4 + j] = b[j]; }
+        }
+    } else if constexpr (OUTPROJ) {
+        // attention output (f32) of this token: slot j of k-step s <- channel 32 s + 16 (j >> 2) + 4 g + (j & 3)
+        const float* op = reinterpret_cast<const float*>(J.o) + (size_t)tok_c * C + 4 * g;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(op + 32 * s);
+            const float4 b = *reinterpret_cast<const float4*>(op + 32 * s + 16);
+            const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) split_h(f[j], ah[s][j], al[s][j]);
+        }
+    }
+    dma_wait();
+    __syncthreads();
+
+    // ---- phase 1: x' = x + b_o + W_o . O, two 16-channel tiles per chunk ----
+    if constexpr (OUTPROJ) {
+#pragma unroll 1
+        for (int c = 0; c < N_OUT; ++c) {
+            step_begin();
+            float4v acc[2];
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                const float4 bo = *reinterpret_cast<const float4*>(&vec[0][32 * c + 16 * T + 4 * g]);
+                acc[T][0] = bo.x; acc[T][1] = bo.y; acc[T][2] = bo.z; acc[T][3] = bo.w;
+            }
+            mma_proj16<!A16>(acc, slot(cc), ah, al, lane);          // f16 attention output: exact operand, no lo half
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (t == c) { xacc[2 * t] += acc[0]; xacc[2 * t + 1] += acc[1]; }
+            step_end();
+        }
+    }
+    if constexpr (LN) ln_to_operands16(xacc, vec[1], vec[2], g, ah, al);
+
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const float4 b2 = *reinterpret_cast<const float4*>(&vec[4][16 * t + 4 * g]);
+        if constexpr (RESID) {
+            xacc[t][0] += b2.x; xacc[t][1] += b2.y; xacc[t][2] += b2.z; xacc[t][3] += b2.w;
+        } else {
+            xacc[t][0] = b2.x; xacc[t][1] = b2.y; xacc[t][2] = b2.z; xacc[t][3] = b2.w;
+        }
+    }
+
+    // ---- phase 2: per hidden tile hc: h = GELU(W_1[hc] . xn + b_1[hc]);  x'' += W_2[:, hc] . h ----
+    auto ffn_pass = [&]() {
+#pragma unroll 1
+        for (int hc = 0; hc < NH; ++hc) {
+            step_begin();
+            float4v hacc[2];
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                const float4 b1 = *reinterpret_cast<const float4*>(&vec[3][32 * hc + 16 * T + 4 * g]);
+                hacc[T][0] = b1.x; hacc[T][1] = b1.y; hacc[T][2] = b1.z; hacc[T][3] = b1.w;
+            }
+            mma_proj16(hacc, slot(cc), ah, al, lane);
+            step_end();
+            step_begin();
+            half8 hh, hl;                                    // hidden channel 32 hc + 16 (j >> 2) + 4 g + (j & 3) = hacc[j >> 2][j & 3]
+#pragma unroll
+            for (int j = 0; j < 8; ++j) split_h(gelu_f(hacc[j >> 2][j & 3]), hh[j], hl[j]);
+            mma_slice16(xacc, slot(cc), hh, hl, lane);
+            step_end();
+        }
+    };
+    ffn_pass();
+
+    auto store_x = [&]() {
+        if (valid && !(QKV && J.pad)) {
+            if constexpr (OUT_NCHW) {
+                float* op = J.out + (size_t)(4 * g) * P + tok;
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) op[(size_t)(16 * t + r) * P] = xacc[t][r];
+            } else {
+                float* op = J.out + (size_t)tok * C + 4 * g;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) *reinterpret_cast<float4*>(op + 16 * t) = make_float4(xacc[t][0], xacc[t][1], xacc[t][2], xacc[t][3]);
+            }
+        }
+    };
+    if constexpr (TAIL == 0) store_x();
+
+    if constexpr (HEAD) {
+        rows_to_operands16(xacc, ah, al);
+        // vec[3..4] are free: their last readers passed the barrier that ended phase 2
+        for (int i = threadIdx.x; i < C; i += X16_THREADS) {
+            vec[3][i] = p.hb_1[ty * C + i];
+            vec[4][i] = p.hb_2[ty * C + i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float4 b2 = *reinterpret_cast<const float4*>(&vec[4][16 * t + 4 * g]);
+            xacc[t][0] = b2.x; xacc[t][1] = b2.y; xacc[t][2] = b2.z; xacc[t][3] = b2.w;
+        }
+        ffn_pass();
+        if (valid) {
+            float* op = J.out + (size_t)(4 * g) * P + tok;      // (C, P) map
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) op[(size_t)(16 * t + r) * P] = xacc[t][r];
+        }
+    }
+
+    if constexpr (QKV) {
+        if (n_tail > 0) {
+            for (int i = threadIdx.x; i < C; i += X16_THREADS) {
+                vec[1][i] = qp->gamma[ty * C + i];
+                vec[2][i] = qp->beta[ty * C + i];
+            }
+            __syncthreads();
+            ln_to_operands16(xacc, vec[1], vec[2], g, ah, al);
+            store_x();                                   // x'' leaves while the first tiles are computed
+            for (int c = 0; c < n_tail; ++c) {
+                const int mat = c / NCH, t = c - mat * NCH;
+                // (the 16 stores of x'' / the 4 of a flush are older than the request made here: vmcnt(4) waits for them too)
+                step_begin();
+                float4v acc[2] = {(float4v)(0.f), (float4v)(0.f)};
+                mma_proj16(acc, slot(cc), ah, al, lane);
+                if (cc + 2 >= n_total) dma_wait();
+                else if (c > 0 && (A16 ? ((c - 1) & 3) == 3 : ((c - 1) & 1))) ring_wait_newest8();    // the flush of step c - 1 stays in flight
+                else ring_wait_newest4();
+#ifndef HMVIT_EXP_NOSTORE
+                if constexpr (A16) store_proj16_h(stg, reinterpret_cast<half_t*>(Qj->y[mat]), t, acc, tk, g, lane, tok_w, P);
+                else store_proj16(stg, reinterpret_cast<float*>(Qj->y[mat]), t, acc, tk, g, lane, tok_w, P);
+#endif
+                wg_barrier();
+                ++cc;
+            }
+        } else {
+            store_x();
+        }
+    }
+}
+
+template <bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW, bool A16>
+__global__ __launch_bounds__(X16_THREADS, 2) void k_out_ffn16(FfnParams p) {
+    tail16_body<OUTPROJ, LN, RESID, OUT_NCHW, 0, false, A16>(p, nullptr);
+}
+template <bool XN, bool A16>
+__global__ __launch_bounds__(X16_THREADS, 2) void k_out_ffn_qkv16(FfnParams p, QkvParams q) {
+    tail16_body<true, true, true, false, 1, XN, A16>(p, &q);
+}
+template <bool A16>
+__global__ __launch_bounds__(X16_THREADS, 2) void k_out_ffn_head16(FfnParams p) {
+    tail16_body<true, true, true, false, 2, false, A16>(p, nullptr);
 }
 
 template <int C, bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW, bool SP>
@@ -843,8 +1361,16 @@ static int launch_ln_qkv_t(const QkvParams& p, int n_jobs, int C, hipStream_t st
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }
-int launch_ln_qkv(const QkvParams& p, int n_jobs, int C, bool split, hipStream_t st) {
+int launch_ln_qkv(const QkvParams& p, int n_jobs, int C, int split, hipStream_t st) {
     if (n_jobs == 0) return HMVIT_OK;
+    HMVIT_CHECK_ARG(split != 2 || C == 256, "mixed precision planes need C = 256 (got %d)", C);
+    if (split && C == 256) {      // 16 tokens per wavefront, images in the x16 layout (weights.py weight_image16)
+        const dim3 grid(cdiv(p.P, X16_TOKENS), n_jobs), block(X16_THREADS);
+        if (split == 2) hipLaunchKernelGGL(k_ln_qkv16<true>, grid, block, 0, st, p);
+        else hipLaunchKernelGGL(k_ln_qkv16<false>, grid, block, 0, st, p);
+        HMVIT_CHECK_LAUNCH();
+        return HMVIT_OK;
+    }
     return split ? launch_ln_qkv_t<true>(p, n_jobs, C, st) : launch_ln_qkv_t<false>(p, n_jobs, C, st);
 }
 
@@ -861,14 +1387,20 @@ static int launch_out_ffn_c(const FfnParams& p, int n_jobs, int variant, hipStre
     return HMVIT_OK;
 }
 
-int launch_out_ffn_qkv(const FfnParams& p, const QkvParams& q, int n_jobs, int C, bool split, hipStream_t st) {
+int launch_out_ffn_qkv(const FfnParams& p, const QkvParams& q, int n_jobs, int C, int split, hipStream_t st) {
     if (n_jobs == 0) return HMVIT_OK;
     HMVIT_CHECK_ARG(C == 256, "out_ffn_qkv: C=%d unsupported (256)", C);
     dim3 grid(cdiv(p.P, CHAIN_TOKENS), n_jobs), block(CHAIN_THREADS);
     // FfnJob::x_nchw (all jobs of a launch alike): the residual is read from (C, P) maps
     if (split) {
-        if (p.job[0].x_nchw) hipLaunchKernelGGL((k_out_ffn_qkv<256, true, true>), grid, block, 0, st, p, q);
-        else hipLaunchKernelGGL((k_out_ffn_qkv<256, false, true>), grid, block, 0, st, p, q);
+        const dim3 grid16(cdiv(p.P, X16_TOKENS), n_jobs), block16(X16_THREADS);
+        if (split == 2) {
+            if (p.job[0].x_nchw) hipLaunchKernelGGL((k_out_ffn_qkv16<true, true>), grid16, block16, 0, st, p, q);
+            else hipLaunchKernelGGL((k_out_ffn_qkv16<false, true>), grid16, block16, 0, st, p, q);
+        } else {
+            if (p.job[0].x_nchw) hipLaunchKernelGGL((k_out_ffn_qkv16<true, false>), grid16, block16, 0, st, p, q);
+            else hipLaunchKernelGGL((k_out_ffn_qkv16<false, false>), grid16, block16, 0, st, p, q);
+        }
     } else {
         if (p.job[0].x_nchw) hipLaunchKernelGGL((k_out_ffn_qkv<256, true, false>), grid, block, 0, st, p, q);
         else hipLaunchKernelGGL((k_out_ffn_qkv<256, false, false>), grid, block, 0, st, p, q);
@@ -877,18 +1409,34 @@ int launch_out_ffn_qkv(const FfnParams& p, const QkvParams& q, int n_jobs, int C
     return HMVIT_OK;
 }
 
-int launch_out_ffn_head(const FfnParams& p, int n_jobs, int C, bool split, hipStream_t st) {
+int launch_out_ffn_head(const FfnParams& p, int n_jobs, int C, int split, hipStream_t st) {
     if (n_jobs == 0) return HMVIT_OK;
     HMVIT_CHECK_ARG(C == 256 && p.w_head && p.hb_1 && p.hb_2, "out_ffn_head: C=%d (256) / head weights missing", C);
     dim3 grid(cdiv(p.P, CHAIN_TOKENS), n_jobs), block(CHAIN_THREADS);
-    if (split) hipLaunchKernelGGL((k_out_ffn_head<256, true>), grid, block, 0, st, p);
+    if (split == 2) hipLaunchKernelGGL(k_out_ffn_head16<true>, dim3(cdiv(p.P, X16_TOKENS), n_jobs), dim3(X16_THREADS), 0, st, p);
+    else if (split) hipLaunchKernelGGL(k_out_ffn_head16<false>, dim3(cdiv(p.P, X16_TOKENS), n_jobs), dim3(X16_THREADS), 0, st, p);
     else hipLaunchKernelGGL((k_out_ffn_head<256, false>), grid, block, 0, st, p);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }
 
-int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, bool split, hipStream_t st) {
+int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, int split, hipStream_t st) {
     if (n_jobs == 0) return HMVIT_OK;
+    HMVIT_CHECK_ARG(split != 2 || C == 256, "mixed precision planes need C = 256 (got %d)", C);
+    if (split && C == 256) {
+        const dim3 grid(cdiv(p.P, X16_TOKENS), n_jobs), block(X16_THREADS);
+        switch (variant) {
+            case FFN_FULL:
+                if (split == 2) hipLaunchKernelGGL((k_out_ffn16<true, true, true, false, true>), grid, block, 0, st, p);
+                else hipLaunchKernelGGL((k_out_ffn16<true, true, true, false, false>), grid, block, 0, st, p);
+                break;
+            case FFN_NO_ATTN: hipLaunchKernelGGL((k_out_ffn16<false, true, true, false, false>), grid, block, 0, st, p); break;
+            case FFN_HEAD_NCHW: hipLaunchKernelGGL((k_out_ffn16<false, false, false, true, false>), grid, block, 0, st, p); break;
+            default: set_error("out_ffn: bad variant %d", variant); return HMVIT_EINVAL;
+        }
+        HMVIT_CHECK_LAUNCH();
+        return HMVIT_OK;
+    }
     switch (C) {
         case 64: return split ? launch_out_ffn_c<64, true>(p, n_jobs, variant, st) : launch_out_ffn_c<64, false>(p, n_jobs, variant, st);
         case 128: return split ? launch_out_ffn_c<128, true>(p, n_jobs, variant, st) : launch_out_ffn_c<128, false>(p, n_jobs, variant, st);

@@ -61,7 +61,8 @@ struct QkvParams {
     int P;
     int in_nchw;
 };
-int launch_ln_qkv(const QkvParams& p, int n_jobs, int C, bool split, hipStream_t st);
+// split: 0 = f16 operands, 1 = split (hi + lo) operands with f32 planes, 2 = split operands with f16 Q / K' / V' / O planes ("mixed")
+int launch_ln_qkv(const QkvParams& p, int n_jobs, int C, int split, hipStream_t st);
 
 struct FfnJob {
     const void* o;           // (P, C) attention output (FFN_FULL): f16, or f32 in split mode
@@ -89,12 +90,12 @@ struct FfnParams {
     const float* hb_2;
 };
 enum { FFN_FULL = 0, FFN_NO_ATTN = 1, FFN_HEAD_NCHW = 2 };
-int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, bool split, hipStream_t st);
+int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, int split, hipStream_t st);
 // k_out_ffn (FFN_FULL) of a stage fused with k_ln_qkv of the next one; job j of both lists = the same agent;
 // FfnJob::pad = 1 suppresses the store of the updated residual row
-int launch_out_ffn_qkv(const FfnParams& p, const QkvParams& q, int n_jobs, int C, bool split, hipStream_t st);
+int launch_out_ffn_qkv(const FfnParams& p, const QkvParams& q, int n_jobs, int C, int split, hipStream_t st);
 // k_out_ffn (FFN_FULL) of the last stage with mlp_head appended; FfnJob::out = (C, P) output map
-int launch_out_ffn_head(const FfnParams& p, int n_jobs, int C, bool split, hipStream_t st);
+int launch_out_ffn_head(const FfnParams& p, int n_jobs, int C, int split, hipStream_t st);
 
 // ---- enc.hip (PointPillar branch) ----
 struct PfnParams {

@@ -27,7 +27,9 @@ NUM_TYPES = _lib.NUM_TYPES
 _PRECISIONS = {"f32": _lib.PREC_F32, "fp32": _lib.PREC_F32, "strict": _lib.PREC_F32,
                "f16": _lib.PREC_F16, "fp16": _lib.PREC_F16, "fast": _lib.PREC_F16,
                # fp32-class products on the f16 matrix pipes (operands split into hi + lo halves, 3 MFMAs per product)
-               "split": _lib.PREC_SPLIT}
+               "split": _lib.PREC_SPLIT,
+               # split arithmetic in the token chains, f16 attention operands (Q / K' / V' / O planes): C = 256
+               "mixed": _lib.PREC_MIXED}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -141,13 +143,14 @@ class _FusionBase(nn.Module):
         key = (prec, str(device)) + tuple((p.data_ptr(), p._version) for p in params)
         if self._folded_key != key:
             dtype = torch.float32 if prec == _lib.PREC_F32 else torch.float16
-            split = prec == _lib.PREC_SPLIT
-            sd = {k: v.to(device) for k, v in self.state_dict().items()}
             blk = self._block_cfg
+            mixed = prec == _lib.PREC_MIXED and blk["input_dim"] == 256
+            split = prec == _lib.PREC_SPLIT or prec == _lib.PREC_MIXED
+            sd = {k: v.to(device) for k, v in self.state_dict().items()}
             folded = {}
             for s, which in enumerate(("window", "grid")):
                 folded[s] = weights.fold_stage(sd, self._block_prefix, which, blk["dim_head"],
-                                               blk["window_size"], dtype, split=split)
+                                               blk["window_size"], dtype, split=split, log2e=mixed if split else None)
             if self._head_prefix is not None:
                 folded["head"] = weights.fold_head(sd, self._head_prefix, dtype, split=split)
             if blk["architect_mode"] == "parallel":
@@ -200,7 +203,7 @@ class _FusionBase(nn.Module):
             d.parallel = 1
             for name, t in w["split"].items():
                 setattr(d, name, t.data_ptr())
-        if prec == _lib.PREC_SPLIT:
+        if prec in (_lib.PREC_SPLIT, _lib.PREC_MIXED):
             mode_h, rl_h, mask_h, self_ident = self._host_small(mode, record_len, mask, pw)
             d.self_identity = int(self_ident)
         else:

@@ -43,7 +43,7 @@ class BevformerPointPillarHetero(nn.Module):
         super().__init__()
         self.camera_encoder = camera_encoder
         fusion_precision = precision
-        if precision == "split":
+        if precision in ("split", "mixed"):
             # the split (hi + lo f16 operand) kernels exist for the fusion; the convolutional encoders / decoder run their
             # exact-f32 kernels in that mode (their f16 kernels are the 1e-3-class fast mode)
             precision = "f32"

@@ -87,6 +87,37 @@ def weight_image(w: torch.Tensor, store_rows: bool = False, linear_k: bool = Fal
     return w[n.expand(-1, K // 16, -1, 8), k.expand(N // 32, -1, -1, -1)].to(torch.float16).contiguous()
 
 
+def weight_image16(w: torch.Tensor) -> torch.Tensor:
+    """(N, K) matrix -> (N/16, K/32, 2, 64, 8) f16 split image of the 16-token kernels (csrc/chain.hip "x16", split mode, C = 256):
+    img[T][s][half][lane][j] = W_half[16 T + (lane & 15)][32 s + 16 (j >> 2) + 4 (lane >> 4) + (j & 3)]
+    (v_mfma_f32_16x16x32_f16 A operand; the k order matches the channels an accumulator lane owns)."""
+    N, K = w.shape
+    if N % 16 or K % 32:
+        raise ValueError(f"weight_image16: ({N}, {K}) must be multiples of (16, 32)")
+    dev = w.device
+    T = torch.arange(N // 16, device=dev)[:, None, None, None]
+    s = torch.arange(K // 32, device=dev)[None, :, None, None]
+    lane = torch.arange(64, device=dev)[None, None, :, None]
+    j = torch.arange(8, device=dev)[None, None, None, :]
+    n = (16 * T + (lane & 15)).expand(-1, K // 32, -1, 8)
+    k = (32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3)).expand(N // 16, -1, -1, -1)
+    hi, lo = split_halves(w.float())
+    return torch.stack([hi[n, k], lo[n, k]], dim=2).contiguous()
+
+
+def ffn_image16(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """x16 weight stream of Linear(C, C) -> GELU -> Linear(C, C): per hidden tile hc (32 hidden channels) the W_1 chunk (row tiles
+    2 hc, 2 hc + 1 x all k-steps) followed by the W_2 slice chunk (all 16 row tiles x k-step hc): (C/32, 2, 16, 2, 64, 8)."""
+    C = w1.shape[1]
+    if tuple(w1.shape) != (C, C) or tuple(w2.shape) != (C, C) or C != 256:
+        raise ValueError("the x16 FFN kernel needs mlp_dim == input_dim == 256")
+    i1 = weight_image16(w1)                                   # (16, 8, 2, 64, 8)
+    i2 = weight_image16(w2)
+    a = i1.reshape(8, 2 * 8, 2, 64, 8)                        # hc: (row tile 2 hc .. 2 hc + 1) x k-step
+    b = i2.permute(1, 0, 2, 3, 4).contiguous()                # (k-step hc, row tile T, half, 64, 8)
+    return torch.stack([a, b], dim=1).contiguous()
+
+
 def ffn_image(w1: torch.Tensor, w2: torch.Tensor, split: bool = False) -> torch.Tensor:
     """Interleaved weight stream of Linear(C, C) -> GELU -> Linear(C, C) for k_out_ffn:
     (C/32, 2, C/16, 64, 8): [hc][0] = image of W_1 rows of hidden tile hc, [hc][1] = fragments
@@ -130,7 +161,10 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
     out["ln_beta"] = stack(f"{prefix}{which}_norm.net.{{t}}.bias")
     per_type = lambda m, fn: torch.stack([fn(m[t]) for t in range(NUM_TYPES)])
     w_q = stack(f"{att}.q_linears.{{t}}.weight") * scale
-    if f16:
+    x16 = split and C == 256          # 16-token split kernels: their own image layout (weight_image16)
+    if x16:
+        out["img_q"] = per_type(w_q, weight_image16)
+    elif f16:
         out["img_q"] = per_type(w_q, lambda m: weight_image(m, store_rows=True, split=split))
     else:
         out["w_q"] = w_q
@@ -149,7 +183,9 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
             b_kv[te, ts, :C] = torch.einsum("hpq,hq->hp", rel_att[e], bk).reshape(C)
             w_kv[te, ts, C:] = torch.einsum("hpq,hpc->hqc", rel_msg[e], wv).reshape(C, C)
             b_kv[te, ts, C:] = torch.einsum("hpq,hp->hq", rel_msg[e], bv).reshape(C)
-    if f16:
+    if x16:
+        out["img_kv"] = torch.stack([per_type(w_kv[te], weight_image16) for te in range(NUM_TYPES)])
+    elif f16:
         out["img_kv"] = torch.stack([per_type(w_kv[te], lambda m: weight_image(m, store_rows=True, split=split)) for te in range(NUM_TYPES)])
     else:
         out["w_kv"] = w_kv
@@ -160,7 +196,9 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
         # negated offsets, i.e. the table flipped along its first axis (index (dr + w - 1)(2w - 1) + dc + w - 1)
         out["bias_frag_neg"] = bias_fragments(sd[f"{att}.relative_position_bias_table.weight"].detach().flip(0), window)
     w_o = stack(f"{att}.a_linears.{{t}}.0.weight")
-    if f16:
+    if x16:
+        out["img_o"] = per_type(w_o, weight_image16)
+    elif f16:
         out["img_o"] = per_type(w_o, lambda m: weight_image(m, linear_k=True, split=split))
     else:
         out["w_o"] = w_o
@@ -169,7 +207,9 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
     out["ffn_ln_beta"] = stack(f"{prefix}{which}_ffd.norm.net.{{t}}.bias")
     w_1 = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.0.weight")
     w_2 = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.3.weight")
-    if f16:
+    if x16:
+        out["img_ffn"] = torch.stack([ffn_image16(w_1[t], w_2[t]) for t in range(NUM_TYPES)])
+    elif f16:
         out["img_ffn"] = torch.stack([ffn_image(w_1[t], w_2[t], split=split) for t in range(NUM_TYPES)])
     else:
         out["w_1"], out["w_2"] = w_1, w_2
@@ -185,7 +225,10 @@ def fold_head(sd: Dict[str, torch.Tensor], prefix: str, dtype: torch.dtype, keep
     out = {"head_b1": stack(f"{prefix}.net.{{t}}.0.bias").contiguous(),
            "head_b2": stack(f"{prefix}.net.{{t}}.3.bias").contiguous()}
     if dtype == torch.float16:
-        out["head_img_ffn"] = torch.stack([ffn_image(w1[t], w2[t], split=split) for t in range(NUM_TYPES)])
+        if split and w1.shape[-1] == 256:
+            out["head_img_ffn"] = torch.stack([ffn_image16(w1[t], w2[t]) for t in range(NUM_TYPES)])
+        else:
+            out["head_img_ffn"] = torch.stack([ffn_image(w1[t], w2[t], split=split) for t in range(NUM_TYPES)])
     else:
         out["head_w1"], out["head_w2"] = w1.contiguous(), w2.contiguous()
     return out

@@ -41,6 +41,12 @@ extern "C" {
                                 fragment images of HMVIT_PREC_F16 with, per k-step, the hi fragment followed by the lo
                                 fragment (twice the size; weights.py weight_image(split=True)); w_q / b_q / bias_frag carry
                                 no log2(e) factor.  Held to the f32 tolerance (1e-4) by the parity tests. */
+#define HMVIT_PREC_MIXED 3   /* HMVIT_PREC_SPLIT arithmetic in every Linear / FFN / LayerNorm / residual (the token chains), but the
+                                attention operands Q / K' / V' / O are stored as f16 planes and the f16 attention kernels run on
+                                them (f32 accumulate and softmax): half the attention's HBM traffic.  C = 256 only (other widths
+                                behave as HMVIT_PREC_SPLIT); w_q / b_q / bias_frag carry log2(e) as in HMVIT_PREC_F16.  Held to the
+                                f32 tolerance (1e-4) by the parity tests on the reference's goldens; the attention-operand rounding
+                                contributes < 1e-5 there. */
 
 /* partition of one attention stage (hetero_fusion.py:387-389 vs :430-431) */
 #define HMVIT_PART_WINDOW 0  /* 'b m d (x w1) (y w2)': contiguous w x w windows */

@@ -12,8 +12,9 @@ from oracle import hmvit_oracle as O
 pytestmark = pytest.mark.gpu
 
 # "split" = fp32-class products on the f16 pipes (hi + lo operand halves): held to the f32 tolerance
-TOL = {"f32": 1e-4, "f16": 1e-3, "split": 1e-4}
-PRECISIONS = ["f32", "f16", "split"]
+# "mixed" = split arithmetic in the token chains + f16 attention operands: also held to the f32 tolerance
+TOL = {"f32": 1e-4, "f16": 1e-3, "split": 1e-4, "mixed": 1e-4}
+PRECISIONS = ["f32", "f16", "split", "mixed"]
 
 
 def _cuda(*ts):
