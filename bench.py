@@ -13,6 +13,8 @@ scene, `value` = scenes processed by all ranks / max-over-ranks wall time ("weak
 Precision modes (--precision; the headline is the one at the reference's precision):
   split  (default) every fp32 product on the f16 matrix pipes as x = hi + lo (two f16 halves per operand, three MFMA
          products per fp32 product, f32 accumulate): held to the fp32 tolerance 1e-4 by tests/test_hip_fusion.py
+  mixed  split-operand chains, attention operands Q / K' / V' / O stored and multiplied as f16 (C = 256 only); 1e-4 on the
+         parity cases, reported under "mixed_a16"
   f32    exact-f32 MFMA (v_mfma_f32_32x32x2_f32), tolerance 1e-4
   f16    f16 operands, f32 accumulate / softmax / LayerNorm / residual: north_star's 1e-3 tolerance mode, reported
          on the same line under "fast_f16" -- narrower than the reference's fp32, so never the headline.
@@ -23,6 +25,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                 reference) timed on the host cores on a bounded crop of the same workload, best thread count of a sweep,
   phases        per-phase milliseconds of one forward (HIP events on the launch stream),
   fast_f16      value / ms_per_step / roofline / phases of the f16-operand mode (1e-3 tolerance),
+  mixed_a16     the same for the "mixed" mode: split-operand fp32 Linear / FFN chains, f16 attention operands (1e-4 on
+                every parity case, but input-dependent -- a side figure),
   strict_f32    scenes/s of the exact-f32 MFMA mode,
   dense_masked_tiles  scenes/s with skip_masked off: `value` skips (ego, source, window) key tiles in which every key
                 is masked (outside the source's field of view) and windows of non-ego agents whose results cannot
@@ -358,6 +362,18 @@ def main(argv=None):
                                   "dtype": DTYPE["f16"], "tolerance": "1e-3 rel-max (north_star's figure), goldens g12 / g13",
                                   "roofline": roof, "phases": ph}
             del fast
+            torch.cuda.empty_cache()
+        if side and precision != "mixed" and c["C"] == 256:
+            mixed = make("mixed")
+            mdt, _ = timed(mixed, args.steps, args.warmup)
+            roof, ph = roofline_of(mixed, "mixed")
+            result["mixed_a16"] = {"value": args.steps / mdt, "unit": "scenes/s", "ms_per_step": mdt / args.steps * 1e3,
+                                   "dtype": DTYPE["mixed"],
+                                   "tolerance": "1e-4 rel-max on every parity case of tests/test_hip_fusion.py (goldens g12 / g13 "
+                                                "included); not the headline because the f16 storage of Q / K' / V' / O is an "
+                                                "input-dependent approximation of the reference's fp32 attention, the split mode is not",
+                                   "roofline": roof, "phases": ph}
+            del mixed
             torch.cuda.empty_cache()
         if side and precision != "f32":
             strict = make("f32")

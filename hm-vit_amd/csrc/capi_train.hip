@@ -545,6 +545,9 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
 
 }  // namespace hmvit
 
+#ifdef HMVIT_PROBE
+namespace hmvit { int debug_x16_trace(unsigned long long* host, int n); }
+#endif
 using namespace hmvit;
 
 extern "C" {
@@ -582,5 +585,9 @@ int hmvit_dropout_mask(float* mask, size_t n, uint64_t seed, uint32_t salt, floa
     c.seed = seed; c.salt = salt; c.p = p;
     return launch_dropout_mask(mask, n, c, reinterpret_cast<hipStream_t>(stream));
 }
+
+#ifdef HMVIT_PROBE
+int hmvit_debug_x16_trace(unsigned long long* host, int n) { return hmvit::debug_x16_trace(host, n); }
+#endif
 
 }  // extern "C"

@@ -995,6 +995,22 @@ __device__ __forceinline__ void store_proj16(float* stg, float* y, int c, const 
 // issue to landing (~1.1-1.3 us) than a step's matrix products (~0.65 us), so with a single chunk of lookahead every step
 // stalled on its successor.  ring_wait(n): all of this wave's memory operations except the newest n requests are complete.
 constexpr int X16_RING = 3;
+#ifdef HMVIT_PROBE
+// cycle stamps of one workgroup, wave 0, lane 0 of the tail kernel: [step][0 begin, 1 requests issued, 2 products done, 3 chunk
+// landed, 4 barrier passed, 5 tile stored]; read back with hmvit_debug_x16_trace (tools/probe/x16_trace.py).  Findings (cfg2, split
+// mode): of ~3000 cycles per step the wave's own 48 products take ~1100, issuing the 4 chunk requests ~320, and ~800 pass at
+// the barrier while the SIMD's other wave finishes its products - the two waves of a SIMD run the same phase at the same
+// time, so the matrix pipe idles during everything that is not a product (about half of a step).  Moving the requests into
+// the product stream made the step longer, not shorter (M0 traffic stalls the MFMA issue): measured and reverted.
+__device__ unsigned long long g_x16_trace[64 * 8];
+#define X16_STAMP(step, slot)                                                                             \
+    do {                                                                                                  \
+        if (blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x == 0 && (step) < 64)                        \
+            g_x16_trace[(step) * 8 + (slot)] = __builtin_readcyclecounter();                              \
+    } while (0)
+#else
+#define X16_STAMP(step, slot) do {} while (0)
+#endif
 __device__ __forceinline__ void ring_wait_newest4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
 // the same when this wave has issued the 4 global stores of a tile flush (store_proj16) between the request it waits for and
 // the newest request: loads and stores share the in-order vmcnt counter, so "newest 8" keeps those stores in flight too - a
@@ -1135,10 +1151,18 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
     auto slot = [&](int i) -> half_t* { return smem + (i % X16_RING) * X16_CHUNK; };
     int cc = 0;                                          // chunk of the current step
     // start of a step: request chunk cc + 2; end of a step: chunk cc + 1 has landed, then the workgroup barrier
-    auto step_begin = [&]() { if (cc + 2 < n_total) stage_chunk16(chunk_ptr(cc + 2), slot(cc + 2)); };
+    // (requesting chunk cc + 2 after the step's products instead of before them was measured: no gain, 5.35 vs 5.30 ms)
+    auto step_begin = [&]() {
+        X16_STAMP(cc, 0);
+        if (cc + 2 < n_total) stage_chunk16(chunk_ptr(cc + 2), slot(cc + 2));
+        X16_STAMP(cc, 1);
+    };
     auto step_end = [&]() {
+        X16_STAMP(cc, 2);
         if (cc + 2 < n_total) ring_wait_newest4(); else dma_wait();
+        X16_STAMP(cc, 3);
         wg_barrier();
+        X16_STAMP(cc, 4);
         ++cc;
     };
     stage_chunk16(chunk_ptr(0), slot(0));
@@ -1444,5 +1468,12 @@ int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, int split
         default: set_error("out_ffn: C=%d unsupported", C); return HMVIT_EINVAL;
     }
 }
+
+#ifdef HMVIT_PROBE
+int debug_x16_trace(unsigned long long* host, int n) {
+    HMVIT_CHECK_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_x16_trace), sizeof(unsigned long long) * (n < 512 ? n : 512)));
+    return HMVIT_OK;
+}
+#endif
 
 }  // namespace hmvit

@@ -1,0 +1,26 @@
+"""Probe build only (make PROBE=1): cycle stamps of one workgroup of the split tail kernel inside the real cfg2 forward."""
+import ctypes, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import hmvit_amd
+from hmvit_amd import _lib, synthetic as S
+prec = sys.argv[1] if len(sys.argv) > 1 else "split"
+cfg = S.make_config(256, 8, 5, voxel=0.4, downsample=1)
+scene = [t.cuda() for t in S.synthetic_scene(5, 256, 200, 704, [1, 1, 1, 1, 1], seed=1)]
+net = S.seeded_fusion(cfg, precision=prec).cuda().eval()
+with torch.no_grad():
+    for _ in range(3):
+        net(*scene)
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 512)()
+fn = _lib.lib.hmvit_debug_x16_trace
+fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+assert fn(buf, 512) == 0
+rows = [[buf[i * 8 + k] for k in range(6)] for i in range(64)]
+t0 = rows[0][0]
+print("step  begin   +issue  +mfma  +wait  +barrier   (store)   total")
+for i, r in enumerate(rows[:50]):
+    if r[0] == 0: continue
+    nxt = rows[i + 1][0] if i + 1 < 64 and rows[i + 1][0] else r[4]
+    st = r[5] - r[3] if r[5] else 0
+    print(f"{i:3d} {r[0]-t0:8d} {r[1]-r[0]:7d} {r[2]-r[1]:6d} {r[3]-r[2]:6d} {r[4]-max(r[3], r[5]):8d} {st:9d} {nxt-r[0]:8d}")
