@@ -13,7 +13,7 @@ def parameter_skeleton(cfg):
     pkg.__path__ = [pkg_dir]
     sys.modules["_hmvit_cpu"] = pkg
     lib = types.ModuleType("_hmvit_cpu._lib")
-    lib.NUM_TYPES, lib.PREC_F32, lib.PREC_F16 = 2, 0, 1
+    lib.NUM_TYPES, lib.PREC_F32, lib.PREC_F16, lib.PREC_SPLIT, lib.PREC_MIXED = 2, 0, 1, 2, 3
     sys.modules["_hmvit_cpu._lib"] = lib
     for name in ("weights", "fusion"):
         spec = importlib.util.spec_from_file_location(f"_hmvit_cpu.{name}", os.path.join(pkg_dir, f"{name}.py"))
