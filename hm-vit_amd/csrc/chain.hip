@@ -860,6 +860,10 @@ __device__ __forceinline__ void stage_chunk16(const half_t* __restrict__ chunk, 
 
 __device__ __forceinline__ float quad_sum(float v) { return xor32_sum(xor16_sum(v)); }   // over the 4 lanes of a token
 
+// (Measured and dropped: issuing the products in pairs over two accumulators so that no MFMA waits for its predecessor's result -
+// the lone wave's 48 products still took ~1120 cycles (projection chunk) / ~1640 (W_2 slice), i.e. the dependent accumulator is
+// not what holds them above the 48 x 17 cycles of bare back-to-back MFMAs; neither is the fragment prefetch depth (8 / 12 / 16
+// measured equal).  What remains is the issue of the 32 ds_read_b128 of a chunk between the products.)
 // fragment f of a chunk: hi fragments feed two MFMAs (x a_lo, x a_hi), lo fragments one (x a_hi)
 // NT16 = 2: projection chunk, fragment f = (row tile f / 16, k-step (f % 16) / 2, half f & 1), accumulators acc[2]
 template <int DEPTH, bool HAS_LO, int f = 0>
@@ -995,18 +999,19 @@ __device__ __forceinline__ void store_proj16(float* stg, float* y, int c, const 
 // issue to landing (~1.1-1.3 us) than a step's matrix products (~0.65 us), so with a single chunk of lookahead every step
 // stalled on its successor.  ring_wait(n): all of this wave's memory operations except the newest n requests are complete.
 constexpr int X16_RING = 3;
+#ifndef HMVIT_X16_DEPHASE
+#define HMVIT_X16_DEPHASE 1
+#endif
+constexpr bool X16_DEPHASE = HMVIT_X16_DEPHASE != 0;
 #ifdef HMVIT_PROBE
-// cycle stamps of one workgroup, wave 0, lane 0 of the tail kernel: [step][0 begin, 1 requests issued, 2 products done, 3 chunk
-// landed, 4 barrier passed, 5 tile stored]; read back with hmvit_debug_x16_trace (tools/probe/x16_trace.py).  Findings (cfg2, split
-// mode): of ~3000 cycles per step the wave's own 48 products take ~1100, issuing the 4 chunk requests ~320, and ~800 pass at
-// the barrier while the SIMD's other wave finishes its products - the two waves of a SIMD run the same phase at the same
-// time, so the matrix pipe idles during everything that is not a product (about half of a step).  Moving the requests into
-// the product stream made the step longer, not shorter (M0 traffic stalls the MFMA issue): measured and reverted.
-__device__ unsigned long long g_x16_trace[64 * 8];
+// cycle stamps of one workgroup of the tail kernel, lane 0 of wave 0 (group A, first 64 rows) and of wave 4 (group B, next 64):
+// [step][0 begin, 1 products done, 2 chunk confirmed (B), 3 mid barrier passed, 4 rest of the step + request done, 5 end barrier
+// passed]; read back with hmvit_debug_x16_trace (tools/probe/x16_trace.py).
+__device__ unsigned long long g_x16_trace[2 * 64 * 8];
 #define X16_STAMP(step, slot)                                                                             \
     do {                                                                                                  \
-        if (blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x == 0 && (step) < 64)                        \
-            g_x16_trace[(step) * 8 + (slot)] = __builtin_readcyclecounter();                              \
+        if (blockIdx.x == 7 && blockIdx.y == 0 && (threadIdx.x & 255) == 0 && (step) < 64)                \
+            g_x16_trace[((threadIdx.x >> 8) * 64 + (step)) * 8 + (slot)] = __builtin_readcyclecounter();  \
     } while (0)
 #else
 #define X16_STAMP(step, slot) do {} while (0)
@@ -1058,8 +1063,12 @@ __global__ __launch_bounds__(X16_THREADS, 2) void k_ln_qkv16(QkvParams p) {
     const int n_chunks = J.n_mat * NCH;
     auto chunk_ptr = [&](int i) -> const half_t* { return J.w[i / NCH] + (size_t)(i % NCH) * X16_CHUNK; };
     auto slot = [&](int i) -> half_t* { return smem + (i % X16_RING) * X16_CHUNK; };
+    // step protocol and the one-barrier skew of waves 4-7: see tail16_body
+    const bool grp_b = X16_DEPHASE && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >= 4;
+    const bool full_wave = tok_w + 16 <= P;
     stage_chunk16(chunk_ptr(0), slot(0));
     if (n_chunks > 1) stage_chunk16(chunk_ptr(1), slot(1));
+    if (grp_b && n_chunks > 2) stage_chunk16(chunk_ptr(2), slot(2));
     float4v x[16];
     const int tok_c = min(tok, P - 1);
     if (p.in_nchw) {
@@ -1083,24 +1092,30 @@ __global__ __launch_bounds__(X16_THREADS, 2) void k_ln_qkv16(QkvParams p) {
     }
     dma_wait();
     __syncthreads();
+    if (grp_b) wg_barrier();
     half8 ah[8], al[8];
     ln_to_operands16(x, lnp, lnp + C, g, ah, al);
+    auto flushes = [](int k) { return k >= 0 && (A16 ? (k & 3) == 3 : (k & 1) != 0); };
     for (int c = 0; c < n_chunks; ++c) {
         const int mat = c / NCH, t = c - mat * NCH;
-        const bool ahead = c + 2 < n_chunks;
-        if (ahead) stage_chunk16(chunk_ptr(c + 2), slot(c + 2));
+        auto ring_wait = [&](bool flush_since) {
+            if (c + 2 < n_chunks && full_wave) { if (flush_since) ring_wait_newest8(); else ring_wait_newest4(); }
+            else dma_wait();
+        };
         float4v acc[2] = {(float4v)(0.f), (float4v)(0.f)};
         mma_proj16(acc, slot(c), ah, al, lane);
-        // chunk c + 1 has landed (c + 2, and the tile flush of step c - 1 if there was one, may still be in flight)
-        if (!ahead) dma_wait();
-        else if (c > 0 && (A16 ? ((c - 1) & 3) == 3 : ((c - 1) & 1))) ring_wait_newest8();
-        else ring_wait_newest4();
-#ifndef HMVIT_EXP_NOSTORE
+        if constexpr (X16_DEPHASE) {
+            if (grp_b) ring_wait(flushes(c - 1));
+            wg_barrier();
+        }
         if constexpr (A16) store_proj16_h(stg, reinterpret_cast<half_t*>(J.y[mat]), t, acc, tk, g, lane, tok_w, P);
         else store_proj16(stg, reinterpret_cast<float*>(J.y[mat]), t, acc, tk, g, lane, tok_w, P);
-#endif
+        const int ahead = c + 2 + (grp_b ? 1 : 0);
+        if (ahead < n_chunks) stage_chunk16(chunk_ptr(ahead), slot(ahead));
+        if (!grp_b) ring_wait(flushes(c));
         wg_barrier();
     }
+    if (X16_DEPHASE && !grp_b) wg_barrier();
 }
 
 // TAIL: 0 = stage tail only (x'' stored), 1 = + next stage's LayerNorm / Q / K' / V', 2 = + mlp_head (output (C, P) map).
@@ -1150,23 +1165,47 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
     };
     auto slot = [&](int i) -> half_t* { return smem + (i % X16_RING) * X16_CHUNK; };
     int cc = 0;                                          // chunk of the current step
-    // start of a step: request chunk cc + 2; end of a step: chunk cc + 1 has landed, then the workgroup barrier
-    // (requesting chunk cc + 2 after the step's products instead of before them was measured: no gain, 5.35 vs 5.30 ms)
-    auto step_begin = [&]() {
-        X16_STAMP(cc, 0);
-        if (cc + 2 < n_total) stage_chunk16(chunk_ptr(cc + 2), slot(cc + 2));
-        X16_STAMP(cc, 1);
+    // A step = [products of chunk cc] barrier [everything else: accumulate / GELU / stage + store, request a chunk] barrier.
+    // The two wavefronts of a SIMD (w, w + 4) would run the same half at the same time and leave the matrix pipe idle during
+    // every second half, so group B (waves 4-7) runs ONE BARRIER BEHIND group A (an extra barrier before its first step, one
+    // for A after its last): B's products overlap A's "everything else" and vice versa, with the same code on both sides.
+    // Ring protocol under that skew (half h = barrier interval; A: products of chunk k in half 2k, rest in 2k + 1; B: 2k + 1,
+    // 2k + 2): chunk k is read in halves 2k and 2k + 1.  A requests its pieces of chunk k + 2 in the rest-half of step k (slot of
+    // chunk k - 1, whose last reader finished in half 2k - 1) and confirms chunk k + 1 at the end of that half; B requests its
+    // pieces of chunk k + 3 in its rest-half of step k (half 2k + 2: slot of chunk k, read until half 2k + 1) and confirms
+    // chunk k + 1 at the end of its products of step k (half 2k + 1) - so every piece of chunk k + 1 is confirmed before the
+    // barrier that opens half 2k + 2.  vmcnt(n) = "all but the newest n operations": n counts the request made since (4) and,
+    // where a tile flush (4 stores) was issued since, those too; partial waves (a store instruction may be skipped) wait for all.
+    const bool grp_b = X16_DEPHASE && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >= 4;
+    const bool full_wave = tok_w + 16 <= P;
+    auto ring_wait = [&](bool flush_since) {
+        if (cc + 2 < n_total && full_wave) { if (flush_since) ring_wait_newest8(); else ring_wait_newest4(); }
+        else dma_wait();
     };
-    auto step_end = [&]() {
-        X16_STAMP(cc, 2);
-        if (cc + 2 < n_total) ring_wait_newest4(); else dma_wait();
+    auto step_begin = [&]() { X16_STAMP(cc, 0); };
+    // end of the products of step cc; flush_prev: the rest-half of step cc - 1 stored a tile
+    auto products_end = [&](bool flush_prev) {
+        X16_STAMP(cc, 1);
+        if constexpr (X16_DEPHASE) {
+            if (grp_b) ring_wait(flush_prev);
+            X16_STAMP(cc, 2);
+            wg_barrier();
+        }
         X16_STAMP(cc, 3);
-        wg_barrier();
+    };
+    // end of step cc; flush_now: this rest-half stored a tile
+    auto step_end = [&](bool flush_now) {
+        const int ahead = cc + 2 + (grp_b ? 1 : 0);
+        if (ahead < n_total) stage_chunk16(chunk_ptr(ahead), slot(ahead));
         X16_STAMP(cc, 4);
+        if (!grp_b) ring_wait(flush_now);
+        wg_barrier();
+        X16_STAMP(cc, 5);
         ++cc;
     };
     stage_chunk16(chunk_ptr(0), slot(0));
     stage_chunk16(chunk_ptr(1), slot(1));
+    if (grp_b && n_total > 2) stage_chunk16(chunk_ptr(2), slot(2));
 
     float4v xacc[16];
     half8 ah[8], al[8];
@@ -1216,6 +1255,7 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
     }
     dma_wait();
     __syncthreads();
+    if (grp_b) wg_barrier();
 
     // ---- phase 1: x' = x + b_o + W_o . O, two 16-channel tiles per chunk ----
     if constexpr (OUTPROJ) {
@@ -1229,10 +1269,11 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
                 acc[T][0] = bo.x; acc[T][1] = bo.y; acc[T][2] = bo.z; acc[T][3] = bo.w;
             }
             mma_proj16<!A16>(acc, slot(cc), ah, al, lane);          // f16 attention output: exact operand, no lo half
+            products_end(false);
 #pragma unroll
             for (int t = 0; t < 8; ++t)
                 if (t == c) { xacc[2 * t] += acc[0]; xacc[2 * t + 1] += acc[1]; }
-            step_end();
+            step_end(false);
         }
     }
     if constexpr (LN) ln_to_operands16(xacc, vec[1], vec[2], g, ah, al);
@@ -1259,13 +1300,15 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
                 hacc[T][0] = b1.x; hacc[T][1] = b1.y; hacc[T][2] = b1.z; hacc[T][3] = b1.w;
             }
             mma_proj16(hacc, slot(cc), ah, al, lane);
-            step_end();
-            step_begin();
+            products_end(false);
             half8 hh, hl;                                    // hidden channel 32 hc + 16 (j >> 2) + 4 g + (j & 3) = hacc[j >> 2][j & 3]
 #pragma unroll
             for (int j = 0; j < 8; ++j) split_h(gelu_f(hacc[j >> 2][j & 3]), hh[j], hl[j]);
+            step_end(false);
+            step_begin();
             mma_slice16(xacc, slot(cc), hh, hl, lane);
-            step_end();
+            products_end(false);
+            step_end(false);
         }
     };
     ffn_pass();
@@ -1321,24 +1364,21 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
             store_x();                                   // x'' leaves while the first tiles are computed
             for (int c = 0; c < n_tail; ++c) {
                 const int mat = c / NCH, t = c - mat * NCH;
-                // (the 16 stores of x'' / the 4 of a flush are older than the request made here: vmcnt(4) waits for them too)
+                // (the 16 stores of x'' are older than the first request made after them: that wait covers them too)
+                auto flushes = [](int k) { return k >= 0 && (A16 ? (k & 3) == 3 : (k & 1) != 0); };
                 step_begin();
                 float4v acc[2] = {(float4v)(0.f), (float4v)(0.f)};
                 mma_proj16(acc, slot(cc), ah, al, lane);
-                if (cc + 2 >= n_total) dma_wait();
-                else if (c > 0 && (A16 ? ((c - 1) & 3) == 3 : ((c - 1) & 1))) ring_wait_newest8();    // the flush of step c - 1 stays in flight
-                else ring_wait_newest4();
-#ifndef HMVIT_EXP_NOSTORE
+                products_end(flushes(c - 1));
                 if constexpr (A16) store_proj16_h(stg, reinterpret_cast<half_t*>(Qj->y[mat]), t, acc, tk, g, lane, tok_w, P);
                 else store_proj16(stg, reinterpret_cast<float*>(Qj->y[mat]), t, acc, tk, g, lane, tok_w, P);
-#endif
-                wg_barrier();
-                ++cc;
+                step_end(flushes(c));
             }
         } else {
             store_x();
         }
     }
+    if (X16_DEPHASE && !grp_b) wg_barrier();             // group A's share of group B's extra first barrier
 }
 
 template <bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW, bool A16>
@@ -1471,7 +1511,7 @@ int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, int split
 
 #ifdef HMVIT_PROBE
 int debug_x16_trace(unsigned long long* host, int n) {
-    HMVIT_CHECK_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_x16_trace), sizeof(unsigned long long) * (n < 512 ? n : 512)));
+    HMVIT_CHECK_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_x16_trace), sizeof(unsigned long long) * (n < 1024 ? n : 1024)));
     return HMVIT_OK;
 }
 #endif

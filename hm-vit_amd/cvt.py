@@ -13,6 +13,7 @@ library's LayerNorm and GEMM kernels (f32; the attention core and its q / k / v 
 from __future__ import annotations
 
 import ctypes
+import weakref
 
 import torch
 from torch import nn
@@ -68,6 +69,20 @@ def _layernorm(x2d, ln: nn.LayerNorm, prec=_F32):
     return y
 
 
+_F16_COPIES = weakref.WeakKeyDictionary()      # parameter -> (data_ptr, _version, (N, K) f16 copy)
+
+
+def _f16_weight(weight, N, K):
+    """The f16 copy of a Linear / 1x1-convolution weight, made once per parameter value: keyed on the parameter object and
+    refreshed when its storage or in-place version counter changes (optimiser step, load_state_dict, .to())."""
+    hit = _F16_COPIES.get(weight)
+    if hit is not None and hit[0] == weight.data_ptr() and hit[1] == weight._version and hit[2].device == weight.device:
+        return hit[2]
+    w2 = weight.detach().reshape(N, K).to(torch.float16).contiguous()
+    _F16_COPIES[weight] = (weight.data_ptr(), weight._version, w2)
+    return w2
+
+
 def _linear_f16(x2d, weight, bias=None, residual=None, gelu=False, out_f32=False):
     """f16 operands (an f32 input is converted first), f32 accumulate, f16 or f32 result; residual (f32) needs out_f32."""
     M, K = x2d.shape
@@ -75,7 +90,7 @@ def _linear_f16(x2d, weight, bias=None, residual=None, gelu=False, out_f32=False
     if x2d.dtype != torch.float16:
         x2d = x2d.to(torch.float16)
     y = torch.empty(M, N, device=x2d.device, dtype=torch.float32 if out_f32 else torch.float16)
-    w2 = weight.detach().reshape(N, K).to(torch.float16).contiguous()
+    w2 = _f16_weight(weight, N, K)
     b2 = None if bias is None else bias.detach().float().contiguous()
     _lib.check(_lib.lib.hmvit_linear(x2d.data_ptr(), w2.data_ptr(), _ptr(b2), _ptr(residual), y.data_ptr(), M, N, K,
                                      1 if gelu else 0, 1 if out_f32 else 0, _lib.PREC_F16, _stream()), "linear")

@@ -103,13 +103,36 @@ class HeteroDecoder(nn.Module):
         self._prep, self._prep_key = prep, key
         return prep
 
+    def _forward_training(self, x, mode):
+        """Training mode (``train_camera.py:163-199``): BatchNorm works on batch statistics and updates its running buffers, and
+        the tail needs gradients - neither exists in the folded inference kernels, and the tail has no HIP backward (it lies
+        outside SURVEY 8(a)'s path).  The layers are ordinary torch modules with the reference's parameter names, so in training
+        they are simply applied in the reference's order (``hetero_decoder.py:55-89``, ``naive_decoder.py:80-92`` with
+        ``use_upsample=False``) under torch autograd; ``.eval()`` switches back to the HIP kernels."""
+        ego = [int(v) for v in (mode[:, 0].tolist() if mode.device.type == "cpu" else mode[:, 0].cpu().tolist())]
+        for v in ego:
+            if v not in (0, 1):
+                raise ValueError(f"Mode but be either 1 or 0 but received {v}")
+        psm, rm = [None] * len(ego), [None] * len(ego)
+        for v, name in ((0, "camera"), (1, "lidar")):
+            idx = [b for b, e in enumerate(ego) if e == v]
+            if not idx:
+                continue
+            t = x[idx, 0]                                  # (n, C, H, W): all egos of this type share the BatchNorm batch
+            for layer in getattr(self, f"{name}_decoder").decoder:
+                t = layer(t)
+            p, r = getattr(self, f"{name}_cls_head")(t), getattr(self, f"{name}_reg_head")(t)
+            for k, b in enumerate(idx):
+                psm[b], rm[b] = p[k], r[k]
+        return torch.stack(psm, dim=0), torch.stack(rm, dim=0)
+
     def forward(self, x, mode, use_upsample=True):
         if use_upsample:
             raise NotImplementedError("HeteroDecoder: only use_upsample=False (the HM-ViT path) is built")
         if x.device.type != "cuda":
             raise RuntimeError("hm-vit_amd runs on the GPU only (HIP kernels, no CPU fallback)")
         if self.training:
-            raise RuntimeError("hmvit_amd.HeteroDecoder folds BatchNorm statistics: call .eval() (inference only)")
+            return self._forward_training(x, mode)
         B, L1, C, H, W = x.shape
         ego = [int(v) for v in (mode[:, 0].tolist() if mode.device.type == "cpu" else mode[:, 0].cpu().tolist())]
         for v in ego:

@@ -63,6 +63,21 @@ class BevformerPointPillarHetero(nn.Module):
         # present in the reference model regardless of the decoder kind (:74-77); unused with hetero_decoder
         self.cls_head = nn.Conv2d(256, config["anchor_number"], kernel_size=1)
         self.reg_head = nn.Conv2d(256, 7 * config["anchor_number"], kernel_size=1)
+        self._fix_camera_backbone = False
+        self._fix_lidar_backbone = False
+
+    # bevformer_point_pillar_hetero.py:78-89: the train script's --fix_camera_backbone / --fix_lidar_backbone
+    def fix_camera_backbone(self):
+        self._fix_camera_backbone = True
+
+    def fix_lidar_backbone(self):
+        self._fix_lidar_backbone = True
+
+    @staticmethod
+    def _freeze_weights(model):
+        model.eval()
+        for param in model.parameters():
+            param.requires_grad = False
 
     @staticmethod
     def _unpad(mode, record_len):
@@ -94,6 +109,10 @@ class BevformerPointPillarHetero(nn.Module):
         # mode / record_len are needed on the host (regrouping, kernel descriptors): ONE combined read-back per forward (the
         # reference synchronises per agent, bevformer_point_pillar_hetero.py:97-112); no caching by tensor identity -- a
         # loader's fresh tensors reuse addresses.  The host copies are handed down, so the fusion does not read back again.
+        if self._fix_lidar_backbone:
+            self._freeze_weights(self.lidar_encoder)
+        if self._fix_camera_backbone and self.camera_encoder is not None:
+            self._freeze_weights(self.camera_encoder)
         m_t, r_t = batch["mode"], batch["record_len"]
         if m_t.device.type != "cpu" or r_t.device.type != "cpu":
             dev = m_t.device if m_t.device.type != "cpu" else r_t.device

@@ -22,6 +22,19 @@ from . import _lib
 GT_RANGE = [-102.4, -102.4, -3, 102.4, 102.4, 1]   # opencood/data_utils/datasets/__init__.py:24
 
 
+def boxes_to_corners_3d(boxes: np.ndarray) -> np.ndarray:
+    """(n, 7) [x, y, z, h, w, l, yaw] ('hwl' order) -> (n, 8, 3) corners (box_utils.py:143-190)."""
+    b = np.asarray(boxes).astype(np.float32).copy()
+    b[:, 3:6] = b[:, [5, 4, 3]]
+    template = np.array([[1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, -1], [1, -1, 1], [1, 1, 1], [-1, 1, 1], [-1, -1, 1]],
+                        dtype=np.float32) / 2
+    c = b[:, None, 3:6] * template[None]
+    cosa, sina = np.cos(b[:, 6]), np.sin(b[:, 6])
+    rot = np.zeros((len(b), 3, 3), dtype=np.float32)
+    rot[:, 0, 0] = cosa; rot[:, 0, 1] = sina; rot[:, 1, 0] = -sina; rot[:, 1, 1] = cosa; rot[:, 2, 2] = 1
+    return np.einsum("nkc,ncd->nkd", c, rot) + b[:, None, 0:3]
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -80,6 +93,78 @@ class VoxelPostprocessor:
         if self.params["order"] == "lhw":
             return np.stack([cx, cy, cz, l_, h_, w_, r_], axis=-1)
         raise ValueError("Unknown bbx order.")
+
+    # voxel_postprocessor.py:74-194 (training targets; host-side numpy like the reference's dataset workers)
+    def generate_label(self, **kwargs) -> dict:
+        """Anchor targets of one sample: ``gt_box_center`` (max_num, 7) [x, y, z, h, w, l, yaw], ``anchors`` (H, W, A, 7),
+        ``mask`` (max_num) -> ``pos_equal_one`` / ``neg_equal_one`` (H, W, A), ``targets`` (H, W, 7 A).
+
+        An anchor is positive for a box when the IoU of their axis-aligned ("stand-up") footprints exceeds ``pos_threshold`` or
+        when it is the best anchor of that box (IoU > 0); negative when its IoU with every box is below ``neg_threshold``
+        (best anchors excepted).  IoU with the legacy ``+ 1`` on widths and heights (``utils/box_overlaps.pyx:17-57``).  Where
+        several boxes claim an anchor the reference's ``np.unique(..., return_index=True)`` keeps the first claim in the order
+        [threshold matches in row-major (anchor, box) order, then best-anchor matches in box order]; reproduced with a stable sort."""
+        if self.params["order"] != "hwl":
+            raise AssertionError("Currently Voxel only supporthwl bbx order.")
+        gt_all = np.asarray(kwargs["gt_box_center"])
+        anchors = np.asarray(kwargs["anchors"])
+        valid = np.asarray(kwargs["mask"]) == 1
+        fmap = anchors.shape[:2]
+        A = self.anchor_num
+        an = anchors.reshape(-1, 7)
+        diag = np.sqrt(an[:, 4] ** 2 + an[:, 5] ** 2)
+        pos = np.zeros((*fmap, A))
+        neg = np.zeros((*fmap, A))
+        targets = np.zeros((*fmap, A * 7))
+
+        def standup(boxes):
+            c = boxes_to_corners_3d(boxes)[:, :4, :2]
+            return np.concatenate([c.min(1), c.max(1)], 1).astype(np.float32)
+
+        sa, sg = standup(an), standup(gt_all[valid])
+        iw = np.minimum(sa[:, None, 2], sg[None, :, 2]) - np.maximum(sa[:, None, 0], sg[None, :, 0]) + np.float32(1)
+        ih = np.minimum(sa[:, None, 3], sg[None, :, 3]) - np.maximum(sa[:, None, 1], sg[None, :, 1]) + np.float32(1)
+        area_a = (sa[:, 2] - sa[:, 0] + np.float32(1)) * (sa[:, 3] - sa[:, 1] + np.float32(1))
+        area_g = (sg[:, 2] - sg[:, 0] + np.float32(1)) * (sg[:, 3] - sg[:, 1] + np.float32(1))
+        inter = iw * ih
+        iou = np.where((iw > 0) & (ih > 0), inter / (area_a[:, None] + area_g[None] - inter), np.float32(0)).astype(np.float32)
+
+        n_gt = iou.shape[1]
+        best = iou.argmax(0) if n_gt else np.zeros(0, np.int64)
+        best_gt = np.arange(n_gt)
+        has = iou[best, best_gt] > 0 if n_gt else np.zeros(0, bool)
+        best, best_gt = best[has], best_gt[has]
+        thr_a, thr_g = np.where(iou > self.params["target_args"]["pos_threshold"])
+        cand_a = np.concatenate([thr_a, best])
+        cand_g = np.concatenate([thr_g, best_gt])
+        order = np.argsort(cand_a, kind="stable")
+        first = np.ones(len(order), bool)
+        first[1:] = cand_a[order][1:] != cand_a[order][:-1]
+        id_pos, id_pos_gt = cand_a[order][first], cand_g[order][first]
+        id_neg = np.where((iou < self.params["target_args"]["neg_threshold"]).all(1))[0]
+
+        ix, iy, iz = np.unravel_index(id_pos, (*fmap, A))
+        pos[ix, iy, iz] = 1
+        # NOTE: like the reference, the box is looked up in the UNFILTERED gt_box_center by its index among the valid boxes
+        g, a_, d = gt_all[id_pos_gt], an[id_pos], diag[id_pos]
+        targets[ix, iy, iz * 7 + 0] = (g[:, 0] - a_[:, 0]) / d
+        targets[ix, iy, iz * 7 + 1] = (g[:, 1] - a_[:, 1]) / d
+        targets[ix, iy, iz * 7 + 2] = (g[:, 2] - a_[:, 2]) / a_[:, 3]
+        targets[ix, iy, iz * 7 + 3] = np.log(g[:, 3] / a_[:, 3])
+        targets[ix, iy, iz * 7 + 4] = np.log(g[:, 4] / a_[:, 4])
+        targets[ix, iy, iz * 7 + 5] = np.log(g[:, 5] / a_[:, 5])
+        targets[ix, iy, iz * 7 + 6] = g[:, 6] - a_[:, 6]
+        ix, iy, iz = np.unravel_index(id_neg, (*fmap, A))
+        neg[ix, iy, iz] = 1
+        ix, iy, iz = np.unravel_index(best, (*fmap, A))
+        neg[ix, iy, iz] = 0
+        return {"pos_equal_one": pos, "neg_equal_one": neg, "targets": targets}
+
+    # voxel_postprocessor.py:196-229
+    @staticmethod
+    def collate_batch(label_batch_list) -> dict:
+        stack = lambda k: torch.from_numpy(np.array([lab[k] for lab in label_batch_list]))
+        return {"targets": stack("targets"), "pos_equal_one": stack("pos_equal_one"), "neg_equal_one": stack("neg_equal_one")}
 
     # voxel_postprocessor.py:232-352
     def post_process(self, data_dict: dict, output_dict: dict):

@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from . import synthetic as S
+from .postprocess import boxes_to_corners_3d
 
 
 def lidar_model_config(nx: int = 512, ny: int = 512, max_cav: int = 5, window: int = 8, small: bool = False) -> dict:
@@ -55,19 +56,6 @@ def postprocess_params(cfg: dict) -> dict:
             "target_args": {"score_threshold": 0.27, "pos_threshold": 0.6, "neg_threshold": 0.45},
             "anchor_args": {"cav_lidar_range": la["lidar_range"], "W": nx // 2, "H": ny // 2, "vw": 0.4, "vh": 0.4, "vd": 4,
                             "l": 3.9, "w": 1.6, "h": 1.56, "r": [0, 90], "num": 2, "feature_stride": 2}}
-
-
-def boxes_to_corners_3d(boxes: np.ndarray) -> np.ndarray:
-    """(n, 7) [x, y, z, h, w, l, yaw] ('hwl' order) -> (n, 8, 3) corners (box_utils.py:143-190)."""
-    b = boxes.astype(np.float32).copy()
-    b[:, 3:6] = b[:, [5, 4, 3]]
-    template = np.array([[1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, -1], [1, -1, 1], [1, 1, 1], [-1, 1, 1], [-1, -1, 1]],
-                        dtype=np.float32) / 2
-    c = b[:, None, 3:6] * template[None]
-    cosa, sina = np.cos(b[:, 6]), np.sin(b[:, 6])
-    rot = np.zeros((len(b), 3, 3), dtype=np.float32)
-    rot[:, 0, 0] = cosa; rot[:, 0, 1] = sina; rot[:, 1, 0] = -sina; rot[:, 1, 1] = cosa; rot[:, 2, 2] = 1
-    return np.einsum("nkc,ncd->nkd", c, rot) + b[:, None, 0:3]
 
 
 class SyntheticReplayDataset:
@@ -109,7 +97,7 @@ class SyntheticReplayDataset:
             clouds.append(np.concatenate([local, rs.uniform(0, 1, (len(local), 1))], 1).astype(np.float32))
         return {"clouds": clouds, "pairwise_t_matrix": S.pairwise_from_poses(poses, self.cfg["max_cav"])[None],
                 "mode": torch.ones(1, self.cfg["max_cav"], dtype=torch.float64), "record_len": torch.tensor([L]),
-                "object_bbx_corners": boxes_to_corners_3d(boxes)}
+                "object_bbx_corners": boxes_to_corners_3d(boxes), "object_bbx_center_valid": boxes}
 
 
 def inference(model, dataset, pre, post, calibrate_top: int | None = 200, log=None) -> dict:

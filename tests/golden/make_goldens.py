@@ -409,6 +409,46 @@ def g10_postprocess():
     print("g10: boxes", frames[0][0].shape, frames[1][0].shape, "AP", ap)
 
 
+def g17_labels():
+    """Reference VoxelPostprocessor.generate_label; its Cython bbox_overlaps (utils/box_overlaps.pyx, not compiled here) is
+    replaced by a numpy loop with the same arithmetic (float32, + 1 on widths / heights, zero unless both overlaps > 0)."""
+    import re
+    from make_goldens_inputs import label_inputs, label_params
+
+    def bbox_overlaps(boxes, query):
+        out = np.zeros((len(boxes), len(query)), np.float32)
+        for k in range(len(query)):
+            qa = np.float32((query[k, 2] - query[k, 0] + 1) * (query[k, 3] - query[k, 1] + 1))
+            iw = np.minimum(boxes[:, 2], query[k, 2]) - np.maximum(boxes[:, 0], query[k, 0]) + np.float32(1)
+            ih = np.minimum(boxes[:, 3], query[k, 3]) - np.maximum(boxes[:, 1], query[k, 1]) + np.float32(1)
+            ua = (boxes[:, 2] - boxes[:, 0] + 1) * (boxes[:, 3] - boxes[:, 1] + 1) + qa - iw * ih
+            ok = (iw > 0) & (ih > 0)
+            out[ok, k] = (iw * ih / ua)[ok]
+        return out
+
+    gt_line = [l for l in open("/root/reference/opencood/data_utils/datasets/__init__.py") if l.startswith("GT_RANGE")][0]
+    _stub("opencood.visualization"); _stub("opencood.visualization.vis_utils")
+    _stub("opencood.utils.box_overlaps", bbox_overlaps=bbox_overlaps)
+    _stub("cv2"); _stub("mmcv", Config=object, DictAction=object)
+    _stub("opencood.data_utils.datasets", GT_RANGE=json.loads(re.search(r"\[.*?\]", gt_line).group(0)))
+    from opencood.data_utils.post_processor.voxel_postprocessor import VoxelPostprocessor
+    params = label_params()
+    pp = VoxelPostprocessor(params, train=True)
+    anchors = pp.generate_anchor_box()
+    out = {}
+    for tag, seed in (("a", 171), ("b", 172)):
+        gt, mask = label_inputs(seed)
+        lab = pp.generate_label(gt_box_center=gt, anchors=anchors, mask=mask)
+        out.update({f"pos_{tag}": lab["pos_equal_one"].astype(np.uint8), f"neg_{tag}": lab["neg_equal_one"].astype(np.uint8),
+                    f"targets_{tag}": lab["targets"]})
+        print("g17", tag, "positives", int(lab["pos_equal_one"].sum()), "negatives", int(lab["neg_equal_one"].sum()))
+    # the collate of two samples
+    col = pp.collate_batch([{"pos_equal_one": out["pos_a"], "neg_equal_one": out["neg_a"], "targets": out["targets_a"]},
+                            {"pos_equal_one": out["pos_b"], "neg_equal_one": out["neg_b"], "targets": out["targets_b"]}])
+    assert tuple(col["targets"].shape) == (2,) + out["targets_a"].shape
+    save("g17_labels.npz", seeds=np.array([171, 172]), **out)
+
+
 def g11_cross_view():
     """CrossViewAttention + BEVEmbedding.grid of the reference, seeded weights / inputs from oracle/cvt_oracle.py."""
     from oracle import cvt_oracle as CO
@@ -437,6 +477,9 @@ def g11_cross_view():
 if __name__ == "__main__":
     if "g11" in sys.argv[1:]:
         g11_cross_view()
+        sys.exit(0)
+    if "g17" in sys.argv[1:]:
+        g17_labels()
         sys.exit(0)
     if "g16" in sys.argv[1:]:
         g16_fax()

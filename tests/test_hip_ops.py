@@ -112,3 +112,69 @@ def test_warp_and_roi_match_golden(lib):
     assert float((got - g["bilinear"]).abs().max()) < 5e-5
     assert int((roi.reshape(n, H, W).cpu() != g["roi"]).sum()) == 0
     assert float(ainv[0, 6]) == 1.0 and float(ainv[3, 6]) == 0.0   # identity flag
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16", "split"])
+@pytest.mark.parametrize("C,window,partition", [(64, 4, 0), (64, 4, 1), (256, 8, 0), (256, 8, 1), (128, 8, 1)])
+def test_window_attention_operator(lib, precision, C, window, partition):
+    """hmvit_window_attention on its own (the exported operator, not the fused forward): projected Q / K' / V' maps of three
+    agents of mixed types in, attention output of every ego out, against torch fp64 composed from the oracle's warp, ROI mask
+    and window partition (which g1 / g2 pin to the reference): warp the source's K' / V' into the ego's frame, add the
+    projection biases, position bias, -inf on masked keys, one softmax over all agents' keys of the window."""
+    from hmvit_amd import weights
+    from oracle import hmvit_oracle as O
+    L, H, W, E = 3, 16, 24, 2
+    M, d, n = C // 32, 32, window * window
+    modes = [1, 0, 1]
+    cav = [1, 1, 1]
+    g = torch.Generator().manual_seed(7 + C + window + partition)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    q, kv = rn(L, H * W, C) * 0.4, rn(L, E, 2, H * W, C) * 0.4
+    b_q, b_kv = rn(2, C) * 0.1, rn(2, 2, 2 * C) * 0.1
+    table = rn((2 * window - 1) ** 2, M)
+    poses = [O.rigid(0.0, 0.0, 0.0), O.rigid(0.25, 3.0, -2.0), O.rigid(-0.4, -2.5, 1.5)]
+    pw = O.pairwise_from_poses(poses, L)[None].float()                         # (1, L, L, 4, 4)
+    ego_e = [0 if modes[i] == modes[0] else 1 for i in range(L)]              # variant index = order of first appearance
+    variant_type = [modes[0], 1 - modes[0]]
+
+    # ---- reference (fp64) ----
+    idx = O.relative_position_index(window)
+    bias = table.double()[idx].permute(2, 0, 1)                               # (M, n, n)
+    ref = torch.zeros(L, H * W, C, dtype=torch.float64)
+    grid = partition == 1
+    for i in range(L):
+        t_to_i = pw[:, :, i]                                                  # (1, L, 4, 4): source j -> ego i
+        e = ego_e[i]
+        kmap = kv[:, e, 0].reshape(L, H, W, C).permute(0, 3, 1, 2)[None]      # (1, L, C, H, W)
+        vmap = kv[:, e, 1].reshape(L, H, W, C).permute(0, 3, 1, 2)[None]
+        kw = O.warp_agents(kmap, t_to_i, 0.4, 2.0).double() + b_kv[modes[i], modes, :C].double()[None, :, :, None, None]
+        vw = O.warp_agents(vmap, t_to_i, 0.4, 2.0).double() + b_kv[modes[i], modes, C:].double()[None, :, :, None, None]
+        vis = O.roi_and_cav_mask(H, W, torch.tensor([cav], dtype=torch.float32), t_to_i, 0.4, 2.0)   # (1, H, W, 1, L)
+        qi = (q[i].double() + b_q[modes[i]].double()).reshape(1, 1, H, W, C).permute(0, 1, 4, 2, 3)
+        qp = O._partition(qi, window, grid)[0, 0].reshape(-1, n, M, d)                                   # (nW, n, M, d)
+        kp = O._partition(kw, window, grid)[0].reshape(L, -1, n, M, d)
+        vp = O._partition(vw, window, grid)[0].reshape(L, -1, n, M, d)
+        mp = O._partition(vis.permute(0, 4, 3, 1, 2).double(), window, grid)[0].reshape(L, -1, n)        # (L, nW, n)
+        sim = torch.einsum("wqhd,lwkhd->whqlk", qp, kp) + bias[None, :, :, None, :]
+        sim = sim.masked_fill(mp.permute(1, 0, 2)[:, None, None] == 0, float("-inf"))
+        att = torch.softmax(sim.reshape(*sim.shape[:3], -1), dim=-1).reshape(sim.shape)
+        o = torch.einsum("whqlk,lwkhd->wqhd", att, vp)
+        X, Y = H // window, W // window
+        ref[i] = O._unpartition(o.reshape(1, 1, X, Y, window, window, C), grid)[0, 0].permute(1, 2, 0).reshape(H * W, C)
+
+    # ---- operator ----
+    prec = {"f32": lib.PREC_F32, "f16": lib.PREC_F16, "split": lib.PREC_SPLIT}[precision]
+    s = 1.4426950408889634 if precision == "f16" else 1.0                    # the f16 kernels take logits in log2 units
+    dt = torch.float16 if precision == "f16" else torch.float32
+    dq, dkv = (q * s).to(dt).cuda(), kv.to(dt).cuda()
+    frag = (weights.bias_fragments(table, window) * s).cuda()
+    dbq, dbkv = (b_q * s).cuda(), b_kv.cuda()
+    ainv = torch.empty(L * L, 8, device="cuda")
+    lib.check(lib.lib.hmvit_pair_affines(pw.cuda().contiguous().data_ptr(), ainv.data_ptr(), L * L, H, W, 0.4, 2.0, _stream()), "aff")
+    out = torch.zeros(L, H * W, C, device="cuda", dtype=dt)
+    lib.check(lib.lib.hmvit_window_attention(dq.data_ptr(), dkv.data_ptr(), dbq.data_ptr(), dbkv.data_ptr(), frag.data_ptr(),
+                                             ainv.data_ptr(), lib.i32_array(modes), lib.i32_array(cav), lib.i32_array(ego_e),
+                                             out.data_ptr(), 1, L, L, L, E, C, H, W, window, partition, prec, 0, _stream()),
+              "window_attention")
+    err = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < {"f32": 2e-5, "f16": 3e-3, "split": 2e-5}[precision], err

@@ -179,3 +179,30 @@ def test_replay_dataset_and_configs(pkg):
     lo, hi = corners.min(1) - 1e-3, corners.max(1) + 1e-3          # axis-aligned hulls of the boxes
     inside = ((ego[:, None, :] >= lo[None]) & (ego[:, None, :] <= hi[None])).all(-1).any(1)
     assert inside.sum() >= 4 * 150                                  # the 150 surface points of every vehicle
+
+
+def test_generate_label_matches_reference_golden(pkg):
+    """Anchor targets of the train loop (voxel_postprocessor.py:74-194) against g17: the reference's generate_label on seeded
+    boxes (several boxes claim the same anchors; one padded slot), bit-exact masks, targets to float round-off."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_goldens_inputs import label_inputs, label_params
+    from hmvit_amd.postprocess import VoxelPostprocessor
+    g = load_golden("g17_labels.npz")
+    pp = VoxelPostprocessor(label_params(), train=True)
+    anchors = pp.generate_anchor_box()
+    labs = []
+    for tag, seed in (("a", 171), ("b", 172)):
+        gt, mask = label_inputs(seed)
+        lab = pp.generate_label(gt_box_center=gt, anchors=anchors, mask=mask)
+        labs.append(lab)
+        assert np.array_equal(lab["pos_equal_one"], g[f"pos_{tag}"].numpy().astype(np.float64))
+        assert np.array_equal(lab["neg_equal_one"], g[f"neg_{tag}"].numpy().astype(np.float64))
+        assert int(lab["pos_equal_one"].sum()) >= 8
+        np.testing.assert_allclose(lab["targets"], g[f"targets_{tag}"].numpy(), rtol=0, atol=1e-6)
+    col = pp.collate_batch(labs)
+    assert tuple(col["pos_equal_one"].shape) == (2,) + labs[0]["pos_equal_one"].shape
+    # no valid box: every anchor negative, no positives
+    lab = pp.generate_label(gt_box_center=np.zeros((4, 7), np.float32), anchors=anchors, mask=np.zeros(4))
+    assert lab["pos_equal_one"].sum() == 0 and lab["neg_equal_one"].all()

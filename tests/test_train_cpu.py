@@ -129,3 +129,37 @@ def test_two_rank_ddp_averages_gradients_and_tolerates_unused_parameters():
         assert torch.allclose(torch.from_numpy(grad), torch.from_numpy(mean), rtol=1e-6, atol=1e-7), name
         n_used += 1
     assert n_used > 40
+
+
+def test_cosine_schedule_and_checkpoint_naming(tmp_path):
+    """Host logic of the train harness (hm-vit_amd/trainer.py): timm's cosine schedule as train_utils.py:247-264 configures it
+    and the net_epoch%d.pth checkpoint convention of train_camera.py:221-225 / train_utils.py:40-75."""
+    import math
+    import hmvit_amd  # noqa: F401
+    from hmvit_amd import trainer as T
+    lin = torch.nn.Linear(4, 4)
+    hypes = T.default_hypes(epoches=40)
+    opt = T.setup_optimizer(hypes, lin)
+    assert isinstance(opt, torch.optim.AdamW) and opt.defaults["eps"] == 1e-10 and opt.defaults["weight_decay"] == 1e-2
+    n_iter = 5
+    sch = T.setup_lr_schedular(hypes, opt, n_iter)
+    assert opt.param_groups[0]["lr"] == 2e-3                               # starts at warmup_lr
+    sch.step_update(25)                                                    # half-way through the 10-epoch warm-up
+    assert abs(opt.param_groups[0]["lr"] - (2e-3 + 25 * (2e-4 - 2e-3) / 50)) < 1e-12
+    sch.step_update(100)                                                   # cosine phase, t not shifted by the warm-up
+    want = 5e-6 + 0.5 * (2e-4 - 5e-6) * (1 + math.cos(math.pi * 100 / 200))
+    assert abs(opt.param_groups[0]["lr"] - want) < 1e-12
+    sch.step_update(200)
+    assert opt.param_groups[0]["lr"] == 5e-6
+    # checkpoints
+    assert T.load_saved_model(str(tmp_path), lin)[0] == 0
+    T.save_checkpoint(lin, str(tmp_path), 0)
+    with torch.no_grad():
+        lin.weight.add_(1.0)
+    T.save_checkpoint(lin, str(tmp_path), 6)
+    assert sorted(os.listdir(tmp_path)) == ["net_epoch1.pth", "net_epoch7.pth"]
+    fresh = torch.nn.Linear(4, 4)
+    epoch, fresh = T.load_saved_model(str(tmp_path), fresh)
+    assert epoch == 7 and torch.equal(fresh.weight, lin.weight)
+    with pytest.raises(NotImplementedError):
+        T.setup_lr_schedular({"lr_scheduler": {"core_method": "step"}}, opt, 1)

@@ -12,15 +12,15 @@ with torch.no_grad():
     for _ in range(3):
         net(*scene)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 512)()
+buf = (ctypes.c_ulonglong * 1024)()
 fn = _lib.lib.hmvit_debug_x16_trace
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
-assert fn(buf, 512) == 0
-rows = [[buf[i * 8 + k] for k in range(6)] for i in range(64)]
-t0 = rows[0][0]
-print("step  begin   +issue  +mfma  +wait  +barrier   (store)   total")
-for i, r in enumerate(rows[:50]):
-    if r[0] == 0: continue
-    nxt = rows[i + 1][0] if i + 1 < 64 and rows[i + 1][0] else r[4]
-    st = r[5] - r[3] if r[5] else 0
-    print(f"{i:3d} {r[0]-t0:8d} {r[1]-r[0]:7d} {r[2]-r[1]:6d} {r[3]-r[2]:6d} {r[4]-max(r[3], r[5]):8d} {st:9d} {nxt-r[0]:8d}")
+assert fn(buf, 1024) == 0
+t0 = buf[0]
+for grp in (0, 1):
+    rows = [[buf[(grp * 64 + i) * 8 + k] for k in range(6)] for i in range(64)]
+    print(f"group {'AB'[grp]}: step  begin  products  confirm  mid-barrier  rest+request  end-barrier  total")
+    for i, r in enumerate(rows[:50]):
+        if r[0] == 0: continue
+        c2 = r[2] if r[2] else r[1]
+        print(f"{i:3d} {r[0]-t0:8d} {r[1]-r[0]:8d} {c2-r[1]:8d} {r[3]-c2:8d} {r[4]-r[3]:10d} {r[5]-r[4]:10d} {r[5]-r[0]:8d}")
