@@ -18,6 +18,7 @@ PyTorch), the optimiser is ``torch.optim.AdamW`` as in the reference, the gradie
 from __future__ import annotations
 
 import ctypes
+import re
 from typing import Dict, List
 
 import torch
@@ -31,11 +32,27 @@ HEAD_KEYS = ("head_w1", "head_b1", "head_w2", "head_b2")
 N_FOLDED = 2 * len(STAGE_KEYS) + len(HEAD_KEYS)
 
 
-def folded_for_training(module) -> List[torch.Tensor]:
+_TYPED_KEY = re.compile(r"(?:net|_linears)\.(\d)\.")
+
+
+def folded_for_training(module, block_types=None, head_types=None) -> List[torch.Tensor]:
     """The f32 folded tensors of a HeteroFusion module in the order [stage 0 keys, stage 1 keys, head keys] plus the two
-    bias_frag_neg tensors (no gradient), computed from the LIVE parameters (autograd tape kept)."""
+    bias_frag_neg tensors (no gradient), computed from the LIVE parameters (autograd tape kept).
+
+    ``block_types`` / ``head_types``: the agent types whose typed sub-modules the reference would call for this batch - every
+    value in ``mode`` (padding slots included: they carry type 0, ``base_transformer.py:138-177``) for the block, the egos'
+    types for ``mlp_head`` (``bevformer_point_pillar_hetero.py:47-48``).  Parameters of the other type are folded detached,
+    so their ``.grad`` stays ``None`` as it does in the reference (no weight decay on them, "unused" for DDP)."""
     sd = dict(module.named_parameters())
     sd.update(dict(module.named_buffers()))
+    head_prefix = module._head_prefix + "."
+    for k in list(sd):
+        m = _TYPED_KEY.search(k)
+        if m is None:
+            continue
+        live = head_types if k.startswith(head_prefix) else block_types
+        if live is not None and int(m.group(1)) not in live:
+            sd[k] = sd[k].detach()
     blk = module._block_cfg
     out, neg = [], []
     for which in ("window", "grid"):
@@ -146,7 +163,8 @@ def fusion_forward_with_grad(module, x, pairwise_t_matrix, mode, record_len, mas
     mode_h, rl_h, mask_h = module._host_small(mode, record_len, mask)
     if not bool((pw[:, idx, idx] == eye).all()):
         raise ValueError("training expects pairwise_t_matrix[b, i, i] to be the identity (as the dataset builds it)")
-    folded, neg = folded_for_training(module)
+    folded, neg = folded_for_training(module, block_types={int(v) for v in mode_h},
+                                      head_types={int(mode_h[b * L]) for b in range(B)})
     drop_p = float(module._block_cfg["drop_out"]) if module.training else 0.0
     seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if drop_p > 0 else 0
     module.last_dropout = (drop_p, seed)
