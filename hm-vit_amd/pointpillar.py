@@ -91,6 +91,7 @@ class PointPillar(nn.Module):
         self.cls_head = nn.Conv2d(args["cls_head_dim"], args["anchor_number"], kernel_size=1)
         self.reg_head = nn.Conv2d(args["cls_head_dim"], 7 * args["anchor_number"], kernel_size=1)
         self.return_features = False
+        self.trace = None            # a list: forward appends (stage name, f32 copy of the stage's output) - error reports only
         self.precision = precision
         self._prep = None
         self._prep_key = None
@@ -195,6 +196,8 @@ class PointPillar(nn.Module):
                                                   ny, n_agents, self.oob_count.data_ptr(), vs, rng, prec, stream),
                        "hmvit_pfn_scatter")
             x, H, W = canvas, ny, nx
+            note = (lambda name, t: self.trace.append((name, t.float().clone()))) if self.trace is not None else (lambda *a: None)
+            note("pfn+scatter", canvas)
             cat = None
             ctot = sum(d["cout"] for d in prep["deblocks"])
             coff = 0
@@ -205,6 +208,7 @@ class PointPillar(nn.Module):
                     y = torch.empty(n_agents, Ho, Wo, layer["cout"], device=dev, dtype=dt)
                     self._conv(x, layer, n_agents, H, W, y, layer["cout"], 0, True, False, prec, stream)
                     x, H, W = y, Ho, Wo
+                note(f"block{len(layers)}x{layers[-1]['cout']}", x)
                 us = de["us"]
                 if cat is None:
                     cat = torch.empty(n_agents, H * us, W * us, ctot, device=dev, dtype=dt)
@@ -215,6 +219,7 @@ class PointPillar(nn.Module):
                                                  stream), "hmvit_conv2d(deconv)")
                 coff += de["cout"]
             x, H, W, C = cat, Hc, Wc, ctot
+            note("deblocks(concat)", cat)
             convs = [layer for pair in prep["shrink"] for layer in pair]
             tail = convs if self.return_features else convs   # heads read the shrunk map
             for i, layer in enumerate(convs):
@@ -224,6 +229,7 @@ class PointPillar(nn.Module):
                 y = torch.empty(n_agents, Ho, Wo, layer["cout"], device=dev, dtype=torch.float32 if last else dt)
                 self._conv(x, layer, n_agents, H, W, y, layer["cout"], 0, True, last, prec, stream)
                 x, H, W, C = y, Ho, Wo, layer["cout"]
+                note(f"shrink{i}", x)
 
             def to_nchw(t32, ch):
                 out = torch.empty(n_agents, ch, H, W, device=dev, dtype=torch.float32)
