@@ -93,7 +93,13 @@ struct Jobs {
     Jobs(hipStream_t s) : a_f32(false), gelu(false), out_f32(true), st(s) { jobs.n = 0; }
     int flush() {
         if (jobs.n == 0) return HMVIT_OK;
+        // f32 operands and results; the products run as split f16 pairs (gemm.hip k_gemm_split: fp32-class accuracy, ~3x the
+        // rate of the exact-f32 MFMA), -DHMVIT_TRAIN_EXACT_F32 restores the exact-f32 kernel
+#ifdef HMVIT_TRAIN_EXACT_F32
         int rc = launch_gemm(jobs, a_f32, gelu, out_f32, HMVIT_PREC_F32, st);
+#else
+        int rc = launch_gemm(jobs, true, gelu, true, HMVIT_PREC_SPLIT, st);
+#endif
         jobs.n = 0;
         return rc;
     }
@@ -481,18 +487,29 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
             HMVIT_CHECK_HIP(hipMemsetAsync(dkg, 0, (size_t)B * n_ego * pl.max_cav * 2 * me * 4, st));
             HMVIT_TRY(launch_attention_bwd(ab, st));
             // biases are added after the gather: their gradients are column sums over the EGO pixels
+            // (one launch per kMaxColsumJobs maps: 11 maps per ego at five agents)
+            ColsumJobs cs;
+            cs.n = 0;
+            auto colsum = [&](const float* y, float* out) -> int {
+                cs.y[cs.n] = y; cs.out[cs.n] = out;
+                if (++cs.n < kMaxColsumJobs) return HMVIT_OK;
+                const int rc = launch_colsum_jobs(cs, P, C, C, st);
+                cs.n = 0;
+                return rc;
+            };
             for (int b = 0; b < B; ++b)
                 for (int i = 0; i < n_ego; ++i) {
                     const int te = d->mode[b * L + i];
-                    HMVIT_TRY(launch_colsum(T4 + (size_t)(b * L + i) * me, P, C, C, gr.b_q + te * C, st));
+                    HMVIT_TRY(colsum(T4 + (size_t)(b * L + i) * me, gr.b_q + te * C));
                     for (int j = 0; j < pl.max_cav; ++j) {
                         const int ts = d->mode[b * L + j];
                         const float* g2 = dkg + ((size_t)((b * n_ego + i) * pl.max_cav + j) * 2) * me;
                         float* db = gr.b_kv + (size_t)(te * T + ts) * 2 * C;
-                        HMVIT_TRY(launch_colsum(g2, P, C, C, db, st));
-                        HMVIT_TRY(launch_colsum(g2 + me, P, C, C, db + C, st));
+                        HMVIT_TRY(colsum(g2, db));
+                        HMVIT_TRY(colsum(g2 + me, db + C));
                     }
                 }
+            HMVIT_TRY(launch_colsum_jobs(cs, P, C, C, st));
             WarpAdjParams wa;
             memset(&wa, 0, sizeof(wa));
             wa.dkg = dkg; wa.ainv = ainv; wa.dkv = dkv;

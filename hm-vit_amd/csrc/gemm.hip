@@ -166,6 +166,122 @@ __global__ __launch_bounds__(256) void k_gemm(GemmJobs jobs) {
     }
 }
 
+// ---- split mode: f32 a (M, K) and f32 w (N, K), every product as (hi + lo) halves on the f16 pipes ----
+// a w^T = a_hi w_hi + a_lo w_hi + a_hi w_lo (+ 2^-22 relative), f32 accumulate, f32 result.  The slabs are split on the way into
+// LDS (hi = f16(x), lo = f16(x - hi)); same 128 x 128 tile and wave arrangement as above.  Used by the training path
+// (csrc/capi_train.hip), whose operands are f32 activations and f32 master weights.
+__device__ __forceinline__ void stage_slab_split(half_t* __restrict__ lds_hi, half_t* __restrict__ lds_lo, const float* __restrict__ g,
+                                                 int row0, int rows_valid, int ld, int k0) {
+    constexpr int LS = GemmCfg<half_t>::LDS_STRIDE;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = tid + 256 * i, row = c >> 4, kc = (c & 15) * 4;
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + row < rows_valid) f = *reinterpret_cast<const float4*>(g + (size_t)(row0 + row) * ld + k0 + kc);
+        const float v[4] = {f.x, f.y, f.z, f.w};
+        half4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = (half_t)v[e];
+            l[e] = (half_t)(v[e] - (float)h[e]);
+        }
+        *reinterpret_cast<half4*>(lds_hi + row * LS + kc) = h;
+        *reinterpret_cast<half4*>(lds_lo + row * LS + kc) = l;
+    }
+}
+
+template <bool GELU>
+__global__ __launch_bounds__(256) void k_gemm_split(GemmJobs jobs) {
+    constexpr int BK = GemmCfg<half_t>::BK, LS = GemmCfg<half_t>::LDS_STRIDE;
+    __shared__ __attribute__((aligned(16))) half_t Ah[BM * LS], Al[BM * LS], Wh[BN * LS], Wl[BN * LS];
+    const GemmJob& J = jobs.j[blockIdx.y];
+    const int M = J.M, N = J.N, K = J.K;
+    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    const int tile = blockIdx.x;
+    if (tile >= tiles_m * tiles_n) return;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, hi = lane >> 5;
+
+    float16v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        stage_slab_split(Ah, Al, reinterpret_cast<const float*>(J.a), m0, M, K, k0);
+        stage_slab_split(Wh, Wl, reinterpret_cast<const float*>(J.w), n0, N, K, k0);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            half8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int o = (wm * 64 + i * 32 + r) * LS + kk * 16 + hi * 8;
+                ah[i] = *reinterpret_cast<const half8*>(Ah + o);
+                al[i] = *reinterpret_cast<const half8*>(Al + o);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int o = (wn * 64 + j * 32 + r) * LS + kk * 16 + hi * 8;
+                bh[j] = *reinterpret_cast<const half8*>(Wh + o);
+                bl[j] = *reinterpret_cast<const half8*>(Wl + o);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    const int npp = J.n_per_plane;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + r;
+        if (n >= N) continue;
+        const float bias = J.bias ? J.bias[n] : 0.f;
+        const int plane = n / npp, nc = n - plane * npp;
+        const size_t ybase = (size_t)plane * J.plane_stride + nc;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                if (m >= M) continue;
+                float v = acc[i][j][e] + bias;
+                if constexpr (GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+                if (J.residual) v += J.residual[(size_t)m * N + n];
+                reinterpret_cast<float*>(J.y)[ybase + (size_t)m * npp] = v;
+            }
+        }
+    }
+}
+
+static int launch_gemm_split(const GemmJobs& jobs, bool gelu, hipStream_t st) {
+    int max_tiles = 0;
+    for (int i = 0; i < jobs.n; ++i) {
+        const GemmJob& j = jobs.j[i];
+        HMVIT_CHECK_ARG(j.K > 0 && j.K % 64 == 0, "gemm (split): K=%d must be a positive multiple of 64", j.K);
+        max_tiles = max(max_tiles, cdiv(j.M, BM) * cdiv(j.N, BN));
+    }
+    if (jobs.n == 0 || max_tiles == 0) return HMVIT_OK;
+    dim3 grid(max_tiles, jobs.n), block(256);
+    if (gelu) hipLaunchKernelGGL((k_gemm_split<true>), grid, block, 0, st, jobs);
+    else hipLaunchKernelGGL((k_gemm_split<false>), grid, block, 0, st, jobs);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
 template <typename T>
 static int launch_gemm_t(const GemmJobs& jobs, bool a_f32, bool gelu, bool out_f32, hipStream_t st) {
     int max_tiles = 0;
@@ -201,6 +317,10 @@ static int launch_gemm_t(const GemmJobs& jobs, bool a_f32, bool gelu, bool out_f
 int launch_gemm(const GemmJobs& jobs, bool a_f32, bool gelu, bool out_f32, int precision,
                 hipStream_t st) {
     if (precision == HMVIT_PREC_F32) return launch_gemm_t<float>(jobs, a_f32, gelu, out_f32, st);
+    if (precision == HMVIT_PREC_SPLIT) {
+        HMVIT_CHECK_ARG(a_f32 && out_f32, "gemm (split): f32 operands and f32 result only%s", "");
+        return launch_gemm_split(jobs, gelu, st);
+    }
     return launch_gemm_t<half_t>(jobs, a_f32, gelu, out_f32, st);
 }
 

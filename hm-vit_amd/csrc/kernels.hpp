@@ -224,7 +224,14 @@ struct WarpAdjParams {
 };
 int launch_warp_adjoint(const WarpAdjParams& p, hipStream_t st);
 // out[n] += sum_m y[m][n]  (bias gradients), y (M, N) with row stride ld
+constexpr int kMaxColsumJobs = 96;
+struct ColsumJobs {
+    const float* y[kMaxColsumJobs];
+    float* out[kMaxColsumJobs];
+    int n;
+};
 int launch_colsum(const float* y, int M, int N, int ld, float* out, hipStream_t st);
+int launch_colsum_jobs(const ColsumJobs& jobs, int M, int N, int ld, hipStream_t st);
 
 // ---- post.hip (detection post-processing) ----
 struct BoxDecodeParams {

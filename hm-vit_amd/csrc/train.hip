@@ -183,23 +183,54 @@ int launch_gemm_tn(const GemmTnJobs& jobs, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 // column sums (bias gradients)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ y, int M, int N, int ld, float* __restrict__ out) {
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
-    const int m0 = blockIdx.y * 1024, m1 = min(M, m0 + 1024);
-    float s = 0.f;
-    if (c < N)
-        for (int m = m0 + rg; m < m1; m += 4) s += y[(size_t)m * ld + c];
-    red[rg][threadIdx.x & 63] = s;
+// y (M, N) row-major with leading dimension ld (N and ld multiples of 4, rows 16-byte aligned): out[c] += sum_m y[m][c].
+// One workgroup = 64 rows x 256 columns: thread (q = tid & 63, rg = tid >> 6) owns columns 4 q .. 4 q + 3 of rows rg, rg + 4, ...
+// (16 independent 16-byte loads in flight), the four row groups meet in LDS, one atomic add per column and workgroup.
+// (The first version walked 1024 rows per workgroup with one 4-byte load in flight per thread: 64 workgroups, 100 us per
+// 16 MB call, 46 % of the backward pass at 176 calls per step.)
+constexpr int COLSUM_ROWS = 64;
+__global__ __launch_bounds__(256) void k_colsum(ColsumJobs jobs, int M, int N, int ld) {
+    __shared__ float4 red[4][64];
+    const float* __restrict__ y = jobs.y[blockIdx.z];
+    float* __restrict__ out = jobs.out[blockIdx.z];
+    const int q = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + 4 * q;
+    const int m0 = blockIdx.y * COLSUM_ROWS;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < N) {
+        float4 v[COLSUM_ROWS / 4];
+#pragma unroll
+        for (int k = 0; k < COLSUM_ROWS / 4; ++k) {
+            const int m = m0 + rg + 4 * k;
+            v[k] = m < M ? *reinterpret_cast<const float4*>(y + (size_t)m * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < COLSUM_ROWS / 4; ++k) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
+    }
+    red[rg][q] = s;
     __syncthreads();
-    if (rg == 0 && c < N) unsafeAtomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (rg == 0 && c < N) {
+        const float4 a = red[0][q], b = red[1][q], d = red[2][q], e = red[3][q];
+        unsafeAtomicAdd(out + c + 0, (a.x + b.x) + (d.x + e.x));
+        unsafeAtomicAdd(out + c + 1, (a.y + b.y) + (d.y + e.y));
+        unsafeAtomicAdd(out + c + 2, (a.z + b.z) + (d.z + e.z));
+        unsafeAtomicAdd(out + c + 3, (a.w + b.w) + (d.w + e.w));
+    }
 }
 
-int launch_colsum(const float* y, int M, int N, int ld, float* out, hipStream_t st) {
-    if (M <= 0 || N <= 0) return HMVIT_OK;
-    hipLaunchKernelGGL(k_colsum, dim3(cdiv(N, 64), cdiv(M, 1024)), dim3(256), 0, st, y, M, N, ld, out);
+// jobs.n maps of the same (M, N, ld) in one launch (several jobs may add into the same out: atomics)
+int launch_colsum_jobs(const ColsumJobs& jobs, int M, int N, int ld, hipStream_t st) {
+    if (M <= 0 || N <= 0 || jobs.n <= 0) return HMVIT_OK;
+    HMVIT_CHECK_ARG(N % 4 == 0 && ld % 4 == 0, "colsum: N=%d / ld=%d must be multiples of 4", N, ld);
+    for (int i = 0; i < jobs.n; ++i) HMVIT_CHECK_ARG(((size_t)jobs.y[i] & 15) == 0, "colsum: map %d is not 16-byte aligned", i);
+    hipLaunchKernelGGL(k_colsum, dim3(cdiv(N, 256), cdiv(M, COLSUM_ROWS), jobs.n), dim3(256), 0, st, jobs, M, N, ld);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
+}
+int launch_colsum(const float* y, int M, int N, int ld, float* out, hipStream_t st) {
+    ColsumJobs j;
+    j.n = 1; j.y[0] = y; j.out[0] = out;
+    return launch_colsum_jobs(j, M, N, ld, st);
 }
 
 // ------------------------------------------------------------------------------------------
