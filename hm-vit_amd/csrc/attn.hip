@@ -1667,6 +1667,9 @@ __device__ __forceinline__ void pcs_compute_loop(const AttnParams& p, PcSharedS&
                     float* o = outp + (size_t)(row * W + col) * C + head * 32 + 8 * g;
                     *reinterpret_cast<float4*>(o) = make_float4(o_acc[qt][0][0] * inv, o_acc[qt][0][1] * inv, o_acc[qt][0][2] * inv, o_acc[qt][0][3] * inv);
                     *reinterpret_cast<float4*>(o + 4) = make_float4(o_acc[qt][1][0] * inv, o_acc[qt][1][1] * inv, o_acc[qt][1][2] * inv, o_acc[qt][1][3] * inv);
+                    // row log-sum-exp for the backward pass (training forward, same layout as k_attention's)
+                    if (p.lse && g == 0)
+                        p.lse[((size_t)(it.b * L + it.ego) * P + row * W + col) * (C / 32) + head] = m_run[qt] + logf(l_acc[qt][0]);
                 }
             }
             __syncthreads();

@@ -242,7 +242,14 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
         {
             AttnParams ap;
             fill_attn(d, pl, si, s, q, kv, o, lse, ainv, ap);
+            // f32 planes either way; with identity self transforms (descriptor flag, window 8, C >= 128) the persistent
+            // split-operand kernel (fp32-class accuracy, ~3x faster than the one-window-per-workgroup exact-f32 kernel)
+            ap.self_identity = d->self_identity;
+#ifdef HMVIT_TRAIN_EXACT_F32
             HMVIT_TRY(launch_attention(ap, HMVIT_PREC_F32, st));
+#else
+            HMVIT_TRY(launch_attention(ap, HMVIT_PREC_SPLIT, st));
+#endif
         }
         // x' = x + Dropout(a_linears(O)) on the ego slots
         for (int b = 0; b < B; ++b) {

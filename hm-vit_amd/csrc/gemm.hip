@@ -170,16 +170,24 @@ __global__ __launch_bounds__(256) void k_gemm(GemmJobs jobs) {
 // a w^T = a_hi w_hi + a_lo w_hi + a_hi w_lo (+ 2^-22 relative), f32 accumulate, f32 result.  The slabs are split on the way into
 // LDS (hi = f16(x), lo = f16(x - hi)); same 128 x 128 tile and wave arrangement as above.  Used by the training path
 // (csrc/capi_train.hip), whose operands are f32 activations and f32 master weights.
-__device__ __forceinline__ void stage_slab_split(half_t* __restrict__ lds_hi, half_t* __restrict__ lds_lo, const float* __restrict__ g,
-                                                 int row0, int rows_valid, int ld, int k0) {
+// a 128 x 64 f32 slab: 8 float4 per thread, fetched into registers one slab ahead of the products (fetch_slab) and split into
+// the LDS planes at the top of the next iteration (put_slab)
+__device__ __forceinline__ void fetch_slab(float4 (&f)[8], const float* __restrict__ g, int row0, int rows_valid, int ld, int k0) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = tid + 256 * i, row = c >> 4, kc = (c & 15) * 4;
+        f[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + row < rows_valid) f[i] = *reinterpret_cast<const float4*>(g + (size_t)(row0 + row) * ld + k0 + kc);
+    }
+}
+__device__ __forceinline__ void put_slab(half_t* __restrict__ lds_hi, half_t* __restrict__ lds_lo, const float4 (&f)[8]) {
     constexpr int LS = GemmCfg<half_t>::LDS_STRIDE;
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int c = tid + 256 * i, row = c >> 4, kc = (c & 15) * 4;
-        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + row < rows_valid) f = *reinterpret_cast<const float4*>(g + (size_t)(row0 + row) * ld + k0 + kc);
-        const float v[4] = {f.x, f.y, f.z, f.w};
+        const float v[4] = {f[i].x, f[i].y, f[i].z, f[i].w};
         half4 h, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -214,10 +222,19 @@ __global__ __launch_bounds__(256) void k_gemm_split(GemmJobs jobs) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    const float* Ag = reinterpret_cast<const float*>(J.a);
+    const float* Wg = reinterpret_cast<const float*>(J.w);
+    float4 fa[8], fw[8];
+    fetch_slab(fa, Ag, m0, M, K, 0);
+    fetch_slab(fw, Wg, n0, N, K, 0);
     for (int k0 = 0; k0 < K; k0 += BK) {
-        stage_slab_split(Ah, Al, reinterpret_cast<const float*>(J.a), m0, M, K, k0);
-        stage_slab_split(Wh, Wl, reinterpret_cast<const float*>(J.w), n0, N, K, k0);
+        put_slab(Ah, Al, fa);
+        put_slab(Wh, Wl, fw);
         __syncthreads();
+        if (k0 + BK < K) {                      // the next slab travels while this one is multiplied
+            fetch_slab(fa, Ag, m0, M, K, k0 + BK);
+            fetch_slab(fw, Wg, n0, N, K, k0 + BK);
+        }
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             half8 ah[2], al[2], bh[2], bl[2];

@@ -189,23 +189,25 @@ int launch_gemm_tn(const GemmTnJobs& jobs, hipStream_t st) {
 // (The first version walked 1024 rows per workgroup with one 4-byte load in flight per thread: 64 workgroups, 100 us per
 // 16 MB call, 46 % of the backward pass at 176 calls per step.)
 constexpr int COLSUM_ROWS = 64;
-__global__ __launch_bounds__(256) void k_colsum(ColsumJobs jobs, int M, int N, int ld) {
+__global__ __launch_bounds__(256) void k_colsum(ColsumJobs jobs, int M, int N, int ld, int rows_per_wg) {
     __shared__ float4 red[4][64];
     const float* __restrict__ y = jobs.y[blockIdx.z];
     float* __restrict__ out = jobs.out[blockIdx.z];
     const int q = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 256 + 4 * q;
-    const int m0 = blockIdx.y * COLSUM_ROWS;
+    const int m_begin = blockIdx.y * rows_per_wg, m_end = min(M, m_begin + rows_per_wg);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < N) {
-        float4 v[COLSUM_ROWS / 4];
+        for (int m0 = m_begin; m0 < m_end; m0 += COLSUM_ROWS) {
+            float4 v[COLSUM_ROWS / 4];
 #pragma unroll
-        for (int k = 0; k < COLSUM_ROWS / 4; ++k) {
-            const int m = m0 + rg + 4 * k;
-            v[k] = m < M ? *reinterpret_cast<const float4*>(y + (size_t)m * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < COLSUM_ROWS / 4; ++k) {
+                const int m = m0 + rg + 4 * k;
+                v[k] = m < m_end ? *reinterpret_cast<const float4*>(y + (size_t)m * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < COLSUM_ROWS / 4; ++k) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
         }
-#pragma unroll
-        for (int k = 0; k < COLSUM_ROWS / 4; ++k) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
     }
     red[rg][q] = s;
     __syncthreads();
@@ -218,12 +220,18 @@ __global__ __launch_bounds__(256) void k_colsum(ColsumJobs jobs, int M, int N, i
     }
 }
 
-// jobs.n maps of the same (M, N, ld) in one launch (several jobs may add into the same out: atomics)
+// jobs.n maps of the same (M, N, ld) in one launch (several jobs may add into the same out: atomics).  Rows per workgroup:
+// enough workgroups to fill the chip (~4096), few enough that the atomics on the handful of output vectors do not serialise
+// the launch (64 rows per workgroup at cfg2 = 31 M atomics on 2 K addresses: 5 ms per launch for 7.9 GB).
 int launch_colsum_jobs(const ColsumJobs& jobs, int M, int N, int ld, hipStream_t st) {
     if (M <= 0 || N <= 0 || jobs.n <= 0) return HMVIT_OK;
     HMVIT_CHECK_ARG(N % 4 == 0 && ld % 4 == 0, "colsum: N=%d / ld=%d must be multiples of 4", N, ld);
     for (int i = 0; i < jobs.n; ++i) HMVIT_CHECK_ARG(((size_t)jobs.y[i] & 15) == 0, "colsum: map %d is not 16-byte aligned", i);
-    hipLaunchKernelGGL(k_colsum, dim3(cdiv(N, 256), cdiv(M, COLSUM_ROWS), jobs.n), dim3(256), 0, st, jobs, M, N, ld);
+    const int col_tiles = cdiv(N, 256);
+    long long want = (long long)M * jobs.n * col_tiles / 4096;          // rows per workgroup for ~4096 workgroups
+    int rows = (int)((want + COLSUM_ROWS - 1) / COLSUM_ROWS) * COLSUM_ROWS;
+    rows = rows < COLSUM_ROWS ? COLSUM_ROWS : (rows > 4096 ? 4096 : rows);
+    hipLaunchKernelGGL(k_colsum, dim3(col_tiles, cdiv(M, rows), jobs.n), dim3(256), 0, st, jobs, M, N, ld, rows);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }

@@ -73,6 +73,7 @@ def _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, 
     d.heads, d.dim_head = C // blk["dim_head"], blk["dim_head"]
     d.window, d.mlp_dim, d.num_iters = blk["window_size"], blk["mlp_dim"], module.num_iters
     d.precision, d.apply_head, d.skip_masked = _lib.PREC_F32, 1, 1
+    d.self_identity = 1            # checked by fusion_forward_with_grad: pairwise_t_matrix[b, i, i] = I
     d.discrete_ratio, d.downsample_rate = float(module.discrete_ratio), float(module.downsample_rate)
     keep = (_lib.i32_array(mode_h), _lib.i32_array(rl_h), _lib.i32_array(mask_h))
     d.mode, d.record_len, d.cav_mask = keep
