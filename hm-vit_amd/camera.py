@@ -22,7 +22,7 @@ from . import _lib
 from .cvt import BEVEmbedding, CrossViewAttention
 from .decoder import NaiveDecoder
 
-_PREC = {"f32": _lib.PREC_F32, "f16": _lib.PREC_F16}
+_PREC = {"f32": _lib.PREC_F32, "f16": _lib.PREC_F16, "split": _lib.PREC_SPLIT}   # split: f32 maps, convolutions on split-f16 MFMA
 _BLOCKS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3]}
 
 
@@ -31,7 +31,7 @@ def _stream():
 
 
 def _cpad(c: int, prec: int) -> int:
-    q = 32 if prec == _lib.PREC_F32 else 64
+    q = 64 if prec == _lib.PREC_F16 else 32
     return (c + q - 1) // q * q
 
 
@@ -199,7 +199,7 @@ class ResnetEncoder(nn.Module):
         if not input_images.is_cuda:
             raise RuntimeError("hm-vit_amd has no CPU path: pass CUDA tensors")
         prec = _PREC[self.precision]
-        dt = torch.float32 if prec == _lib.PREC_F32 else torch.float16
+        dt = torch.float16 if prec == _lib.PREC_F16 else torch.float32
         prep = self._prep.get(self, prec, lambda: self._build(prec, dt))
         b, l, m, h, w, c = input_images.shape
         x = prep["stem"](input_images.reshape(b * l * m, h, w, c))        # NHWC already
@@ -264,10 +264,10 @@ class CrossViewModule(nn.Module):
             raise RuntimeError("hmvit_amd.CrossViewModule: eval mode only")
         b, l, n = batch["inputs"].shape[:3]
         prec = _PREC[self.precision]
-        dt = torch.float32 if prec == _lib.PREC_F32 else torch.float16
+        dt = torch.float16 if prec == _lib.PREC_F16 else torch.float32
         prep = self._prep.get(self, prec, lambda: self._build(prec, dt))
         for cross_view in self.cross_views:
-            cross_view.cross_attend.precision = self.precision
+            cross_view.cross_attend.precision = "f32" if self.precision == "split" else self.precision   # split: f32 attention, split-operand convolutions
         I_inv = batch["intrinsic"].reshape(b * l, n, 3, 3).float().inverse()      # 3x3 inverses: host-side plumbing, as the reference
         E_inv = batch["extrinsic"].reshape(b * l, n, 4, 4).float()
         x = self.bev_embedding.get_prior().detach().float()[None].repeat(b * l, 1, 1, 1).contiguous()
@@ -307,7 +307,7 @@ class CvtCameraEncoder(nn.Module):
         cam = batch_camera["camera"]
         n_agents = cam.shape[0]
         prec = _PREC[self.precision]
-        dt = torch.float32 if prec == _lib.PREC_F32 else torch.float16
+        dt = torch.float16 if prec == _lib.PREC_F16 else torch.float32
         convs = self._prep.get(self.decoder, prec, lambda: self._build(prec, dt))
         feats = self.encoder(cam[None])
         x = self.cvm({"inputs": cam[None], "intrinsic": batch_camera["intrinsic"][None], "extrinsic": batch_camera["extrinsic"][None],

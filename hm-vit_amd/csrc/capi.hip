@@ -869,7 +869,7 @@ int hmvit_conv2d_ex(const void* x, const void* w, const float* bias, const void*
                     int Cout, int ksize, int stride, int pad, int relu, int upsample2, int out_f32, int precision, void* stream) {
     HMVIT_CHECK_ARG(x && w && y, "conv2d_ex: null pointer");
     HMVIT_CHECK_ARG(!(upsample2 & 1) || (H % 2 == 0 && W % 2 == 0), "conv2d_ex: upsampled size %dx%d must be even", H, W);
-    HMVIT_CHECK_ARG(!(residual && out_f32 && precision != HMVIT_PREC_F32), "conv2d_ex: residual needs the precision's element type");
+    HMVIT_CHECK_ARG(!(residual && out_f32 && precision == HMVIT_PREC_F16), "conv2d_ex: residual needs the precision's element type");
     ConvParams p;
     memset(&p, 0, sizeof(p));
     p.x = x; p.w = w; p.bias = bias; p.y = y;

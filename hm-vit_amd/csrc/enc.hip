@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_pfn_scatter(PfnParams p) {
 int launch_pfn_scatter(const PfnParams& p, int precision, hipStream_t st) {
     if (p.n_pillars <= 0) return HMVIT_OK;
     dim3 grid(cdiv(p.n_pillars, 4)), block(256);
-    if (precision == HMVIT_PREC_F32)
+    if (precision != HMVIT_PREC_F16)                       // f32 canvas for the exact-f32 and the split-operand convolutions
         hipLaunchKernelGGL((k_pfn_scatter<float>), grid, block, 0, st, p);
     else
         hipLaunchKernelGGL((k_pfn_scatter<half_t>), grid, block, 0, st, p);
@@ -124,15 +124,21 @@ __device__ __forceinline__ int conv_row_channel(int rho) {
     return 16 * (q >> 1) + 8 * h + 4 * (q & 1) + e;
 }
 
-template <typename T, int CBN, int CBM>
+// SPLIT (T = float): f32 map, f32 weights, f32 result like the exact-f32 instantiation, but every product runs on the f16 pipes
+// as (hi + lo) halves - x w = x_hi w_hi + x_lo w_hi + x_hi w_lo, f32 accumulate (the scheme of the fusion's split mode, DESIGN
+// 5.0).  A 32-deep K slab is split on its way into LDS: a staged row holds [32 hi | 32 lo | pad] halves, i.e. the f16
+// kernel's 72-half row, so the LDS footprint and the conflict-free fragment reads are the f16 kernel's.
+template <typename T, int CBN, int CBM, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
-    constexpr int BK = ConvCfg<T>::BK, LS = ConvCfg<T>::LS;
+    static_assert(!SPLIT || sizeof(T) == 4, "the split instantiation reads f32 operands");
+    using TL = typename std::conditional<SPLIT, half_t, T>::type;        // LDS element
+    constexpr int BK = ConvCfg<T>::BK, LS = SPLIT ? 72 : ConvCfg<T>::LS;
     constexpr int MI = CBM / 64;         // 32-pixel MFMA tiles per wave (pixel tile of 128 or, for small maps, 64)
     constexpr int RPT = CBM / 32;        // staged A rows per thread (8 chunks per row)
     constexpr int RPW = CBN / 32;        // staged W rows per thread
     constexpr int NJ = CBN / 64;         // 32-channel MFMA tiles per wave
-    __shared__ __attribute__((aligned(16))) T As[2][CBM * LS];
-    __shared__ __attribute__((aligned(16))) T Ws[2][CBN * LS];
+    __shared__ __attribute__((aligned(16))) TL As[2][CBM * LS];
+    __shared__ __attribute__((aligned(16))) TL Ws[2][CBN * LS];
 
     const int M = p.N * p.Ho * p.Wo;
     const int Ncols = p.deconv_s ? p.deconv_s * p.deconv_s * p.Cout : p.Cout;
@@ -250,7 +256,16 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * VE;
-            if constexpr (sizeof(T) == 2) {
+            if constexpr (SPLIT) {
+                half4 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[e] = (half_t)ra[SET][i][e];
+                    l[e] = (half_t)(ra[SET][i][e] - (float)h[e]);
+                }
+                *reinterpret_cast<half4*>(As[buf] + row * LS + kc) = h;
+                *reinterpret_cast<half4*>(As[buf] + row * LS + 32 + kc) = l;
+            } else if constexpr (sizeof(T) == 2) {
                 *reinterpret_cast<half8*>(As[buf] + row * LS + kc) = ra[SET][i];
             } else {
                 float* da = reinterpret_cast<float*>(As[buf]) + row * LS + kc;   // LS = 33 floats: rows are not 16-byte aligned
@@ -261,7 +276,16 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * VE;
-            if constexpr (sizeof(T) == 2) {
+            if constexpr (SPLIT) {
+                half4 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[e] = (half_t)rw[SET][i][e];
+                    l[e] = (half_t)(rw[SET][i][e] - (float)h[e]);
+                }
+                *reinterpret_cast<half4*>(Ws[buf] + row * LS + kc) = h;
+                *reinterpret_cast<half4*>(Ws[buf] + row * LS + 32 + kc) = l;
+            } else if constexpr (sizeof(T) == 2) {
                 *reinterpret_cast<half8*>(Ws[buf] + row * LS + kc) = rw[SET][i];
             } else {
                 float* dw = reinterpret_cast<float*>(Ws[buf]) + row * LS + kc;
@@ -289,7 +313,32 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
         if (k0 + 2 * BK < Ktot) load_slab(k0 + 2 * BK, Same{});
         // D[channel][pixel]: the weights are the A operand, so that an accumulator lane owns one output pixel and
         // runs of 4 consecutive channels (vector stores in the epilogue instead of 2-byte ones)
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                half8 ah[MI], al[MI], bh[NJ], bl[NJ];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const half_t* q = As[PAR] + (wm * (CBM / 2) + i * 32 + r) * LS + kk * 16 + hi * 8;
+                    ah[i] = *reinterpret_cast<const half8*>(q);
+                    al[i] = *reinterpret_cast<const half8*>(q + 32);
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const half_t* q = Ws[PAR] + (wn * (CBN / 2) + j * 32 + r) * LS + kk * 16 + hi * 8;
+                    bh[j] = *reinterpret_cast<const half8*>(q);
+                    bl[j] = *reinterpret_cast<const half8*>(q + 32);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk) {
                 half8 a[MI], b[NJ];
@@ -619,7 +668,7 @@ int launch_maxpool(const void* x, void* y, int N, int H, int W, int C, int ksize
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     const size_t n = (size_t)N * Ho * Wo * (C / 8);
     if (n == 0) return HMVIT_OK;
-    if (precision == HMVIT_PREC_F32)
+    if (precision != HMVIT_PREC_F16)
         hipLaunchKernelGGL((k_maxpool<float>), dim3((unsigned)cdiv((long long)n, 256)), dim3(256), 0, st, (const float*)x, (float*)y, N, H, W, C, Ho, Wo, ksize, stride, pad);
     else
         hipLaunchKernelGGL((k_maxpool<half_t>), dim3((unsigned)cdiv((long long)n, 256)), dim3(256), 0, st, (const half_t*)x, (half_t*)y, N, H, W, C, Ho, Wo, ksize, stride, pad);
@@ -628,7 +677,8 @@ int launch_maxpool(const void* x, void* y, int N, int H, int W, int C, int ksize
 }
 
 int launch_conv(const ConvParams& p, int precision, hipStream_t st) {
-    const int bk = precision == HMVIT_PREC_F32 ? ConvCfg<float>::BK : ConvCfg<half_t>::BK;
+    const bool f32_maps = precision == HMVIT_PREC_F32 || precision == HMVIT_PREC_SPLIT;   // element type of x / w / residual
+    const int bk = f32_maps ? ConvCfg<float>::BK : ConvCfg<half_t>::BK;
     HMVIT_CHECK_ARG(p.rowpack || (p.Cin > 0 && p.Cin % bk == 0), "conv: Cin=%d must be a multiple of %d", p.Cin, bk);
     HMVIT_CHECK_ARG(!p.rowpack || (p.Cin == 4 && (p.KH * 32) % bk == 0 && !p.deconv_s && !p.up2 &&
                                    (p.Ho - 1) * p.stride + p.KH <= p.H && (p.Wo - 1) * p.stride + 8 <= p.W),
@@ -641,13 +691,13 @@ int launch_conv(const ConvParams& p, int precision, hipStream_t st) {
     const int Ncols = p.deconv_s ? p.deconv_s * p.deconv_s * p.Cout : p.Cout;
     const bool narrow = Ncols <= 64;
     {   // the gathers address the input and the weights with 32-bit byte offsets (buffer loads)
-        const size_t es = precision == HMVIT_PREC_F32 ? 4 : 2;
+        const size_t es = f32_maps ? 4 : 2;
         const size_t xb = (size_t)p.N * p.H * p.W * p.Cin * es, wb = (size_t)Ncols * (p.rowpack ? p.KH * 32 : p.KH * p.KW * p.Cin) * es;
         HMVIT_CHECK_ARG(xb < 0xfffffff0ull && wb < 0xfffffff0ull, "conv: input (%zu bytes) or weights (%zu bytes) exceed the 4 GB a launch can address",
                         xb, wb);
     }
     // 3 x 3 / stride 1 / pad 1 in f16: the patch-in-LDS kernel (one fetch per input pixel and channel slab instead of nine)
-    if (precision != HMVIT_PREC_F32 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && !p.deconv_s && !p.rowpack &&
+    if (!f32_maps && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && !p.deconv_s && !p.rowpack &&
         p.Cin % 64 == 0 && p.Cout % 8 == 0 && p.y_coff % 8 == 0 && p.y_ctot % 8 == 0 && p.Ho == p.H && p.Wo == p.W &&
         !p.no_patch && !HMVIT_ENV("HMVIT_CONV_NO_PATCH")) {
         const int tiles = p.N * cdiv(p.Ho, 8) * cdiv(p.Wo, 16);
@@ -663,7 +713,12 @@ int launch_conv(const ConvParams& p, int precision, hipStream_t st) {
     const bool small = cdiv(M, 128) * cdiv(Ncols, narrow ? 64 : 128) < 256;
     dim3 grid(cdiv(M, small ? 64 : 128) * cdiv(Ncols, narrow ? 64 : 128)), block(256);
 #define HMVIT_CONV_CASE(T, N_, M_) hipLaunchKernelGGL((k_conv<T, N_, M_>), grid, block, 0, st, p)
-    if (precision == HMVIT_PREC_F32) {
+    if (precision == HMVIT_PREC_SPLIT) {
+#define HMVIT_CONV_SPLIT(N_, M_) hipLaunchKernelGGL((k_conv<float, N_, M_, true>), grid, block, 0, st, p)
+        if (narrow) { if (small) HMVIT_CONV_SPLIT(64, 64); else HMVIT_CONV_SPLIT(64, 128); }
+        else { if (small) HMVIT_CONV_SPLIT(128, 64); else HMVIT_CONV_SPLIT(128, 128); }
+#undef HMVIT_CONV_SPLIT
+    } else if (precision == HMVIT_PREC_F32) {
         if (narrow) { if (small) HMVIT_CONV_CASE(float, 64, 64); else HMVIT_CONV_CASE(float, 64, 128); }
         else { if (small) HMVIT_CONV_CASE(float, 128, 64); else HMVIT_CONV_CASE(float, 128, 128); }
     } else {

@@ -14,7 +14,7 @@ from torch import nn
 
 from . import _lib
 
-_PREC = {"f32": _lib.PREC_F32, "f16": _lib.PREC_F16}
+_PREC = {"f32": _lib.PREC_F32, "f16": _lib.PREC_F16, "split": _lib.PREC_SPLIT}   # split: f32 maps, convolutions on split-f16 MFMA
 
 
 class NaiveDecoder(nn.Module):
@@ -56,7 +56,7 @@ class NaiveCompressor(nn.Module):
         if self._prep is None:
             self._prep = _Prepared()
         prec = _PREC[self.precision]
-        dt = torch.float32 if prec == _lib.PREC_F32 else torch.float16
+        dt = torch.float16 if prec == _lib.PREC_F16 else torch.float32
         convs = self._prep.get(self, prec, lambda: [_Conv(self.encoder[0], self.encoder[1], prec, dt),
                                                     _Conv(self.decoder[0], self.decoder[1], prec, dt),
                                                     _Conv(self.decoder[3], self.decoder[4], prec, dt)])
@@ -85,7 +85,7 @@ class HeteroDecoder(nn.Module):
         key = (prec, str(device)) + tuple((t.data_ptr(), t._version) for t in tensors)
         if key == self._prep_key:
             return self._prep
-        dt = torch.float32 if prec == _lib.PREC_F32 else torch.float16
+        dt = torch.float16 if prec == _lib.PREC_F16 else torch.float32
 
         def conv(c, bn=None):
             w, b = c.weight.detach().float(), c.bias.detach().float()
@@ -140,7 +140,7 @@ class HeteroDecoder(nn.Module):
                 raise ValueError(f"Mode but be either 1 or 0 but received {v}")
         dev = x.device
         prec = _PREC[self.precision]
-        dt = torch.float32 if prec == _lib.PREC_F32 else torch.float16
+        dt = torch.float16 if prec == _lib.PREC_F16 else torch.float32
         prep = self._prepare(dev, prec)
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         A = self.camera_cls_head.out_channels

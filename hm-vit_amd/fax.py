@@ -282,10 +282,10 @@ class FAXModule(nn.Module):
             raise RuntimeError("hmvit_amd.FAXModule: eval mode only")
         b, l, n = batch["camera"].shape[:3]
         prec = _PREC[self.precision]
-        dt = torch.float32 if prec == _lib.PREC_F32 else torch.float16
+        dt = torch.float16 if prec == _lib.PREC_F16 else torch.float32
         prep = self._prep.get(self, prec, lambda: self._build(prec, dt))
         for cv in self.cross_views:
-            cv.precision = self.precision
+            cv.precision = "f32" if self.precision == "split" else self.precision
         I_inv = batch["intrinsic"].reshape(b * l, n, 3, 3).float().inverse()      # 3x3 inverses: host-side plumbing, as the reference
         E_inv = batch["extrinsic"].reshape(b * l, n, 4, 4).float()
         x = self.bev_embedding.get_prior().detach().float()[None].repeat(b * l, 1, 1, 1).contiguous()
@@ -340,7 +340,7 @@ class FaxCameraEncoder(nn.Module):
             raise NotImplementedError("FaxCameraEncoder serves the HM-ViT camera slot: call set_return_features() first")
         cam = batch_camera["camera"]
         prec = _PREC[self.precision]
-        dt = torch.float32 if prec == _lib.PREC_F32 else torch.float16
+        dt = torch.float16 if prec == _lib.PREC_F16 else torch.float32
         dec = self.decoder.decoder
         convs = self._prep.get(self.decoder, prec, lambda: [_Conv(dec[i], dec[i + 1], prec, dt) for i in range(0, len(dec), 3)])
         feats = self.encoder(cam[:, None])                                          # camera.unsqueeze(1): (N, 1, n, ...)

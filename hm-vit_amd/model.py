@@ -44,9 +44,9 @@ class BevformerPointPillarHetero(nn.Module):
         self.camera_encoder = camera_encoder
         fusion_precision = precision
         if precision in ("split", "mixed"):
-            # the split (hi + lo f16 operand) kernels exist for the fusion; the convolutional encoders / decoder run their
-            # exact-f32 kernels in that mode (their f16 kernels are the 1e-3-class fast mode)
-            precision = "f32"
+            # fp32-parity modes: the convolutional encoders / decoder keep f32 maps and run their convolutions on split-f16
+            # operands too (csrc/enc.hip k_conv<float, ..., SPLIT>); "mixed" only differs inside the fusion
+            precision = "split"
         self.lidar_encoder = PointPillar(config["lidar"], precision=precision)
         self.compression = False
         if config.get("compression", 0) > 0:             # bevformer_point_pillar_hetero.py:69-71 (the shipped yaml uses 0)

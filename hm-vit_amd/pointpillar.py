@@ -20,7 +20,7 @@ from torch import nn
 
 from . import _lib
 
-_PREC = {"f32": _lib.PREC_F32, "f16": _lib.PREC_F16}
+_PREC = {"f32": _lib.PREC_F32, "f16": _lib.PREC_F16, "split": _lib.PREC_SPLIT}   # split: f32 maps, convolutions on split-f16 MFMA
 
 
 def _block(cin, cout, n_layers, stride):
@@ -111,7 +111,7 @@ class PointPillar(nn.Module):
         key = (prec, str(device)) + tuple((t.data_ptr(), t._version) for t in tensors)
         if key == self._prep_key:
             return self._prep
-        dt = torch.float32 if prec == _lib.PREC_F32 else torch.float16
+        dt = torch.float16 if prec == _lib.PREC_F16 else torch.float32
 
         def conv(c, bn=None):
             w = c.weight.detach().float()                       # (Cout, Cin, k, k)
@@ -169,7 +169,7 @@ class PointPillar(nn.Module):
             raise RuntimeError("hmvit_amd.PointPillar folds BatchNorm statistics: call .eval() (inference only)")
         dev = vf.device
         prec = _PREC[self.precision]
-        dt = torch.float32 if prec == _lib.PREC_F32 else torch.float16
+        dt = torch.float16 if prec == _lib.PREC_F16 else torch.float32
         prep = self._prepare(dev, prec)
         nx, ny, nz = [int(v) for v in self.scatter_cfg["grid_size"]]
         assert nz == 1

@@ -55,7 +55,7 @@ def _camera_net(cfg, precision, seed):
     return net.cuda().eval()
 
 
-@pytest.mark.parametrize("precision,tol", [("f32", 3e-4), ("f16", 1e-2)])
+@pytest.mark.parametrize("precision,tol", [("f32", 3e-4), ("split", 3e-4), ("f16", 1e-2)])
 def test_fax_camera_encoder_vs_oracle(precision, tol):
     cfg = FO.make_camera_config(image=64)
     net = _camera_net(cfg, precision, seed=9)

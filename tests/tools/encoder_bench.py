@@ -12,13 +12,13 @@ sd = PO.random_state_dict(args, seed=1)
 vf, vc, vn = PO.synthetic_pillars(n_agents, 20000, nx, ny, args, seed=2)
 batch = {"processed_lidar": {"voxel_features": vf.cuda(), "voxel_coords": vc.cuda(), "voxel_num_points": vn.cuda()},
          "record_len": torch.tensor([n_agents])}
-for prec in ("f16", "f32"):
+for prec in ("f16", "split", "f32"):
     net = hmvit_amd.PointPillar(args, precision=prec)
     net.load_state_dict(sd, strict=False)
     net = net.cuda().eval()
     net.set_return_features()
     y = net(batch); torch.cuda.synchronize()
-    n = 5 if prec == "f16" else 2
+    n = 5 if prec != "f32" else 2
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
