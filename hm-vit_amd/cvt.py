@@ -13,7 +13,6 @@ library's LayerNorm and GEMM kernels (f32; the attention core and its q / k / v 
 from __future__ import annotations
 
 import ctypes
-import weakref
 
 import torch
 from torch import nn
@@ -69,17 +68,15 @@ def _layernorm(x2d, ln: nn.LayerNorm, prec=_F32):
     return y
 
 
-_F16_COPIES = weakref.WeakKeyDictionary()      # parameter -> (data_ptr, _version, (N, K) f16 copy)
-
-
 def _f16_weight(weight, N, K):
-    """The f16 copy of a Linear / 1x1-convolution weight, made once per parameter value: keyed on the parameter object and
-    refreshed when its storage or in-place version counter changes (optimiser step, load_state_dict, .to())."""
-    hit = _F16_COPIES.get(weight)
+    """The f16 copy of a Linear / 1x1-convolution weight, made once per parameter value: kept as an attribute of the parameter
+    object itself (a dictionary keyed by tensors would compare them elementwise) and refreshed when its storage, device or
+    in-place version counter changes (optimiser step, load_state_dict, .to())."""
+    hit = getattr(weight, "_hmvit_f16_copy", None)
     if hit is not None and hit[0] == weight.data_ptr() and hit[1] == weight._version and hit[2].device == weight.device:
         return hit[2]
     w2 = weight.detach().reshape(N, K).to(torch.float16).contiguous()
-    _F16_COPIES[weight] = (weight.data_ptr(), weight._version, w2)
+    weight._hmvit_f16_copy = (weight.data_ptr(), weight._version, w2)
     return w2
 
 
