@@ -258,6 +258,11 @@ class CrossViewModule(nn.Module):
                  for b in layer] for layer in self.layers]
 
     def forward(self, batch):
+        from .cvt import split_linears
+        with split_linears(self.precision == "split"):      # f32 Linears on split-f16 operands in the fp32-parity fast mode
+            return self._forward(batch)
+
+    def _forward(self, batch):
         """batch: 'inputs' (b, l, n, ...) only for its leading shape, 'intrinsic' (b, l, n, 3, 3), 'extrinsic' (b, l, n, 4, 4),
         'features': list of (b, l, n, C, h, w).  Returns (b, l, dim, H, W)."""
         if self.training:

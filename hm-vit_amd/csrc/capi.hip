@@ -788,7 +788,7 @@ int hmvit_linear(const void* a, const void* w, const float* bias, const float* r
     GemmJob& j = jobs.j[0];
     j.a = a; j.w = w; j.bias = bias; j.residual = residual; j.y = y;
     j.M = M; j.N = N; j.K = K; j.n_per_plane = N; j.plane_stride = 0;
-    return launch_gemm(jobs, false, gelu != 0, out_f32 != 0, precision, reinterpret_cast<hipStream_t>(stream));
+    return launch_gemm(jobs, precision == HMVIT_PREC_SPLIT, gelu != 0, out_f32 != 0, precision, reinterpret_cast<hipStream_t>(stream));
 }
 
 int hmvit_pair_affines(const float* pairwise_t, float* ainv, int n, int H, int W, float discrete_ratio,

@@ -12,6 +12,7 @@ library's LayerNorm and GEMM kernels (f32; the attention core and its q / k / v 
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 
 import torch
@@ -94,13 +95,30 @@ def _linear_f16(x2d, weight, bias=None, residual=None, gelu=False, out_f32=False
     return y
 
 
+_SPLIT_LINEARS = [False]
+
+
+@contextlib.contextmanager
+def split_linears(enabled: bool):
+    """Inside the block the f32 Linears of this module family (``_linear``) run their products on split-f16 operands
+    (HMVIT_PREC_SPLIT: f32 in, f32 out, fp32-class accuracy, the f16 matrix pipes) instead of the exact-f32 MFMA; set by the
+    camera encoders for ``precision="split"``."""
+    old = _SPLIT_LINEARS[0]
+    _SPLIT_LINEARS[0] = bool(enabled)
+    try:
+        yield
+    finally:
+        _SPLIT_LINEARS[0] = old
+
+
 def _linear(x2d, weight, bias=None, residual=None, gelu=False):
     M, K = x2d.shape
     N = weight.shape[0]
     y = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
     w2 = weight.reshape(N, K).contiguous()
+    prec = _lib.PREC_SPLIT if (_SPLIT_LINEARS[0] and K % 64 == 0) else _F32
     _lib.check(_lib.lib.hmvit_linear(x2d.data_ptr(), w2.data_ptr(), _ptr(bias), _ptr(residual), y.data_ptr(), M, N, K,
-                                     1 if gelu else 0, 1, _F32, _stream()), "linear")
+                                     1 if gelu else 0, 1, prec, _stream()), "linear")
     return y
 
 

@@ -278,6 +278,11 @@ class FAXModule(nn.Module):
                           "c": _Conv(d[0][5], d[0][6], prec, dt)} for d in self.downsample_layers]}
 
     def forward(self, batch):
+        from .cvt import split_linears
+        with split_linears(self.precision == "split"):      # f32 Linears on split-f16 operands in the fp32-parity fast mode
+            return self._forward(batch)
+
+    def _forward(self, batch):
         if self.training:
             raise RuntimeError("hmvit_amd.FAXModule: eval mode only")
         b, l, n = batch["camera"].shape[:3]

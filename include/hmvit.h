@@ -40,7 +40,10 @@ extern "C" {
                                 three MFMAs per product, f32 accumulate; Q / K' / V' / O planes are f32.  Reads the
                                 fragment images of HMVIT_PREC_F16 with, per k-step, the hi fragment followed by the lo
                                 fragment (twice the size; weights.py weight_image(split=True)); w_q / b_q / bias_frag carry
-                                no log2(e) factor.  Held to the f32 tolerance (1e-4) by the parity tests. */
+                                no log2(e) factor.  Held to the f32 tolerance (1e-4) by the parity tests.
+                                In the single operators: hmvit_conv2d / _ex / _rowpack take f32 maps and f32 weights (exactly the
+                                HMVIT_PREC_F32 layouts) and split each K slab on the way into LDS; hmvit_linear needs f32 a / w / y
+                                (out_f32 = 1); hmvit_pfn_scatter / hmvit_maxpool2d treat it as HMVIT_PREC_F32 (f32 maps). */
 #define HMVIT_PREC_MIXED 3   /* HMVIT_PREC_SPLIT arithmetic in every Linear / FFN / LayerNorm / residual (the token chains), but the
                                 attention operands Q / K' / V' / O are stored as f16 planes and the f16 attention kernels run on
                                 them (f32 accumulate and softmax): half the attention's HBM traffic.  C = 256 only (other widths

@@ -85,6 +85,29 @@ def test_linear(lib, prec, M, N, K, gelu, res, out_f32):
     assert rel_max_err(y.double(), ref) < tol
 
 
+@pytest.mark.parametrize("M,N,K", [(200, 192, 64), (1000, 768, 256), (129, 130, 128)])
+@pytest.mark.parametrize("gelu,res", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_linear_split(lib, M, N, K, gelu, res):
+    """HMVIT_PREC_SPLIT: f32 operands and result, products as (hi + lo) f16 halves - held to fp32 round-off class."""
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") / K ** 0.5
+    bias = torch.randn(N, device="cuda")
+    r = torch.randn(M, N, device="cuda") if res else None
+    y = torch.empty(M, N, device="cuda")
+    lib.check(lib.lib.hmvit_linear(a.data_ptr(), w.data_ptr(), bias.data_ptr(), r.data_ptr() if res else None, y.data_ptr(),
+                                   M, N, K, gelu, 1, lib.PREC_SPLIT, _stream()), "linear")
+    ref = a.double() @ w.double().t() + bias.double()
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    if res:
+        ref = ref + r.double()
+    assert rel_max_err(y.double(), ref) < 4e-6
+    with pytest.raises(ValueError):          # f16 result is not offered in this mode
+        lib.check(lib.lib.hmvit_linear(a.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), M, N, K, 0, 0, lib.PREC_SPLIT,
+                                       _stream()), "linear")
+
+
 def test_linear_rejects_bad_k(lib):
     a = torch.zeros(8, 48, device="cuda")
     with pytest.raises(ValueError):
