@@ -864,13 +864,20 @@ __device__ __forceinline__ float quad_sum(float v) { return xor32_sum(xor16_sum(
 // the lone wave's 48 products still took ~1120 cycles (projection chunk) / ~1640 (W_2 slice), i.e. the dependent accumulator is
 // not what holds them above the 48 x 17 cycles of bare back-to-back MFMAs; neither is the fragment prefetch depth (8 / 12 / 16
 // measured equal).  What remains is the issue of the 32 ds_read_b128 of a chunk between the products.)
+// HMVIT_X16_REFILL_LAG: after the products of fragment f the ring slot of fragment f - LAG is refilled (0: the slot just
+// consumed).  Measured 0 / 1 / 2: tails 5.25 / 5.21 / 5.16 ms - the refill does not wait on the MFMA that read the slot.
+#ifndef HMVIT_X16_REFILL_LAG
+#define HMVIT_X16_REFILL_LAG 0
+#endif
 // fragment f of a chunk: hi fragments feed two MFMAs (x a_lo, x a_hi), lo fragments one (x a_hi)
 // NT16 = 2: projection chunk, fragment f = (row tile f / 16, k-step (f % 16) / 2, half f & 1), accumulators acc[2]
 template <int DEPTH, bool HAS_LO, int f = 0>
 struct MmaProj16 {
     static __device__ __forceinline__ void run(float4v (&acc)[2], unsigned addr, const half8 (&ah)[8], const half8 (&al)[8], half8 (&w)[DEPTH]) {
         constexpr int F = 32, T = f / 16, s = (f % 16) / 2;
-        constexpr int outstanding = (F - f - 1) < (DEPTH - 1) ? (F - f - 1) : (DEPTH - 1);
+        constexpr int LAG = HMVIT_X16_REFILL_LAG;             // the slot refilled after fragment f is the one fragment f - LAG used
+        constexpr int issued = (DEPTH + (f > LAG ? f - LAG : 0)) < F ? (DEPTH + (f > LAG ? f - LAG : 0)) : F;
+        constexpr int outstanding = issued - (f + 1);
         lgkm_wait<outstanding>();
         if constexpr ((f & 1) == 0) {
             if constexpr (HAS_LO) acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[f % DEPTH], al[s], acc[T], 0, 0, 0);
@@ -878,9 +885,9 @@ struct MmaProj16 {
         } else {
             acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[f % DEPTH], ah[s], acc[T], 0, 0, 0);
         }
-        if constexpr (f + DEPTH < F) {
+        if constexpr (f >= LAG && f - LAG + DEPTH < F) {
             __builtin_amdgcn_sched_barrier(0);
-            lds_read_frag<(f + DEPTH) * 1024>(w[f % DEPTH], addr);
+            lds_read_frag<(f - LAG + DEPTH) * 1024>(w[(f - LAG) % DEPTH], addr);
         }
         if constexpr (f + 1 < F) MmaProj16<DEPTH, HAS_LO, f + 1>::run(acc, addr, ah, al, w);
     }
@@ -907,7 +914,9 @@ template <int DEPTH, int f = 0>
 struct MmaSlice16 {
     static __device__ __forceinline__ void run(float4v (&xacc)[16], unsigned addr, const half8& hh, const half8& hl, half8 (&w)[DEPTH]) {
         constexpr int F = 32, T = f / 2;
-        constexpr int outstanding = (F - f - 1) < (DEPTH - 1) ? (F - f - 1) : (DEPTH - 1);
+        constexpr int LAG = HMVIT_X16_REFILL_LAG;
+        constexpr int issued = (DEPTH + (f > LAG ? f - LAG : 0)) < F ? (DEPTH + (f > LAG ? f - LAG : 0)) : F;
+        constexpr int outstanding = issued - (f + 1);
         lgkm_wait<outstanding>();
         if constexpr ((f & 1) == 0) {
             xacc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[f % DEPTH], hl, xacc[T], 0, 0, 0);
@@ -915,9 +924,9 @@ struct MmaSlice16 {
         } else {
             xacc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[f % DEPTH], hh, xacc[T], 0, 0, 0);
         }
-        if constexpr (f + DEPTH < F) {
+        if constexpr (f >= LAG && f - LAG + DEPTH < F) {
             __builtin_amdgcn_sched_barrier(0);
-            lds_read_frag<(f + DEPTH) * 1024>(w[f % DEPTH], addr);
+            lds_read_frag<(f - LAG + DEPTH) * 1024>(w[(f - LAG) % DEPTH], addr);
         }
         if constexpr (f + 1 < F) MmaSlice16<DEPTH, f + 1>::run(xacc, addr, hh, hl, w);
     }

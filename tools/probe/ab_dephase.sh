@@ -8,9 +8,10 @@ run() {  # $1 = label, $2 = extra flags
 import json,sys; r=json.loads(sys.stdin.read()); print('$1', '$p', round(r['ms_per_step'],3), {k:v['ms_total'] for k,v in r['phases'].items()})"
   done
 }
-run dephase_d8 ""
-timeout 900 python -m pytest tests/test_hip_fusion.py -x -q -k "(split or mixed) and (g4 or g5 or full_size or native or sweep or batch2)" 2>&1 | tail -3
-run dephase_d12 "-DHMVIT_X16_DEPTH=12"
-run dephase_d16 "-DHMVIT_X16_DEPTH=16"
-run inphase_d12 "-DHMVIT_X16_DEPHASE=0 -DHMVIT_X16_DEPTH=12"
-run inphase_d8 "-DHMVIT_X16_DEPHASE=0"
+run lag0 ""
+timeout 900 python -m pytest tests/test_hip_fusion.py -x -q -k "(split or mixed) and (g4 or g5 or full_size or native)" 2>&1 | tail -2
+run lag1 "-DHMVIT_X16_REFILL_LAG=1"
+timeout 900 python -m pytest tests/test_hip_fusion.py -x -q -k "(split or mixed) and (g4 or g5 or full_size or native)" 2>&1 | tail -2
+run lag2 "-DHMVIT_X16_REFILL_LAG=2"
+run lag2_d12 "-DHMVIT_X16_REFILL_LAG=2 -DHMVIT_X16_DEPTH=12"
+run lag1_inphase "-DHMVIT_X16_REFILL_LAG=1 -DHMVIT_X16_DEPHASE=0"
