@@ -119,6 +119,19 @@ def test_fusion_vs_oracle_native_window8(precision, modes, n_valid):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("H,W", [(24, 40), (8, 24)])
+def test_fusion_ragged_token_count(precision, H, W):
+    """Maps whose token count is not a multiple of the chain kernels' 128-token workgroups (960 = 7.5 workgroups, 192 = 1.5):
+    the last workgroup runs with empty wavefronts (the vmcnt bookkeeping of the split kernels takes its conservative path)."""
+    cfg = O.make_config(256, 8, 3, voxel=0.4, downsample=4)
+    sd = O.random_state_dict(cfg, seed=23)
+    scene = O.synthetic_scene(3, 256, H, W, [1, 0, 1], n_valid=3, seed=12, tx_step=5.0, ty_step=-3.0)
+    ref = O.hetero_fusion(*scene, sd, cfg)
+    y = _fusion(cfg, sd, precision)(*_cuda(*scene)).cpu()
+    assert rel_max_err(y, ref) < TOL[precision]
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
 def test_fusion_parallel_mode_vs_oracle(precision):
     """architect_mode='parallel' (SplitAttn merge), 2 iterations, mixed types, window 8."""
     cfg = O.make_config(256, 8, 4, voxel=0.4, downsample=4, arch="parallel")
