@@ -164,6 +164,140 @@ __global__ __launch_bounds__(256) void k_gemm_tn(GemmTnJobs jobs) {
     if (do_bias && tid < 128 && n0 + tid < J.N) unsafeAtomicAdd(J.dbias + n0 + tid, colsum);
 }
 
+// The same product on the f16 pipes (split operands, fp32-class accuracy; -DHMVIT_TRAIN_EXACT_F32 keeps k_gemm_tn): the
+// contraction index of v_mfma_f32_32x32x16_f16 must run along an operand's 8-half register, so the slabs are staged
+// TRANSPOSED - LDS row = column of dY (or of A), 32 tokens per row as (hi, lo) planes.  A thread fetches two consecutive token
+// rows of four columns and writes four 32-bit (token pair) words per plane; 16-byte blocks of a row are XOR-swizzled with
+// the row index so that the 64 lanes of a store hit 32 banks twice (free) instead of 4 banks sixteen times.
+constexpr int TS_BM = 32, TS_LS = 40;      // tokens per slab, halves per LDS row (32 + padding: 80-byte rows keep 16-byte alignment)
+
+__device__ __forceinline__ int ts_addr(int row, int token) {       // half index of (row, token) in a transposed plane
+    const int blk = (token >> 3) ^ ((row >> 4) & 3);
+    return row * TS_LS + blk * 8 + (token & 7);
+}
+
+__global__ __launch_bounds__(256) void k_gemm_tn_split(GemmTnJobs jobs) {
+    __shared__ __attribute__((aligned(16))) half_t Dh[128 * TS_LS], Dl[128 * TS_LS], Ah[128 * TS_LS], Al[128 * TS_LS];
+    __shared__ float red[16][128];
+    const GemmTnJob& J = jobs.j[blockIdx.z];
+    const int tiles_k = (J.K + 127) / 128, tiles_n = (J.N + 127) / 128;
+    if ((int)blockIdx.x >= tiles_k * tiles_n) return;
+    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
+    const int n0 = tn * 128, k0 = tk * 128;
+    const int m_begin = blockIdx.y * TN_ROWS;
+    if (m_begin >= J.M) return;
+    const int m_end = min(J.M, m_begin + TN_ROWS);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wn = wave >> 1, wk = wave & 1, r = lane & 31, hi = lane >> 5;
+
+    float16v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const bool do_bias = J.dbias != nullptr && tk == 0;
+    float4 bsum[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+
+    // item = tid + 256 i: token pair (item >> 5), column group item & 31 (columns 4 cg .. 4 cg + 3)
+    float4 fd[2][2], fa[2][2];
+    auto fetch = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int item = tid + 256 * i, pr = item >> 5, cg = item & 31;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int m = m0 + 2 * pr + t;
+                fd[i][t] = fa[i][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < m_end) {
+                    if (n0 + 4 * cg < J.N) fd[i][t] = *reinterpret_cast<const float4*>(J.dy + (size_t)m * J.ld_dy + n0 + 4 * cg);
+                    if (k0 + 4 * cg < J.K) fa[i][t] = *reinterpret_cast<const float4*>(J.a + (size_t)m * J.ld_a + k0 + 4 * cg);
+                }
+            }
+        }
+    };
+    auto put_plane = [&](half_t* ph, half_t* pl, const float4& x0, const float4& x1, int pr, int cg) {
+        const float v0[4] = {x0.x, x0.y, x0.z, x0.w}, v1[4] = {x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const half_t h0 = (half_t)v0[e], h1 = (half_t)v1[e];
+            half2v hh, ll;
+            hh[0] = h0; hh[1] = h1;
+            ll[0] = (half_t)(v0[e] - (float)h0); ll[1] = (half_t)(v1[e] - (float)h1);
+            const int o = ts_addr(4 * cg + e, 2 * pr);
+            *reinterpret_cast<half2v*>(ph + o) = hh;
+            *reinterpret_cast<half2v*>(pl + o) = ll;
+        }
+    };
+    fetch(m_begin);
+    for (int m0 = m_begin; m0 < m_end; m0 += TS_BM) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int item = tid + 256 * i, pr = item >> 5, cg = item & 31;
+            put_plane(Dh, Dl, fd[i][0], fd[i][1], pr, cg);
+            put_plane(Ah, Al, fa[i][0], fa[i][1], pr, cg);
+            if (do_bias) {
+                bsum[i].x += fd[i][0].x + fd[i][1].x; bsum[i].y += fd[i][0].y + fd[i][1].y;
+                bsum[i].z += fd[i][0].z + fd[i][1].z; bsum[i].w += fd[i][0].w + fd[i][1].w;
+            }
+        }
+        __syncthreads();
+        if (m0 + TS_BM < m_end) fetch(m0 + TS_BM);        // the next slab travels during the products
+#pragma unroll
+        for (int kk = 0; kk < TS_BM / 16; ++kk) {
+            half8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int o = ts_addr(wn * 64 + i * 32 + r, kk * 16 + hi * 8);
+                ah[i] = *reinterpret_cast<const half8*>(Dh + o);
+                al[i] = *reinterpret_cast<const half8*>(Dl + o);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int o = ts_addr(wk * 64 + j * 32 + r, kk * 16 + hi * 8);
+                bh[j] = *reinterpret_cast<const half8*>(Ah + o);
+                bl[j] = *reinterpret_cast<const half8*>(Al + o);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = k0 + wk * 64 + j * 32 + r;
+            if (k >= J.K) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wn * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                if (n < J.N) unsafeAtomicAdd(J.dw + (size_t)n * J.K + k, acc[i][j][e]);
+            }
+        }
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int item = tid + 256 * i, pr = item >> 5, cg = item & 31;
+            *reinterpret_cast<float4*>(&red[pr][4 * cg]) = bsum[i];
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < J.N) {
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sum += red[q][tid];
+            unsafeAtomicAdd(J.dbias + n0 + tid, sum);
+        }
+    }
+}
+
 int launch_gemm_tn(const GemmTnJobs& jobs, hipStream_t st) {
     if (jobs.n == 0) return HMVIT_OK;
     int max_tiles = 0, max_slices = 0;
@@ -175,7 +309,11 @@ int launch_gemm_tn(const GemmTnJobs& jobs, hipStream_t st) {
         max_slices = max(max_slices, cdiv(j.M, TN_ROWS));
     }
     if (max_tiles == 0 || max_slices == 0) return HMVIT_OK;
+#ifdef HMVIT_TRAIN_EXACT_F32
     hipLaunchKernelGGL(k_gemm_tn, dim3(max_tiles, max_slices, jobs.n), dim3(256), 0, st, jobs);
+#else
+    hipLaunchKernelGGL(k_gemm_tn_split, dim3(max_tiles, max_slices, jobs.n), dim3(256), 0, st, jobs);
+#endif
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }
