@@ -23,7 +23,8 @@ from .cvt import BEVEmbedding, CrossViewAttention
 from .decoder import NaiveDecoder
 
 _PREC = {"f32": _lib.PREC_F32, "f16": _lib.PREC_F16, "split": _lib.PREC_SPLIT}   # split: f32 maps, convolutions on split-f16 MFMA
-_BLOCKS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3]}
+_BLOCKS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3], 50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
+_EXPANSION = {18: 1, 34: 1, 50: 4, 101: 4, 152: 4}      # BasicBlock / Bottleneck (resnet_ms.py:27-31)
 
 
 def _stream():
@@ -151,6 +152,24 @@ class _BasicBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
 
 
+class _BottleneckBlock(nn.Module):
+    """torchvision ``Bottleneck`` of the ResNet-50 / 101 / 152 trunks: 1x1 (-> planes) - 3x3 with the stride (the "v1.5"
+    placement torchvision has used since 0.3) - 1x1 (-> 4 planes), identity or 1x1-strided downsample, ReLU after the sum."""
+
+    def __init__(self, cin, planes, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if stride != 1 or cin != planes * 4:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4))
+
+
 class _ResNet(nn.Module):
     def __init__(self, num_layers):
         super().__init__()
@@ -162,8 +181,13 @@ class _ResNet(nn.Module):
         for li, (nb, co) in enumerate(zip(_BLOCKS[num_layers], (64, 128, 256, 512))):
             blocks = []
             for bi in range(nb):
-                blocks.append(_BasicBlock(cin, co, 2 if (li > 0 and bi == 0) else 1))
-                cin = co
+                stride = 2 if (li > 0 and bi == 0) else 1
+                if _EXPANSION[num_layers] == 1:
+                    blocks.append(_BasicBlock(cin, co, stride))
+                    cin = co
+                else:
+                    blocks.append(_BottleneckBlock(cin, co, stride))
+                    cin = 4 * co
             setattr(self, f"layer{li + 1}", nn.Sequential(*blocks))
 
 
@@ -172,13 +196,15 @@ class ResnetEncoder(nn.Module):
         super().__init__()
         self.num_layers = params["num_layers"]
         if self.num_layers not in _BLOCKS:
-            raise ValueError(f"{self.num_layers} is not a valid number of resnet layers (18 / 34: BasicBlock ResNets are built)")
+            raise ValueError("{} is not a valid number of resnet layers".format(self.num_layers))       # resnet_ms.py:33-36
         self.idx_pick = params["id_pick"]
         self.encoder = _ResNet(self.num_layers)
         self.precision = precision
         self._prep = _Prepared()
         ih, iw = params["image_height"], params["image_width"]
-        self.output_shapes = [torch.Size([1, 1, 1, c, ih // s, iw // s]) for c, s in ((64, 4), (128, 8), (256, 16), (512, 32))]
+        ex = _EXPANSION[self.num_layers]
+        self.channels = [64 * ex, 128 * ex, 256 * ex, 512 * ex]
+        self.output_shapes = [torch.Size([1, 1, 1, c, ih // s, iw // s]) for c, s in zip(self.channels, (4, 8, 16, 32))]
         if isinstance(self.idx_pick, list):
             self.output_shapes = [self.output_shapes[i] for i in self.idx_pick]
 
@@ -189,6 +215,7 @@ class ResnetEncoder(nn.Module):
             blocks = []
             for blk in getattr(e, f"layer{li + 1}"):
                 blocks.append({"c1": _Conv(blk.conv1, blk.bn1, prec, dt), "c2": _Conv(blk.conv2, blk.bn2, prec, dt),
+                               "c3": _Conv(blk.conv3, blk.bn3, prec, dt) if hasattr(blk, "conv3") else None,
                                "down": _Conv(blk.downsample[0], blk.downsample[1], prec, dt) if blk.downsample is not None else None})
             prep["layers"].append(blocks)
         return prep
@@ -212,8 +239,11 @@ class ResnetEncoder(nn.Module):
         for li, blocks in enumerate(prep["layers"]):
             for blk in blocks:
                 idt = blk["down"](x, relu=False) if blk["down"] is not None else x
-                x = blk["c2"](blk["c1"](x), relu=True, residual=idt)
-            c_real = (64, 128, 256, 512)[li]
+                if blk["c3"] is None:
+                    x = blk["c2"](blk["c1"](x), relu=True, residual=idt)
+                else:
+                    x = blk["c3"](blk["c2"](blk["c1"](x)), relu=True, residual=idt)
+            c_real = self.channels[li]
             f = _to_nchw(x, c_real)
             outs.append(f.reshape(b, l, m, *f.shape[1:]))
         return [outs[i] for i in self.idx_pick] if isinstance(self.idx_pick, list) else outs[self.idx_pick]

@@ -20,7 +20,8 @@ from torch import Tensor
 
 from . import cvt_oracle as CO
 
-_BLOCKS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3]}
+_BLOCKS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3], 50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
+_EXPANSION = {18: 1, 34: 1, 50: 4, 101: 4, 152: 4}
 
 
 def _bn(x, sd, p, eps=1e-5):
@@ -38,8 +39,14 @@ def resnet_features(images: Tensor, sd: Dict[str, Tensor], num_layers: int, pref
             q = f"{p}.layer{li + 1}.{bi}"
             stride = 2 if (li > 0 and bi == 0) else 1
             idt = x
-            y = F.relu(_bn(F.conv2d(x, sd[f"{q}.conv1.weight"], stride=stride, padding=1), sd, f"{q}.bn1"))
-            y = _bn(F.conv2d(y, sd[f"{q}.conv2.weight"], padding=1), sd, f"{q}.bn2")
+            if _EXPANSION[num_layers] == 4:
+                # torchvision Bottleneck (published definition, v1.5: the stride sits on the 3x3 convolution)
+                y = F.relu(_bn(F.conv2d(x, sd[f"{q}.conv1.weight"]), sd, f"{q}.bn1"))
+                y = F.relu(_bn(F.conv2d(y, sd[f"{q}.conv2.weight"], stride=stride, padding=1), sd, f"{q}.bn2"))
+                y = _bn(F.conv2d(y, sd[f"{q}.conv3.weight"]), sd, f"{q}.bn3")
+            else:
+                y = F.relu(_bn(F.conv2d(x, sd[f"{q}.conv1.weight"], stride=stride, padding=1), sd, f"{q}.bn1"))
+                y = _bn(F.conv2d(y, sd[f"{q}.conv2.weight"], padding=1), sd, f"{q}.bn2")
             if f"{q}.downsample.0.weight" in sd:
                 idt = _bn(F.conv2d(x, sd[f"{q}.downsample.0.weight"], stride=stride), sd, f"{q}.downsample.1")
             x = F.relu(y + idt)
@@ -139,6 +146,14 @@ def random_state_dict(cfg: dict, seed: int = 0) -> Dict[str, Tensor]:
     for li, (nb, co) in enumerate(zip(_BLOCKS[cfg["encoder"]["num_layers"]], (64, 128, 256, 512))):
         for bi in range(nb):
             q = f"encoder.encoder.layer{li + 1}.{bi}"
+            if _EXPANSION[cfg["encoder"]["num_layers"]] == 4:
+                conv(f"{q}.conv1", co, cin, 1); bn(f"{q}.bn1", co)
+                conv(f"{q}.conv2", co, co, 3); bn(f"{q}.bn2", co)
+                conv(f"{q}.conv3", 4 * co, co, 1); bn(f"{q}.bn3", 4 * co)
+                if bi == 0:
+                    conv(f"{q}.downsample.0", 4 * co, cin, 1); bn(f"{q}.downsample.1", 4 * co)
+                cin = 4 * co
+                continue
             conv(f"{q}.conv1", co, cin, 3); bn(f"{q}.bn1", co)
             conv(f"{q}.conv2", co, co, 3); bn(f"{q}.bn2", co)
             if bi == 0 and (li > 0):
