@@ -206,8 +206,10 @@ def main(argv=None):
     if args.stub:
         dev = torch.device("cpu")
     else:
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
+        # one GPU per rank; on a box with fewer GPUs than ranks (the 1-GPU rehearsal `--gpus 2 --backend gloo`) ranks share devices
+        local_dev = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_dev)
+        dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
