@@ -126,16 +126,18 @@ def load_saved_model(saved_path: str, model):
     return initial, model
 
 
-def init_distributed_mode() -> dict:
-    """multi_gpu_utils.py:16-37 for a torchrun launch on one node; rendezvous on 127.0.0.1 unless the launcher says otherwise."""
+def init_distributed_mode(backend: str = "nccl") -> dict:
+    """multi_gpu_utils.py:16-37 for a torchrun launch on one node; rendezvous on 127.0.0.1 unless the launcher says otherwise.
+    ``backend="gloo"`` with more ranks than GPUs (ranks then share devices) is the 1-GPU rehearsal of the loop; "nccl" is RCCL."""
     if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
         return {"distributed": False, "rank": 0, "world_size": 1, "gpu": 0}
     import torch.distributed as dist
     rank, world, gpu = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", 0))
+    gpu %= max(1, torch.cuda.device_count())
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     torch.cuda.set_device(gpu)
-    dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+    dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
     dist.barrier()
     return {"distributed": True, "rank": rank, "world_size": world, "gpu": gpu}
 
@@ -248,11 +250,12 @@ def main(argv=None):
                     help="do NOT freeze the LiDAR encoder (raises: the encoder kernels have no backward pass)")
     ap.add_argument("--model_dir", default=None, help="folder with net_epoch%%d.pth to resume from / save into")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("hm-vit_amd has no CPU path: this needs an MI355X")
-    info = init_distributed_mode()
+    info = init_distributed_mode(args.backend)
     hypes = default_hypes(args.epochs)
     cfg, model, pre, post, ds = build(args)
     init_epoch = 0
