@@ -14,7 +14,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMVIT_LIB", os.path.join(_HERE, "libhmvit.so"))   # HMVIT_LIB: ablation builds of tools/probe
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 PREC_F32, PREC_F16, PREC_SPLIT, PREC_MIXED = 0, 1, 2, 3
 PART_WINDOW, PART_GRID = 0, 1
 NUM_TYPES = 2
@@ -79,6 +79,10 @@ _SIGNATURES = {
     "hmvit_fusion_backward": (C.c_int, [C.POINTER(FusionTrainDesc), C.c_void_p, C.c_void_p, C.POINTER(StageGrads)] +
                               [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]),
     "hmvit_dropout_mask": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_float, C.c_void_p]),
+    "hmvit_gemm_tn": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
+    "hmvit_bn_train_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "hmvit_bn_train_apply": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "hmvit_bn_train_backward": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hmvit_nchw_to_tokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hmvit_tokens_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hmvit_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p, C.c_void_p, C.c_void_p, C.c_int,

@@ -610,6 +610,44 @@ int hmvit_dropout_mask(float* mask, size_t n, uint64_t seed, uint32_t salt, floa
     return launch_dropout_mask(mask, n, c, reinterpret_cast<hipStream_t>(stream));
 }
 
+int hmvit_gemm_tn(const float* dy, const float* a, float* dw, float* dbias, int M, int N, int K, int ld_dy, int ld_a, void* stream) {
+    HMVIT_CHECK_ARG(dy && a && dw && M > 0 && N > 0 && K > 0 && ld_dy >= N && ld_a >= K, "gemm_tn: bad argument");
+    GemmTnJobs jobs;
+    jobs.n = 1;
+    GemmTnJob& j = jobs.j[0];
+    j.dy = dy; j.a = a; j.dw = dw; j.dbias = dbias; j.M = M; j.N = N; j.K = K; j.ld_dy = ld_dy; j.ld_a = ld_a;
+    return launch_gemm_tn(jobs, reinterpret_cast<hipStream_t>(stream));
+}
+
+int hmvit_bn_train_stats(const float* x, float* sums, int M, int C, void* stream) {
+    HMVIT_CHECK_ARG(x && sums, "bn_train_stats: null pointer");
+    BnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.out = sums; a.M = M; a.C = C;
+    return launch_bn(a, 0, 0, reinterpret_cast<hipStream_t>(stream));
+}
+
+int hmvit_bn_train_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,
+                         int M, int C, int relu, void* stream) {
+    HMVIT_CHECK_ARG(x && mean && rstd && gamma && beta && y, "bn_train_apply: null pointer");
+    BnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.out = y; a.M = M; a.C = C; a.relu = relu;
+    return launch_bn(a, 0, 1, reinterpret_cast<hipStream_t>(stream));
+}
+
+int hmvit_bn_train_backward(const float* x, const float* y, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                            float* sums, float* dx, int M, int C, int relu, void* stream) {
+    HMVIT_CHECK_ARG(x && dy && mean && rstd && gamma && sums && dx && (y || !relu), "bn_train_backward: null pointer");
+    BnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.y = y; a.dy = dy; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.M = M; a.C = C; a.relu = relu;
+    a.out = sums;
+    HMVIT_TRY(launch_bn(a, 1, 0, reinterpret_cast<hipStream_t>(stream)));
+    a.sums = sums; a.out = dx;
+    return launch_bn(a, 1, 1, reinterpret_cast<hipStream_t>(stream));
+}
+
 #ifdef HMVIT_PROBE
 int hmvit_debug_x16_trace(unsigned long long* host, int n) { return hmvit::debug_x16_trace(host, n); }
 #endif

@@ -232,6 +232,20 @@ struct ColsumJobs {
 };
 int launch_colsum(const float* y, int M, int N, int ld, float* out, hipStream_t st);
 int launch_colsum_jobs(const ColsumJobs& jobs, int M, int N, int ld, hipStream_t st);
+// training-mode BatchNorm (+ ReLU) on (M, C) maps: csrc/train.hip k_bn_reduce / k_bn_apply
+struct BnArgs {
+    const float* x;        // (M, C) pre-normalisation values
+    const float* y;        // (M, C) forward output (backward: the ReLU mask), or null without ReLU
+    const float* dy;       // (M, C) backward only
+    const float* mean;     // (C)
+    const float* rstd;     // (C)
+    const float* gamma;    // (C)
+    const float* beta;     // (C) forward only
+    const float* sums;     // (2 C) backward apply: sum g, sum g xhat
+    float* out;            // reduce: (2 C) accumulated;  apply: (M, C)
+    int M, C, relu;
+};
+int launch_bn(const BnArgs& a, int bwd, int apply, hipStream_t st);
 
 // ---- post.hip (detection post-processing) ----
 struct BoxDecodeParams {

@@ -380,6 +380,121 @@ int launch_colsum(const float* y, int M, int N, int ld, float* out, hipStream_t 
 }
 
 // ------------------------------------------------------------------------------------------
+// BatchNorm2d in training mode (batch statistics) fused with ReLU, on NHWC maps viewed as (M = N H W, C): the normalisation of
+// the detection tail's convolution blocks when the model trains (naive_decoder.py:45-54 under nn.Module.train()).
+//   forward   sums[c] += sum_m x, sums[C + c] += sum_m x^2          (k_bn_reduce<0>)
+//             y = relu(gamma (x - mean) rstd + beta)                 (k_bn_apply<0>)
+//   backward  g = dy [y > 0];  sums[c] += sum g, sums[C + c] += sum g xhat          (k_bn_reduce<1>)
+//             dx = gamma rstd (g - sums[c] / M - xhat sums[C + c] / M)              (k_bn_apply<1>)
+// Same blocking as k_colsum (64 rows x 256 channels per pass, rows per workgroup scaled to the launch).
+// ------------------------------------------------------------------------------------------
+
+template <int BWD>
+__global__ __launch_bounds__(256) void k_bn_reduce(BnArgs a, int rows_per_wg) {
+    __shared__ float4 red[2][4][64];
+    const int q = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + 4 * q;
+    const int m_begin = blockIdx.y * rows_per_wg, m_end = min(a.M, m_begin + rows_per_wg);
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < a.C) {
+        float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {1.f, 1.f, 1.f, 1.f};
+        if (BWD) {
+            const float4 m4 = *reinterpret_cast<const float4*>(a.mean + c), r4 = *reinterpret_cast<const float4*>(a.rstd + c);
+            mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w; rs[0] = r4.x; rs[1] = r4.y; rs[2] = r4.z; rs[3] = r4.w;
+        }
+        for (int m = m_begin + rg; m < m_end; m += 4) {
+            const size_t o = (size_t)m * a.C + c;
+            const float4 xv = *reinterpret_cast<const float4*>(a.x + o);
+            const float x[4] = {xv.x, xv.y, xv.z, xv.w};
+            if (BWD) {
+                const float4 dv = *reinterpret_cast<const float4*>(a.dy + o);
+                float g[4] = {dv.x, dv.y, dv.z, dv.w};
+                if (a.relu) {
+                    const float4 yv = *reinterpret_cast<const float4*>(a.y + o);
+                    const float y[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = y[e] > 0.f ? g[e] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s0[e] += g[e]; s1[e] = fmaf(g[e], (x[e] - mu[e]) * rs[e], s1[e]); }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s0[e] += x[e]; s1[e] = fmaf(x[e], x[e], s1[e]); }
+            }
+        }
+    }
+    red[0][rg][q] = make_float4(s0[0], s0[1], s0[2], s0[3]);
+    red[1][rg][q] = make_float4(s1[0], s1[1], s1[2], s1[3]);
+    __syncthreads();
+    if (rg < 2 && c < a.C) {
+        const float4 p0 = red[rg][0][q], p1 = red[rg][1][q], p2 = red[rg][2][q], p3 = red[rg][3][q];
+        float* o = a.out + rg * a.C + c;
+        unsafeAtomicAdd(o + 0, (p0.x + p1.x) + (p2.x + p3.x));
+        unsafeAtomicAdd(o + 1, (p0.y + p1.y) + (p2.y + p3.y));
+        unsafeAtomicAdd(o + 2, (p0.z + p1.z) + (p2.z + p3.z));
+        unsafeAtomicAdd(o + 3, (p0.w + p1.w) + (p2.w + p3.w));
+    }
+}
+
+template <int BWD>
+__global__ __launch_bounds__(256) void k_bn_apply(BnArgs a) {
+    const size_t n4 = (size_t)a.M * a.C / 4;
+    const float inv_m = 1.f / (float)a.M;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % (size_t)a.C);
+        const float4 xv = reinterpret_cast<const float4*>(a.x)[i];
+        const float4 m4 = *reinterpret_cast<const float4*>(a.mean + c), r4 = *reinterpret_cast<const float4*>(a.rstd + c);
+        const float4 g4 = *reinterpret_cast<const float4*>(a.gamma + c);
+        const float x[4] = {xv.x, xv.y, xv.z, xv.w}, mu[4] = {m4.x, m4.y, m4.z, m4.w}, rs[4] = {r4.x, r4.y, r4.z, r4.w};
+        const float ga[4] = {g4.x, g4.y, g4.z, g4.w};
+        float r[4];
+        if (BWD) {
+            const float4 dv = reinterpret_cast<const float4*>(a.dy)[i];
+            float g[4] = {dv.x, dv.y, dv.z, dv.w};
+            if (a.relu) {
+                const float4 yv = reinterpret_cast<const float4*>(a.y)[i];
+                const float y[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = y[e] > 0.f ? g[e] : 0.f;
+            }
+            const float4 sb = *reinterpret_cast<const float4*>(a.sums + c), sg = *reinterpret_cast<const float4*>(a.sums + a.C + c);
+            const float db[4] = {sb.x, sb.y, sb.z, sb.w}, dg[4] = {sg.x, sg.y, sg.z, sg.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = ga[e] * rs[e] * (g[e] - db[e] * inv_m - (x[e] - mu[e]) * rs[e] * dg[e] * inv_m);
+        } else {
+            const float4 b4 = *reinterpret_cast<const float4*>(a.beta + c);
+            const float be[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                r[e] = fmaf((x[e] - mu[e]) * rs[e], ga[e], be[e]);
+                if (a.relu) r[e] = fmaxf(r[e], 0.f);
+            }
+        }
+        reinterpret_cast<float4*>(a.out)[i] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+int launch_bn(const BnArgs& a, int bwd, int apply, hipStream_t st) {
+    if (a.M <= 0 || a.C <= 0) return HMVIT_OK;
+    HMVIT_CHECK_ARG(a.C % 4 == 0, "batch norm: C=%d must be a multiple of 4", a.C);
+    if (apply) {
+        const size_t n4 = (size_t)a.M * a.C / 4;
+        const int blocks = (int)((n4 + 255) / 256 < 16384 ? (n4 + 255) / 256 : 16384);
+        if (bwd) hipLaunchKernelGGL((k_bn_apply<1>), dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_bn_apply<0>), dim3(blocks), dim3(256), 0, st, a);
+    } else {
+        const int col_tiles = cdiv(a.C, 256);
+        long long want = (long long)a.M * col_tiles / 2048;
+        int rows = (int)((want + 63) / 64) * 64;
+        rows = rows < 64 ? 64 : (rows > 8192 ? 8192 : rows);
+        if (bwd) hipLaunchKernelGGL((k_bn_reduce<1>), dim3(col_tiles, cdiv(a.M, rows)), dim3(256), 0, st, a, rows);
+        else hipLaunchKernelGGL((k_bn_reduce<0>), dim3(col_tiles, cdiv(a.M, rows)), dim3(256), 0, st, a, rows);
+    }
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // LayerNorm backward
 // ------------------------------------------------------------------------------------------
 constexpr int LNB_TOK = 16;   // tokens per wavefront

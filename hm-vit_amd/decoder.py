@@ -103,25 +103,40 @@ class HeteroDecoder(nn.Module):
         self._prep, self._prep_key = prep, key
         return prep
 
-    def _forward_training(self, x, mode):
-        """Training mode (``train_camera.py:163-199``): BatchNorm works on batch statistics and updates its running buffers, and
-        the tail needs gradients - neither exists in the folded inference kernels, and the tail has no HIP backward (it lies
-        outside SURVEY 8(a)'s path).  The layers are ordinary torch modules with the reference's parameter names, so in training
-        they are simply applied in the reference's order (``hetero_decoder.py:55-89``, ``naive_decoder.py:80-92`` with
-        ``use_upsample=False``) under torch autograd; ``.eval()`` switches back to the HIP kernels."""
+    def _forward_training(self, x, mode, torch_modules: bool = False):
+        """Training mode (``train_camera.py:163-199``): BatchNorm works on batch statistics and updates its running buffers,
+        and the tail needs gradients.  The layers are applied in the reference's order (``hetero_decoder.py:55-89``,
+        ``naive_decoder.py:80-92`` with ``use_upsample=False``) through hm-vit_amd/tail_train.py: every convolution, the
+        batch-statistics reductions, the normalisation and all their adjoints are libhmvit kernels behind
+        ``torch.autograd.Function``s (f32 maps, split-f16 products); the parameters stay the reference's ``nn.Module``
+        parameters.  ``torch_modules=True`` applies the modules themselves instead (the tests' reference for this path).
+        ``.eval()`` switches back to the folded inference kernels."""
+        from . import tail_train as TT
         ego = [int(v) for v in (mode[:, 0].tolist() if mode.device.type == "cpu" else mode[:, 0].cpu().tolist())]
         for v in ego:
             if v not in (0, 1):
                 raise ValueError(f"Mode but be either 1 or 0 but received {v}")
+        if x.device.type != "cuda":
+            raise RuntimeError("hm-vit_amd runs on the GPU only (HIP kernels, no CPU fallback)")
         psm, rm = [None] * len(ego), [None] * len(ego)
         for v, name in ((0, "camera"), (1, "lidar")):
             idx = [b for b, e in enumerate(ego) if e == v]
             if not idx:
                 continue
+            layers = getattr(self, f"{name}_decoder").decoder
+            cls_head, reg_head = getattr(self, f"{name}_cls_head"), getattr(self, f"{name}_reg_head")
             t = x[idx, 0]                                  # (n, C, H, W): all egos of this type share the BatchNorm batch
-            for layer in getattr(self, f"{name}_decoder").decoder:
-                t = layer(t)
-            p, r = getattr(self, f"{name}_cls_head")(t), getattr(self, f"{name}_reg_head")(t)
+            if torch_modules:
+                for layer in layers:
+                    t = layer(t)
+                p, r = cls_head(t), reg_head(t)
+            else:
+                t = t.float().permute(0, 2, 3, 1).contiguous()            # NHWC
+                for k in range(0, len(layers), 3):                          # [Conv2d 3x3, BatchNorm2d, ReLU] blocks
+                    conv, bn = layers[k], layers[k + 1]
+                    t = TT.bn_relu_module(TT.Conv3x3.apply(t, conv.weight, conv.bias), bn)
+                p = TT.Conv1x1.apply(t, cls_head.weight, cls_head.bias).permute(0, 3, 1, 2)
+                r = TT.Conv1x1.apply(t, reg_head.weight, reg_head.bias).permute(0, 3, 1, 2)
             for k, b in enumerate(idx):
                 psm[b], rm[b] = p[k], r[k]
         return torch.stack(psm, dim=0), torch.stack(rm, dim=0)

@@ -21,8 +21,8 @@ What it mirrors, piece by piece (citations into /root/reference/opencood):
 
 What trains on which code: the fusion (the hot path) runs its HIP forward AND backward kernels (hm-vit_amd/train.py); the frozen
 LiDAR encoder runs its HIP inference kernels (``fix_lidar_backbone``, the reference's own option; un-frozen encoders raise);
-the detection tail (``HeteroDecoder``: four 3x3 convolutions + BatchNorm in batch-statistics mode + two 1x1 heads) has no HIP
-backward and trains through torch's own modules - it is the part of the model outside SURVEY 8(a)'s path.
+the detection tail (``HeteroDecoder``: four 3x3 convolutions + BatchNorm in batch-statistics mode + ReLU + two 1x1 heads) runs
+HIP forward and backward kernels as well (hm-vit_amd/tail_train.py).
 
     python -m hmvit_amd.trainer --epochs 2 --frames 8                      (one GPU)
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m hmvit_amd.trainer --epochs 2

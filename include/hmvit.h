@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HMVIT_ABI_VERSION 7
+#define HMVIT_ABI_VERSION 8
 
 #define HMVIT_OK 0
 #define HMVIT_EINVAL (-22)   /* bad argument / unsupported shape */
@@ -236,6 +236,24 @@ int hmvit_fusion_backward(const HmvitFusionTrainDesc* desc, const float* d_out, 
                           float* d_head_w1, float* d_head_b1, float* d_head_w2, float* d_head_b2, void* workspace,
                           size_t workspace_bytes, void* stream);
 int hmvit_dropout_mask(float* mask, size_t n, uint64_t seed, uint32_t salt, float p, void* stream);
+
+/* ---- training-mode operators of the detection tail (hetero_decoder.py:7-89 / naive_decoder.py:45-54 under train()) ---- */
+
+/* Weight / bias gradient of a Linear or of one tap of a convolution: dw (N, K) += dy^T a, dbias (N) += column sums of dy
+ * (dbias may be NULL).  dy (M, N) with row stride ld_dy, a (M, K) with row stride ld_a, f32; N, K, ld multiples of 4; the
+ * products run on split-f16 operands (fp32-class accuracy).  dw / dbias are ACCUMULATED into (atomics). */
+int hmvit_gemm_tn(const float* dy, const float* a, float* dw, float* dbias, int M, int N, int K, int ld_dy, int ld_a, void* stream);
+
+/* nn.BatchNorm2d on batch statistics + ReLU over NHWC maps viewed as (M = N H W, C), C % 4 == 0, f32:
+ *   stats:    sums[c] += sum_m x[m][c], sums[C + c] += sum_m x[m][c]^2   (zero-fill sums first; the caller forms mean / rstd)
+ *   apply:    y = relu?(gamma (x - mean) rstd + beta)
+ *   backward: g = dy [y > 0] (relu) or dy; sums[c] += sum g = dbeta, sums[C + c] += sum g xhat = dgamma (zero-fill first);
+ *             dx = gamma rstd (g - dbeta / M - xhat dgamma / M) */
+int hmvit_bn_train_stats(const float* x, float* sums, int M, int C, void* stream);
+int hmvit_bn_train_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,
+                         int M, int C, int relu, void* stream);
+int hmvit_bn_train_backward(const float* x, const float* y, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                            float* sums, float* dx, int M, int C, int relu, void* stream);
 
 /* ---- single operators (used by the parity tests; same kernels as the fused forward) ---- */
 

@@ -46,9 +46,53 @@ def test_train_loop_learns_saves_and_resumes(tmp_path):
         out = model(batch)
         x, mask = hmvit_amd.model.regroup(model.lidar_encoder(model._lidar_batch(batch, torch.ones(3, dtype=torch.int))), [3], 3)
         fused = model.fusion_net(x, batch["pairwise_t_matrix"], batch["mode"].int(), batch["record_len"], mask)
-        ref_psm, ref_rm = model.decoder._forward_training(fused.unsqueeze(1), torch.ones(1, 3, dtype=torch.int))
+        ref_psm, ref_rm = model.decoder._forward_training(fused.unsqueeze(1), torch.ones(1, 3, dtype=torch.int), torch_modules=True)
     assert float((out["psm"] - ref_psm).abs().max() / ref_psm.abs().max()) < 1e-4
     assert float((out["rm"] - ref_rm).abs().max() / ref_rm.abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("modes", [[[1, 1], [1, 0]], [[0, 1], [1, 1], [0, 0]]])
+def test_tail_training_kernels_match_torch_modules(modes):
+    """The detection tail in training mode on libhmvit (conv3x3 / BatchNorm on batch statistics + ReLU / 1x1 heads, forward and
+    backward, hm-vit_amd/tail_train.py) against the same torch modules under torch autograd: outputs, input gradient, every
+    parameter gradient and the running statistics."""
+    import copy
+    import hmvit_amd
+    from oracle import decoder_oracle as DO
+    torch.manual_seed(5)
+    params = DO.make_params()
+    net = hmvit_amd.HeteroDecoder(params, precision="split")
+    net.load_state_dict(DO.random_state_dict(params, 31), strict=True)
+    net = net.cuda().train()
+    ref = copy.deepcopy(net)
+    B = len(modes)
+    mode = torch.tensor(modes)
+    x = torch.randn(B, 1, 256, 12, 10, device="cuda")
+    gp, gr = torch.randn(B, 2, 12, 10, device="cuda"), torch.randn(B, 14, 12, 10, device="cuda")
+    outs = []
+    for m, torch_modules in ((net, False), (ref, True)):
+        xi = x.clone().requires_grad_(True)
+        psm, rm = m._forward_training(xi, mode, torch_modules=torch_modules)
+        ((psm * gp).sum() + (rm * gr).sum()).backward()
+        outs.append((psm.detach(), rm.detach(), xi.grad))
+    err = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+    assert err(outs[0][0], outs[1][0]) < 1e-4 and err(outs[0][1], outs[1][1]) < 1e-4
+    assert err(outs[0][2], outs[1][2]) < 2e-4
+    used = 0
+    # a convolution bias in front of a BatchNorm has a gradient that is zero in exact arithmetic (the batch mean absorbs it):
+    # round-off noise on both sides, held to 1e-3 of the model's largest gradient instead of to its own magnitude
+    gmax = max(float(q.grad.abs().max()) for q in ref.parameters() if q.grad is not None)
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        if q.grad is None:
+            assert p.grad is None, k
+            continue
+        used += 1
+        scale = max(float(q.grad.abs().max()), 1e-3 * gmax)
+        e = float((p.grad - q.grad).abs().max()) / scale
+        assert e < 5e-4, (k, e)
+    assert used >= 12
+    for (k, a), (_, b) in zip(net.named_buffers(), ref.named_buffers()):
+        assert err(a.float(), b.float()) < 1e-5 if a.is_floating_point() else bool((a == b).all()), k
 
 
 def test_unfrozen_encoder_raises():
