@@ -51,6 +51,23 @@ def test_train_loop_learns_saves_and_resumes(tmp_path):
     assert float((out["rm"] - ref_rm).abs().max() / ref_rm.abs().max()) < 1e-4
 
 
+def _tail_reference(dec, x, modes):
+    """hetero_decoder.py:55-89 with use_upsample=False on the module's own layers (any device / dtype)."""
+    ego = [m[0] for m in modes]
+    psm, rm = [None] * len(ego), [None] * len(ego)
+    for v, name in ((0, "camera"), (1, "lidar")):
+        idx = [b for b, e in enumerate(ego) if e == v]
+        if not idx:
+            continue
+        t = x[idx, 0]
+        for layer in getattr(dec, f"{name}_decoder").decoder:
+            t = layer(t)
+        p, r = getattr(dec, f"{name}_cls_head")(t), getattr(dec, f"{name}_reg_head")(t)
+        for k, b in enumerate(idx):
+            psm[b], rm[b] = p[k], r[k]
+    return torch.stack(psm), torch.stack(rm)
+
+
 @pytest.mark.parametrize("modes", [[[1, 1], [1, 0]], [[0, 1], [1, 1], [0, 0]]])
 def test_tail_training_kernels_match_torch_modules(modes):
     """The detection tail in training mode on libhmvit (conv3x3 / BatchNorm on batch statistics + ReLU / 1x1 heads, forward and
@@ -63,21 +80,36 @@ def test_tail_training_kernels_match_torch_modules(modes):
     params = DO.make_params()
     net = hmvit_amd.HeteroDecoder(params, precision="split")
     net.load_state_dict(DO.random_state_dict(params, 31), strict=True)
+    # reference: the same torch modules in float64 on the CPU (the GPU library convolutions behind torch are free to pick
+    # reduced-precision algorithms, which made a float32 GPU reference flaky at the 1e-3 level)
+    ref = copy.deepcopy(net).double().train()
     net = net.cuda().train()
-    ref = copy.deepcopy(net)
     B = len(modes)
     mode = torch.tensor(modes)
-    x = torch.randn(B, 1, 256, 12, 10, device="cuda")
-    gp, gr = torch.randn(B, 2, 12, 10, device="cuda"), torch.randn(B, 14, 12, 10, device="cuda")
+    x = torch.randn(B, 1, 256, 12, 10)
+    gp, gr = torch.randn(B, 2, 12, 10), torch.randn(B, 14, 12, 10)
     outs = []
-    for m, torch_modules in ((net, False), (ref, True)):
-        xi = x.clone().requires_grad_(True)
-        psm, rm = m._forward_training(xi, mode, torch_modules=torch_modules)
-        ((psm * gp).sum() + (rm * gr).sum()).backward()
-        outs.append((psm.detach(), rm.detach(), xi.grad))
-    err = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+    for m, torch_modules, conv in ((net, False, lambda t: t.cuda()), (ref, True, lambda t: t.double())):
+        xi = conv(x).clone().requires_grad_(True)
+        if torch_modules:
+            psm, rm = _tail_reference(m, xi, modes)
+        else:
+            psm, rm = m._forward_training(xi, mode)
+        ((psm * conv(gp)).sum() + (rm * conv(gr)).sum()).backward()
+        outs.append((psm.detach().cpu().double(), rm.detach().cpu().double(), xi.grad.cpu().double()))
+    err = lambda a, b: float((a.cpu().double() - b.cpu().double()).abs().max() / b.abs().max().clamp_min(1e-12))
     assert err(outs[0][0], outs[1][0]) < 1e-4 and err(outs[0][1], outs[1][1]) < 1e-4
-    assert err(outs[0][2], outs[1][2]) < 2e-4
+
+    def close(a, b, tol, floor=0.0, outliers=1e-4):
+        """Gradients pass through ReLU masks: an activation within round-off of zero (about one in a million, and the batch
+        statistics are summed with atomics, so which one varies from run to run) flips its mask on one side and moves a handful
+        of gradient entries by a finite amount.  Held: rms error, and all but a fraction `outliers` of the entries to `tol` of
+        the largest entry (or of `floor`, for tensors that are zero in exact arithmetic)."""
+        a, b = a.cpu().double(), b.cpu().double()
+        scale = max(float(b.abs().max()), floor, 1e-12)
+        d = (a - b).abs() / scale
+        return float(d.pow(2).mean().sqrt()) < tol / 4 and float((d > tol).double().mean()) <= outliers
+    assert close(outs[0][2], outs[1][2], 2e-4)
     used = 0
     # a convolution bias in front of a BatchNorm has a gradient that is zero in exact arithmetic (the batch mean absorbs it):
     # round-off noise on both sides, held to 1e-3 of the model's largest gradient instead of to its own magnitude
@@ -87,12 +119,10 @@ def test_tail_training_kernels_match_torch_modules(modes):
             assert p.grad is None, k
             continue
         used += 1
-        scale = max(float(q.grad.abs().max()), 1e-3 * gmax)
-        e = float((p.grad - q.grad).abs().max()) / scale
-        assert e < 5e-4, (k, e)
+        assert close(p.grad, q.grad, 5e-4, floor=1e-3 * gmax, outliers=1e-3), k
     assert used >= 12
     for (k, a), (_, b) in zip(net.named_buffers(), ref.named_buffers()):
-        assert err(a.float(), b.float()) < 1e-5 if a.is_floating_point() else bool((a == b).all()), k
+        assert err(a, b) < 1e-5 if a.is_floating_point() else bool((a.cpu() == b).all()), k
 
 
 def test_unfrozen_encoder_raises():
