@@ -166,7 +166,10 @@ class PointPillar(nn.Module):
         if vf.device.type != "cuda":
             raise RuntimeError("hm-vit_amd runs on the GPU only (HIP kernels, no CPU fallback)")
         if self.training:
-            raise RuntimeError("hmvit_amd.PointPillar folds BatchNorm statistics: call .eval() (inference only)")
+            # batch-statistics BatchNorm and gradients: the training-mode layer functions (hm-vit_amd/encoder_train.py); the folded
+            # inference kernels below serve .eval()
+            from .encoder_train import pointpillar_train_forward
+            return pointpillar_train_forward(self, data_dict)
         dev = vf.device
         prec = _PREC[self.precision]
         dt = torch.float16 if prec == _lib.PREC_F16 else torch.float32

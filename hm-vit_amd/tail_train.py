@@ -28,25 +28,30 @@ def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
-def _conv(x, w_rows, bias, cin, cout, k, pad):
+def _conv(x, w_rows, bias, cin, cout, k, pad, stride=1):
     n, H, W, _ = x.shape
-    y = torch.empty(n, H, W, cout, device=x.device, dtype=torch.float32)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    y = torch.empty(n, Ho, Wo, cout, device=x.device, dtype=torch.float32)
     _lib.check(_lib.lib.hmvit_conv2d(x.data_ptr(), w_rows.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
-                                     n, H, W, cin, cout, k, 1, pad, 0, cout, 0, 0, 1, _lib.PREC_SPLIT, _stream(x.device)), "conv2d")
+                                     n, H, W, cin, cout, k, stride, pad, 0, cout, 0, 0, 1, _lib.PREC_SPLIT, _stream(x.device)),
+               "conv2d")
     return y
 
 
 class Conv3x3(torch.autograd.Function):
-    """x (n, H, W, Cin) NHWC, weight (Cout, Cin, 3, 3), bias (Cout) -> (n, H, W, Cout); stride 1, padding 1."""
+    """x (n, H, W, Cin) NHWC, weight (Cout, Cin, 3, 3), bias (Cout) or None -> (n, Ho, Wo, Cout); padding 1, stride 1 or 2
+    (``ZeroPad2d(1)`` + stride-2 convolution without padding, base_bev_backbone.py:41-45, is the stride-2 case).  A strided
+    convolution's adjoints are the stride-1 ones applied to the output gradient with zeros inserted between its pixels."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, stride=1):
         x = x.contiguous()
         co, ci = weight.shape[:2]
         w_rows = weight.detach().permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous()
         with torch.cuda.device(x.device):
-            y = _conv(x, w_rows, bias.detach().contiguous(), ci, co, 3, 1)
+            y = _conv(x, w_rows, bias.detach().contiguous() if bias is not None else None, ci, co, 3, 1, stride)
         ctx.save_for_backward(x, weight)
+        ctx.stride, ctx.has_bias = stride, bias is not None
         return y
 
     @staticmethod
@@ -56,6 +61,11 @@ class Conv3x3(torch.autograd.Function):
         co, ci = weight.shape[:2]
         n, H, W, _ = x.shape
         dev = x.device
+        if ctx.stride != 1:
+            s = ctx.stride
+            dyz = torch.zeros(n, H, W, co, device=dev, dtype=torch.float32)
+            dyz[:, ::s, ::s][:, :dy.shape[1], :dy.shape[2]] = dy
+            dy = dyz
         with torch.cuda.device(dev):
             # dx[p][ci] = sum_{tap, co} dy[p - tap][co] w[co][ci][tap]: a 3x3 convolution of dy with flipped, swapped weights
             w_t = weight.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(ci, 9 * co).contiguous()
@@ -78,7 +88,8 @@ class Conv3x3(torch.autograd.Function):
                     tap = ky * 3 + kx
                     _lib.check(_lib.lib.hmvit_gemm_tn(dyp.data_ptr(), a.data_ptr(), dw[tap].data_ptr(),
                                                       db.data_ptr() if tap == 0 else None, Mp, co, ci, co, ci, st), "gemm_tn")
-        return dx, dw.view(3, 3, co, ci).permute(2, 3, 0, 1).contiguous(), db
+        return (dx if ctx.needs_input_grad[0] else None, dw.view(3, 3, co, ci).permute(2, 3, 0, 1).contiguous(),
+                db if ctx.has_bias else None, None)
 
 
 class BnRelu(torch.autograd.Function):

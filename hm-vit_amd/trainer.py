@@ -19,8 +19,9 @@ What it mirrors, piece by piece (citations into /root/reference/opencood):
                                                              found in the folder with ``strict=False``;
   * labels             ``data_utils/post_processor/voxel_postprocessor.py:74-229`` (hm-vit_amd/postprocess.py ``generate_label``).
 
-What trains on which code: the fusion (the hot path) runs its HIP forward AND backward kernels (hm-vit_amd/train.py); the frozen
-LiDAR encoder runs its HIP inference kernels (``fix_lidar_backbone``, the reference's own option; un-frozen encoders raise);
+What trains on which code: the fusion (the hot path) runs its HIP forward AND backward kernels (hm-vit_amd/train.py); the LiDAR
+encoder runs frozen on its HIP inference kernels (``fix_lidar_backbone``, the reference's own option, the default here) or trains
+on libhmvit too (``--train_lidar_backbone``, hm-vit_amd/encoder_train.py);
 the detection tail (``HeteroDecoder``: four 3x3 convolutions + BatchNorm in batch-statistics mode + ReLU + two 1x1 heads) runs
 HIP forward and backward kernels as well (hm-vit_amd/tail_train.py).
 
@@ -247,7 +248,7 @@ def main(argv=None):
     ap.add_argument("--small", action="store_true", help="PointPillar layer_nums [1, 2, 2]")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"], help="precision of the frozen encoder's kernels")
     ap.add_argument("--train_lidar_backbone", action="store_true",
-                    help="do NOT freeze the LiDAR encoder (raises: the encoder kernels have no backward pass)")
+                    help="do NOT freeze the LiDAR encoder: PointPillar trains too (hm-vit_amd/encoder_train.py)")
     ap.add_argument("--model_dir", default=None, help="folder with net_epoch%%d.pth to resume from / save into")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL)")

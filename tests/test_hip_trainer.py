@@ -103,12 +103,12 @@ def test_tail_training_kernels_match_torch_modules(modes):
     def close(a, b, tol, floor=0.0, outliers=1e-4):
         """Gradients pass through ReLU masks: an activation within round-off of zero (about one in a million, and the batch
         statistics are summed with atomics, so which one varies from run to run) flips its mask on one side and moves a handful
-        of gradient entries by a finite amount.  Held: rms error, and all but a fraction `outliers` of the entries to `tol` of
+        of gradient entries by a finite amount.  Held: rms error, and all but max(2, `outliers` x numel) of the entries to `tol` of
         the largest entry (or of `floor`, for tensors that are zero in exact arithmetic)."""
         a, b = a.cpu().double(), b.cpu().double()
         scale = max(float(b.abs().max()), floor, 1e-12)
         d = (a - b).abs() / scale
-        return float(d.pow(2).mean().sqrt()) < tol / 4 and float((d > tol).double().mean()) <= outliers
+        return float(d.pow(2).mean().sqrt()) < tol / 4 and float((d > tol).double().sum()) <= max(2.0, outliers * d.numel())
     assert close(outs[0][2], outs[1][2], 2e-4)
     used = 0
     # a convolution bias in front of a BatchNorm has a gradient that is zero in exact arithmetic (the batch mean absorbs it):
@@ -125,13 +125,112 @@ def test_tail_training_kernels_match_torch_modules(modes):
         assert err(a, b) < 1e-5 if a.is_floating_point() else bool((a.cpu() == b).all()), k
 
 
-def test_unfrozen_encoder_raises():
+def _pointpillar_reference(net, vf, vc, vn, n_agents):
+    """PointPillar.forward (features) from the module's own torch layers, any device / dtype: pillar_vfe.py:105-146,31-53,
+    point_pillar_scatter.py:14-47, base_bev_backbone.py:89-122, downsample_conv.py:32-51."""
+    from hmvit_amd.encoder_train import pfn_features
+    nx, ny, _ = [int(v) for v in net.scatter_cfg["grid_size"]]
+    pfn = net.pillar_vfe.pfn_layers[0]
+    feats = pfn_features(vf, vc.long(), vn, net.args["voxel_size"], net.args["lidar_range"])
+    h = pfn.linear(feats)
+    h = torch.relu(pfn.norm(h.permute(0, 2, 1)).permute(0, 2, 1)).max(dim=1)[0]
+    canvas = torch.zeros(n_agents, 64, ny * nx, dtype=h.dtype)
+    for b in range(n_agents):
+        m = vc[:, 0] == b
+        canvas[b][:, (vc[m, 2] * nx + vc[m, 3]).long()] = h[m].t()
+    x = canvas.view(n_agents, 64, ny, nx)
+    ups = []
+    for blk, de in zip(net.backbone.blocks, net.backbone.deblocks):
+        x = blk(x)
+        ups.append(de(x))
+    x = torch.cat(ups, dim=1)
+    for dc in net.shrink_conv.layers:
+        x = dc.double_conv(x)
+    return x
+
+
+def test_pointpillar_training_matches_torch_modules():
+    """The LiDAR encoder in training mode on libhmvit (hm-vit_amd/encoder_train.py: PFN Linear + BatchNorm1d, strided 3x3
+    convolutions, transposed convolutions, BatchNorm2d on batch statistics, shrink header - forward and backward) against its own
+    torch layers in float64 on the CPU: features, every parameter gradient, running statistics."""
+    import copy
+    import hmvit_amd
+    from oracle import pointpillar_oracle as PO
+    args = PO.make_args(64, 48, small=True)
+    sd = PO.random_state_dict(args, seed=3)
+    vf, vc, vn = PO.synthetic_pillars(2, 400, 64, 48, args, seed=4)
+    net = hmvit_amd.PointPillar(args, precision="split")
+    net.load_state_dict(sd, strict=True)
+    net.set_return_features()
+    ref = copy.deepcopy(net).double().train()
+    ref32 = copy.deepcopy(net).float().train()          # torch's own float32 run: the yardstick for what float32 can hold here
+    net = net.cuda().train()
+    y = net({"processed_lidar": {"voxel_features": vf.cuda(), "voxel_coords": vc.cuda(), "voxel_num_points": vn.cuda()}, "n_agents": 2})
+    y_ref = _pointpillar_reference(ref, vf.double(), vc, vn, 2)
+    y_32 = _pointpillar_reference(ref32, vf.float(), vc, vn, 2)
+    assert y.shape == y_ref.shape
+    g = torch.randn(y_ref.shape, generator=torch.Generator().manual_seed(1))
+    (y * g.cuda()).sum().backward()
+    (y_ref * g.double()).sum().backward()
+    (y_32 * g).sum().backward()
+    err = lambda a, b: float((a.cpu().double() - b.cpu().double()).abs().max() / b.abs().max().clamp_min(1e-12))
+    assert err(y.detach(), y_ref.detach()) < 1e-4
+
+    def close(a, b, tol, floor, outliers=1e-3):      # ReLU / max masks may flip at round-off: see the tail test above
+        a, b = a.cpu().double(), b.cpu().double()
+        d = (a - b).abs() / max(float(b.abs().max()), floor, 1e-12)
+        return float(d.pow(2).mean().sqrt()) < tol / 4 and float((d > tol).double().mean()) <= outliers
+    gmax = max(float(q.grad.abs().max()) for q in ref.parameters() if q.grad is not None)
+    used, worst = 0, {}
+
+    def rel(a, b, floor):
+        """(rms error, entries off by more than 4e-3 as a multiple of the allowance max(2, numel / 1000)), both relative to the tensor's
+        largest entry (or `floor`)"""
+        a, b = a.cpu().double(), b.cpu().double()
+        d = (a - b).abs() / max(float(b.abs().max()), floor, 1e-12)
+        return float(d.pow(2).mean().sqrt()), float((d > 4e-3).double().sum()) / max(2.0, 1e-3 * d.numel())   # > 1: too many
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        if q.grad is None:
+            assert p.grad is None, k
+            continue
+        used += 1
+        worst[k] = rel(p.grad, q.grad, 1e-3 * gmax)
+    # Ten layers of tiny-batch BatchNorm backward, ReLU and max masks: torch's own float32 run is 1-1.5e-3 (rms, relative to the
+    # tensor's largest entry) away from float64 on the deepest parameters.  The HIP path is held to that yardstick: no tensor
+    # more than 3x further from float64 than torch-float32 is (floor 2e-4), at most max(2, numel / 1000) entries off by 4e-3.
+    yard = {k: rel(p.grad, q.grad, 1e-3 * gmax)[0] for (k, p), (_, q) in zip(ref32.named_parameters(), ref.named_parameters())
+            if q.grad is not None}
+    bad = {k: (v, yard[k]) for k, v in worst.items() if not (v[0] < max(3 * yard[k], 2e-4) and v[1] <= 1.0)}
+    assert not bad, bad
+    assert used >= 30
+    for (k, a), (_, b) in zip(net.named_buffers(), ref.named_buffers()):
+        if a.is_floating_point():
+            assert err(a, b) < 1e-4, k
+    # eval() goes back to the folded inference kernels and sees the updated running statistics
+    net.eval(); ref.eval()
+    with torch.no_grad():
+        ye = net({"processed_lidar": {"voxel_features": vf.cuda(), "voxel_coords": vc.cuda(), "voxel_num_points": vn.cuda()}, "n_agents": 2})
+        ye_ref = _pointpillar_reference(ref, vf.double(), vc, vn, 2)
+    assert err(ye, ye_ref) < 2e-4
+
+
+def test_whole_model_trains_with_unfrozen_encoder():
+    """train_camera.py without --fix_lidar_backbone: encoder, fusion and detection tail all on the tape; one AdamW step moves
+    parameters of all three."""
     import hmvit_amd  # noqa: F401
     from hmvit_amd import trainer as T
 
     class A(_Args):
         train_lidar_backbone = True
+    hypes = T.default_hypes(epoches=1)
     cfg, model, pre, post, ds = T.build(A)
-    model = model.cuda().train()
-    with pytest.raises(RuntimeError):
-        model(T.to_batch(ds[0], pre, "cuda"))
+    model = model.cuda()
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    res = T.train(model, ds, pre, hypes)
+    assert res["epoch_loss"][0] == res["epoch_loss"][0]
+    after = model.state_dict()
+    moved = lambda k: float((after[k].float() - before[k].float()).abs().max())
+    assert moved("lidar_encoder.pillar_vfe.pfn_layers.0.linear.weight") > 0
+    assert moved("lidar_encoder.backbone.blocks.0.1.weight") > 0 and moved("lidar_encoder.backbone.deblocks.2.0.weight") > 0
+    assert moved("lidar_encoder.shrink_conv.layers.0.double_conv.2.bias") > 0
+    assert moved("fusion_net.hetero_fusion_block.grid_attention.relation_msg") > 0 and moved("decoder.lidar_reg_head.weight") > 0
