@@ -95,57 +95,113 @@ int launch_bn_relu_tokens(const float* x, const float* scale, const float* shift
     return HMVIT_OK;
 }
 
-// q (b, n, Q, heads * 32), k (b, n, K, heads * 32), v (b, n * K, heads * 32) -> out (b, Q, heads * 32).
-// One thread per query (64 per workgroup), one head per workgroup; K / V tiles of 64 keys staged in LDS; online softmax
-// over the n cameras' keys.
+// q (b, n, Q, heads * 32), k (b, n, K, heads * 32), v (b, n * K, heads * 32) -> out (b, Q, heads * 32), exact f32.
+// One workgroup = 64 queries of one head of one agent, one wavefront per 16 queries; K / V tiles of 64 keys staged in LDS and
+// shared by the four waves; online softmax over the keys of ALL cameras (the queries differ per camera).
+// v_mfma_f32_16x16x4_f32 (lane (l, g) supplies A[row l][k g], B[k g][col l], receives D[row 4 g + r][col l]):
+//   logits transposed, S^T[key][query] = K Q^T: a lane owns ONE query (column l) and keys 4 g + r of each 16-key sub-tile, so
+//   the row maximum / sum are lane-local plus two cross-lane steps (lanes l, l ^ 16, l ^ 32);
+//   O^T[d][query] = V^T P^T: the accumulator of S^T is directly the B operand, step r of a sub-tile contracting over the keys
+//   {4 g + r}; the A operand V^T is read from LDS in that order.
+// (Round 1 ran one thread per query with scalar FMAs: 7.3 ms at the shipped level-1 size - 5 agents x 4 cameras x 4096 keys,
+// 1024 queries - half of the camera branch's fp32-parity time.)
 // bias: optional (heads, Q, K) additive logit bias (n_cam = 1): the relative-position bias of FAX's self-attention
 // (fax_modules.py:122-160).
-__global__ __launch_bounds__(64) void k_cross_attention(const float* __restrict__ q, const float* __restrict__ k,
-                                                        const float* __restrict__ v, float* __restrict__ out, int n_cam, int Q,
-                                                        int K, int heads, float scale, const float* __restrict__ bias) {
-    constexpr int D = 32;
-    __shared__ float Ks[64][D + 1], Vs[64][D + 1];
-    const int b = blockIdx.z, head = blockIdx.y, qi = blockIdx.x * 64 + threadIdx.x;
+typedef float float4m __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float xlane_max4(float v) {      // over the four lanes that share l = lane & 15
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float xlane_sum4(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+__global__ __launch_bounds__(256) void k_cross_attention(const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ v, float* __restrict__ out, int n_cam, int Q,
+                                                         int K, int heads, float scale, const float* __restrict__ bias) {
+    constexpr int D = 32, KS = D + 1;
+    __shared__ float Ks[64 * KS], Vs[64 * KS];
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l = lane & 15, g = lane >> 4;
     const int HD = heads * D;
+    const int qi = blockIdx.x * 64 + wave * 16 + l;
     const bool valid = qi < Q;
-    float acc[D], m_run = -INFINITY, l_run = 0.f;
-#pragma unroll
-    for (int d = 0; d < D; ++d) acc[d] = 0.f;
+    const int qc = valid ? qi : Q - 1;
+    float4m o_acc[2] = {(float4m)(0.f), (float4m)(0.f)};
+    float m_run = -INFINITY, l_part = 0.f;       // l_part: this lane's share of the denominator (keys 4 g + r)
+    const int skey = tid >> 2, sd0 = (tid & 3) * 8;          // staging: key, first channel
     for (int cam = 0; cam < n_cam; ++cam) {
-        float qv[D];
-        const float* qp = q + (((size_t)(b * n_cam + cam) * Q + (valid ? qi : 0)) * HD + head * D);
+        float qf[8];
+        const float* qp = q + (((size_t)(b * n_cam + cam) * Q + qc) * HD + head * D);
 #pragma unroll
-        for (int d = 0; d < D; ++d) qv[d] = qp[d] * scale;
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = qp[4 * ks + g] * scale;
         for (int k0 = 0; k0 < K; k0 += 64) {
-            const int kk = k0 + threadIdx.x;
             __syncthreads();
-            if (kk < K) {
-                const float* kp = k + (((size_t)(b * n_cam + cam) * K + kk) * HD + head * D);
-                const float* vp = v + (((size_t)b * n_cam * K + (size_t)cam * K + kk) * HD + head * D);
-#pragma unroll
-                for (int d = 0; d < D; ++d) { Ks[threadIdx.x][d] = kp[d]; Vs[threadIdx.x][d] = vp[d]; }
+            {
+                const int kk = k0 + skey;
+                float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, b0 = a0, b1 = a0;
+                if (kk < K) {
+                    const float* kp = k + (((size_t)(b * n_cam + cam) * K + kk) * HD + head * D + sd0);
+                    const float* vp = v + (((size_t)b * n_cam * K + (size_t)cam * K + kk) * HD + head * D + sd0);
+                    a0 = *reinterpret_cast<const float4*>(kp); a1 = *reinterpret_cast<const float4*>(kp + 4);
+                    b0 = *reinterpret_cast<const float4*>(vp); b1 = *reinterpret_cast<const float4*>(vp + 4);
+                }
+                float* kd = Ks + skey * KS + sd0;
+                float* vd = Vs + skey * KS + sd0;
+                kd[0] = a0.x; kd[1] = a0.y; kd[2] = a0.z; kd[3] = a0.w; kd[4] = a1.x; kd[5] = a1.y; kd[6] = a1.z; kd[7] = a1.w;
+                vd[0] = b0.x; vd[1] = b0.y; vd[2] = b0.z; vd[3] = b0.w; vd[4] = b1.x; vd[5] = b1.y; vd[6] = b1.z; vd[7] = b1.w;
             }
             __syncthreads();
-            const int cnt = min(64, K - k0);
-            const float* brow = bias ? bias + ((size_t)head * Q + (valid ? qi : 0)) * K + k0 : nullptr;
-            for (int j = 0; j < cnt; ++j) {
-                float s = brow ? brow[j] : 0.f;
+            float4m s[4];
 #pragma unroll
-                for (int d = 0; d < D; ++d) s = fmaf(qv[d], Ks[j][d], s);
-                const float m_new = fmaxf(m_run, s);
-                const float alpha = __expf(m_run - m_new), pj = __expf(s - m_new);
-                l_run = l_run * alpha + pj;
+            for (int kt = 0; kt < 4; ++kt) {
+                s[kt] = (float4m)(0.f);
+                if (bias) {
 #pragma unroll
-                for (int d = 0; d < D; ++d) acc[d] = fmaf(acc[d], alpha, pj * Vs[j][d]);
-                m_run = m_new;
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = k0 + kt * 16 + 4 * g + r;
+                        s[kt][r] = key < K ? bias[((size_t)head * Q + qc) * K + key] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[(kt * 16 + l) * KS + 4 * ks + g], qf[ks], s[kt], 0, 0, 0);
             }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (k0 + kt * 16 + 4 * g + r >= K) s[kt][r] = -INFINITY;
+                    mx = fmaxf(mx, s[kt][r]);
+                }
+            const float m_new = fmaxf(m_run, xlane_max4(mx));
+            const float alpha = __expf(m_run - m_new);          // m_new is finite: a tile holds at least one real key
+            l_part *= alpha;
+            o_acc[0] *= alpha; o_acc[1] *= alpha;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pj = __expf(s[kt][r] - m_new);
+                    l_part += pj;
+                    // contraction step over the keys {4 g' + r}: A = V^T[d = dt * 16 + l][key 4 g + r], B = this lane's p
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+                        o_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vs[(kt * 16 + 4 * g + r) * KS + dt * 16 + l], pj, o_acc[dt], 0, 0, 0);
+                }
+            }
+            m_run = m_new;
         }
     }
+    const float inv = 1.f / xlane_sum4(l_part);
     if (valid) {
-        float* op = out + (((size_t)b * Q + qi) * HD + head * D);
-        const float inv = 1.f / l_run;
+        // o_acc[dt][r] = O^T[d = dt * 16 + 4 g + r][query l]
+        float* op = out + (((size_t)b * Q + qi) * HD + head * D + 4 * g);
 #pragma unroll
-        for (int d = 0; d < D; ++d) op[d] = acc[d] * inv;
+        for (int dt = 0; dt < 2; ++dt)
+            *reinterpret_cast<float4*>(op + dt * 16) = make_float4(o_acc[dt][0] * inv, o_acc[dt][1] * inv, o_acc[dt][2] * inv, o_acc[dt][3] * inv);
     }
 }
 
@@ -154,7 +210,7 @@ int launch_cross_attention(const float* q, const float* k, const float* v, float
     HMVIT_CHECK_ARG(dim_head == 32, "cross_attention: dim_head=%d (32)", dim_head);
     HMVIT_CHECK_ARG(!bias || n_cam == 1, "cross_attention: a logit bias needs n_cam = 1 (got %d)", n_cam);
     if (b <= 0 || Q <= 0) return HMVIT_OK;
-    hipLaunchKernelGGL(k_cross_attention, dim3(cdiv(Q, 64), heads, b), dim3(64), 0, st, q, k, v, out, n_cam, Q, K, heads,
+    hipLaunchKernelGGL(k_cross_attention, dim3(cdiv(Q, 64), heads, b), dim3(256), 0, st, q, k, v, out, n_cam, Q, K, heads,
                        1.f / sqrtf((float)dim_head), bias);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
