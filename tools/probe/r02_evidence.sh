@@ -15,7 +15,8 @@ for p in f32 split f16; do timeout 600 python tests/tools/ap_replay.py --precisi
 (python tests/tools/train_bench.py native 5 2>&1 | tail -1; python tests/tools/train_bench.py cfg2 3 2>&1 | tail -1;
  python -m hmvit_amd.trainer --epochs 2 --frames 6 --agents 5 --grid 512 192 2>/dev/null | tail -1;
  python -m hmvit_amd.trainer --epochs 2 --frames 6 --agents 5 --grid 512 192 --train_lidar_backbone 2>/dev/null | tail -1) > profiles/r02_train.txt; echo "train rc=$?"
-(python tests/tools/model_bench.py f16 split f32 2>&1 | grep model; python tests/tools/encoder_bench.py 2>&1 | grep PointPillar;
+(python tests/tools/model_bench.py f16 split f32 2>&1 | grep model; python tests/tools/model_bench.py --hetero f16 split 2>&1 | grep model;
+ python tests/tools/encoder_bench.py 2>&1 | grep PointPillar;
  python tests/tools/camera_bench.py f16 split f32 2>&1 | grep Cvt) > profiles/r02_model.txt; echo "model rc=$?"
 cp profiles/r02_* profiles/pmc_traffic.json gpurun_out/r02/profiles/
 cut -c1-400 profiles/r02_bench.json; cat profiles/r02_train.txt profiles/r02_model.txt
