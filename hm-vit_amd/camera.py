@@ -192,7 +192,7 @@ class _ResNet(nn.Module):
 
 
 class ResnetEncoder(nn.Module):
-    def __init__(self, params: dict, precision: str = "f16"):
+    def __init__(self, params: dict, precision: str = "split"):
         super().__init__()
         self.num_layers = params["num_layers"]
         if self.num_layers not in _BLOCKS:
@@ -266,7 +266,7 @@ class Bottleneck(nn.Module):
 
 
 class CrossViewModule(nn.Module):
-    def __init__(self, config: dict, precision: str = "f16"):
+    def __init__(self, config: dict, precision: str = "split"):
         super().__init__()
         middle, dim = config["middle"], config["dim"]
         self.backbone_output_shape = config["backbone_output_shape"]
@@ -322,7 +322,7 @@ class CrossViewModule(nn.Module):
 class CvtCameraEncoder(nn.Module):
     """config: {'encoder': ResnetEncoder params, 'cvm': CrossViewModule config, 'decoder': NaiveDecoder params}."""
 
-    def __init__(self, config: dict, precision: str = "f16"):
+    def __init__(self, config: dict, precision: str = "split"):
         super().__init__()
         self.encoder = ResnetEncoder(config["encoder"], precision=precision)
         self.cvm = CrossViewModule(config["cvm"], precision=precision)

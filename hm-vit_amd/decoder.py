@@ -36,7 +36,7 @@ class NaiveCompressor(nn.Module):
     conv3x3(C/r -> C) + BN + ReLU, conv3x3(C -> C) + BN + ReLU.  Same constructor and ``state_dict`` names; eval mode
     (BatchNorm folded into the convolutions); ``forward(x (N, C, H, W)) -> (N, C, H, W)`` on the implicit-GEMM kernel."""
 
-    def __init__(self, input_dim: int, compress_raito: int, precision: str = "f16"):
+    def __init__(self, input_dim: int, compress_raito: int, precision: str = "split"):
         super().__init__()
         mid = input_dim // compress_raito
         self.encoder = nn.Sequential(nn.Conv2d(input_dim, mid, 3, 1, 1), nn.BatchNorm2d(mid, eps=1e-3, momentum=0.01), nn.ReLU())
@@ -68,7 +68,7 @@ class NaiveCompressor(nn.Module):
 
 
 class HeteroDecoder(nn.Module):
-    def __init__(self, params: dict, precision: str = "f16"):
+    def __init__(self, params: dict, precision: str = "split"):
         super().__init__()
         dim = params["num_ch_dec"][0]
         self.camera_decoder = NaiveDecoder(params)

@@ -246,7 +246,7 @@ class FAXModule(nn.Module):
     """fax_modules.py:448-525; ``forward(batch)`` with 'camera' (b, l, n, ...) for its leading shape, 'intrinsic' (b, l, n, 3, 3),
     'extrinsic' (b, l, n, 4, 4), 'features': list of (b, l, n, C, h, w) -> (b, l, dim[-1], H, W)."""
 
-    def __init__(self, config: dict, precision: str = "f16"):
+    def __init__(self, config: dict, precision: str = "split"):
         super().__init__()
         middle, dim = config["middle"], config["dim"]
         self.backbone_output_shape = config["backbone_output_shape"]
@@ -324,7 +324,7 @@ class FaxCameraEncoder(nn.Module):
     {'encoder': ResnetEncoder params, 'fax': FAXModule config, 'decoder': NaiveDecoder params}; ``forward(batch_camera)`` with
     'camera' (N, n_cam, H, W, 3), 'intrinsic' (N, n_cam, 3, 3), 'extrinsic' (N, n_cam, 4, 4) -> (N, num_ch_dec[0], Hb, Wb)."""
 
-    def __init__(self, config: dict, precision: str = "f16"):
+    def __init__(self, config: dict, precision: str = "split"):
         super().__init__()
         self.encoder = ResnetEncoder(config["encoder"], precision=precision)
         fax = dict(config["fax"])

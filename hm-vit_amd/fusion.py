@@ -105,7 +105,7 @@ class _FusionBase(nn.Module):
     """Shared launch logic.  Subclasses provide ``_block_prefix`` / ``_head_prefix`` and
     ``_block_cfg``."""
 
-    precision = "f16"
+    precision = "split"          # the reference's fp32 arithmetic on the f16 matrix pipes (1e-4); "f16" is the opt-in fast mode
     skip_masked = True
 
     def _init_runtime(self):
@@ -282,7 +282,7 @@ class HeteroFusion(_FusionBase):
     _block_prefix = "hetero_fusion_block"
     _head_prefix = "mlp_head"
 
-    def __init__(self, config: dict, precision: str = "f16"):
+    def __init__(self, config: dict, precision: str = "split"):
         super().__init__()
         self.downsample_rate = config["spatial_transform"]["downsample_rate"]
         self.discrete_ratio = config["spatial_transform"]["voxel_size"][0]

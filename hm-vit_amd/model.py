@@ -39,7 +39,7 @@ def regroup(features: torch.Tensor, record_len, max_len: int):
 
 
 class BevformerPointPillarHetero(nn.Module):
-    def __init__(self, config: dict, camera_encoder: nn.Module = None, precision: str = "f16"):
+    def __init__(self, config: dict, camera_encoder: nn.Module = None, precision: str = "split"):
         super().__init__()
         self.camera_encoder = camera_encoder
         fusion_precision = precision

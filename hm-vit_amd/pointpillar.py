@@ -79,7 +79,7 @@ class _DownsampleConv(nn.Module):
 
 
 class PointPillar(nn.Module):
-    def __init__(self, args: dict, precision: str = "f16"):
+    def __init__(self, args: dict, precision: str = "split"):
         super().__init__()
         self.args = args
         self.pillar_vfe = _PillarVFE(args["pillar_vfe"])

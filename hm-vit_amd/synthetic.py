@@ -47,7 +47,7 @@ def synthetic_scene(L: int, C: int, H: int, W: int, modes, seed: int = 1, B: int
     return x, pw, mode, record_len, mask
 
 
-def seeded_fusion(cfg: dict, precision: str = "f16", seed: int = 0):
+def seeded_fusion(cfg: dict, precision: str = "split", seed: int = 0):
     """HeteroFusion with its default initialisation drawn under ``torch.manual_seed(seed)`` (default init, bias
     table ~ N(0, 1) = nn.Embedding's default), LayerNorm affine perturbed away from (1, 0) so that it matters."""
     from .fusion import HeteroFusion

@@ -100,16 +100,18 @@ def test_tail_training_kernels_match_torch_modules(modes):
     err = lambda a, b: float((a.cpu().double() - b.cpu().double()).abs().max() / b.abs().max().clamp_min(1e-12))
     assert err(outs[0][0], outs[1][0]) < 1e-4 and err(outs[0][1], outs[1][1]) < 1e-4
 
-    def close(a, b, tol, floor=0.0, outliers=1e-4):
+    def close(a, b, tol, floor=0.0):
         """Gradients pass through ReLU masks: an activation within round-off of zero (about one in a million, and the batch
-        statistics are summed with atomics, so which one varies from run to run) flips its mask on one side and moves a handful
-        of gradient entries by a finite amount.  Held: rms error, and all but max(2, `outliers` x numel) of the entries to `tol` of
-        the largest entry (or of `floor`, for tensors that are zero in exact arithmetic)."""
+        statistics are summed with atomics, so which one varies from run to run) flips its mask on one side, and the flip of one
+        unit of a late layer reaches, through the 3x3 convolutions before it, thousands of entries of an early gradient at the
+        1e-3 level (seen: 8.5e-4 of the largest entry).  A wrong tap or a missing term shows at the 0.1-1 level, so the bound
+        is: rms error < `tol`, no entry further than 20 `tol`, relative to the largest entry (or to `floor`, for tensors that
+        are zero in exact arithmetic)."""
         a, b = a.cpu().double(), b.cpu().double()
         scale = max(float(b.abs().max()), floor, 1e-12)
         d = (a - b).abs() / scale
-        return float(d.pow(2).mean().sqrt()) < tol / 4 and float((d > tol).double().sum()) <= max(2.0, outliers * d.numel())
-    assert close(outs[0][2], outs[1][2], 2e-4)
+        return float(d.pow(2).mean().sqrt()) < tol and float(d.max()) < 20 * tol
+    assert close(outs[0][2], outs[1][2], 3e-4)
     used = 0
     # a convolution bias in front of a BatchNorm has a gradient that is zero in exact arithmetic (the batch mean absorbs it):
     # round-off noise on both sides, held to 1e-3 of the model's largest gradient instead of to its own magnitude
@@ -119,7 +121,7 @@ def test_tail_training_kernels_match_torch_modules(modes):
             assert p.grad is None, k
             continue
         used += 1
-        assert close(p.grad, q.grad, 5e-4, floor=1e-3 * gmax, outliers=1e-3), k
+        assert close(p.grad, q.grad, 5e-4, floor=1e-3 * gmax), k
     assert used >= 12
     for (k, a), (_, b) in zip(net.named_buffers(), ref.named_buffers()):
         assert err(a, b) < 1e-5 if a.is_floating_point() else bool((a.cpu() == b).all()), k
@@ -176,10 +178,6 @@ def test_pointpillar_training_matches_torch_modules():
     err = lambda a, b: float((a.cpu().double() - b.cpu().double()).abs().max() / b.abs().max().clamp_min(1e-12))
     assert err(y.detach(), y_ref.detach()) < 1e-4
 
-    def close(a, b, tol, floor, outliers=1e-3):      # ReLU / max masks may flip at round-off: see the tail test above
-        a, b = a.cpu().double(), b.cpu().double()
-        d = (a - b).abs() / max(float(b.abs().max()), floor, 1e-12)
-        return float(d.pow(2).mean().sqrt()) < tol / 4 and float((d > tol).double().mean()) <= outliers
     gmax = max(float(q.grad.abs().max()) for q in ref.parameters() if q.grad is not None)
     used, worst = 0, {}
 
