@@ -468,10 +468,15 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
 // Needs Cin % 64 == 0, Cout % 8 == 0 (vector epilogue), no deconvolution; the decoder's nearest x2 upsampling of the input
 // is an addressing mode of the patch gather.
 // ------------------------------------------------------------------------------------------
-template <int CBN>
+// SPLIT: f32 map / weights / result, products on split-f16 operands as in k_conv<float, ..., SPLIT>: a channel slab is 32 deep, a
+// staged row (patch pixel or weight row) holds [32 hi | 32 lo | pad] halves - the same 72-half rows, LDS footprint and
+// fragment addressing as the f16 kernel; a 16-byte piece is 4 floats instead of 8 halves.
+template <int CBN, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
-    using T = half_t;
-    constexpr int BK = 64, LS = 72, TH = 8, TW = 16, PW = TW + 2, NPIX = (TH + 2) * PW;   // 180 patch pixels
+    using T = half_t;                                            // LDS element
+    using TG = typename std::conditional<SPLIT, float, half_t>::type;   // element in global memory
+    constexpr int BK = SPLIT ? 32 : 64, PE = 16 / (int)sizeof(TG);      // channels per slab, elements per 16-byte piece
+    constexpr int LS = 72, TH = 8, TW = 16, PW = TW + 2, NPIX = (TH + 2) * PW;   // 180 patch pixels
     constexpr int RPW = CBN / 32, NJ = CBN / 64, MI = 2;
     constexpr int NPP = (NPIX * 8 + 255) / 256;           // 16-byte patch pieces per thread (6, the last one partial)
     __shared__ __attribute__((aligned(16))) T Ps[NPIX * LS];
@@ -486,9 +491,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, hi = lane >> 5;
-    const T* x = reinterpret_cast<const T*>(p.x);
-    const T* w = reinterpret_cast<const T*>(p.w);
-    const int4v rs_x = conv_rsrc(x, (size_t)p.N * p.H * p.W * p.Cin * sizeof(T) >> (p.up2 ? 2 : 0)), rs_w = conv_rsrc(w, (size_t)p.Cout * Ktot * sizeof(T));
+    const TG* x = reinterpret_cast<const TG*>(p.x);
+    const TG* w = reinterpret_cast<const TG*>(p.w);
+    const int4v rs_x = conv_rsrc(x, (size_t)p.N * p.H * p.W * p.Cin * sizeof(TG) >> (p.up2 ? 2 : 0)), rs_w = conv_rsrc(w, (size_t)p.Cout * Ktot * sizeof(TG));
 
     // patch pieces of this thread: byte offset of (pixel, 16-byte chunk) for channel slab 0, out-of-map pixels read zeros
     unsigned poff[NPP];
@@ -501,15 +506,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
         const bool ok = q < NPIX * 8 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         // up2: logical pixel (iy, ix) of the nearest-upsampled map is physical pixel (iy / 2, ix / 2) of the half-size input
         const int pixel = p.up2 ? (n * (p.H >> 1) + (iy >> 1)) * (p.W >> 1) + (ix >> 1) : (n * p.H + iy) * p.W + ix;
-        poff[i] = ok ? (unsigned)(pixel * p.Cin + ch * 8) * 2u : 0xffffffffu;
-        plds[i] = q < NPIX * 8 ? pp * LS + ch * 8 : -1;
+        poff[i] = ok ? (unsigned)(pixel * p.Cin + ch * PE) * (unsigned)sizeof(TG) : 0xffffffffu;
+        plds[i] = q < NPIX * 8 ? pp * LS + ch * PE : -1;
     }
     unsigned wrow[RPW];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         const int c = tid + 256 * i, row = c >> 3;
         const int nrow = n0 + (row & ~31) + conv_row_channel(row & 31);
-        wrow[i] = nrow < p.Cout ? (unsigned)(((size_t)nrow * Ktot + (c & 7) * 8) * sizeof(T)) : 0xffffffffu;
+        wrow[i] = nrow < p.Cout ? (unsigned)(((size_t)nrow * Ktot + (c & 7) * PE) * sizeof(TG)) : 0xffffffffu;
     }
     // patch row (in halves) of the two 32-pixel tiles of this wave: pixel wm * 64 + i * 32 + r of the 8 x 16 block
     int pbase[MI];
@@ -527,27 +532,42 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    half8 rp[NPP], rw[RPW];
+    int4v rp[NPP], rw[RPW];                        // 16-byte pieces: 8 halves, or 4 floats (SPLIT)
+    auto put = [&](T* dst, const int4v& piece) {   // one piece into its LDS row (SPLIT: as hi / lo halves)
+        if constexpr (SPLIT) {
+            const float4v f = __builtin_bit_cast(float4v, piece);
+            half4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[e] = (half_t)f[e];
+                l[e] = (half_t)(f[e] - (float)h[e]);
+            }
+            *reinterpret_cast<half4*>(dst) = h;
+            *reinterpret_cast<half4*>(dst + 32) = l;
+        } else {
+            *reinterpret_cast<half8*>(dst) = __builtin_bit_cast(half8, piece);
+        }
+    };
     auto load_patch = [&](int ci0) {
 #pragma unroll
         for (int i = 0; i < NPP; ++i)
-            rp[i] = __builtin_bit_cast(half8, llvm_raw_buffer_load_b128(rs_x, (int)(poff[i] == 0xffffffffu ? poff[i] : poff[i] + (unsigned)ci0 * 2u), 0, 0));
+            rp[i] = llvm_raw_buffer_load_b128(rs_x, (int)(poff[i] == 0xffffffffu ? poff[i] : poff[i] + (unsigned)ci0 * (unsigned)sizeof(TG)), 0, 0);
     };
     auto store_patch = [&]() {
 #pragma unroll
         for (int i = 0; i < NPP; ++i)
-            if (plds[i] >= 0) *reinterpret_cast<half8*>(Ps + plds[i]) = rp[i];
+            if (plds[i] >= 0) put(Ps + plds[i], rp[i]);
     };
     auto load_w = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < RPW; ++i)
-            rw[i] = __builtin_bit_cast(half8, llvm_raw_buffer_load_b128(rs_w, (int)(wrow[i] == 0xffffffffu ? wrow[i] : wrow[i] + (unsigned)k0 * 2u), 0, 0));
+            rw[i] = llvm_raw_buffer_load_b128(rs_w, (int)(wrow[i] == 0xffffffffu ? wrow[i] : wrow[i] + (unsigned)k0 * (unsigned)sizeof(TG)), 0, 0);
     };
     auto store_w = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const int c = tid + 256 * i;
-            *reinterpret_cast<half8*>(Ws[buf] + (c >> 3) * LS + (c & 7) * 8) = rw[i];
+            put(Ws[buf] + (c >> 3) * LS + (c & 7) * PE, rw[i]);
         }
     };
 
@@ -573,6 +593,21 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     b[j] = *reinterpret_cast<const half8*>(Ws[cur] + (wn * (CBN / 2) + j * 32 + r) * LS + kk * 16 + hi * 8);
+                if constexpr (SPLIT) {
+                    half8 al[MI], bl[NJ];
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) al[i] = *reinterpret_cast<const half8*>(Ps + pbase[i] + tapoff + kk * 16 + 32);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        bl[j] = *reinterpret_cast<const half8*>(Ws[cur] + (wn * (CBN / 2) + j * 32 + r) * LS + kk * 16 + hi * 8 + 32);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], a[i], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], al[i], acc[i][j], 0, 0, 0);
+                        }
+                }
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -610,16 +645,16 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
                     v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
                 }
                 if (p.res) {
-                    const half8 rv = *reinterpret_cast<const half8*>(reinterpret_cast<const T*>(p.res) + opix * p.Cout + co);
+                    const TG* rp8 = reinterpret_cast<const TG*>(p.res) + opix * p.Cout + co;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rp8[e];
                 }
                 if (p.relu) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
                 const size_t o = opix * p.y_ctot + p.y_coff + co;
-                if (p.out_f32) {
+                if (p.out_f32 || SPLIT) {
                     float* yp = reinterpret_cast<float*>(p.y) + o;
                     *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
                     *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -697,13 +732,17 @@ int launch_conv(const ConvParams& p, int precision, hipStream_t st) {
                         xb, wb);
     }
     // 3 x 3 / stride 1 / pad 1 in f16: the patch-in-LDS kernel (one fetch per input pixel and channel slab instead of nine)
-    if (!f32_maps && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && !p.deconv_s && !p.rowpack &&
-        p.Cin % 64 == 0 && p.Cout % 8 == 0 && p.y_coff % 8 == 0 && p.y_ctot % 8 == 0 && p.Ho == p.H && p.Wo == p.W &&
+    const bool split = precision == HMVIT_PREC_SPLIT;
+    if ((!f32_maps || split) && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && !p.deconv_s && !p.rowpack &&
+        p.Cin % (split ? 32 : 64) == 0 && p.Cout % 8 == 0 && p.y_coff % 8 == 0 && p.y_ctot % 8 == 0 && p.Ho == p.H && p.Wo == p.W &&
         !p.no_patch && !HMVIT_ENV("HMVIT_CONV_NO_PATCH")) {
         const int tiles = p.N * cdiv(p.Ho, 8) * cdiv(p.Wo, 16);
         if (tiles * cdiv(p.Cout, narrow ? 64 : 128) >= 256) {       // enough workgroups to cover the CUs
             dim3 grid3(tiles * cdiv(p.Cout, narrow ? 64 : 128));
-            if (narrow) hipLaunchKernelGGL((k_conv3<64>), grid3, dim3(256), 0, st, p);
+            if (split) {
+                if (narrow) hipLaunchKernelGGL((k_conv3<64, true>), grid3, dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((k_conv3<128, true>), grid3, dim3(256), 0, st, p);
+            } else if (narrow) hipLaunchKernelGGL((k_conv3<64>), grid3, dim3(256), 0, st, p);
             else hipLaunchKernelGGL((k_conv3<128>), grid3, dim3(256), 0, st, p);
             HMVIT_CHECK_LAUNCH();
             return HMVIT_OK;

@@ -242,6 +242,40 @@ def test_conv3x3_patch_kernel(N, cin, cout, H, W, res, out_f32):
     assert rel_max_err(y.double(), y_generic.double()) < 1e-3      # same products, different summation order per tap
 
 
+@pytest.mark.parametrize("N,cin,cout,H,W,res,up2", [(5, 128, 256, 44, 75, True, False), (8, 64, 64, 64, 66, False, False),
+                                                    (6, 96, 136, 40, 48, False, False), (6, 128, 128, 42, 80, False, True)])
+def test_conv3x3_patch_kernel_split(N, cin, cout, H, W, res, up2):
+    """The same patch-in-LDS kernel in split precision (f32 map / weights / residual / result, split-f16 products): ragged tiles, a
+    channel count that is a multiple of 32 but not of 64, the residual operand and the upsampled-input mode, against torch fp64
+    at fp32 round-off class; and against the generic split kernel."""
+    from hmvit_amd import _lib
+    torch.manual_seed(N * cin + cout + 1)
+    h, w_ = (H // 2, W // 2) if up2 else (H, W)
+    x = torch.randn(N, cin, h, w_, device="cuda")
+    w = torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5
+    b = torch.randn(cout, device="cuda")
+    r = torch.randn(N, cout, H, W, device="cuda") if res else None
+    xin = F.interpolate(x.double(), scale_factor=2, mode="nearest") if up2 else x.double()
+    ref = F.conv2d(xin, w.double(), b.double(), 1, 1)
+    if res:
+        ref = ref + r.double()
+    ref = F.relu(ref)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    wn = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    rn = r.permute(0, 2, 3, 1).contiguous() if res else None
+
+    def run(generic=False):
+        y = torch.empty(N, H, W, cout, device="cuda", dtype=torch.float32)
+        _lib.check(_lib.lib.hmvit_conv2d_ex(xn.data_ptr(), wn.data_ptr(), b.data_ptr(), rn.data_ptr() if res else None, y.data_ptr(), N, H, W,
+                                            cin, cout, 3, 1, 1, 1, (2 if generic else 0) | (1 if up2 else 0), 1, _lib.PREC_SPLIT, _stream()),
+                   "conv2d_ex")
+        return y
+    y = run()
+    assert rel_max_err(y.permute(0, 3, 1, 2).double(), ref) < 4e-6
+    y_generic = run(generic=True)
+    assert rel_max_err(y.double(), y_generic.double()) < 4e-6
+
+
 def test_conv3x3_patch_kernel_upsampled_input():
     """Same kernel with the decoder's operand mode: the input is the nearest x2 upsampling of a half-size map."""
     import os
