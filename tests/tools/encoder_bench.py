@@ -17,8 +17,11 @@ for prec in ("f16", "split", "f32"):
     net.load_state_dict(sd, strict=False)
     net = net.cuda().eval()
     net.set_return_features()
-    y = net(batch); y = net(batch); torch.cuda.synchronize()      # two warm-up calls: weight preparation, allocator growth
-    n = 5 if prec != "f32" else 2
+    torch.cuda.empty_cache()
+    for _ in range(4):                                            # warm-up: weight preparation, allocator growth
+        y = net(batch)
+    torch.cuda.synchronize()
+    n = 10
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
