@@ -591,12 +591,16 @@ int launch_layernorm_bwd(const float* x, const float* dy, const float* gamma, co
 //   T tiles  S^T[key][query]   -> contraction over keys:    dQ^T = K^T dS^T
 //   N tiles  S[query][key]     -> contraction over queries: dV = P^T dO, dK = dS^T Q
 // The probabilities come from the saved log-sum-exp: P = exp(S + mask - lse), dS = P o (dP - D), D = rowsum(dO o O).
+// Two wavefronts per head: each takes two of the four 16-key tiles of a chunk (its dK / dV tiles are complete, its dQ is a partial
+// sum over its keys and meets the other wave's in LDS once at the end).  With one wave per head a workgroup had two waves and a
+// CU four - one per SIMD, so the gather of a chunk and its products never overlapped.
 template <int WIN, int HG>
-__global__ __launch_bounds__(HG * 64, 1) void k_attention_bwd(AttnBwdParams bp) {
+__global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp) {
     const AttnParams& p = bp.f;
     constexpr int N = WIN * WIN, NQT = N / 16, SPC = 64 / N, NB = (WIN == 8) ? 7 : 1;
     constexpr int CH = HG * 32, QS = CH + 2, KS = CH + 2;
-    constexpr int TPK = CH / 8, KPP = HG * 64 / TPK;
+    constexpr int THREADS = HG * 128;
+    constexpr int TPK = CH / 8, KPP = THREADS / TPK;
     __shared__ __attribute__((aligned(16))) float Qs[N * QS];
     __shared__ __attribute__((aligned(16))) float dOs[N * QS];
     __shared__ __attribute__((aligned(16))) float Ks[64 * KS];
@@ -609,7 +613,8 @@ __global__ __launch_bounds__(HG * 64, 1) void k_attention_bwd(AttnBwdParams bp) 
     const int win = blockIdx.x / NG, hg = blockIdx.x - win * NG;
     const int ego = blockIdx.y, b = blockIdx.z;
     const int wx = win / Y, wy = win - wx * Y;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (tid >> 6) % HG, khalf = (tid >> 6) / HG;       // head of the group, half of the key tiles
     const int lq = lane & 15, g = lane >> 4;
     const int head = hg * HG + wave;
     const int te = p.mode[b * L + ego], ev = p.ego_e[b * L + ego];
@@ -633,7 +638,7 @@ __global__ __launch_bounds__(HG * 64, 1) void k_attention_bwd(AttnBwdParams bp) 
                 dOs[n * QS + cl + e] = doplane[o + e];
             }
         }
-        for (int i = tid; i < N * HG; i += HG * 64) {
+        for (int i = tid; i < N * HG; i += THREADS) {
             const int n = i / HG, hh = i - n * HG;
             int row, col;
             token_pixel(p.partition, WIN, X, Y, wx, wy, n, row, col);
@@ -645,11 +650,12 @@ __global__ __launch_bounds__(HG * 64, 1) void k_attention_bwd(AttnBwdParams bp) 
             Lse[n][hh] = p.lse[((size_t)(b * L + ego) * P + row * W + col) * heads + hg * HG + hh];
         }
     }
-    float4v biasT[NB], biasN[NB], dbias[NB];
+    // (the bias fragments themselves are re-read from global per tile pair: 14 fragment registers sets spilled the kernel)
+    float4v dbias[NB];
+    const float* biasT_g = p.bias_frag + ((size_t)head * NB * 64 + lane) * 4;
+    const float* biasN_g = bp.bias_frag_neg + ((size_t)head * NB * 64 + lane) * 4;
 #pragma unroll
     for (int v = 0; v < NB; ++v) {
-        biasT[v] = *reinterpret_cast<const float4v*>(p.bias_frag + ((size_t)(head * NB + v) * 64 + lane) * 4);
-        biasN[v] = *reinterpret_cast<const float4v*>(bp.bias_frag_neg + ((size_t)(head * NB + v) * 64 + lane) * 4);
         dbias[v] = (float4v)(0.f);
     }
     float4v dq_acc[NQT][2];
@@ -717,8 +723,9 @@ __global__ __launch_bounds__(HG * 64, 1) void k_attention_bwd(AttnBwdParams bp) 
         any_visible = __syncthreads_or(any_visible);
 
         if (any_visible) {
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
+            // (the key tile index stays a compile-time constant: it selects the bias fragment registers)
+            auto key_tile = [&](auto kt_c) {
+                constexpr int kt = decltype(kt_c)::value;
                 // operands of key tile kt: rows (kt*16 + lq) x k (4 ks + g), and the "row 4g + r, column lq" form of K
                 float kf[8], vf[8], kfd[4][2];
 #pragma unroll
@@ -753,7 +760,7 @@ __global__ __launch_bounds__(HG * 64, 1) void k_attention_bwd(AttnBwdParams bp) 
                         }
                     const int bvT = (WIN == 8) ? (qt - kt + 3) : 0, bvN = (WIN == 8) ? (kt - qt + 3) : 0;
                     // ---- T orientation: rows = keys 4g + r, column = query lq ----
-                    float4v sT = biasT[bvT], dpT = (float4v)(0.f);
+                    float4v sT = *reinterpret_cast<const float4v*>(biasT_g + bvT * 256), dpT = (float4v)(0.f);
 #pragma unroll
                     for (int ks = 0; ks < 8; ++ks) {
                         sT = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[ks], qf[ks], sT, 0, 0, 0);
@@ -770,7 +777,7 @@ __global__ __launch_bounds__(HG * 64, 1) void k_attention_bwd(AttnBwdParams bp) 
                         for (int dt = 0; dt < 2; ++dt)
                             dq_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kfd[r][dt], dsT[r], dq_acc[qt][dt], 0, 0, 0);
                     // ---- N orientation: rows = queries 4g + r, column = key lq ----
-                    float4v sN = biasN[bvN], dpN = (float4v)(0.f);
+                    float4v sN = *reinterpret_cast<const float4v*>(biasN_g + bvN * 256), dpN = (float4v)(0.f);
 #pragma unroll
                     for (int ks = 0; ks < 8; ++ks) {
                         sN = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[ks], kf[ks], sN, 0, 0, 0);
@@ -807,13 +814,38 @@ __global__ __launch_bounds__(HG * 64, 1) void k_attention_bwd(AttnBwdParams bp) 
                         }
                     }
                 }
+            };
+            if (khalf == 0) {
+                key_tile(std::integral_constant<int, 0>{});
+                key_tile(std::integral_constant<int, 1>{});
+            } else {
+                key_tile(std::integral_constant<int, 2>{});
+                key_tile(std::integral_constant<int, 3>{});
             }
         }
         __syncthreads();
     }
 
+    // the two key halves of a head meet: the second wave's partial dQ through LDS (the K tile is free after the last barrier)
+    {
+        float4v* xch = reinterpret_cast<float4v*>(Ks);            // [head][qt][dt][lane]
+        if (khalf == 1) {
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) xch[((wave * NQT + qt) * 2 + dt) * 64 + lane] = dq_acc[qt][dt];
+        }
+        __syncthreads();
+        if (khalf == 0) {
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) dq_acc[qt][dt] += xch[((wave * NQT + qt) * 2 + dt) * 64 + lane];
+        }
+    }
     // dQ^T tiles: lane holds channels dt*16 + 4g + (0..3) of query qt*16 + lq
     float* dqp = bp.dq + (size_t)(b * L + ego) * P * C;
+    if (khalf == 0)
 #pragma unroll
     for (int qt = 0; qt < NQT; ++qt) {
         int row, col;
@@ -834,7 +866,7 @@ template <int WIN, int HG>
 static int launch_attn_bwd_t(const AttnBwdParams& p, hipStream_t st) {
     const int NG = p.f.C / (HG * 32);
     dim3 grid((p.f.H / WIN) * (p.f.W / WIN) * NG, p.f.n_ego, p.f.B);
-    hipLaunchKernelGGL((k_attention_bwd<WIN, HG>), grid, dim3(HG * 64), 0, st, p);
+    hipLaunchKernelGGL((k_attention_bwd<WIN, HG>), grid, dim3(HG * 128), 0, st, p);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }
