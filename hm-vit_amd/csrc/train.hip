@@ -723,16 +723,25 @@ __global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp)
         any_visible = __syncthreads_or(any_visible);
 
         if (any_visible) {
-            // (the key tile index stays a compile-time constant: it selects the bias fragment registers)
+            auto split8 = [](const float* src, half8& h, half8& l) {        // 8 consecutive f32 of an LDS row -> hi / lo halves
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = src[e];
+                    h[e] = (half_t)x;
+                    l[e] = (half_t)(x - (float)h[e]);
+                }
+            };
+            // (the key tile index stays a compile-time constant: it selects the bias fragment)
             auto key_tile = [&](auto kt_c) {
                 constexpr int kt = decltype(kt_c)::value;
                 // operands of key tile kt: rows (kt*16 + lq) x k (4 ks + g), and the "row 4g + r, column lq" form of K
-                float kf[8], vf[8], kfd[4][2];
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    kf[ks] = Ks[(kt * 16 + lq) * KS + hoff + ks * 4 + g];
-                    vf[ks] = Vs[(kt * 16 + lq) * KS + hoff + ks * 4 + g];
-                }
+                // The four products over the 32 channels of a head (S^T, dP^T, S, dP) run on split-f16 operands (three
+                // v_mfma_f32_16x16x32_f16 instead of eight v_mfma_f32_16x16x4_f32: lane (l, g) supplies channels 8 g .. 8 g + 7 of
+                // row l, the accumulator layout is the same); the products over keys / queries below stay exact f32.
+                half8 kh, kl, vh, vl;
+                float kfd[4][2];
+                split8(Ks + (kt * 16 + lq) * KS + hoff + 8 * g, kh, kl);
+                split8(Vs + (kt * 16 + lq) * KS + hoff + 8 * g, vh, vl);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -745,12 +754,10 @@ __global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp)
 
 #pragma unroll
                 for (int qt = 0; qt < NQT; ++qt) {
-                    float qf[8], dof[8], qfd[4][2], dofd[4][2];
-#pragma unroll
-                    for (int ks = 0; ks < 8; ++ks) {
-                        qf[ks] = Qs[(qt * 16 + lq) * QS + hoff + ks * 4 + g];
-                        dof[ks] = dOs[(qt * 16 + lq) * QS + hoff + ks * 4 + g];
-                    }
+                    float qfd[4][2], dofd[4][2];
+                    half8 qh, ql, doh, dol;
+                    split8(Qs + (qt * 16 + lq) * QS + hoff + 8 * g, qh, ql);
+                    split8(dOs + (qt * 16 + lq) * QS + hoff + 8 * g, doh, dol);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -761,11 +768,12 @@ __global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp)
                     const int bvT = (WIN == 8) ? (qt - kt + 3) : 0, bvN = (WIN == 8) ? (kt - qt + 3) : 0;
                     // ---- T orientation: rows = keys 4g + r, column = query lq ----
                     float4v sT = *reinterpret_cast<const float4v*>(biasT_g + bvT * 256), dpT = (float4v)(0.f);
-#pragma unroll
-                    for (int ks = 0; ks < 8; ++ks) {
-                        sT = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[ks], qf[ks], sT, 0, 0, 0);
-                        dpT = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[ks], dof[ks], dpT, 0, 0, 0);
-                    }
+                    sT = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, sT, 0, 0, 0);
+                    sT = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql, sT, 0, 0, 0);
+                    sT = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh, sT, 0, 0, 0);
+                    dpT = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, doh, dpT, 0, 0, 0);
+                    dpT = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, dol, dpT, 0, 0, 0);
+                    dpT = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, doh, dpT, 0, 0, 0);
                     const float lseT = Lse[qt * 16 + lq][wave], dT = Dl[qt * 16 + lq][wave];
                     float4v dsT;
 #pragma unroll
@@ -778,11 +786,12 @@ __global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp)
                             dq_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kfd[r][dt], dsT[r], dq_acc[qt][dt], 0, 0, 0);
                     // ---- N orientation: rows = queries 4g + r, column = key lq ----
                     float4v sN = *reinterpret_cast<const float4v*>(biasN_g + bvN * 256), dpN = (float4v)(0.f);
-#pragma unroll
-                    for (int ks = 0; ks < 8; ++ks) {
-                        sN = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[ks], kf[ks], sN, 0, 0, 0);
-                        dpN = __builtin_amdgcn_mfma_f32_16x16x4f32(dof[ks], vf[ks], dpN, 0, 0, 0);
-                    }
+                    sN = __builtin_amdgcn_mfma_f32_16x16x32_f16(ql, kh, sN, 0, 0, 0);
+                    sN = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh, kl, sN, 0, 0, 0);
+                    sN = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh, kh, sN, 0, 0, 0);
+                    dpN = __builtin_amdgcn_mfma_f32_16x16x32_f16(dol, vh, dpN, 0, 0, 0);
+                    dpN = __builtin_amdgcn_mfma_f32_16x16x32_f16(doh, vl, dpN, 0, 0, 0);
+                    dpN = __builtin_amdgcn_mfma_f32_16x16x32_f16(doh, vh, dpN, 0, 0, 0);
                     float4v pN, dsN;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
