@@ -731,13 +731,21 @@ __global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp)
                     l[e] = (half_t)(x - (float)h[e]);
                 }
             };
+            auto split4 = [](float a, float b, float c, float d, half4& h, half4& l) {
+                const float v[4] = {a, b, c, d};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[e] = (half_t)v[e];
+                    l[e] = (half_t)(v[e] - (float)h[e]);
+                }
+            };
             // (the key tile index stays a compile-time constant: it selects the bias fragment)
             auto key_tile = [&](auto kt_c) {
                 constexpr int kt = decltype(kt_c)::value;
                 // operands of key tile kt: rows (kt*16 + lq) x k (4 ks + g), and the "row 4g + r, column lq" form of K
                 // The four products over the 32 channels of a head (S^T, dP^T, S, dP) run on split-f16 operands (three
                 // v_mfma_f32_16x16x32_f16 instead of eight v_mfma_f32_16x16x4_f32: lane (l, g) supplies channels 8 g .. 8 g + 7 of
-                // row l, the accumulator layout is the same); the products over keys / queries below stay exact f32.
+                // row l, the accumulator layout is the same), and so do the products over the 16 keys / queries of a tile (v_mfma_f32_16x16x16_f16).
                 half8 kh, kl, vh, vl;
                 float kfd[4][2];
                 split8(Ks + (kt * 16 + lq) * KS + hoff + 8 * g, kh, kl);
@@ -746,6 +754,9 @@ __global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp)
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) kfd[r][dt] = Ks[(kt * 16 + 4 * g + r) * KS + hoff + dt * 16 + lq];
+                half4 kdh[2], kdl[2];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) split4(kfd[0][dt], kfd[1][dt], kfd[2][dt], kfd[3][dt], kdh[dt], kdl[dt]);
                 const float4v maddT = *reinterpret_cast<const float4v*>(maskadd + kt * 16 + 4 * g);
                 const float maddN = maskadd[kt * 16 + lq];
                 float4v dk_acc[2], dv_acc[2];
@@ -779,11 +790,16 @@ __global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dsT[r] = expf(sT[r] + maddT[r] - lseT) * (dpT[r] - dT);
                     dbias[bvT] += dsT;
+                    {   // dQ^T += K^T dS^T over this tile's 16 keys: the lane's four values ARE the operand of v_mfma_f32_16x16x16_f16
+                        half4 dsh, dsl;
+                        split4(dsT[0], dsT[1], dsT[2], dsT[3], dsh, dsl);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt)
-                            dq_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kfd[r][dt], dsT[r], dq_acc[qt][dt], 0, 0, 0);
+                        for (int dt = 0; dt < 2; ++dt) {
+                            dq_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(kdl[dt], dsh, dq_acc[qt][dt], 0, 0, 0);
+                            dq_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(kdh[dt], dsl, dq_acc[qt][dt], 0, 0, 0);
+                            dq_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(kdh[dt], dsh, dq_acc[qt][dt], 0, 0, 0);
+                        }
+                    }
                     // ---- N orientation: rows = queries 4g + r, column = key lq ----
                     float4v sN = *reinterpret_cast<const float4v*>(biasN_g + bvN * 256), dpN = (float4v)(0.f);
                     sN = __builtin_amdgcn_mfma_f32_16x16x32_f16(ql, kh, sN, 0, 0, 0);
@@ -798,13 +814,23 @@ __global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp)
                         pN[r] = expf(sN[r] + maddN - Lse[qt * 16 + 4 * g + r][wave]);
                         dsN[r] = pN[r] * (dpN[r] - Dl[qt * 16 + 4 * g + r][wave]);
                     }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                    {   // dV += P^T dO, dK += dS^T Q over this tile's 16 queries
+                        half4 ph, pl, sh, sl;
+                        split4(pN[0], pN[1], pN[2], pN[3], ph, pl);
+                        split4(dsN[0], dsN[1], dsN[2], dsN[3], sh, sl);
 #pragma unroll
                         for (int dt = 0; dt < 2; ++dt) {
-                            dv_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pN[r], dofd[r][dt], dv_acc[dt], 0, 0, 0);
-                            dk_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsN[r], qfd[r][dt], dk_acc[dt], 0, 0, 0);
+                            half4 oh, ol, qh4, ql4;
+                            split4(dofd[0][dt], dofd[1][dt], dofd[2][dt], dofd[3][dt], oh, ol);
+                            split4(qfd[0][dt], qfd[1][dt], qfd[2][dt], qfd[3][dt], qh4, ql4);
+                            dv_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(pl, oh, dv_acc[dt], 0, 0, 0);
+                            dv_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(ph, ol, dv_acc[dt], 0, 0, 0);
+                            dv_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(ph, oh, dv_acc[dt], 0, 0, 0);
+                            dk_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(sl, qh4, dk_acc[dt], 0, 0, 0);
+                            dk_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(sh, ql4, dk_acc[dt], 0, 0, 0);
+                            dk_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(sh, qh4, dk_acc[dt], 0, 0, 0);
                         }
+                    }
                 }
                 // ---- store: lane holds keys kt*16 + 4g + r, channel head*32 + dt*16 + lq ----
 #pragma unroll
