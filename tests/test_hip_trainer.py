@@ -232,3 +232,26 @@ def test_whole_model_trains_with_unfrozen_encoder():
     assert moved("lidar_encoder.backbone.blocks.0.1.weight") > 0 and moved("lidar_encoder.backbone.deblocks.2.0.weight") > 0
     assert moved("lidar_encoder.shrink_conv.layers.0.double_conv.2.bias") > 0
     assert moved("fusion_net.hetero_fusion_block.grid_attention.relation_msg") > 0 and moved("decoder.lidar_reg_head.weight") > 0
+
+
+def test_two_rank_ddp_training_on_one_gpu():
+    """The train loop under torch.distributed.run with two ranks (sharded frames, DistributedDataParallel buckets over the custom
+    autograd Functions, unused parameters) - both ranks share this box's GPU, so the process group is gloo; on a multi-GPU node the
+    same command with --backend nccl is the RCCL run."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "hmvit_amd.trainer", "--epochs", "2", "--frames", "4", "--agents", "3", "--grid", "128", "96",
+           "--small", "--backend", "gloo"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["world_size"] == 2 and res["steps"] >= 3
+    assert all(l == l for l in res["epoch_loss"]) and res["epoch_loss"][-1] < res["epoch_loss"][0]
