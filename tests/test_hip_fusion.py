@@ -131,6 +131,24 @@ def test_fusion_ragged_token_count(precision, H, W):
     assert rel_max_err(y, ref) < TOL[precision]
 
 
+@pytest.mark.parametrize("scale", [1.0, 64.0, 1024.0])
+def test_fp32_parity_modes_under_sharpening_attention(scale):
+    """The query projections scaled up: logits grow in proportion and the softmax approaches a one-hot pick of a key.  The split
+    mode (and the exact-f32 mode) must not care - its error is fp32 round-off class - while the mixed mode's f16 rounding of the
+    attention operands shows once the attention is sharp (measured 4.5e-6 / 1.4e-5 / 5.8e-5 / 1.7e-4 at x1 / x64 / x256 / x1024,
+    tests/tools/peaked_attention.py): that input dependence is why `split`, not `mixed`, is the reference-precision mode."""
+    cfg = O.make_config(256, 8, 3, voxel=0.4, downsample=4)
+    sd = O.random_state_dict(cfg, seed=7)
+    for k in list(sd):
+        if "q_linears" in k:
+            sd[k] = sd[k] * scale
+    scene = O.synthetic_scene(3, 256, 32, 48, [1, 0, 1], n_valid=3, seed=3, tx_step=6.0, ty_step=-4.0)
+    ref = O.hetero_fusion(*scene, sd, cfg)
+    err = {p: rel_max_err(_fusion(cfg, sd, p)(*_cuda(*scene)).cpu(), ref) for p in ("f32", "split", "mixed")}
+    assert err["f32"] < 1e-5 and err["split"] < 1e-5, err
+    assert err["mixed"] < (1e-4 if scale <= 64 else 1e-3), err
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_fusion_parallel_mode_vs_oracle(precision):
     """architect_mode='parallel' (SplitAttn merge), 2 iterations, mixed types, window 8."""
