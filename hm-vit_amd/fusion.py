@@ -16,6 +16,7 @@ output does not carry autograd history.  No CPU path: CPU tensors raise.
 from __future__ import annotations
 
 import ctypes
+import warnings
 from typing import Dict, Optional
 
 import torch
@@ -175,7 +176,16 @@ class _FusionBase(nn.Module):
             raise RuntimeError("hmvit_amd: this call needs gradients / training-mode dropout, which the fused inference "
                                "launch does not provide; call .eval() and run under torch.no_grad()")
         B, L, Cc, H, W = x.shape
-        prec = _PRECISIONS[self.precision]
+        precision = self.precision
+        if precision != "f32" and self._block_cfg["mlp_dim"] != self._block_cfg["input_dim"]:
+            # the fused chain kernels (f16 / split / mixed) are built for mlp_dim == input_dim (the shipped yaml); any other FFN
+            # width runs the un-fused exact-f32 kernels - same results at the reference's precision, slower
+            if not getattr(self, "_warned_mlp", False):
+                warnings.warn(f"hmvit_amd: mlp_dim={self._block_cfg['mlp_dim']} != input_dim={self._block_cfg['input_dim']}: "
+                              f"precision {precision!r} falls back to the exact-f32 kernels", stacklevel=3)
+                self._warned_mlp = True
+            precision = "f32"
+        prec = _PRECISIONS[precision]
         x = x.detach().to(torch.float32).contiguous()
         pw = pairwise_t_matrix.detach().to(device=x.device, dtype=torch.float32).contiguous()
         if tuple(pw.shape) != (B, L, L, 4, 4):
