@@ -30,6 +30,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   mixed_a16     the same for the "mixed" mode: split-operand fp32 Linear / FFN chains, f16 attention operands (1e-4 on
                 every parity case, but input-dependent -- a side figure),
   strict_f32    scenes/s of the exact-f32 MFMA mode,
+  train_step    milliseconds of one training step of the fusion (forward with dropout + backward + AdamW) on the same scene,
   dense_masked_tiles  scenes/s with skip_masked off: `value` skips (ego, source, window) key tiles in which every key
                 is masked (outside the source's field of view) and windows of non-ego agents whose results cannot
                 reach ego 0's output row; this is the same forward without those two shortcuts.
@@ -396,6 +397,33 @@ def main(argv=None):
             k = max(2, args.steps // 5)
             result["strict_f32"] = {"value": k / timed(strict, k, 1)[0], "unit": "scenes/s", "dtype": DTYPE["f32"]}
             del strict
+        if side:
+            # BASELINE configs[4] is the train loop: its fusion part on this GPU (HIP forward with dropout + HIP backward + AdamW,
+            # hm-vit_amd/train.py) on the same scene, as a side figure
+            torch.cuda.empty_cache()
+            from hmvit_amd import train as T
+            tnet = make("f32").train()
+            opt = T.make_optimizer(tnet.parameters())
+            target = torch.zeros(1, c["C"], c["H"], c["W"], device=dev)
+
+            def train_once():
+                opt.zero_grad()
+                loss = (tnet(*scene) - target).pow(2).mean()
+                loss.backward()
+                opt.step()
+            train_once()
+            sync()
+            t0 = time.perf_counter()
+            k = 3
+            for _ in range(k):
+                train_once()
+            sync()
+            result["train_step"] = {"ms_per_step": (time.perf_counter() - t0) / k * 1e3, "unit": "ms",
+                                    "what": "HeteroFusion forward (dropout 0.1) + backward + AdamW step on one scene of this workload, "
+                                            "exact-f32 / split-f16 training kernels",
+                                    "peak_memory_GiB": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
+            del tnet, opt, target
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(c, args.num_iters, seed=1)
     if rank == 0:
