@@ -11,10 +11,12 @@ from .voxelizer import SpVoxelPreprocessor  # noqa: F401
 from .cvt import BEVEmbedding, CrossAttention, CrossViewAttention  # noqa: F401
 from .camera import ResnetEncoder, CrossViewModule, CvtCameraEncoder  # noqa: F401
 from .fax import CrossViewSwapAttention, FAXModule, FaxCameraEncoder  # noqa: F401
+from .train import PointPillarLoss, make_optimizer, train_step  # noqa: F401  (training: loss / optimiser / one step; loop in .trainer)
 
 # the precision mode that is held to the reference's own fp32 tolerance (1e-4) and that bench.py reports as the headline
 REFERENCE_PRECISION = "split"
 
 __all__ = ["HeteroFusion", "HeteroFusionBlock", "PointPillar", "HeteroDecoder", "NaiveCompressor", "BevformerPointPillarHetero",
            "VoxelPostprocessor", "quad_iou", "caluclate_tp_fp", "calculate_ap", "voc_ap", "SpVoxelPreprocessor", "BEVEmbedding", "CrossAttention", "CrossViewAttention",
-           "ResnetEncoder", "CrossViewModule", "CvtCameraEncoder", "CrossViewSwapAttention", "FAXModule", "FaxCameraEncoder"]
+           "ResnetEncoder", "CrossViewModule", "CvtCameraEncoder", "CrossViewSwapAttention", "FAXModule", "FaxCameraEncoder",
+           "PointPillarLoss", "make_optimizer", "train_step"]
