@@ -117,6 +117,16 @@ __device__ __forceinline__ int4v conv_rsrc(const void* base, size_t bytes) {
     return rs;
 }
 
+// Staged row of 16-byte piece c (8 pieces per row).  f16 rows go to LDS as one 16-byte store per piece (groups of 8 lanes = one
+// row).  The split kernels store 8-byte (hi) + 8-byte (lo) halves: ds_write_b64 is served in groups of 16 lanes over 32 banks, and
+// with rows of 144 bytes two CONSECUTIVE rows in a group collide on 12 of their 16 banks (measured: 33-40 % of the LDS cycles of
+// the split convolutions were bank conflicts) - so a group takes rows r and r + 4 of its wave's 8 rows (144 * 4 = 16 banks apart).
+template <bool SPLIT>
+__device__ __forceinline__ int stage_row(int c) {
+    if constexpr (SPLIT) return ((c >> 6) << 3) | (((c >> 3) & 1) << 2) | ((c >> 4) & 3);
+    else return c >> 3;
+}
+
 // channel (inside a 32-channel tile) whose weight row is staged as LDS / MFMA row rho: an accumulator lane (pixel r, half
 // hi) owns rows 8 q + 4 hi + e, which become two runs of eight consecutive channels (cf. weights.py store_row_order)
 __device__ __forceinline__ int conv_row_channel(int rho) {
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
     bool rvalid[RPT];
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-        const int row = (tid + 256 * i) >> 3;
+        const int row = stage_row<SPLIT>(tid + 256 * i);
         const int m = m0 + row;
         rvalid[i] = m < M;
         const int mm = rvalid[i] ? m : 0;
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
     bool wvalid[RPW];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
-        const int c = tid + 256 * i, row = c >> 3;
+        const int c = tid + 256 * i, row = stage_row<SPLIT>(c);
         const int nrow = n0 + (row & ~31) + conv_row_channel(row & 31);   // output channel whose weights go to LDS row `row`
         wvalid[i] = nrow < Ncols;
         wrow[i] = (unsigned)(((size_t)(wvalid[i] ? nrow : 0) * Ktot + (c & 7) * VE) * sizeof(T));
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
         constexpr int SET = decltype(set_c)::value;
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * VE;
+            const int c = tid + 256 * i, row = stage_row<SPLIT>(c), kc = (c & 7) * VE;
             if constexpr (SPLIT) {
                 half4 h, l;
 #pragma unroll
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
         }
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * VE;
+            const int c = tid + 256 * i, row = stage_row<SPLIT>(c), kc = (c & 7) * VE;
             if constexpr (SPLIT) {
                 half4 h, l;
 #pragma unroll
@@ -500,19 +510,19 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
     int plds[NPP];
 #pragma unroll
     for (int i = 0; i < NPP; ++i) {
-        const int q = tid + 256 * i, pp = q >> 3, ch = q & 7;
+        const int q = tid + 256 * i, pp = stage_row<SPLIT>(q), ch = q & 7;
         const int pr = pp / PW, pc = pp - pr * PW;
         const int iy = oy0 + pr - 1, ix = ox0 + pc - 1;
-        const bool ok = q < NPIX * 8 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const bool ok = pp < NPIX && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         // up2: logical pixel (iy, ix) of the nearest-upsampled map is physical pixel (iy / 2, ix / 2) of the half-size input
         const int pixel = p.up2 ? (n * (p.H >> 1) + (iy >> 1)) * (p.W >> 1) + (ix >> 1) : (n * p.H + iy) * p.W + ix;
         poff[i] = ok ? (unsigned)(pixel * p.Cin + ch * PE) * (unsigned)sizeof(TG) : 0xffffffffu;
-        plds[i] = q < NPIX * 8 ? pp * LS + ch * PE : -1;
+        plds[i] = pp < NPIX ? pp * LS + ch * PE : -1;
     }
     unsigned wrow[RPW];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
-        const int c = tid + 256 * i, row = c >> 3;
+        const int c = tid + 256 * i, row = stage_row<SPLIT>(c);
         const int nrow = n0 + (row & ~31) + conv_row_channel(row & 31);
         wrow[i] = nrow < p.Cout ? (unsigned)(((size_t)nrow * Ktot + (c & 7) * PE) * sizeof(TG)) : 0xffffffffu;
     }
@@ -567,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const int c = tid + 256 * i;
-            put(Ws[buf] + (c >> 3) * LS + (c & 7) * PE, rw[i]);
+            put(Ws[buf] + stage_row<SPLIT>(c) * LS + (c & 7) * PE, rw[i]);
         }
     };
 
