@@ -109,7 +109,9 @@ def warp_affine(src: Tensor, A: Tensor, mode: str = "bilinear") -> Tensor:
     dst_norm_from_src_norm = norm @ (M @ torch.inverse(norm))
     src_norm_from_dst_norm = torch.inverse(dst_norm_from_src_norm)
     grid = F.affine_grid(src_norm_from_dst_norm[:, :2], [N, C, H, W], align_corners=True)
-    return F.grid_sample(src, grid, mode=mode, padding_mode="zeros", align_corners=True)
+    # (the sampling positions are always the reference's fp32 ones; a float64 `src` - the "truth" runs of the precision
+    # stress tests - only changes the arithmetic of the blend)
+    return F.grid_sample(src, grid.to(src.dtype), mode=mode, padding_mode="zeros", align_corners=True)
 
 
 def warp_agents(x: Tensor, t_to_target: Tensor, discrete_ratio: float,
@@ -323,18 +325,20 @@ def hetero_fusion_block(x: Tensor, pairwise_t: Tensor, mode: Tensor, record_len:
 
 
 def hetero_fusion(x: Tensor, pairwise_t: Tensor, mode: Tensor, record_len: Tensor,
-                  mask: Tensor, sd: Dict[str, Tensor], cfg: dict, drop_masks=None) -> Tensor:
+                  mask: Tensor, sd: Dict[str, Tensor], cfg: dict, drop_masks=None,
+                  dtype: torch.dtype = torch.float32) -> Tensor:
     """HeteroFusion.forward (bevformer_point_pillar_hetero.py:39-49).  Plain torch, so torch.autograd differentiates it:
     the gradient checker of the HIP backward pass.  drop_masks: None (eval) or, per iteration, [window, grid] triples of
     Dropout masks replaying a training-mode run (fusion_stage).
 
     x (B, L, C, H, W) f32; pairwise_t (B, L, L, 4, 4), [b, i, j] maps agent i -> agent j;
     mode (B, L) int 1 = lidar / 0 = camera (padding 0); record_len (B,); mask (B, L) 1/0.
-    Returns (B, C, H, W)."""
-    sd = {k: v.to(torch.float32) if v.is_floating_point() else v for k, v in sd.items()}
+    Returns (B, C, H, W).  dtype=torch.float64 evaluates the same network on the same fp32 sampling geometry in double
+    precision: the yardstick that tells fp32 round-off of the reference apart from error of the implementation under test."""
+    sd = {k: v.to(dtype) if v.is_floating_point() else v for k, v in sd.items()}
     mode = mode.to(torch.int64)
     pairwise_t = pairwise_t.to(torch.float32)
-    x = x.to(torch.float32)
+    x = x.to(dtype)
     for it in range(cfg["num_iters"]):
         x = hetero_fusion_block(x, pairwise_t, mode, record_len, mask, sd,
                                 "hetero_fusion_block", cfg["hetero_fusion_block"],

@@ -20,6 +20,7 @@ What is frozen:
                         offset 3 / every 16th col + col offset 5) + the first and last full rows + per-channel moments.
                         ~2.5 min and ~16 GB on 8 cores.
   g13_fusion_cfg3.npz   same at configs[2]'s type pattern 10110 (mixed camera / LiDAR agent types).
+  g18_fusion_cfg4.npz   same at configs[3]'s type pattern 00000 (all camera agents, ego_mode=camera).
   g14_loss.npz          PointPillarLoss.forward (loss/point_pillar_loss.py:68-142; cls_weight 1, reg 2) on seeded head outputs /
                         targets (B=2, 2 anchors, 8x12, a few positives, one NaN target): total / reg / conf loss and the
                         gradients with respect to psm and rm.
@@ -237,6 +238,10 @@ def g12_fusion_cfg2():
 
 def g13_fusion_cfg3():
     _fusion_full_size("g13_fusion_cfg3.npz", [1, 0, 1, 1, 0], 131, 2)
+
+
+def g18_fusion_cfg4():
+    _fusion_full_size("g18_fusion_cfg4.npz", [0, 0, 0, 0, 0], 181, 3)
 
 
 def g16_fax():
@@ -495,6 +500,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "g13" in sys.argv[1:]:
         g13_fusion_cfg3()
+        sys.exit(0)
+    if "g18" in sys.argv[1:]:
+        g18_fusion_cfg4()
         sys.exit(0)
     if "g10" in sys.argv[1:]:
         g10_postprocess()
