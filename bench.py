@@ -160,6 +160,84 @@ def cpu_baseline(cfgd, num_iters, seed):
                                 "122.8 s/scene = 0.0081 scenes/s at cfg2 (BASELINE.md section 2)"}
 
 
+def train_bench(args, c, dev, rank, world, scene, make, barrier, D):
+    """`--train`: the per-rank train step of train_camera.py:163-199 on the fusion (the hot path): every rank holds its own
+    scene, the model is wrapped in DistributedDataParallel(find_unused_parameters=True) as train_camera.py:126-131 does, and the
+    only exchange of a step is DDP's bucketed gradient all-reduce (RCCL over xGMI with --backend nccl).  Timed like the
+    inference line (barrier + synchronise on both sides, max over ranks); besides ms_per_step the line carries the same step
+    without the exchange (`no_sync`), their difference (the all-reduce time that backward does not hide) and a stand-alone
+    all-reduce of one gradient-sized buffer."""
+    import torch
+    import torch.distributed as dist
+    if args.stub:
+        class Stub(torch.nn.Module):           # CPU stand-in with an unused parameter (find_unused_parameters must cope)
+            def __init__(self):
+                super().__init__()
+                self.a, self.unused = torch.nn.Linear(64, 64), torch.nn.Linear(8, 8)
+
+            def forward(self, *_):
+                return self.a(torch.ones(4, 64))
+        torch.manual_seed(0)
+        net = Stub()
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+        target = torch.zeros(4, 64)
+    else:
+        from hmvit_amd import train as T
+        net = make("f32").train()
+        opt = T.make_optimizer(net.parameters())
+        target = torch.zeros(1, c["C"], c["H"], c["W"], device=dev)
+    model = net
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=None if args.stub else [dev.index],
+                                                          find_unused_parameters=True)
+
+    def step(sync_grads=True):
+        opt.zero_grad()
+        if world > 1 and not sync_grads:
+            with model.no_sync():
+                (model(*scene) - target).pow(2).mean().backward()
+        else:
+            (model(*scene) - target).pow(2).mean().backward()
+        opt.step()
+
+    def timed(n, sync_grads):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(sync_grads)
+        barrier()
+        return D.max_over_ranks(time.perf_counter() - t0, dev)
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    dt = timed(args.steps, True)
+    dt_local = timed(args.steps, False) if world > 1 else dt
+    n_grad = sum(p.numel() for p in net.parameters() if p.grad is not None)
+    ar_ms = None
+    if world > 1:
+        buf = torch.zeros(max(1, n_grad), device=dev)
+        dist.all_reduce(buf)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            dist.all_reduce(buf)
+        barrier()
+        ar_ms = D.max_over_ranks(time.perf_counter() - t0, dev) / 5 * 1e3
+    units = D.sum_over_ranks(float(args.steps), dev)
+    res = {"metric": "train steps/sec (HeteroFusion forward + backward + gradient all-reduce + AdamW, one scene per rank)",
+           "value": units / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "stub" if args.stub else "f32 master weights; exact-f32 / split-f16 training kernels", "data": "stub" if args.stub else "synthetic",
+           "config": {"workload": "stub" if args.stub else f"{args.config}: train step of the fusion on one scene per rank, dropout 0.1, AdamW",
+                      "parallelism": f"dp{world}: DistributedDataParallel(find_unused_parameters=True), backend {args.backend}"},
+           "ms_per_step_no_sync": dt_local / args.steps * 1e3,
+           "allreduce_exposed_ms": max(0.0, (dt - dt_local) / args.steps * 1e3),
+           "allreduce_standalone_ms": ar_ms, "gradient_bytes": 4 * n_grad}
+    if not args.stub:
+        res["peak_memory_GiB"] = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    return res
+
+
 def spawn_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes BEFORE anything in this
     process touches the GPU (a process that has initialised HIP must never exec), forward rank 0's stdout, return the worst
@@ -197,6 +275,9 @@ def main(argv=None):
     ap.add_argument("--no-strict", action="store_true", help="skip the side figures (fast_f16, strict_f32, dense_masked_tiles)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --stub: CPU test of the launch logic")
     ap.add_argument("--stub", action="store_true", help="replace the forward by a CPU stand-in (tests/test_dist_cpu.py)")
+    ap.add_argument("--train", action="store_true",
+                    help="the training half of north_star instead of the inference headline: one DistributedDataParallel train step "
+                         "per rank (HeteroFusion forward with dropout + HIP backward + gradient all-reduce on RCCL + AdamW)")
     args = ap.parse_args(argv)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -269,6 +350,15 @@ def main(argv=None):
         dt = time.perf_counter() - t0
         # job time = slowest rank; units = what all ranks processed (hm-vit_amd/dist.py)
         return D.max_over_ranks(dt, dev), D.sum_over_ranks(float(steps), dev)
+
+    if args.train:
+        result = train_bench(args, c, dev, rank, world, scene, make, barrier, D)
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     net = make(precision)
     dt, units = timed(net, args.steps, args.warmup)

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMVIT_LIB", os.path.join(_HERE, "libhmvit.so"))   # HMVIT_LIB: ablation builds of tools/probe
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 PREC_F32, PREC_F16, PREC_SPLIT, PREC_MIXED = 0, 1, 2, 3
 PART_WINDOW, PART_GRID = 0, 1
 NUM_TYPES = 2
@@ -29,7 +29,17 @@ c_i32p = C.POINTER(C.c_int32)
 class StageWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "ln_gamma", "ln_beta", "w_q", "b_q", "w_kv", "b_kv", "bias_frag", "w_o", "b_o",
-        "ffn_ln_gamma", "ffn_ln_beta", "w_1", "b_1", "w_2", "b_2", "img_q", "img_kv", "img_o", "img_ffn")]
+        "ffn_ln_gamma", "ffn_ln_beta", "w_1", "b_1", "w_2", "b_2", "img_q", "img_kv", "img_o", "img_ffn", "scales")]
+
+
+class StageScales(C.Structure):
+    """HmvitStageScales (include/hmvit.h): the power-of-two range normalisation of the split-operand modes."""
+    _fields_ = [("c_q", C.c_float * 2), ("c_k", (C.c_float * 2) * 2), ("c_v", (C.c_float * 2) * 2), ("k_logit", C.c_float),
+                ("c_o", C.c_float * 2), ("c_1", C.c_float * 2), ("s_g", C.c_float * 2), ("k_2", C.c_float * 2)]
+
+
+class HeadScales(C.Structure):
+    _fields_ = [("w1", C.c_float * 2), ("w2", C.c_float * 2), ("l1", C.c_float * 2), ("b1max", C.c_float * 2)]
 
 
 class FusionDesc(C.Structure):
@@ -48,6 +58,7 @@ class FusionDesc(C.Structure):
         ("parallel", C.c_int32),
         ("split_fc1", C.c_void_p), ("split_ln_g", C.c_void_p), ("split_ln_b", C.c_void_p),
         ("split_fc2", C.c_void_p),
+        ("head_scales", C.c_void_p),
         ("self_identity", C.c_int32),
     ]
 

@@ -154,6 +154,7 @@ __global__ __launch_bounds__(HG * 64, (sizeof(T) == 2 ? 2 : 1)) void k_attention
     const int te = p.mode[b * L + ego];
     const int ev = p.ego_e[b * L + ego];
     const int ch0 = hg * CH;               // first channel of this head group
+    const float kl = p.k_logit != 0.f ? p.k_logit : 1.f;   // f32 planes carried at a power of two (HmvitStageScales::k_logit)
 
     const T* qplanes = reinterpret_cast<const T*>(p.q);
     const T* kvplanes = reinterpret_cast<const T*>(p.kv);
@@ -323,13 +324,13 @@ __global__ __launch_bounds__(HG * 64, (sizeof(T) == 2 ? 2 : 1)) void k_attention
                 const float m_new = fmaxf(m_run[qt], mx);
                 const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
                 float alpha, rs = 0.f;
-                if constexpr (F16) alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_safe); else alpha = expf(m_run[qt] - m_safe);   // f16 mode: logits are in log2 units
+                if constexpr (F16) alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_safe); else alpha = expf((m_run[qt] - m_safe) * kl);   // f16 mode: logits are in log2 units
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float e;
-                        if constexpr (F16) e = __builtin_amdgcn_exp2f(s[kt][r] - m_safe); else e = expf(s[kt][r] - m_safe);
+                        if constexpr (F16) e = __builtin_amdgcn_exp2f(s[kt][r] - m_safe); else e = expf((s[kt][r] - m_safe) * kl);
                         s[kt][r] = e;
                         rs += e;
                     }
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(HG * 64, (sizeof(T) == 2 ? 2 : 1)) void k_attention
         if constexpr (!F16) {
             // training: the row's log-sum-exp lets the backward pass rebuild the probabilities (train.hip)
             if (p.lse && g == 0)
-                p.lse[((size_t)(b * L + ego) * P + row * W + col) * (C / 32) + head] = m_run[qt] + logf(l_run[qt]);
+                p.lse[((size_t)(b * L + ego) * P + row * W + col) * (C / 32) + head] = m_run[qt] * kl + logf(l_run[qt]);
         }
         T* o = outp + (size_t)(row * W + col) * C + head * 32 + 4 * g;
 #pragma unroll
@@ -428,7 +429,39 @@ struct PcCursor {
     int started;
 };
 
+// World-ordered list (p.sched, launch_attn_schedule): the list is cut into segments of sched_sub x (items per XCD step); XCD x
+// takes segments x, x + 8, ... and its workgroups walk a segment in sched_sub steps of consecutive items, so that what an
+// XCD's workgroups gather at any moment - for ALL egos - lies under the same few hundred pixels of ground.
+__device__ __forceinline__ bool pc_fetch_sched(const AttnParams& p, int X, int Y, int NG, PcCursor& cur, PcItem& it) {
+    const int wpx = gridDim.x >> 3, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int tps = wpx / NG, t = j / NG, sub = p.sched_sub;
+    while (true) {
+        if (!cur.started) { cur.trow = x; cur.tcol = 0; cur.started = 1; }
+        else if (++cur.tcol == sub) { cur.tcol = 0; cur.trow += 8; }
+        if (cur.trow * sub * tps >= p.n_sched) return false;
+        const int pos = (cur.trow * sub + cur.tcol) * tps + t;
+        if (pos >= p.n_sched) continue;
+        const int* a = p.sched + __builtin_amdgcn_readfirstlane(pos);
+        unsigned w;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(a) : "memory");
+        const int wy = w & 1023, wx = (w >> 10) & 1023, ego = (w >> 20) & 15, s = w >> 24;
+        if (p.prune) {
+            const unsigned* v_ = p.vis_mask + __builtin_amdgcn_readfirstlane(((s * p.n_ego + ego) * X + wx) * Y + wy);
+            unsigned v;
+            asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(v_) : "memory");
+            if (v >> 31) continue;
+        }
+        it.b = __builtin_amdgcn_readfirstlane(s);
+        it.ego = __builtin_amdgcn_readfirstlane(ego);
+        it.wx = __builtin_amdgcn_readfirstlane(wx);
+        it.wy = __builtin_amdgcn_readfirstlane(wy);
+        it.hg = __builtin_amdgcn_readfirstlane(j % NG);
+        return true;
+    }
+}
+
 __device__ __forceinline__ bool pc_fetch(const AttnParams& p, int X, int Y, int NG, bool ego_fastest, PcCursor& cur, PcItem& it) {
+    if (p.sched) return pc_fetch_sched(p, X, Y, NG, cur, it);
     const int wpx = gridDim.x >> 3, x = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int TH = wpx / NG / 8;                       // tile = TH x 8 windows
     const int ntx = (X + TH - 1) / TH, nty = (Y + 7) / 8;
@@ -1518,7 +1551,10 @@ __device__ __forceinline__ void pcs_loader_loop(const AttnParams& p, PcSharedS& 
 __device__ __forceinline__ void pcs_compute_loop(const AttnParams& p, PcSharedS& sm, int wave, int lane) {
     using SM = PcSharedS;
     constexpr int QS = SM::QS, KS = SM::KS, VS = SM::VS, LWG = SM::LWG;
-    constexpr float LOG2E = 1.4426950408889634f;
+    // the planes (and the bias fragments) carry the logits at a power of two (HmvitStageScales::k_logit brings them back to
+    // natural units): it rides on the log2(e) factor of the exp2 argument, the running maximum stays in plane units
+    const float kl = p.k_logit != 0.f ? p.k_logit : 1.f;
+    const float LOG2E = 1.4426950408889634f * kl;
     const int hl = wave;
     const int C = p.C, H = p.H, W = p.W, L = p.L, P = H * W;
     const int X = H / 8, Y = W / 8, NG = C / SM::CH;
@@ -1669,7 +1705,7 @@ __device__ __forceinline__ void pcs_compute_loop(const AttnParams& p, PcSharedS&
                     *reinterpret_cast<float4*>(o + 4) = make_float4(o_acc[qt][1][0] * inv, o_acc[qt][1][1] * inv, o_acc[qt][1][2] * inv, o_acc[qt][1][3] * inv);
                     // row log-sum-exp for the backward pass (training forward, same layout as k_attention's)
                     if (p.lse && g == 0)
-                        p.lse[((size_t)(it.b * L + it.ego) * P + row * W + col) * (C / 32) + head] = m_run[qt] + logf(l_acc[qt][0]);
+                        p.lse[((size_t)(it.b * L + it.ego) * P + row * W + col) * (C / 32) + head] = m_run[qt] * kl + logf(l_acc[qt][0]);
                 }
             }
             __syncthreads();
@@ -1791,6 +1827,92 @@ int launch_window_need(const AttnParams& p, const unsigned char* from, unsigned 
     HMVIT_CHECK_ARG(p.window == 8 && p.H % 8 == 0 && p.W % 8 == 0, "window_need: window=%d (8)", p.window);
     if (p.B <= 0 || p.n_ego <= 0) return HMVIT_OK;
     hipLaunchKernelGGL(k_window_need, dim3(cdiv(p.H * p.W, 256), p.n_ego, p.B * (from ? p.n_ego : 1)), dim3(256), 0, st, p, from, to);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// World-ordered work list of the local (window) stages.  The rows of source j that a window gathers lie under the window's
+// WORLD position, whichever ego owns it: windows of different egos over the same ground read the same rows of every source map.
+// The (sample, ego, window) items are therefore sorted by the position of their centre in the frame of agent 0 of the sample
+// (through the pair affines the gather itself uses) along a boustrophedon of 16-pixel bands cut into 8-pixel cells, and the
+// persistent kernels walk that list (pc_fetch_sched): the items an XCD holds at any time then share their gathers in its L2
+// across egos - each source row is fetched about once per XCD instead of once per ego.  Counting sort, three small launches.
+// ------------------------------------------------------------------------------------------
+constexpr int SCHED_MARGIN = 256, SCHED_BAND = 16, SCHED_CELL = 8;
+static inline int sched_cols(int W) { return cdiv(W + 2 * SCHED_MARGIN, SCHED_CELL); }
+static inline int sched_keys(int H, int W) { return cdiv(H + 2 * SCHED_MARGIN, SCHED_BAND) * sched_cols(W); }
+size_t attn_schedule_bytes(int B, int n_ego, int H, int W) {
+    const size_t n = (size_t)B * n_ego * (H / 8) * (W / 8);
+    return (2 * n + (size_t)B * sched_keys(H, W) + 1) * sizeof(int) + 256;
+}
+
+__device__ __forceinline__ int sched_key(const AttnParams& p, int b, int ego, int wx, int wy) {
+    const float* a = p.ainv + ((size_t)(b * p.L + 0) * p.L + ego) * 8;      // ego pixel -> pixel of agent 0 of the sample
+    const float u = wy * 8 + 3.5f, v = wx * 8 + 3.5f;
+    float sx = u, sy = v;
+    if (a[6] == 0.f) {
+        sx = fmaf(a[0], u, fmaf(a[1], v, a[2]));
+        sy = fmaf(a[3], u, fmaf(a[4], v, a[5]));
+    }
+    const int He = p.H + 2 * SCHED_MARGIN, We = p.W + 2 * SCHED_MARGIN;
+    const int r = (int)fminf(fmaxf(sy + SCHED_MARGIN, 0.f), (float)(He - 1));
+    const int c = (int)fminf(fmaxf(sx + SCHED_MARGIN, 0.f), (float)(We - 1));
+    const int ncol = (We + SCHED_CELL - 1) / SCHED_CELL, band = r / SCHED_BAND, col = c / SCHED_CELL;
+    const int nband = (He + SCHED_BAND - 1) / SCHED_BAND;
+    return (b * nband + band) * ncol + ((band & 1) ? ncol - 1 - col : col);
+}
+__global__ __launch_bounds__(256) void k_sched_count(AttnParams p, int n, int* __restrict__ keys, int* __restrict__ hist) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int X = p.H / 8, Y = p.W / 8;
+    const int wy = i % Y, wx = (i / Y) % X, ego = (i / (X * Y)) % p.n_ego, b = i / (X * Y * p.n_ego);
+    const int k = sched_key(p, b, ego, wx, wy);
+    keys[i] = k;
+    atomicAdd(hist + k, 1);
+}
+// exclusive prefix sum of hist[0, n) in place, one workgroup
+__global__ __launch_bounds__(1024) void k_sched_scan(int* __restrict__ hist, int n) {
+    __shared__ int part[1024];
+    const int per = (n + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, n);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += hist[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - s;
+    for (int i = lo; i < hi; ++i) {
+        const int c = hist[i];
+        hist[i] = run;
+        run += c;
+    }
+}
+__global__ __launch_bounds__(256) void k_sched_fill(AttnParams p, int n, const int* __restrict__ keys, int* __restrict__ offs,
+                                                    int* __restrict__ sched) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int X = p.H / 8, Y = p.W / 8;
+    const int wy = i % Y, wx = (i / Y) % X, ego = (i / (X * Y)) % p.n_ego, b = i / (X * Y * p.n_ego);
+    const int pos = atomicAdd(offs + keys[i], 1);   // order inside a cell is immaterial (items are independent)
+    sched[pos] = wy | (wx << 10) | (ego << 20) | (b << 24);
+}
+// ws: attn_schedule_bytes(B, n_ego, H, W) bytes; the list (n = B n_ego H/8 W/8 packed items) starts at ws
+int launch_attn_schedule(const AttnParams& p, int* ws, hipStream_t st) {
+    const int X = p.H / 8, Y = p.W / 8, n = p.B * p.n_ego * X * Y;
+    HMVIT_CHECK_ARG(X <= 1024 && Y <= 1024 && p.n_ego <= 16 && p.B <= 128, "attention schedule: map %dx%d / n_ego=%d / B=%d too large", p.H, p.W, p.n_ego, p.B);
+    const int nk = p.B * sched_keys(p.H, p.W);
+    int* sched = ws;
+    int* keys = ws + n;
+    int* hist = ws + 2 * n;
+    HMVIT_CHECK_HIP(hipMemsetAsync(hist, 0, (size_t)(nk + 1) * sizeof(int), st));
+    hipLaunchKernelGGL(k_sched_count, dim3(cdiv(n, 256)), dim3(256), 0, st, p, n, keys, hist);
+    hipLaunchKernelGGL(k_sched_scan, dim3(1), dim3(1024), 0, st, hist, nk);
+    hipLaunchKernelGGL(k_sched_fill, dim3(cdiv(n, 256)), dim3(256), 0, st, p, n, keys, hist, sched);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }

@@ -27,7 +27,7 @@ struct Plan {
     int B, L, C, H, W, P, mlp, n_slots, max_cav, E_max;
     size_t es;
     // byte offsets into the workspace
-    size_t off_xs, off_xn, off_q, off_kv, off_o, off_hid, off_ainv, off_ytok, off_xa, off_xb, off_gap, off_sw, off_vis, off_need, total;
+    size_t off_xs, off_xn, off_q, off_kv, off_o, off_hid, off_ainv, off_ytok, off_xa, off_xb, off_gap, off_sw, off_vis, off_need, off_sched, total;
 };
 
 int check_desc(const HmvitFusionDesc* d) {
@@ -82,6 +82,7 @@ static void make_plan(const HmvitFusionDesc* d, Plan& pl) {
     pl.off_ytok = carve((size_t)pl.B * pl.P * pl.C * 4);
     pl.off_vis = carve((size_t)pl.n_slots * pl.P / 64 * 4 + 256);   // visible-chunk bits of the attention windows
     pl.off_need = carve(2 * ((size_t)pl.n_slots * pl.P / 64) + 256);      // reachable windows of the stage before the pruned one
+    pl.off_sched = carve(attn_schedule_bytes(pl.B, pl.max_cav, pl.H, pl.W));   // world-ordered item list of the local stages
     pl.off_xa = pl.off_xb = pl.off_gap = pl.off_sw = 0;
     if (d->parallel) {
         // branch outputs of the parallel block + SplitAttn scratch
@@ -500,15 +501,19 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
         j.xs_out = (first && direct_x) ? nullptr : xs + (size_t)slot * map_elems;
         j.type = t;
         int nm = 0;
+        const HmvitStageScales* sc = split ? wt.scales : nullptr;
+        for (int i = 0; i < 5; ++i) j.c[i] = 1.f;
         if (l < si.n_ego) {
             j.w[nm] = reinterpret_cast<const half_t*>(wt.img_q) + (size_t)t * img_elems;
             j.y[nm] = qb + (size_t)slot * map_bytes;
+            if (sc) j.c[nm] = sc->c_q[t];
             ++nm;
         }
         for (int e = 0; e < si.E; ++e) {
             const half_t* wkv = reinterpret_cast<const half_t*>(wt.img_kv) +
                                 (size_t)(si.e_type[e] * HMVIT_NUM_TYPES + t) * 2 * img_elems;
             char* ykv = kvb + (size_t)(slot * si.E + e) * 2 * map_bytes;
+            if (sc) { j.c[nm] = sc->c_k[si.e_type[e]][t]; j.c[nm + 1] = sc->c_v[si.e_type[e]][t]; }
             j.w[nm] = wkv;             j.y[nm] = ykv;             ++nm;
             j.w[nm] = wkv + img_elems; j.y[nm] = ykv + map_bytes; ++nm;
         }
@@ -536,6 +541,20 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
             need_prev = need_last + nb;
             HMVIT_TRY(launch_window_need(ap, need_last, need_prev, st));
         }
+    }
+
+    // World-ordered item list of the local stages (launch_attn_schedule): one list per forward, for the launches that run all
+    // max_cav egos through a persistent kernel
+    const int* sched = nullptr;
+    int sched_sub = 4;
+    if (const char* e = HMVIT_ENV("HMVIT_SCHED_SUB")) sched_sub = atoi(e);
+    if (d->window == 8 && C > 64 && pl.max_cav > 1 && pl.max_cav <= 8 && d->skip_masked && sched_sub > 0 && d->H % 8 == 0 && d->W % 8 == 0) {
+        AttnParams ap;
+        memset(&ap, 0, sizeof(ap));
+        ap.ainv = ainv; ap.B = B; ap.L = L; ap.n_ego = pl.max_cav; ap.H = d->H; ap.W = d->W;
+        int* ws_s = reinterpret_cast<int*>(ws + pl.off_sched);
+        HMVIT_TRY(launch_attn_schedule(ap, ws_s, st));
+        sched = ws_s;
     }
 
     bool qkv_done = false;   // this stage's Q / K' / V' were produced by the previous stage's fused tail
@@ -574,6 +593,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                 ap.B = B; ap.L = L; ap.n_ego = n_ego; ap.n_src = n_src; ap.E = E; ap.C = C; ap.H = d->H; ap.W = d->W;
                 ap.window = d->window; ap.partition = s == 0 ? HMVIT_PART_WINDOW : HMVIT_PART_GRID;
                 ap.skip_masked = d->skip_masked;
+                ap.k_logit = (split == 1 && wt.scales) ? wt.scales->k_logit : 1.f;   // f32 planes at their own power of two
                 for (int i = 0; i < pl.n_slots; ++i) {
                     ap.mode[i] = (int8_t)d->mode[i];
                     ap.cav[i] = (int8_t)(d->cav_mask[i] != 0);
@@ -591,6 +611,11 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                     HMVIT_TRY(launch_tile_vis(ap, vis, need, st));
                     ap.vis_mask = vis;
                     ap.prune = need != nullptr;
+                    if (s == 0 && sched && n_ego == pl.max_cav) {   // local stage over all egos: world-ordered items
+                        ap.sched = sched;
+                        ap.n_sched = B * n_ego * (d->H / 8) * (d->W / 8);
+                        ap.sched_sub = sched_sub;
+                    }
                 }
                 HMVIT_TRY(launch_attention(ap, split == 1 ? HMVIT_PREC_SPLIT : HMVIT_PREC_F16, st));
             }
@@ -608,6 +633,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                 fb.p.ln_g = wt.ffn_ln_gamma; fb.p.ln_b = wt.ffn_ln_beta;
                 fb.p.w_ffn = reinterpret_cast<const half_t*>(wt.img_ffn); fb.p.b_1 = wt.b_1; fb.p.b_2 = wt.b_2;
                 fb.p.P = P; fb.p.W = d->W;
+                set_ffn_scales(fb.p, split ? wt.scales : nullptr, split ? d->head_scales : nullptr);
                 fb.variant = FFN_FULL;
                 if (fuse) {
                     const int it2 = s == 1 ? it + 1 : it, s2 = 1 - s;
@@ -704,6 +730,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
         fb.n = 0; fb.C = C; fb.st = st; fb.variant = FFN_HEAD_NCHW; fb.split = split;
         fb.p.w_ffn = reinterpret_cast<const half_t*>(d->head_img_ffn); fb.p.b_1 = d->head_b1; fb.p.b_2 = d->head_b2;
         fb.p.P = P;
+        set_ffn_scales(fb.p, nullptr, split ? d->head_scales : nullptr);
         for (int b = 0; b < B; ++b) {
             FfnJob j;
                             j.need = nullptr; j.x_nchw = 0;

@@ -489,6 +489,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, SP ? 1 : 2) void k_ln_qkv(QkvParams 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         mma_chunk_op<KK, (KK < 8 ? KK : 8), SP>(acc, buf, act, lane);
+        if constexpr (SP) acc *= J.c[mat];
 #ifndef HMVIT_EXP_NOWAIT
         dma_wait();
 #endif
@@ -580,15 +581,37 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
                 xacc[t][4 * j + 0] = f.x; xacc[t][4 * j + 1] = f.y; xacc[t][4 * j + 2] = f.z; xacc[t][4 * j + 3] = f.w;
             }
     }
-    // accumulator-layout f32 rows -> operands (x itself as the operand of mlp_head)
+    // split mode: range normalisation (HmvitStageScales), see tail16_body; all 1 / unused in f16 mode
+    float c_1 = p.c_1[ty], s_g = p.s_g[ty], k_2 = p.k_2[ty], b1_pre = 1.f;
+    const float c_o = p.c_o[ty];
+    // accumulator-layout f32 rows -> operands (x itself as the operand of mlp_head; split mode: scaled per token)
     auto acc_to_operands = [&]() {
+        float s_tok = 1.f;
+        if constexpr (SP) {
+            c_1 = 1.f; s_g = 1.f; k_2 = 1.f;
+            if (p.dyn_head) {
+                float r = 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) r = fmaxf(r, fabsf(xacc[t][e]));
+                float lo_, hi_;
+                xor32_pair(r, lo_, hi_);
+                r = fmaxf(lo_, hi_);
+                s_tok = pow2_scale(r);
+                b1_pre = p.head.w1[ty] * s_tok;
+                c_1 = pow2_inv(b1_pre);
+                s_g = pow2_scale(fmaf(p.head.l1[ty], r, p.head.b1max[ty]));
+                k_2 = p.head.w2[ty] * s_g;
+            }
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int sx = 0; sx < 2; ++sx)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    if constexpr (SP) split_h(xacc[t][8 * sx + q], act.hi[2 * t + sx][q], act.lo[2 * t + sx][q]);
+                    if constexpr (SP) split_h(xacc[t][8 * sx + q] * s_tok, act.hi[2 * t + sx][q], act.lo[2 * t + sx][q]);
                     else act.hi[2 * t + sx][q] = (half_t)xacc[t][8 * sx + q];
                 }
     };
@@ -632,7 +655,10 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
             mma_chunk_op<KK, 4, SP>(acc, buf, act, lane);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                if (t == c) xacc[t] += acc;
+                if (t == c) {
+                    if constexpr (SP) xacc[t] = acc * c_o + xacc[t];   // b_o arrives pre-divided by c_o
+                    else xacc[t] += acc;
+                }
             dma_wait();
             wg_barrier();
         }
@@ -645,9 +671,15 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float4 b2 = *reinterpret_cast<const float4*>(&vec[4][32 * t + 8 * j + 4 * hi]);
-            if constexpr (RESID) {
+            if constexpr (RESID && SP) {   // the row is carried as x k_2 through W_2's products; b_2 arrives as b_2 k_2
+                xacc[t][4 * j + 0] = fmaf(xacc[t][4 * j + 0], k_2, b2.x); xacc[t][4 * j + 1] = fmaf(xacc[t][4 * j + 1], k_2, b2.y);
+                xacc[t][4 * j + 2] = fmaf(xacc[t][4 * j + 2], k_2, b2.z); xacc[t][4 * j + 3] = fmaf(xacc[t][4 * j + 3], k_2, b2.w);
+            } else if constexpr (RESID) {
                 xacc[t][4 * j + 0] += b2.x; xacc[t][4 * j + 1] += b2.y;
                 xacc[t][4 * j + 2] += b2.z; xacc[t][4 * j + 3] += b2.w;
+            } else if constexpr (SP) {     // mlp_head: per-token k_2, b_2 at its true scale
+                xacc[t][4 * j + 0] = b2.x * k_2; xacc[t][4 * j + 1] = b2.y * k_2;
+                xacc[t][4 * j + 2] = b2.z * k_2; xacc[t][4 * j + 3] = b2.w * k_2;
             } else {
                 xacc[t][4 * j + 0] = b2.x; xacc[t][4 * j + 1] = b2.y;
                 xacc[t][4 * j + 2] = b2.z; xacc[t][4 * j + 3] = b2.w;
@@ -661,11 +693,15 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
 #pragma unroll 1
     for (int hc = 0; hc < NH; ++hc) {
         const half_t* w1c = wfp + (size_t)(2 * hc) * Cfg::CHUNK_HALVES;
-        float16v hacc;
+        float16v hacc;                 // f16 mode: starts from b_1; split mode: from 0, h = hacc c_1 + b_1 below
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float4 b1 = *reinterpret_cast<const float4*>(&vec[3][32 * hc + 8 * j + 4 * hi]);
+            // split mode: b_1 / c_1 (the stage's own chain: pre-divided on the host, b1_pre = 1; mlp_head: per token)
             hacc[4 * j + 0] = b1.x; hacc[4 * j + 1] = b1.y; hacc[4 * j + 2] = b1.z; hacc[4 * j + 3] = b1.w;
+            if constexpr (SP) {
+                hacc[4 * j + 0] *= b1_pre; hacc[4 * j + 1] *= b1_pre; hacc[4 * j + 2] *= b1_pre; hacc[4 * j + 3] *= b1_pre;
+            }
         }
         stage_chunk<C, SP>(w1c + Cfg::CHUNK_HALVES, ring1);          // W_2 slice hc
         mma_chunk_op<KK, 4, SP>(hacc, ring0, act, lane);
@@ -680,7 +716,7 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                if constexpr (SP) split_h(gelu_f(hacc[8 * s + q]), hop[s][q], hopl[s][q]);
+                if constexpr (SP) split_h(gelu_f(hacc[8 * s + q] * c_1) * s_g, hop[s][q], hopl[s][q]);
                 else hop[s][q] = (half_t)gelu_f(hacc[8 * s + q]);
             }
 #pragma unroll
@@ -702,6 +738,11 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
     }
     };
     ffn_pass(wf);
+    if constexpr (SP) {
+        const float k_inv = pow2_inv(k_2);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xacc[t] *= k_inv;
+    }
 
     auto store_x = [&]() {
         if (valid && !(QKV && J.pad)) {   // pad = 1: x'' is not needed in memory (fused launch before the pruned stage)
@@ -767,8 +808,16 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
             for (int j = 0; j < 4; ++j) {
                 const float4 b2 = *reinterpret_cast<const float4*>(&vec[4][32 * t + 8 * j + 4 * hi]);
                 xacc[t][4 * j + 0] = b2.x; xacc[t][4 * j + 1] = b2.y; xacc[t][4 * j + 2] = b2.z; xacc[t][4 * j + 3] = b2.w;
+                if constexpr (SP) {
+                    xacc[t][4 * j + 0] *= k_2; xacc[t][4 * j + 1] *= k_2; xacc[t][4 * j + 2] *= k_2; xacc[t][4 * j + 3] *= k_2;
+                }
             }
         ffn_pass(wh);
+        if constexpr (SP) {
+            const float k_inv = pow2_inv(k_2);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) xacc[t] *= k_inv;
+        }
         if (valid) {
             float* op = J.out + (size_t)(4 * hi) * P + tok;      // (C, P) map
 #pragma unroll
@@ -808,6 +857,7 @@ __device__ __forceinline__ void out_ffn_body(const FfnParams& p, const QkvParams
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = 0.f;
                 mma_chunk_op<KK, 4, SP>(acc, buf, act, lane);
+                if constexpr (SP) acc *= Q.c[mat];
 #ifndef HMVIT_EXP_NOWAIT
                 dma_wait();
 #endif
@@ -946,11 +996,20 @@ __device__ __forceinline__ void mma_slice16(float4v (&xacc)[16], const half_t* b
 }
 
 // f32 rows in accumulator layout -> operand halves: slot j of k-step s <- x[2 s + (j >> 2)][j & 3]
-__device__ __forceinline__ void rows_to_operands16(const float4v (&x)[16], half8 (&ah)[8], half8 (&al)[8]) {
+__device__ __forceinline__ void rows_to_operands16(const float4v (&x)[16], half8 (&ah)[8], half8 (&al)[8], float sc) {
 #pragma unroll
     for (int s = 0; s < 8; ++s)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) split_h(x[2 * s + (j >> 2)][j & 3], ah[s][j], al[s][j]);
+        for (int j = 0; j < 8; ++j) split_h(x[2 * s + (j >> 2)][j & 3] * sc, ah[s][j], al[s][j]);
+}
+// max |x| over the token's 256 channels (the 4 lanes of the token each hold 64)
+__device__ __forceinline__ float row_absmax16(const float4v (&x)[16]) {
+    float m = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(x[t][r]));
+    return max_over_lane_groups(m);
 }
 // LayerNorm of the token held by 4 lanes, straight into operand halves (gamma / beta from LDS)
 __device__ __forceinline__ void ln_to_operands16(const float4v (&x)[16], const float* __restrict__ lg, const float* __restrict__ lb, int g,
@@ -987,11 +1046,11 @@ __device__ __forceinline__ void ln_to_operands16(const float4v (&x)[16], const f
 
 // two projected row tiles (32 channels 32 c .. 32 c + 31) of the wave's 16 tokens -> f32 plane, through the wave's staging rows:
 // chunks (2 k, 2 k + 1) fill 64 channels = 256 bytes per token, then 4 store instructions write 4 x (4 tokens x 256 bytes)
-__device__ __forceinline__ void store_proj16(float* stg, float* y, int c, const float4v (&acc)[2], int tk, int g, int lane, int tok_w, int P) {
+__device__ __forceinline__ void store_proj16(float* stg, float* y, int c, const float4v (&acc)[2], float cm, int tk, int g, int lane, int tok_w, int P) {
     constexpr int C = 256;
     float* d = stg + tk * X16_STG_ROW + 32 * (c & 1) + 4 * g;
-    *reinterpret_cast<float4*>(d) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
-    *reinterpret_cast<float4*>(d + 16) = make_float4(acc[1][0], acc[1][1], acc[1][2], acc[1][3]);
+    *reinterpret_cast<float4*>(d) = make_float4(acc[0][0] * cm, acc[0][1] * cm, acc[0][2] * cm, acc[0][3] * cm);
+    *reinterpret_cast<float4*>(d + 16) = make_float4(acc[1][0] * cm, acc[1][1] * cm, acc[1][2] * cm, acc[1][3] * cm);
     if (c & 1) {
         float* yo = y + (size_t)tok_w * C + 64 * (c >> 1);
 #pragma unroll
@@ -1033,7 +1092,7 @@ __device__ __forceinline__ void ring_wait_newest8() { asm volatile("s_waitcnt vm
 
 // "mixed" precision mode (A16): the projected Q / K' / V' planes are f16 (they are attention operands, rounded once; the f16
 // attention kernels consume them), 128 channels = 256 bytes per token and flush
-__device__ __forceinline__ void store_proj16_h(float* stg_f, half_t* y, int c, const float4v (&acc)[2], int tk, int g, int lane, int tok_w, int P) {
+__device__ __forceinline__ void store_proj16_h(float* stg_f, half_t* y, int c, const float4v (&acc)[2], float cm, int tk, int g, int lane, int tok_w, int P) {
     constexpr int C = 256, ROW = 2 * X16_STG_ROW;          // halves per staged token row (128 channels + padding)
     half_t* stg = reinterpret_cast<half_t*>(stg_f);
     half_t* d = stg + tk * ROW + 32 * (c & 3) + 4 * g;
@@ -1041,7 +1100,7 @@ __device__ __forceinline__ void store_proj16_h(float* stg_f, half_t* y, int c, c
     for (int T = 0; T < 2; ++T) {
         half4 h;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = (half_t)acc[T][r];
+        for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[T][r] * cm);
         *reinterpret_cast<half4*>(d + 16 * T) = h;
     }
     if ((c & 3) == 3) {
@@ -1105,8 +1164,10 @@ __global__ __launch_bounds__(X16_THREADS, 2) void k_ln_qkv16(QkvParams p) {
     half8 ah[8], al[8];
     ln_to_operands16(x, lnp, lnp + C, g, ah, al);
     auto flushes = [](int k) { return k >= 0 && (A16 ? (k & 3) == 3 : (k & 1) != 0); };
+    const float cq0 = J.c[0], cq1 = J.c[1], cq2 = J.c[2], cq3 = J.c[3], cq4 = J.c[4];
     for (int c = 0; c < n_chunks; ++c) {
         const int mat = c / NCH, t = c - mat * NCH;
+        const float cm = mat == 0 ? cq0 : mat == 1 ? cq1 : mat == 2 ? cq2 : mat == 3 ? cq3 : cq4;
         auto ring_wait = [&](bool flush_since) {
             if (c + 2 < n_chunks && full_wave) { if (flush_since) ring_wait_newest8(); else ring_wait_newest4(); }
             else dma_wait();
@@ -1117,8 +1178,8 @@ __global__ __launch_bounds__(X16_THREADS, 2) void k_ln_qkv16(QkvParams p) {
             if (grp_b) ring_wait(flushes(c - 1));
             wg_barrier();
         }
-        if constexpr (A16) store_proj16_h(stg, reinterpret_cast<half_t*>(J.y[mat]), t, acc, tk, g, lane, tok_w, P);
-        else store_proj16(stg, reinterpret_cast<float*>(J.y[mat]), t, acc, tk, g, lane, tok_w, P);
+        if constexpr (A16) store_proj16_h(stg, reinterpret_cast<half_t*>(J.y[mat]), t, acc, cm, tk, g, lane, tok_w, P);
+        else store_proj16(stg, reinterpret_cast<float*>(J.y[mat]), t, acc, cm, tk, g, lane, tok_w, P);
         const int ahead = c + 2 + (grp_b ? 1 : 0);
         if (ahead < n_chunks) stage_chunk16(chunk_ptr(ahead), slot(ahead));
         if (!grp_b) ring_wait(flushes(c));
@@ -1239,7 +1300,28 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
             xacc[t][0] = f.x; xacc[t][1] = f.y; xacc[t][2] = f.z; xacc[t][3] = f.w;
         }
     }
-    if constexpr (!OUTPROJ && !LN) rows_to_operands16(xacc, ah, al);   // mlp_head: x itself is the operand
+    // range normalisation (HmvitStageScales): uniform powers of two for the stage's own chain; the stand-alone mlp_head launch
+    // (!OUTPROJ && !LN) multiplies the un-normalised row itself and takes per-token factors (head_token_scales)
+    float c_1 = p.c_1[ty], s_g = p.s_g[ty], k_2 = p.k_2[ty];
+    float b1_pre = 1.f;             // mlp_head only: the hidden accumulator starts from b_1 b1_pre = b_1 / c_1
+    const float c_o = p.c_o[ty];
+    // mlp_head on a raw row: operand scale from the row's own maximum, the hidden bound from |h| <= l1 max|x| + max|b_1|
+    auto head_token_scales = [&](float& s_tok) {
+        s_tok = 1.f; c_1 = 1.f; s_g = 1.f; k_2 = 1.f; b1_pre = 1.f;
+        if (p.dyn_head) {
+            const float r = row_absmax16(xacc);
+            s_tok = pow2_scale(r);
+            b1_pre = p.head.w1[ty] * s_tok;
+            c_1 = pow2_inv(b1_pre);
+            s_g = pow2_scale(fmaf(p.head.l1[ty], r, p.head.b1max[ty]));
+            k_2 = p.head.w2[ty] * s_g;
+        }
+    };
+    if constexpr (!OUTPROJ && !LN) {   // mlp_head: x itself is the operand
+        float s_tok;
+        head_token_scales(s_tok);
+        rows_to_operands16(xacc, ah, al, s_tok);
+    }
     if constexpr (OUTPROJ && A16) {
         // attention output (f16, exact operand: no lo half) of this token
         const half_t* op = reinterpret_cast<const half_t*>(J.o) + (size_t)tok_c * C + 4 * g;
@@ -1271,7 +1353,7 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
 #pragma unroll 1
         for (int c = 0; c < N_OUT; ++c) {
             step_begin();
-            float4v acc[2];
+            float4v acc[2];                                          // starts from b_o / c_o (pre-divided on the host)
 #pragma unroll
             for (int T = 0; T < 2; ++T) {
                 const float4 bo = *reinterpret_cast<const float4*>(&vec[0][32 * c + 16 * T + 4 * g]);
@@ -1281,38 +1363,47 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
             products_end(false);
 #pragma unroll
             for (int t = 0; t < 8; ++t)
-                if (t == c) { xacc[2 * t] += acc[0]; xacc[2 * t + 1] += acc[1]; }
+                if (t == c) { xacc[2 * t] = acc[0] * c_o + xacc[2 * t]; xacc[2 * t + 1] = acc[1] * c_o + xacc[2 * t + 1]; }
             step_end(false);
         }
     }
     if constexpr (LN) ln_to_operands16(xacc, vec[1], vec[2], g, ah, al);
 
+    // the row is carried as x k_2 while W_2's (scaled) products accumulate into it.  Stage chain: b_2 arrives as b_2 k_2;
+    // mlp_head (no residual, per-token k_2): b_2 at its true scale
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const float4 b2 = *reinterpret_cast<const float4*>(&vec[4][16 * t + 4 * g]);
         if constexpr (RESID) {
-            xacc[t][0] += b2.x; xacc[t][1] += b2.y; xacc[t][2] += b2.z; xacc[t][3] += b2.w;
+            xacc[t][0] = fmaf(xacc[t][0], k_2, b2.x); xacc[t][1] = fmaf(xacc[t][1], k_2, b2.y);
+            xacc[t][2] = fmaf(xacc[t][2], k_2, b2.z); xacc[t][3] = fmaf(xacc[t][3], k_2, b2.w);
         } else {
-            xacc[t][0] = b2.x; xacc[t][1] = b2.y; xacc[t][2] = b2.z; xacc[t][3] = b2.w;
+            xacc[t][0] = b2.x * k_2; xacc[t][1] = b2.y * k_2; xacc[t][2] = b2.z * k_2; xacc[t][3] = b2.w * k_2;
         }
     }
 
     // ---- phase 2: per hidden tile hc: h = GELU(W_1[hc] . xn + b_1[hc]);  x'' += W_2[:, hc] . h ----
-    auto ffn_pass = [&]() {
+    // DYN (mlp_head on a raw row): per-token factors, b_1 at its true scale; otherwise b_1 arrives as b_1 / c_1
+    auto ffn_pass = [&](auto dyn_c) {
+        constexpr bool DYN = decltype(dyn_c)::value;
 #pragma unroll 1
         for (int hc = 0; hc < NH; ++hc) {
             step_begin();
-            float4v hacc[2];
+            float4v hacc[2];                                 // starts from b_1 / c_1
 #pragma unroll
             for (int T = 0; T < 2; ++T) {
                 const float4 b1 = *reinterpret_cast<const float4*>(&vec[3][32 * hc + 16 * T + 4 * g]);
-                hacc[T][0] = b1.x; hacc[T][1] = b1.y; hacc[T][2] = b1.z; hacc[T][3] = b1.w;
+                if constexpr (DYN) {
+                    hacc[T][0] = b1.x * b1_pre; hacc[T][1] = b1.y * b1_pre; hacc[T][2] = b1.z * b1_pre; hacc[T][3] = b1.w * b1_pre;
+                } else {
+                    hacc[T][0] = b1.x; hacc[T][1] = b1.y; hacc[T][2] = b1.z; hacc[T][3] = b1.w;
+                }
             }
             mma_proj16(hacc, slot(cc), ah, al, lane);
             products_end(false);
             half8 hh, hl;                                    // hidden channel 32 hc + 16 (j >> 2) + 4 g + (j & 3) = hacc[j >> 2][j & 3]
 #pragma unroll
-            for (int j = 0; j < 8; ++j) split_h(gelu_f(hacc[j >> 2][j & 3]), hh[j], hl[j]);
+            for (int j = 0; j < 8; ++j) split_h(gelu_f(hacc[j >> 2][j & 3] * c_1) * s_g, hh[j], hl[j]);
             step_end(false);
             step_begin();
             mma_slice16(xacc, slot(cc), hh, hl, lane);
@@ -1320,7 +1411,12 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
             step_end(false);
         }
     };
-    ffn_pass();
+    ffn_pass(std::integral_constant<bool, !OUTPROJ && !LN>{});
+    {
+        const float k_inv = pow2_inv(k_2);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) xacc[t] *= k_inv;
+    }
 
     auto store_x = [&]() {
         if (valid && !(QKV && J.pad)) {
@@ -1340,7 +1436,9 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
     if constexpr (TAIL == 0) store_x();
 
     if constexpr (HEAD) {
-        rows_to_operands16(xacc, ah, al);
+        float s_tok;
+        head_token_scales(s_tok);
+        rows_to_operands16(xacc, ah, al, s_tok);
         // vec[3..4] are free: their last readers passed the barrier that ended phase 2
         for (int i = threadIdx.x; i < C; i += X16_THREADS) {
             vec[3][i] = p.hb_1[ty * C + i];
@@ -1350,9 +1448,14 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const float4 b2 = *reinterpret_cast<const float4*>(&vec[4][16 * t + 4 * g]);
-            xacc[t][0] = b2.x; xacc[t][1] = b2.y; xacc[t][2] = b2.z; xacc[t][3] = b2.w;
+            xacc[t][0] = b2.x * k_2; xacc[t][1] = b2.y * k_2; xacc[t][2] = b2.z * k_2; xacc[t][3] = b2.w * k_2;
         }
-        ffn_pass();
+        ffn_pass(std::integral_constant<bool, true>{});
+        {
+            const float k_inv = pow2_inv(k_2);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) xacc[t] *= k_inv;
+        }
         if (valid) {
             float* op = J.out + (size_t)(4 * g) * P + tok;      // (C, P) map
 #pragma unroll
@@ -1371,16 +1474,18 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
             __syncthreads();
             ln_to_operands16(xacc, vec[1], vec[2], g, ah, al);
             store_x();                                   // x'' leaves while the first tiles are computed
+            const float cq0 = Qj->c[0], cq1 = Qj->c[1], cq2 = Qj->c[2], cq3 = Qj->c[3], cq4 = Qj->c[4];
             for (int c = 0; c < n_tail; ++c) {
                 const int mat = c / NCH, t = c - mat * NCH;
+                const float cm = mat == 0 ? cq0 : mat == 1 ? cq1 : mat == 2 ? cq2 : mat == 3 ? cq3 : cq4;
                 // (the 16 stores of x'' are older than the first request made after them: that wait covers them too)
                 auto flushes = [](int k) { return k >= 0 && (A16 ? (k & 3) == 3 : (k & 1) != 0); };
                 step_begin();
                 float4v acc[2] = {(float4v)(0.f), (float4v)(0.f)};
                 mma_proj16(acc, slot(cc), ah, al, lane);
                 products_end(flushes(c - 1));
-                if constexpr (A16) store_proj16_h(stg, reinterpret_cast<half_t*>(Qj->y[mat]), t, acc, tk, g, lane, tok_w, P);
-                else store_proj16(stg, reinterpret_cast<float*>(Qj->y[mat]), t, acc, tk, g, lane, tok_w, P);
+                if constexpr (A16) store_proj16_h(stg, reinterpret_cast<half_t*>(Qj->y[mat]), t, acc, cm, tk, g, lane, tok_w, P);
+                else store_proj16(stg, reinterpret_cast<float*>(Qj->y[mat]), t, acc, cm, tk, g, lane, tok_w, P);
                 step_end(flushes(c));
             }
         } else {

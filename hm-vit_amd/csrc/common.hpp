@@ -129,6 +129,16 @@ __device__ __forceinline__ float max_over_lane_groups(float x) {
     return max_raw(a, b);
 }
 
+// Range normalisation of the split operands (HmvitStageScales, include/hmvit.h): power-of-two factors, so every scaling and
+// its inverse are exact.  pow2_scale(y): the power of two s with y s in [2^13, 2^14) (y >= 0; exponent clamped to 2^+-40);
+// pow2_inv(s) = 1 / s for a power of two.
+__device__ __forceinline__ float pow2_scale(float y) {
+    int e = (int)((__float_as_uint(y) >> 23) & 0xffu);
+    e = min(max(e, 127 - 40), 127 + 40);
+    return __uint_as_float((unsigned)(127 + 13 + 127 - e) << 23);
+}
+__device__ __forceinline__ float pow2_inv(float s) { return __uint_as_float(0x7f000000u - __float_as_uint(s)); }
+
 // pixel (row, col) of token `n` (row-major inside the w x w window) of window (wx, wy)
 // for the two partitions (hetero_fusion.py:387-389 / :430-431)
 __device__ __forceinline__ void token_pixel(int partition, int window, int X, int Y, int wx, int wy,

@@ -11,6 +11,9 @@
 // Same tile as gemm.hip: 128 output pixels x 128 output channels per workgroup, 2x2 wavefronts,
 // v_mfma_f32_32x32x16_f16 (f16 mode) or v_mfma_f32_32x32x2_f32 (exact f32 mode).
 #include <type_traits>
+#include <algorithm>
+#include <atomic>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -160,6 +163,15 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, hi = lane >> 5;
     const T* x = reinterpret_cast<const T*>(p.x);
     const T* w = reinterpret_cast<const T*>(p.w);
+    // split mode: range normalisation of both operands (ConvParams::absmax)
+    float sx = 1.f, sw = 1.f, s_inv = 1.f;
+    if constexpr (SPLIT) {
+        if (p.absmax) {
+            sx = pow2_scale(__uint_as_float(p.absmax[0]));
+            sw = pow2_scale(__uint_as_float(p.absmax[1]));
+            s_inv = pow2_inv(sx) * pow2_inv(sw);
+        }
+    }
 
     // the rows this thread stages: decode (image, oy, ox) once
     int rn[RPT], roy[RPT], rox[RPT];
@@ -270,8 +282,9 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
                 half4 h, l;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    h[e] = (half_t)ra[SET][i][e];
-                    l[e] = (half_t)(ra[SET][i][e] - (float)h[e]);
+                    const float v = ra[SET][i][e] * sx;
+                    h[e] = (half_t)v;
+                    l[e] = (half_t)(v - (float)h[e]);
                 }
                 *reinterpret_cast<half4*>(As[buf] + row * LS + kc) = h;
                 *reinterpret_cast<half4*>(As[buf] + row * LS + 32 + kc) = l;
@@ -290,8 +303,9 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
                 half4 h, l;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    h[e] = (half_t)rw[SET][i][e];
-                    l[e] = (half_t)(rw[SET][i][e] - (float)h[e]);
+                    const float v = rw[SET][i][e] * sw;
+                    h[e] = (half_t)v;
+                    l[e] = (half_t)(v - (float)h[e]);
                 }
                 *reinterpret_cast<half4*>(Ws[buf] + row * LS + kc) = h;
                 *reinterpret_cast<half4*>(Ws[buf] + row * LS + 32 + kc) = l;
@@ -415,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
                     const size_t o = pix * p.y_ctot + p.y_coff + co;
                     float v[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = acc[i][j][8 * qq + e];
+                    for (int e = 0; e < 8; ++e) v[e] = SPLIT ? acc[i][j][8 * qq + e] * s_inv : acc[i][j][8 * qq + e];
                     if (p.bias) {
                         const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co), b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
                         v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
@@ -456,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
                         const int dye = s ? sube / s : 0, dxe = s ? sube - dye * s : 0;
                         const size_t pixe = s ? ((size_t)n * p.Ho * s + oy * s + dye) * (p.Wo * s) + ox * s + dxe : (size_t)m;
                         const size_t oe = pixe * p.y_ctot + p.y_coff + coe;
-                        float ve = acc[i][j][8 * qq + e] + (p.bias ? p.bias[coe] : 0.f);
+                        float ve = (SPLIT ? acc[i][j][8 * qq + e] * s_inv : acc[i][j][8 * qq + e]) + (p.bias ? p.bias[coe] : 0.f);
                         if (p.res) ve += (float)reinterpret_cast<const T*>(p.res)[pixe * p.Cout + coe];
                         if (p.relu) ve = fmaxf(ve, 0.f);
                         if (p.out_f32) reinterpret_cast<float*>(p.y)[oe] = ve;
@@ -542,10 +556,19 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // split mode: range normalisation of both operands (ConvParams::absmax)
+    float sx = 1.f, sw = 1.f, s_inv = 1.f;
+    if constexpr (SPLIT) {
+        if (p.absmax) {
+            sx = pow2_scale(__uint_as_float(p.absmax[0]));
+            sw = pow2_scale(__uint_as_float(p.absmax[1]));
+            s_inv = pow2_inv(sx) * pow2_inv(sw);
+        }
+    }
     int4v rp[NPP], rw[RPW];                        // 16-byte pieces: 8 halves, or 4 floats (SPLIT)
-    auto put = [&](T* dst, const int4v& piece) {   // one piece into its LDS row (SPLIT: as hi / lo halves)
+    auto put = [&](T* dst, const int4v& piece, float sc) {   // one piece into its LDS row (SPLIT: scaled, as hi / lo halves)
         if constexpr (SPLIT) {
-            const float4v f = __builtin_bit_cast(float4v, piece);
+            const float4v f = __builtin_bit_cast(float4v, piece) * sc;
             half4 h, l;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -566,7 +589,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
     auto store_patch = [&]() {
 #pragma unroll
         for (int i = 0; i < NPP; ++i)
-            if (plds[i] >= 0) put(Ps + plds[i], rp[i]);
+            if (plds[i] >= 0) put(Ps + plds[i], rp[i], sx);
     };
     auto load_w = [&](int k0) {
 #pragma unroll
@@ -577,7 +600,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const int c = tid + 256 * i;
-            put(Ws[buf] + stage_row<SPLIT>(c) * LS + (c & 7) * PE, rw[i]);
+            put(Ws[buf] + stage_row<SPLIT>(c) * LS + (c & 7) * PE, rw[i], sw);
         }
     };
 
@@ -649,7 +672,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
                 if (co >= p.Cout) continue;
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = acc[i][j][8 * qq + e];
+                for (int e = 0; e < 8; ++e) v[e] = SPLIT ? acc[i][j][8 * qq + e] * s_inv : acc[i][j][8 * qq + e];
                 if (p.bias) {
                     const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co), b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
                     v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
@@ -721,7 +744,49 @@ int launch_maxpool(const void* x, void* y, int N, int H, int W, int C, int ksize
     return HMVIT_OK;
 }
 
-int launch_conv(const ConvParams& p, int precision, hipStream_t st) {
+// split mode: max |x| and max |w| of one convolution, as f32 bit patterns (non-negative floats order like unsigned integers)
+__global__ __launch_bounds__(256) void k_absmax2(const float* __restrict__ x, size_t nx, const float* __restrict__ w, size_t nw,
+                                                 unsigned* __restrict__ slot) {
+    const bool is_w = blockIdx.y != 0;
+    const float* a = is_w ? w : x;
+    const size_t n = is_w ? nw : nx, n4 = n / 4;
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(a)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(a[n4 * 4 + threadIdx.x]));
+    // NaN / Inf inputs: fmaxf drops NaN; an Inf maximum gives the smallest scale and the Inf propagates through the products
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slot + (is_w ? 1 : 0), __float_as_uint(m));
+}
+// ring of result slots: a launch takes the next one (stream-ordered use: zeroed, filled, read by its own three stream operations)
+constexpr int kAbsmaxSlots = 4096;
+__device__ unsigned g_conv_absmax[kAbsmaxSlots][2];
+
+int launch_conv(const ConvParams& p_in, int precision, hipStream_t st) {
+    ConvParams p = p_in;
+    p.absmax = nullptr;
+    if (precision == HMVIT_PREC_SPLIT) {
+        static std::atomic<unsigned> next_slot{0};
+        static unsigned* bases[64] = {};      // per device: the symbol's address is looked up once (not during a graph capture)
+        int dev = 0;
+        HMVIT_CHECK_HIP(hipGetDevice(&dev));
+        HMVIT_CHECK_ARG(dev >= 0 && dev < 64, "conv: device ordinal %d", dev);
+        if (!bases[dev]) HMVIT_CHECK_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&bases[dev]), HIP_SYMBOL(g_conv_absmax)));
+        unsigned* base = bases[dev];
+        unsigned* slot = base + 2 * (next_slot.fetch_add(1) % kAbsmaxSlots);
+        const size_t nx = ((size_t)p.N * p.H * p.W * p.Cin) >> (p.up2 ? 2 : 0);
+        const int ncols = p.deconv_s ? p.deconv_s * p.deconv_s * p.Cout : p.Cout;
+        const size_t nw = (size_t)ncols * (p.rowpack ? p.KH * 32 : p.KH * p.KW * p.Cin);
+        HMVIT_CHECK_HIP(hipMemsetAsync(slot, 0, 2 * sizeof(unsigned), st));
+        const unsigned blocks = (unsigned)std::min<size_t>(2048, std::max<size_t>(1, (std::max(nx, nw) / 4 + 255) / 256));
+        hipLaunchKernelGGL(k_absmax2, dim3(blocks, 2), dim3(256), 0, st, reinterpret_cast<const float*>(p.x), nx,
+                           reinterpret_cast<const float*>(p.w), nw, slot);
+        HMVIT_CHECK_LAUNCH();
+        p.absmax = slot;
+    }
     const bool f32_maps = precision == HMVIT_PREC_F32 || precision == HMVIT_PREC_SPLIT;   // element type of x / w / residual
     const int bk = f32_maps ? ConvCfg<float>::BK : ConvCfg<half_t>::BK;
     HMVIT_CHECK_ARG(p.rowpack || (p.Cin > 0 && p.Cin % bk == 0), "conv: Cin=%d must be a multiple of %d", p.Cin, bk);

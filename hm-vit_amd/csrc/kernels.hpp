@@ -51,6 +51,7 @@ struct QkvJob {
     float* xs_out;           // token-major copy written when in_nchw (nullptr: not needed)
     const half_t* w[5];      // weight images (NT chunks each): [Q] K'(e0) V'(e0) [K'(e1) V'(e1)]
     void* y[5];              // output planes (P, C): f16, or f32 in split mode
+    float c[5];              // split modes: plane = accumulator * c (HmvitStageScales c_q / c_k / c_v; 1 when not in use)
     int n_mat;
     int type;
 };
@@ -88,7 +89,24 @@ struct FfnParams {
     const half_t* w_head;    // k_out_ffn_head only: mlp_head image (T, 2 NH chunks) and biases (T, C)
     const float* hb_1;
     const float* hb_2;
+    // split modes: power-of-two range normalisation (HmvitStageScales / HmvitHeadScales, include/hmvit.h); all 1 / dyn_head = 0
+    // when the tensors are at their true scale.  b_o arrives pre-divided by c_o and b_2 pre-multiplied by k_2.
+    float c_o[HMVIT_NUM_TYPES], c_1[HMVIT_NUM_TYPES], s_g[HMVIT_NUM_TYPES], k_2[HMVIT_NUM_TYPES];
+    HmvitHeadScales head;    // mlp_head (k_out_ffn_head, FFN_HEAD_NCHW): operand scaled per token when dyn_head
+    int dyn_head;
 };
+// FfnParams scale fields <- a stage's scales (null: all 1)
+inline void set_ffn_scales(FfnParams& p, const HmvitStageScales* sc, const HmvitHeadScales* hs) {
+    for (int t = 0; t < HMVIT_NUM_TYPES; ++t) {
+        p.c_o[t] = sc ? sc->c_o[t] : 1.f;
+        p.c_1[t] = sc ? sc->c_1[t] : 1.f;
+        p.s_g[t] = sc ? sc->s_g[t] : 1.f;
+        p.k_2[t] = sc ? sc->k_2[t] : 1.f;
+    }
+    p.dyn_head = hs ? 1 : 0;
+    if (hs) p.head = *hs;
+    else for (int t = 0; t < HMVIT_NUM_TYPES; ++t) p.head.w1[t] = p.head.w2[t] = 1.f, p.head.l1[t] = p.head.b1max[t] = 0.f;
+}
 enum { FFN_FULL = 0, FFN_NO_ATTN = 1, FFN_HEAD_NCHW = 2 };
 int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, int split, hipStream_t st);
 // k_out_ffn (FFN_FULL) of a stage fused with k_ln_qkv of the next one; job j of both lists = the same agent;
@@ -125,6 +143,8 @@ struct ConvParams {
     const void* res;          // optional residual (N, Ho, Wo, Cout) in the precision's element type, added before the ReLU
     int no_patch;             // 1: never take the patch-in-LDS 3 x 3 kernel (A/B checks of the two kernels against each other)
     int up2;                  // 1: the input is the nearest-neighbour x2 upsampling of x (N, H/2, W/2, Cin); H, W are the upsampled sizes
+    const unsigned* absmax;   // split mode (set by launch_conv): device (|x|max, |w|max) as f32 bit patterns; both operands are
+                              // brought to [2^13, 2^14) by a power of two on their way into LDS and the product is scaled back
     int rowpack;              // 1: few-channel stem.  x is a physically zero-padded (N, H, W, 4) map, output pixel (oy, ox) reads
                               // rows oy*stride .. + KH - 1 and pixels ox*stride .. + 7 of it; w is (Ncols, KH * 32) with
                               // k = ky * 32 + px * 4 + ci; Ho, Wo are given, pad / KW / Cin are not used
@@ -164,12 +184,19 @@ struct AttnParams {
     int self_identity;               // caller's guarantee that every self transform pairwise_t[b, i, i] is the identity
                                      // (needed by the split-precision persistent kernel, which has no general-self loader)
     float* lse;               // optional (B, L, P, heads) f32: log-sum-exp of every query row (f32 kernel; kept for the backward pass)
+    const int* sched;         // optional world-ordered item list of the persistent kernels (launch_attn_schedule), n_sched items
+    int n_sched, sched_sub;   // sched_sub: steps per list segment (pc_fetch_sched)
+    float k_logit;            // f32-plane kernels: logits formed from the planes * k_logit = natural units (HmvitStageScales;
+                              // 0 is read as 1: descriptors that never heard of it)
     int8_t mode[kMaxSlots];   // (B, L)
     int8_t cav[kMaxSlots];    // (B, L)
     int8_t ego_e[kMaxSlots];  // (B, L): K/V variant used by ego (b, i)
 };
 int launch_attention(const AttnParams& p, int precision, hipStream_t st);
 int launch_tile_vis(const AttnParams& p, unsigned* vis_mask, const unsigned char* need, hipStream_t st);
+// world-ordered work list of a local-partition stage with p.n_ego egos (p.ainv, B, L, H, W are read); ws: attn_schedule_bytes
+size_t attn_schedule_bytes(int B, int n_ego, int H, int W);
+int launch_attn_schedule(const AttnParams& p, int* ws, hipStream_t st);
 // to[(b * n_ego + k) * (H/8) * (W/8) + window] = 1 when an ego reads a key / value inside that 8 x 8 window of agent k's
 // map: ego 0 over its whole map (from = nullptr: the reads of the pruned last stage), or every ego j over the windows
 // marked in `from` (plus those windows themselves).  `to` must be zeroed by the caller.

@@ -49,10 +49,17 @@ class NaiveCompressor(nn.Module):
 
     def forward(self, x):
         from .camera import _Conv, _Prepared, _to_nchw, _to_nhwc      # shared convolution plumbing (channel padding, BN fold)
-        if self.training:
-            raise RuntimeError("hmvit_amd.NaiveCompressor folds BatchNorm statistics: call .eval() (inference only)")
         if x.device.type != "cuda":
             raise RuntimeError("hm-vit_amd runs on the GPU only (HIP kernels, no CPU fallback)")
+        if self.training:
+            # batch-statistics BatchNorm + gradients: the training kernels of the detection tail (hm-vit_amd/tail_train.py)
+            from . import tail_train as TT
+            if (self.input_dim // 1) % 32 or self.encoder[0].out_channels % 32:
+                raise NotImplementedError("NaiveCompressor training: channel counts must be multiples of 32 (compress ratio <= 8)")
+            t = x.float().permute(0, 2, 3, 1).contiguous()
+            for conv, bn in ((self.encoder[0], self.encoder[1]), (self.decoder[0], self.decoder[1]), (self.decoder[3], self.decoder[4])):
+                t = TT.bn_relu_module(TT.Conv3x3.apply(t, conv.weight, conv.bias), bn)
+            return t.permute(0, 3, 1, 2).contiguous()
         if self._prep is None:
             self._prep = _Prepared()
         prec = _PREC[self.precision]

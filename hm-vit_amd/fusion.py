@@ -108,6 +108,7 @@ class _FusionBase(nn.Module):
 
     precision = "split"          # the reference's fp32 arithmetic on the f16 matrix pipes (1e-4); "f16" is the opt-in fast mode
     skip_masked = True
+    _warned_eval_grad = False
 
     def _init_runtime(self):
         self._folded = None
@@ -159,8 +160,33 @@ class _FusionBase(nn.Module):
                 folded["split"] = {k: sd[f"{pre}split_attn.{n}"].detach().float().contiguous()
                                    for k, n in (("split_fc1", "fc1.weight"), ("split_ln_g", "bn1.weight"),
                                                 ("split_ln_b", "bn1.bias"), ("split_fc2", "fc2.weight"))}
+            # HmvitStageScales / HmvitHeadScales as ctypes structs (host memory the descriptor points into)
+            for s_ in (0, 1):
+                folded[s_]["scales"] = self._scales_struct(folded[s_].get("scales"))
+            if "head" in folded:
+                hs = folded["head"].get("head_scales")
+                if hs is not None:
+                    st = _lib.HeadScales()
+                    for name in ("w1", "w2", "l1", "b1max"):
+                        for t in range(NUM_TYPES):
+                            getattr(st, name)[t] = hs[name][t]
+                    folded["head"]["head_scales"] = st
             self._folded, self._folded_key = folded, key
         return self._folded
+
+    @staticmethod
+    def _scales_struct(sc):
+        if sc is None:
+            return None
+        st = _lib.StageScales()
+        for t in range(NUM_TYPES):
+            for name in ("c_q", "c_o", "c_1", "s_g", "k_2"):
+                getattr(st, name)[t] = sc[name][t]
+            for t2 in range(NUM_TYPES):
+                st.c_k[t][t2] = sc["c_k"][t][t2]
+                st.c_v[t][t2] = sc["c_v"][t][t2]
+        st.k_logit = sc["k_logit"]
+        return st
 
     def _make_desc(self, x, pairwise_t_matrix, mode, record_len, mask, apply_head: bool, num_iters: int):
         blk = self._block_cfg
@@ -205,10 +231,16 @@ class _FusionBase(nn.Module):
         d.x, d.pairwise_t, d.out = x.data_ptr(), pw.data_ptr(), out.data_ptr()
         for s in range(2):
             for name, _ in _lib.StageWeights._fields_:
-                setattr(d.stage[s], name, w[s][name].data_ptr() if name in w[s] else None)
+                if name == "scales":
+                    sc = w[s].get("scales")
+                    d.stage[s].scales = ctypes.addressof(sc) if sc is not None else None
+                else:
+                    setattr(d.stage[s], name, w[s][name].data_ptr() if name in w[s] else None)
         if apply_head:
             for name in ("head_w1", "head_b1", "head_w2", "head_b2", "head_img_ffn"):
                 setattr(d, name, w["head"][name].data_ptr() if name in w["head"] else None)
+            hs = w["head"].get("head_scales")
+            d.head_scales = ctypes.addressof(hs) if hs is not None else None
         if blk["architect_mode"] == "parallel":
             d.parallel = 1
             for name, t in w["split"].items():
@@ -316,7 +348,18 @@ class HeteroFusion(_FusionBase):
         default state); set ``force_autograd = True`` to record such a call."""
         if not torch.is_grad_enabled():
             return False
-        return bool(self.training or x.requires_grad or self.force_autograd)
+        if self.training or x.requires_grad or self.force_autograd:
+            return True
+        # eval mode, grad mode on, input off the tape.  The reference would still record a graph here whenever a parameter
+        # requires grad (their default state), e.g. an eval-mode fine-tune behind a frozen encoder; this module treats the call
+        # as inference (the fused launch, no 40 GB of saved activations) and says so once
+        if not _FusionBase._warned_eval_grad and any(p.requires_grad for p in self.parameters()):
+            _FusionBase._warned_eval_grad = True
+            warnings.warn("hmvit_amd.HeteroFusion: eval-mode call with grad mode on and an input that does not require grad runs as "
+                          "INFERENCE (no autograd graph, parameters get no gradient).  Wrap inference in torch.no_grad() to "
+                          "silence this; set `module.force_autograd = True` (or train(), or x.requires_grad_()) to record the "
+                          "backward pass.", stacklevel=3)
+        return False
 
     force_autograd = False
 

@@ -51,7 +51,7 @@ class BevformerPointPillarHetero(nn.Module):
         self.compression = False
         if config.get("compression", 0) > 0:             # bevformer_point_pillar_hetero.py:69-71 (the shipped yaml uses 0)
             self.compression = True
-            self.naive_compressor = NaiveCompressor(256, config["compression"], precision=precision)
+            self.compressor = NaiveCompressor(256, config["compression"], precision=precision)   # the reference's attribute name
         self.fusion_net = HeteroFusion(config["hetero_fusion"], precision=fusion_precision)
         self.lidar_encoder.set_return_features()
         if self.camera_encoder is not None:
@@ -149,7 +149,7 @@ class BevformerPointPillarHetero(nn.Module):
             x[(flat_mode == 0).to(x.device)] = camera_features.to(x.dtype)
             x[(flat_mode == 1).to(x.device)] = lidar_features
         if self.compression:                              # :116-117, on the concatenated agent maps
-            x = self.naive_compressor(x)
+            x = self.compressor(x)
         x, mask = regroup(x, rl, max_cav)
         fused = self.fusion_net(x, pairwise_t_matrix, mode, record_len, mask)
         psm, rm = self.decoder(fused.unsqueeze(1), mode, use_upsample=False)

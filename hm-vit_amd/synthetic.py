@@ -61,3 +61,42 @@ def seeded_fusion(cfg: dict, precision: str = "split", seed: int = 0):
                 m.bias.add_(0.1 * torch.randn_like(m.bias))
     torch.random.set_rng_state(state)
     return net
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# camera agents of the synthetic scenes (trainer.py / replay.py / bench.py --train): the CVT camera lift in the model's camera
+# slot (hm-vit_amd/camera.py: CvtCameraEncoder), images, pinhole intrinsics and camera -> ego extrinsics of four cameras
+# ---------------------------------------------------------------------------------------------------------------------
+def camera_config(image: int = 64, num_layers: int = 18, bev_h: int = 32, bev_w: int = 32, dim: int = 128) -> dict:
+    """CvtCameraEncoder config with the structure of ``opcamera/cvt.yaml:49-84``: ResNet-`num_layers` on `image` x `image` cameras,
+    pyramid levels 1 and 3 (``id_pick``), (bev_h / 8) x (bev_w / 8) BEV queries, ``NaiveDecoder(dim -> [256, 256])`` with two x2
+    up-samplings, i.e. a (256, bev_h / 2, bev_w / 2) BEV map per camera agent."""
+    enc = {"num_layers": num_layers, "pretrained": False, "image_height": image, "image_width": image, "id_pick": [1, 3]}
+    h1, h3 = image // 8, image // 32
+    cvm = {"dim": dim, "middle": [2, 2], "backbone_output_shape": [[1, 1, 4, 128, h1, h1], [1, 1, 4, 512, h3, h3]],
+           "bev_embedding": {"sigma": 1.0, "bev_height": bev_h, "bev_width": bev_w, "h_meters": 100.0, "w_meters": 100.0, "offset": 0.0,
+                             "decoder_blocks": [128, 128, 64]},
+           "cross_view": {"image_width": image, "image_height": image, "no_image_features": False, "heads": 4, "dim_head": 32,
+                          "qkv_bias": True, "skip": True}}
+    return {"encoder": enc, "cvm": cvm, "decoder": {"input_dim": dim, "num_layer": 2, "num_ch_dec": [256, 256]}}
+
+
+def synthetic_cameras(n_agents: int, image: int, seed: int = 0) -> dict:
+    """``camera`` (N, 4, image, image, 3) ~ N(0, 1) (the dataset hands over ImageNet-normalised RGB, ``rgb_preprocessor.py:16-30``),
+    ``intrinsic`` (N, 4, 3, 3) with the focal length of the reference's test yaml (335.64 px at 800 px, rescaled) and
+    ``extrinsic`` (N, 4, 4, 4) camera -> ego of four cameras looking forward / left / back / right from the roof."""
+    gen = torch.Generator().manual_seed(seed)
+    cam = torch.randn(n_agents, 4, image, image, 3, generator=gen)
+    f = 335.64 * image / 800.0
+    K = torch.tensor([[f, 0.0, image / 2], [0.0, f, image / 2], [0.0, 0.0, 1.0]])
+    ext = torch.zeros(n_agents, 4, 4, 4)
+    for a in range(n_agents):
+        for c in range(4):
+            yaw = c * math.pi / 2 + 0.05 * float(torch.randn(1, generator=gen))
+            cs, sn = math.cos(yaw), math.sin(yaw)
+            T = torch.eye(4)
+            # camera axes (x right, y down, z forward) expressed in the ego frame (x forward, y left, z up)
+            T[:3, :3] = torch.tensor([[sn, 0.0, cs], [-cs, 0.0, sn], [0.0, -1.0, 0.0]])
+            T[:3, 3] = torch.tensor([1.5 * cs, 1.5 * sn, 1.6 + 0.02 * a])
+            ext[a, c] = T
+    return {"camera": cam, "intrinsic": K.repeat(n_agents, 4, 1, 1), "extrinsic": ext, "cav2cam_extrinsic": ext.clone()}

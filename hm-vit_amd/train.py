@@ -125,6 +125,15 @@ class FusionTrainFunction(torch.autograd.Function):
         module, host, drop_p, seed, x, pw, neg, folded, saved = ctx.launch
         mode_h, rl_h, mask_h = host
         d_out = d_out.detach().to(torch.float32).contiguous()
+        # The backward kernels form their products on split-f16 operands (x = hi + lo, two f16 halves): gradients of a real loss
+        # reach this point at 1e-4 ... 1e-7 (focal loss normalised by the positives), where the lo half falls under f16's
+        # 2^-24 floor.  The backward pass is LINEAR in d_out, so it runs on d_out 2^k (max |.| brought to [2^9, 2^10)) and every
+        # result is multiplied by 2^-k: exact, and independent of the scale of the loss.  No host synchronisation.
+        amax = d_out.abs().max()
+        k = torch.where(torch.isfinite(amax) & (amax > 0), 9.0 - torch.floor(torch.log2(amax.clamp_min(1e-38))), torch.zeros_like(amax))
+        k = k.clamp(-100.0, 100.0)
+        d_out = d_out * torch.exp2(k)
+        unscale = torch.exp2(-k)
         t, keep = _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, None, saved, None)
         need = _lib.lib.hmvit_fusion_backward_workspace_bytes(ctypes.byref(t))
         if need == 0:
@@ -144,6 +153,9 @@ class FusionTrainFunction(torch.autograd.Function):
                                                       hg[1].data_ptr(), hg[2].data_ptr(), hg[3].data_ptr(), ws.data_ptr(),
                                                       ws.numel(), ctypes.c_void_p(stream)), "hmvit_fusion_backward")
         ctx.launch = None
+        d_x.mul_(unscale)
+        for g in grads:
+            g.mul_(unscale)
         return (None, None, None, None, d_x, None, None, None) + tuple(grads)
 
 
@@ -159,9 +171,15 @@ def fusion_forward_with_grad(module, x, pairwise_t_matrix, mode, record_len, mas
         raise NotImplementedError("training is built for architect_mode 'sequential' (the shipped yaml)")
     B, L = x.shape[:2]
     pw = pairwise_t_matrix.to(device=x.device, dtype=torch.float32)
+    if tuple(pw.shape) != (B, L, L, 4, 4):
+        raise ValueError(f"pairwise_t_matrix must be {(B, L, L, 4, 4)}, got {tuple(pw.shape)}")
     eye = torch.eye(4, device=x.device)
     idx = torch.arange(L, device=x.device)
     mode_h, rl_h, mask_h = module._host_small(mode, record_len, mask)
+    if len(mode_h) != B * L or len(mask_h) != B * L or len(rl_h) != B:
+        raise ValueError("mode / mask must be (B, L) and record_len (B,)")
+    if any(not 1 <= int(n) <= L for n in rl_h):
+        raise ValueError(f"record_len entries must lie in [1, {L}], got {list(rl_h)}")
     if not bool((pw[:, idx, idx] == eye).all()):
         raise ValueError("training expects pairwise_t_matrix[b, i, i] to be the identity (as the dataset builds it)")
     folded, neg = folded_for_training(module, block_types={int(v) for v in mode_h},

@@ -151,13 +151,36 @@ class SyntheticTrainDataset(R.SyntheticReplayDataset):
     (``mixed/intermediate_fusion_dataset.py:398-415``): ``object_bbx_center`` / ``object_bbx_mask`` padded to ``max_num`` and the
     ``label_dict`` of ``VoxelPostprocessor.generate_label`` on the ego's anchors."""
 
-    def __init__(self, cfg, n_frames, post, n_agents=None, n_obj=12, seed=7, max_num=100):
+    def __init__(self, cfg, n_frames, post, n_agents=None, n_obj=12, seed=7, max_num=100, camera_ratio: float = 0.0,
+                 ego_mode: str = "mixed", camera_image: int = 64):
+        """``camera_ratio`` / ``ego_mode``: the modality roll of ``basedataset.py:193-200`` - every non-ego agent is a camera agent
+        with probability ``camera_to_lidar_ratio``, the ego is ``lidar`` / ``camera`` or rolled like the others (``mixed``).  A frame
+        with camera agents carries ``camera`` / ``intrinsic`` / ``extrinsic`` / ``cav2cam_extrinsic`` for ALL its agents next to
+        the point clouds, as ``collate_batch`` hands them over (``mixed/intermediate_fusion_dataset.py:398-415``); ``mode`` says
+        which sensor of an agent the model reads."""
         super().__init__(cfg, n_frames, n_agents=n_agents, n_obj=n_obj, seed=seed)
         self.post, self.max_num = post, max_num
         self.anchors = post.generate_anchor_box()
+        self.camera_ratio, self.ego_mode, self.camera_image = camera_ratio, ego_mode, camera_image
+
+    def roll_modes(self, idx):
+        rs = np.random.RandomState(self.seed + 77 + 1000 * idx)
+        m = [0 if rs.uniform() < self.camera_ratio else 1 for _ in range(self.n_agents)]
+        if self.ego_mode == "lidar":
+            m[0] = 1
+        elif self.ego_mode == "camera":
+            m[0] = 0
+        return m
 
     def __getitem__(self, idx):
         frame = super().__getitem__(idx)
+        if self.camera_ratio > 0 or self.ego_mode == "camera":
+            from . import synthetic as S
+            modes = self.roll_modes(idx)
+            mode = torch.zeros(1, self.cfg["max_cav"], dtype=torch.float64)       # padding slots: 0 (base_camera_lidar_dataset.py:178)
+            mode[0, : self.n_agents] = torch.tensor(modes, dtype=torch.float64)
+            frame["mode"] = mode
+            frame.update(S.synthetic_cameras(self.n_agents, self.camera_image, seed=self.seed + 31 + 1000 * idx))
         boxes = frame["object_bbx_center_valid"]
         center = np.zeros((self.max_num, 7), np.float32)
         mask = np.zeros(self.max_num, np.float32)
@@ -172,17 +195,36 @@ def to_batch(frame: dict, pre, device) -> dict:
     """One frame -> the ``batch['ego']`` dict the model and the criterion take (pillarisation on the device, csrc/vox.hip)."""
     lidar = pre.collate_batch([pre.preprocess(c) for c in frame["clouds"]])
     label = {k: v.to(device=device, dtype=torch.float32) for k, v in frame["label_dict"].items()}
-    return {"mode": frame["mode"].to(device), "record_len": frame["record_len"].to(device),
-            "pairwise_t_matrix": frame["pairwise_t_matrix"].to(device), "processed_lidar": lidar, "label_dict": label}
+    batch = {"mode": frame["mode"].to(device), "record_len": frame["record_len"].to(device),
+             "pairwise_t_matrix": frame["pairwise_t_matrix"].to(device), "processed_lidar": lidar, "label_dict": label}
+    for k in ("camera", "intrinsic", "extrinsic", "cav2cam_extrinsic"):
+        if k in frame:
+            batch[k] = frame[k].to(device)
+    return batch
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 # the loop
 # ---------------------------------------------------------------------------------------------------------------------
+def validate(model, val_dataset, pre, criterion, device) -> float:
+    """The validation pass of ``train_camera.py:201-220``: ``model.eval()`` per batch, ``torch.no_grad()``, mean of the
+    criterion over the validation frames (every rank runs the whole split, as the reference's un-sharded ``val_loader``).
+    ``eval()`` flips the swapped-in modules to their inference kernels (BatchNorm running statistics, no dropout, the fused
+    fusion launch) and ``train()`` at the top of the next step flips them back."""
+    losses = []
+    with torch.no_grad():
+        for i in range(len(val_dataset)):
+            model.eval()
+            batch = to_batch(val_dataset[i], pre, device)
+            losses.append(float(criterion(model(batch), batch["label_dict"])))
+    return sum(losses) / max(1, len(losses))
+
+
 def train(model, dataset, pre, hypes: dict, saved_path: str | None = None, init_epoch: int = 0, dist_info: dict | None = None,
-          log=None) -> dict:
-    """train_camera.py:133-230 (no validation split, tensorboard or AMP).  Frames shard over ranks as ``DistributedSampler``
-    does (rank r takes frames r, r + world, ...; the permutation is reseeded per epoch by ``set_epoch``)."""
+          log=None, val_dataset=None) -> dict:
+    """train_camera.py:133-230 (no tensorboard or AMP).  Frames shard over ranks as ``DistributedSampler`` does (rank r takes
+    frames r, r + world, ...; the permutation is reseeded per epoch by ``set_epoch``); ``val_dataset``: the validation split,
+    run every ``eval_freq`` epochs (:201-220)."""
     info = dist_info or {"distributed": False, "rank": 0, "world_size": 1, "gpu": 0}
     device = next(model.parameters()).device
     model_without_ddp = model
@@ -195,7 +237,7 @@ def train(model, dataset, pre, hypes: dict, saved_path: str | None = None, init_
     num_steps = (len(dataset) + world - 1) // world
     scheduler = setup_lr_schedular(hypes, optimizer, num_steps)
     epoches = hypes["train_params"]["epoches"]
-    history, t_step, n_step = [], 0.0, 0
+    history, val_history, t_step, n_step = [], [], 0.0, 0
     for epoch in range(init_epoch, max(epoches, init_epoch)):
         order = np.random.RandomState(epoch).permutation(len(dataset)) if world > 1 else np.arange(len(dataset))
         mine = [int(order[(rank + k * world) % len(order)]) for k in range(num_steps)]      # padded like DistributedSampler
@@ -221,22 +263,41 @@ def train(model, dataset, pre, hypes: dict, saved_path: str | None = None, init_
                 log(f"[epoch {epoch}][{i + 1}/{num_steps}] loss {losses[-1]:.4f} conf {float(criterion.loss_dict['conf_loss']):.4f} "
                     f"loc {float(criterion.loss_dict['reg_loss']):.4f} lr {optimizer.param_groups[0]['lr']:.2e}")
         history.append(sum(losses) / len(losses))
+        if val_dataset is not None and epoch % hypes["train_params"]["eval_freq"] == 0:
+            val = validate(model, val_dataset, pre, criterion, device)
+            val_history.append(val)
+            if log:
+                log("At epoch %d, the validation loss is %f" % (epoch, val))
         if saved_path and rank == 0 and epoch % hypes["train_params"]["save_freq"] == 0:
             save_checkpoint(model_without_ddp, saved_path, epoch)
-    return {"epoch_loss": history, "ms_per_step": 1e3 * t_step / max(1, n_step), "steps": n_step, "world_size": world}
+    return {"epoch_loss": history, "val_loss": val_history, "ms_per_step": 1e3 * t_step / max(1, n_step), "steps": n_step,
+            "world_size": world}
 
 
 def build(args):
     from . import BevformerPointPillarHetero, SpVoxelPreprocessor, VoxelPostprocessor
     cfg = R.lidar_model_config(args.grid[0], args.grid[1], max_cav=args.agents, small=args.small)
     torch.manual_seed(args.seed)
-    model = BevformerPointPillarHetero(cfg, precision=args.precision)
+    camera_encoder = None
+    mixed = args.camera_ratio > 0 or args.ego_mode == "camera"
+    if mixed:
+        # camera agents: the CVT lift in the model's camera slot, producing the LiDAR branch's (256, ny / 4, nx / 4) BEV map; it
+        # runs frozen (train_camera.py's --fix_camera_backbone: the camera encoders have no backward pass yet)
+        from . import synthetic as S
+        from .camera import CvtCameraEncoder
+        camera_encoder = CvtCameraEncoder(S.camera_config(args.camera_image, 18, bev_h=args.grid[1] // 2, bev_w=args.grid[0] // 2),
+                                          precision="f32" if args.precision == "f32" else "f16")
+    model = BevformerPointPillarHetero(cfg, camera_encoder=camera_encoder, precision=args.precision)
+    if mixed:
+        model.fix_camera_backbone()
     if not args.train_lidar_backbone:
         model.fix_lidar_backbone()
     pre = SpVoxelPreprocessor(R.preprocess_params(cfg), train=True)
     post = VoxelPostprocessor(R.postprocess_params(cfg), train=True)
-    ds = SyntheticTrainDataset(cfg, args.frames, post, n_agents=args.agents, seed=args.seed + 7)
-    return cfg, model, pre, post, ds
+    kw = dict(n_agents=args.agents, camera_ratio=args.camera_ratio, ego_mode=args.ego_mode, camera_image=args.camera_image)
+    ds = SyntheticTrainDataset(cfg, args.frames, post, seed=args.seed + 7, **kw)
+    val = SyntheticTrainDataset(cfg, args.val_frames, post, seed=args.seed + 100007, **kw) if args.val_frames > 0 else None
+    return cfg, model, pre, post, ds, val
 
 
 def main(argv=None):
@@ -247,6 +308,11 @@ def main(argv=None):
     ap.add_argument("--grid", type=int, nargs=2, default=[256, 128], metavar=("NX", "NY"))
     ap.add_argument("--small", action="store_true", help="PointPillar layer_nums [1, 2, 2]")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"], help="precision of the frozen encoder's kernels")
+    ap.add_argument("--val_frames", type=int, default=2, help="frames of the validation split (0: no validation pass)")
+    ap.add_argument("--camera_ratio", type=float, default=0.0,
+                    help="camera_to_lidar_ratio of the modality roll (basedataset.py:193-200); > 0 puts the CVT lift in the camera slot")
+    ap.add_argument("--ego_mode", default="mixed", choices=["mixed", "lidar", "camera"])
+    ap.add_argument("--camera_image", type=int, default=64, help="camera image size of the synthetic frames")
     ap.add_argument("--train_lidar_backbone", action="store_true",
                     help="do NOT freeze the LiDAR encoder: PointPillar trains too (hm-vit_amd/encoder_train.py)")
     ap.add_argument("--model_dir", default=None, help="folder with net_epoch%%d.pth to resume from / save into")
@@ -258,13 +324,13 @@ def main(argv=None):
         raise SystemExit("hm-vit_amd has no CPU path: this needs an MI355X")
     info = init_distributed_mode(args.backend)
     hypes = default_hypes(args.epochs)
-    cfg, model, pre, post, ds = build(args)
+    cfg, model, pre, post, ds, val = build(args)
     init_epoch = 0
     if args.model_dir and os.path.exists(args.model_dir):
         init_epoch, model = load_saved_model(args.model_dir, model)
     model = model.to(f"cuda:{info['gpu']}")
     res = train(model, ds, pre, hypes, saved_path=args.model_dir, init_epoch=init_epoch, dist_info=info,
-                log=print if args.verbose and info["rank"] == 0 else None)
+                log=print if args.verbose and info["rank"] == 0 else None, val_dataset=val)
     if info["rank"] == 0:
         res.update(agents=args.agents, grid=args.grid, frames=args.frames)
         print(json.dumps(res))

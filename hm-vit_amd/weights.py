@@ -52,6 +52,41 @@ def store_row_order(r):
     return 16 * (j >> 1) + 8 * hi + 4 * (j & 1) + i
 
 
+# ---------------------------------------------------------------------------------------------
+# range normalisation of the split-operand modes (HmvitStageScales, include/hmvit.h)
+# ---------------------------------------------------------------------------------------------
+TOP = 2.0 ** 14          # operands are carried at a power of two that puts their static bound just below this (f16 max 65504)
+
+
+def pow2_floor(v: float) -> float:
+    """Largest power of two <= v (1 for non-positive / non-finite v); clamped to 2^+-40 so that products of a few of them stay
+    far inside the f32 range."""
+    import math
+    if not (v > 0.0) or math.isinf(v) or math.isnan(v):
+        return 1.0
+    return 2.0 ** max(-40, min(40, math.floor(math.log2(v))))
+
+
+def scale_for(bound: float) -> float:
+    """Power of two s with bound * s in (TOP / 2, TOP]."""
+    return pow2_floor(TOP / bound) if bound > 0 else 1.0
+
+
+def ln_bound(gamma: torch.Tensor, beta: torch.Tensor) -> float:
+    """|LayerNorm(x)_c| <= sqrt(C) max|gamma| + max|beta|: the normalised row has 2-norm <= sqrt(C)."""
+    C = gamma.shape[-1]
+    return float(C ** 0.5 * gamma.abs().max() + beta.abs().max())
+
+
+def linear_of_ln_bound(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias=None) -> float:
+    """max_n |w_n . LayerNorm(x) + b_n| <= max_n (||w_n * gamma||_2 sqrt(C) + |w_n . beta| + |b_n|)  (Cauchy-Schwarz)."""
+    C = w.shape[-1]
+    b = (w * gamma).norm(dim=-1) * C ** 0.5 + (w @ beta).abs()
+    if bias is not None:
+        b = b + bias.abs()
+    return float(b.max())
+
+
 def split_halves(w: torch.Tensor):
     """x = hi + lo with hi = f16(x), lo = f16(x - hi): the operand pair of the split precision mode (22+ mantissa bits)."""
     hi = w.to(torch.float16)
@@ -155,21 +190,13 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
     rel_att = f(f"{att}.relation_att")     # (4, M, d, d) [e, h, p, q]
     rel_msg = f(f"{att}.relation_msg")
 
-    out: Dict[str, torch.Tensor] = {}
+    # ---- the folded tensors at their true scale, f32 ----
+    raw: Dict[str, torch.Tensor] = {}
     stack = lambda fmt: torch.stack([f(fmt.format(t=t)) for t in range(NUM_TYPES)])
-    out["ln_gamma"] = stack(f"{prefix}{which}_norm.net.{{t}}.weight")
-    out["ln_beta"] = stack(f"{prefix}{which}_norm.net.{{t}}.bias")
-    per_type = lambda m, fn: torch.stack([fn(m[t]) for t in range(NUM_TYPES)])
-    w_q = stack(f"{att}.q_linears.{{t}}.weight") * scale
-    x16 = split and C == 256          # 16-token split kernels: their own image layout (weight_image16)
-    if x16:
-        out["img_q"] = per_type(w_q, weight_image16)
-    elif f16:
-        out["img_q"] = per_type(w_q, lambda m: weight_image(m, store_rows=True, split=split))
-    else:
-        out["w_q"] = w_q
-    out["b_q"] = stack(f"{att}.q_linears.{{t}}.bias") * scale
-
+    raw["ln_gamma"] = stack(f"{prefix}{which}_norm.net.{{t}}.weight")
+    raw["ln_beta"] = stack(f"{prefix}{which}_norm.net.{{t}}.bias")
+    raw["w_q"] = stack(f"{att}.q_linears.{{t}}.weight") * scale
+    raw["b_q"] = stack(f"{att}.q_linears.{{t}}.bias") * scale
     w_kv = torch.empty(NUM_TYPES, NUM_TYPES, 2 * C, C, device=rel_att.device)
     b_kv = torch.empty(NUM_TYPES, NUM_TYPES, 2 * C, device=rel_att.device)
     for te in range(NUM_TYPES):
@@ -183,39 +210,114 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
             b_kv[te, ts, :C] = torch.einsum("hpq,hq->hp", rel_att[e], bk).reshape(C)
             w_kv[te, ts, C:] = torch.einsum("hpq,hpc->hqc", rel_msg[e], wv).reshape(C, C)
             b_kv[te, ts, C:] = torch.einsum("hpq,hp->hq", rel_msg[e], bv).reshape(C)
+    raw["w_kv"], raw["b_kv"] = w_kv, b_kv
+    raw["bias_frag"] = bias_fragments(sd[f"{att}.relative_position_bias_table.weight"], window, keep_graph) * (LOG2E if log2e else 1.0)
+    raw["w_o"] = stack(f"{att}.a_linears.{{t}}.0.weight")
+    raw["b_o"] = stack(f"{att}.a_linears.{{t}}.0.bias")
+    raw["ffn_ln_gamma"] = stack(f"{prefix}{which}_ffd.norm.net.{{t}}.weight")
+    raw["ffn_ln_beta"] = stack(f"{prefix}{which}_ffd.norm.net.{{t}}.bias")
+    raw["w_1"] = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.0.weight")
+    raw["w_2"] = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.3.weight")
+    raw["b_1"] = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.0.bias")
+    raw["b_2"] = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.3.bias")
+
+    out: Dict[str, torch.Tensor] = {}
+    if split:
+        # split-operand modes: every tensor goes to the kernels at the power of two stage_scales() assigns it (exact)
+        sc, mul = stage_scales(raw, planes_scaled=not log2e)
+        for k, m in mul.items():
+            raw[k] = raw[k] * m
+        out["scales"] = sc
+    per_type = lambda m, fn: torch.stack([fn(m[t]) for t in range(NUM_TYPES)])
+    x16 = split and C == 256          # 16-token split kernels: their own image layout (weight_image16)
+    w_q, w_kv, w_o, w_1, w_2 = raw["w_q"], raw["w_kv"], raw["w_o"], raw["w_1"], raw["w_2"]
     if x16:
+        out["img_q"] = per_type(w_q, weight_image16)
         out["img_kv"] = torch.stack([per_type(w_kv[te], weight_image16) for te in range(NUM_TYPES)])
+        out["img_o"] = per_type(w_o, weight_image16)
+        out["img_ffn"] = torch.stack([ffn_image16(w_1[t], w_2[t]) for t in range(NUM_TYPES)])
     elif f16:
+        out["img_q"] = per_type(w_q, lambda m: weight_image(m, store_rows=True, split=split))
         out["img_kv"] = torch.stack([per_type(w_kv[te], lambda m: weight_image(m, store_rows=True, split=split)) for te in range(NUM_TYPES)])
+        out["img_o"] = per_type(w_o, lambda m: weight_image(m, linear_k=True, split=split))
+        out["img_ffn"] = torch.stack([ffn_image(w_1[t], w_2[t], split=split) for t in range(NUM_TYPES)])
     else:
-        out["w_kv"] = w_kv
-    out["b_kv"] = b_kv
-    out["bias_frag"] = bias_fragments(sd[f"{att}.relative_position_bias_table.weight"], window, keep_graph) * (LOG2E if log2e else 1.0)
+        out["w_q"], out["w_kv"], out["w_o"], out["w_1"], out["w_2"] = w_q, w_kv, w_o, w_1, w_2
+    for k in ("ln_gamma", "ln_beta", "b_q", "b_kv", "bias_frag", "b_o", "ffn_ln_gamma", "ffn_ln_beta", "b_1", "b_2"):
+        out[k] = raw[k]
     if keep_graph:
         # the backward kernel also forms the un-transposed logit tiles: their bias is the fragment set of the table with
         # negated offsets, i.e. the table flipped along its first axis (index (dr + w - 1)(2w - 1) + dc + w - 1)
         out["bias_frag_neg"] = bias_fragments(sd[f"{att}.relative_position_bias_table.weight"].detach().flip(0), window)
-    w_o = stack(f"{att}.a_linears.{{t}}.0.weight")
-    if x16:
-        out["img_o"] = per_type(w_o, weight_image16)
-    elif f16:
-        out["img_o"] = per_type(w_o, lambda m: weight_image(m, linear_k=True, split=split))
+    return {k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in out.items()}
+
+
+def stage_scales(raw: Dict[str, torch.Tensor], planes_scaled: bool):
+    """Power-of-two range normalisation of one stage for the split-operand modes (HmvitStageScales, include/hmvit.h).
+    raw: the folded f32 tensors of fold_stage (ln_*, w_q, b_q, w_kv, b_kv, bias_frag, w_o, b_o, ffn_ln_*, w_1, b_1, w_2, b_2).
+    Returns (scales dict of python floats / nested lists, dict of per-tensor multipliers to apply before building the images).
+    planes_scaled: the Q / K' / V' / O planes are f32 and carried at their own power of two (split mode); False = true-scale
+    planes (mixed mode: f16 planes read by the f16 attention kernels)."""
+    T = NUM_TYPES
+    C = raw["w_q"].shape[-1]
+    g_n, b_n, g_f, b_f = raw["ln_gamma"], raw["ln_beta"], raw["ffn_ln_gamma"], raw["ffn_ln_beta"]
+    a_n = [scale_for(ln_bound(g_n[t], b_n[t])) for t in range(T)]
+    a_f = [scale_for(ln_bound(g_f[t], b_f[t])) for t in range(T)]
+    wmax = lambda m: float(m.abs().max())
+    wq_s = [scale_for(wmax(raw["w_q"][t])) for t in range(T)]
+    wk_s = [[scale_for(wmax(raw["w_kv"][te, ts, :C])) for ts in range(T)] for te in range(T)]
+    wv_s = [[scale_for(wmax(raw["w_kv"][te, ts, C:])) for ts in range(T)] for te in range(T)]
+    wo_s = [scale_for(wmax(raw["w_o"][t])) for t in range(T)]
+    w1_s = [scale_for(wmax(raw["w_1"][t])) for t in range(T)]
+    w2_s = [scale_for(wmax(raw["w_2"][t])) for t in range(T)]
+    if planes_scaled:
+        s_q = [scale_for(linear_of_ln_bound(raw["w_q"][t], g_n[t], b_n[t], raw["b_q"][t])) for t in range(T)]
+        s_k_free = [[scale_for(linear_of_ln_bound(raw["w_kv"][te, ts, :C], g_n[ts], b_n[ts], raw["b_kv"][te, ts, :C]))
+                     for ts in range(T)] for te in range(T)]
+        # one logit scale per stage (the position bias is a single tensor and one softmax mixes all source types)
+        s_qk = min(s_q[te] * s_k_free[te][ts] for te in range(T) for ts in range(T))
+        s_k = [[s_qk / s_q[te] for ts in range(T)] for te in range(T)]
+        # one value scale per ego type (the attention output sums over the source types)
+        s_v = [min(scale_for(linear_of_ln_bound(raw["w_kv"][te, ts, C:], g_n[ts], b_n[ts], raw["b_kv"][te, ts, C:]))
+                   for ts in range(T)) for te in range(T)]
     else:
-        out["w_o"] = w_o
-    out["b_o"] = stack(f"{att}.a_linears.{{t}}.0.bias")
-    out["ffn_ln_gamma"] = stack(f"{prefix}{which}_ffd.norm.net.{{t}}.weight")
-    out["ffn_ln_beta"] = stack(f"{prefix}{which}_ffd.norm.net.{{t}}.bias")
-    w_1 = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.0.weight")
-    w_2 = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.3.weight")
-    if x16:
-        out["img_ffn"] = torch.stack([ffn_image16(w_1[t], w_2[t]) for t in range(NUM_TYPES)])
-    elif f16:
-        out["img_ffn"] = torch.stack([ffn_image(w_1[t], w_2[t], split=split) for t in range(NUM_TYPES)])
-    else:
-        out["w_1"], out["w_2"] = w_1, w_2
-    out["b_1"] = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.0.bias")
-    out["b_2"] = stack(f"{prefix}{which}_ffd.fn.net.{{t}}.3.bias")
-    return {k: v.contiguous() for k, v in out.items()}
+        s_q, s_k, s_v, s_qk = [1.0] * T, [[1.0] * T for _ in range(T)], [1.0] * T, 1.0
+    h_bound = [linear_of_ln_bound(raw["w_1"][t], g_f[t], b_f[t], raw["b_1"][t]) for t in range(T)]
+    s_g = [scale_for(h_bound[t]) for t in range(T)]
+    sc = {
+        "c_q": [s_q[t] / (wq_s[t] * a_n[t]) for t in range(T)],
+        "c_k": [[s_k[te][ts] / (wk_s[te][ts] * a_n[ts]) for ts in range(T)] for te in range(T)],
+        "c_v": [[s_v[te] / (wv_s[te][ts] * a_n[ts]) for ts in range(T)] for te in range(T)],
+        "k_logit": 1.0 / s_qk,
+        "c_o": [1.0 / (s_v[t] * wo_s[t]) for t in range(T)],
+        "c_1": [1.0 / (a_f[t] * w1_s[t]) for t in range(T)],
+        "s_g": s_g,
+        "k_2": [w2_s[t] * s_g[t] for t in range(T)],
+    }
+    dev = raw["w_q"].device
+    vec = lambda v: torch.tensor(v, dtype=torch.float32, device=dev)
+    mul = {
+        "ln_gamma": vec(a_n)[:, None], "ln_beta": vec(a_n)[:, None],
+        "ffn_ln_gamma": vec(a_f)[:, None], "ffn_ln_beta": vec(a_f)[:, None],
+        "w_q": vec(wq_s)[:, None, None], "b_q": vec(s_q)[:, None],
+        "w_kv": torch.cat([vec(wk_s)[:, :, None, None].expand(T, T, C, 1), vec(wv_s)[:, :, None, None].expand(T, T, C, 1)], dim=2),
+        "b_kv": torch.cat([vec(s_k)[:, :, None].expand(T, T, C), vec(s_v)[:, None, None].expand(T, T, C)], dim=2),
+        "bias_frag": vec(s_qk),
+        "w_o": vec(wo_s)[:, None, None], "b_o": 1.0 / vec(sc["c_o"])[:, None],
+        "w_1": vec(w1_s)[:, None, None], "b_1": 1.0 / vec(sc["c_1"])[:, None],
+        "w_2": vec(w2_s)[:, None, None], "b_2": vec(sc["k_2"])[:, None],
+    }
+    return sc, mul
+
+
+def head_scales(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor):
+    """HmvitHeadScales + the multipliers of the two mlp_head weight matrices."""
+    T = NUM_TYPES
+    w1_s = [scale_for(float(w1[t].abs().max())) for t in range(T)]
+    w2_s = [scale_for(float(w2[t].abs().max())) for t in range(T)]
+    sc = {"w1": w1_s, "w2": w2_s, "l1": [float(w1[t].abs().sum(-1).max()) for t in range(T)],
+          "b1max": [float(b1[t].abs().max()) for t in range(T)]}
+    return sc, w1_s, w2_s
 
 
 def fold_head(sd: Dict[str, torch.Tensor], prefix: str, dtype: torch.dtype, keep_graph: bool = False, split: bool = False) -> Dict[str, torch.Tensor]:
@@ -224,6 +326,11 @@ def fold_head(sd: Dict[str, torch.Tensor], prefix: str, dtype: torch.dtype, keep
     w1, w2 = stack(f"{prefix}.net.{{t}}.0.weight"), stack(f"{prefix}.net.{{t}}.3.weight")
     out = {"head_b1": stack(f"{prefix}.net.{{t}}.0.bias").contiguous(),
            "head_b2": stack(f"{prefix}.net.{{t}}.3.bias").contiguous()}
+    if split:
+        sc, w1_s, w2_s = head_scales(w1, out["head_b1"], w2)
+        out["head_scales"] = sc
+        w1 = w1 * torch.tensor(w1_s, dtype=w1.dtype, device=w1.device)[:, None, None]
+        w2 = w2 * torch.tensor(w2_s, dtype=w2.dtype, device=w2.device)[:, None, None]
     if dtype == torch.float16:
         if split and w1.shape[-1] == 256:
             out["head_img_ffn"] = torch.stack([ffn_image16(w1[t], w2[t]) for t in range(NUM_TYPES)])

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HMVIT_ABI_VERSION 8
+#define HMVIT_ABI_VERSION 9
 
 #define HMVIT_OK 0
 #define HMVIT_EINVAL (-22)   /* bad argument / unsupported shape */
@@ -89,6 +89,33 @@ extern "C" {
  * img_ffn (T, C/32, 2, C/16, 64, 8) interleaves, for every hidden tile hc, the image of
  * W_1 rows [32 hc, 32 hc + 32) with the fragments (t, 2 hc + s), t < C/32, s < 2, of the image of
  * W_2 (requires mlp_dim == C). */
+/* Range normalisation of the split-operand modes (HMVIT_PREC_SPLIT / HMVIT_PREC_MIXED).  A split product forms x = hi + lo
+ * from two f16 halves, and f16 has 5 exponent bits: operands above 65504 overflow, operands whose lo half falls below 2^-14
+ * lose it.  So every operand of those modes is carried at a power-of-two multiple that puts its STATIC bound (LayerNorm
+ * output: sqrt(C) max|gamma| + max|beta|; a Linear of a LayerNorm output: Cauchy-Schwarz over the weight rows; GELU(h): |h|)
+ * just below 2^14, and the products are brought back by the factors below - all exact powers of two, computed once per
+ * parameter version by hm-vit_amd/weights.py:fold_stage, which also pre-scales the tensors it applies to (ln_*, b_q, b_kv,
+ * bias_frag, b_o, b_1, b_2 and the weight images).  The only data-dependent operand, the un-normalised residual row that
+ * mlp_head multiplies (bevformer_point_pillar_hetero.py:48), is scaled per token inside the kernel (HmvitHeadScales).
+ * A null `scales` pointer means "all 1": tensors at their true scale (HMVIT_PREC_F32 / HMVIT_PREC_F16, training). */
+typedef struct HmvitStageScales {
+    float c_q[HMVIT_NUM_TYPES];                     /* Q plane  = accumulator * c_q[t], t = agent type                      */
+    float c_k[HMVIT_NUM_TYPES][HMVIT_NUM_TYPES];    /* K' plane = accumulator * c_k[t_ego][t_src]                           */
+    float c_v[HMVIT_NUM_TYPES][HMVIT_NUM_TYPES];
+    float k_logit;                                  /* logits formed from the planes * k_logit = natural units (one value
+                                                       per stage: bias_frag is pre-multiplied by 1 / k_logit)              */
+    float c_o[HMVIT_NUM_TYPES];                     /* x' = x + accumulator * c_o[t]  (b_o pre-divided by c_o)              */
+    float c_1[HMVIT_NUM_TYPES];                     /* h  = accumulator * c_1[t]      (b_1 pre-divided by c_1)              */
+    float s_g[HMVIT_NUM_TYPES];                     /* GELU(h) * s_g[t] = operand of the second Linear                      */
+    float k_2[HMVIT_NUM_TYPES];                     /* the residual row is carried as x * k_2[t] while W_2's products
+                                                       accumulate into it (b_2 pre-multiplied by k_2)                      */
+} HmvitStageScales;
+typedef struct HmvitHeadScales {                    /* mlp_head: operand scaled per token, 2^e with |row| 2^e < 2^14        */
+    float w1[HMVIT_NUM_TYPES], w2[HMVIT_NUM_TYPES]; /* power-of-two multiples the two weight images are stored at           */
+    float l1[HMVIT_NUM_TYPES];                      /* max row L1 norm of W_1 (true scale): |h| <= l1 max|x| + b1max        */
+    float b1max[HMVIT_NUM_TYPES];
+} HmvitHeadScales;
+
 typedef struct HmvitStageWeights {
     const float* ln_gamma;
     const float* ln_beta;
@@ -109,6 +136,7 @@ typedef struct HmvitStageWeights {
     const void* img_kv;
     const void* img_o;
     const void* img_ffn;
+    const HmvitStageScales* scales;   /* HOST pointer (read during the call), or NULL = all 1 */
 } HmvitStageWeights;
 
 /* One HeteroFusion / HeteroFusionBlock forward.
@@ -154,6 +182,7 @@ typedef struct HmvitFusionDesc {
     const float* split_ln_g;
     const float* split_ln_b;
     const float* split_fc2;
+    const HmvitHeadScales* head_scales;   /* HOST pointer, or NULL = head_img_ffn at its true scale and no per-token scaling */
     int32_t self_identity;        /* 1: the caller guarantees pairwise_t[b, i, i] = I for every agent (what the reference's
                                      datasets produce, mixed/intermediate_fusion_dataset.py:163-202); lets HMVIT_PREC_SPLIT use
                                      its persistent attention kernel.  0: unknown (always correct, slower in split mode) */

@@ -23,17 +23,19 @@ def naive_decoder(x: Tensor, sd: Dict[str, Tensor], prefix: str, num_layer: int)
     return x
 
 
-def hetero_decoder(x: Tensor, mode: Tensor, sd: Dict[str, Tensor], params: dict, prefix: str = ""):
-    """x (B, 1, C, H, W), mode (B, L): decoder and heads picked by the ego type mode[:, 0]."""
+def hetero_decoder(x: Tensor, mode: Tensor, sd: Dict[str, Tensor], params: dict, prefix: str = "",
+                   dtype: torch.dtype = torch.float32):
+    """x (B, 1, C, H, W), mode (B, L): decoder and heads picked by the ego type mode[:, 0].  dtype=torch.float64: the same
+    layers in double precision (yardstick of the precision stress tests)."""
     pre = f"{prefix}." if prefix else ""
-    sd = {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}
+    sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
     B = x.shape[0]
     psm, rm = [None] * B, [None] * B
     for t, name in ((0, "camera"), (1, "lidar")):
         idx = [b for b in range(B) if int(mode[b, 0]) == t]
         if not idx:
             continue
-        f = naive_decoder(x[idx, 0].float(), sd, f"{pre}{name}_decoder", params["num_layer"])
+        f = naive_decoder(x[idx, 0].to(dtype), sd, f"{pre}{name}_decoder", params["num_layer"])
         p = F.conv2d(f, sd[f"{pre}{name}_cls_head.weight"], sd[f"{pre}{name}_cls_head.bias"])
         r = F.conv2d(f, sd[f"{pre}{name}_reg_head.weight"], sd[f"{pre}{name}_reg_head.bias"])
         for j, b in enumerate(idx):

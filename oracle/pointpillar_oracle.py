@@ -81,11 +81,13 @@ def shrink_conv(x: Tensor, sd: Dict[str, Tensor], cfg: dict, prefix: str = "shri
     return x
 
 
-def point_pillar_features(voxel_features, voxel_coords, voxel_num_points, sd, args, n_agents: int) -> Tensor:
-    """PointPillar.forward up to ``spatial_features_2d`` (point_pillar.py:35-54)."""
-    sd = {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}
+def point_pillar_features(voxel_features, voxel_coords, voxel_num_points, sd, args, n_agents: int,
+                          dtype: torch.dtype = torch.float32) -> Tensor:
+    """PointPillar.forward up to ``spatial_features_2d`` (point_pillar.py:35-54).  dtype=torch.float64: the same layers in
+    double precision (yardstick of the precision stress tests)."""
+    sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
     nx, ny, nz = args["point_pillar_scatter"]["grid_size"]
-    pf = pillar_vfe(voxel_features.float(), voxel_num_points, voxel_coords, sd, args["voxel_size"], args["lidar_range"])
+    pf = pillar_vfe(voxel_features.to(dtype), voxel_num_points, voxel_coords, sd, args["voxel_size"], args["lidar_range"])
     canvas = scatter(pf, voxel_coords, n_agents, int(ny), int(nx))
     x = bev_backbone(canvas, sd, args["base_bev_backbone"])
     if "shrink_header" in args:

@@ -86,3 +86,24 @@ def test_bench_under_a_launcher_environment():
     assert all(p.returncode == 0 for p in procs), outs[0][1].decode()[-2000:]
     assert json.loads(outs[0][0].decode().strip().splitlines()[-1])["n_gpus"] == 2
     assert not [l for l in outs[1][0].decode().splitlines() if l.startswith("{")]   # only rank 0 reports
+
+
+def test_bench_train_mode_two_ranks_ddp():
+    """`python bench.py --train --gpus 2`: the training half of north_star - one DistributedDataParallel step per rank with the
+    gradient all-reduce as the only exchange (find_unused_parameters=True, train_camera.py:126-131).  CPU stand-in model (with
+    an unused parameter) over gloo: exercises the spawn / DDP / no_sync / stand-alone all-reduce / reporting path."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--train", "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--backend", "gloo", "--stub"], env=env, capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["unit"] == "steps/s" and "dp2" in r["config"]["parallelism"]
+    assert r["value"] > 0 and abs(r["value"] - 2 * 3 / (r["ms_per_step"] * 3e-3)) / r["value"] < 1e-6
+    assert r["gradient_bytes"] == 4 * (64 * 64 + 64)              # the unused Linear(8, 8) has no gradient
+    assert r["allreduce_standalone_ms"] > 0 and r["ms_per_step_no_sync"] > 0 and r["allreduce_exposed_ms"] >= 0

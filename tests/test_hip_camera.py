@@ -26,7 +26,7 @@ def test_resnet_encoder_vs_oracle(precision, tol):
     batch = CAM.synthetic_batch(2, cfg, seed=4)
     ref = CAM.resnet_encoder(batch["camera"][None], sd, cfg["encoder"], prefix="encoder.encoder")
     out = net(batch["camera"][None].cuda())
-    assert [tuple(o.shape) for o in out] == [tuple(r.shape) for r in ref] == [tuple(s) for s in net.output_shapes] or True
+    assert [tuple(o.shape) for o in out] == [tuple(r.shape) for r in ref]
     for o, r in zip(out, ref):
         assert o.shape == r.shape and rel_max_err(o.cpu(), r) < tol
 

@@ -80,3 +80,65 @@ def test_fusion_dynamic_range(precision, case):
           f"   (fp32 oracle vs float64: {noise['rel_max']:.2e} / {noise['rms_rel']:.2e} / {noise['p999']:.2e})")
     assert e["rel_max"] < max(1e-4, 4 * noise["rel_max"])
     assert e["rms_rel"] < max(1e-4, 4 * noise["rms_rel"])
+
+
+# ---- convolutional modules in the split mode: PointPillar encoder and HeteroDecoder ----
+def _report(tag, y, truth, ref32):
+    noise, e = error_report(ref32, truth), error_report(y, truth)
+    print(f"\nrange[{tag}] rel-max {e['rel_max']:.2e} rms-rel {e['rms_rel']:.2e} p99.9 {e['p999']:.2e}"
+          f"   (fp32 oracle vs float64: {noise['rel_max']:.2e} / {noise['rms_rel']:.2e} / {noise['p999']:.2e})")
+    assert torch.isfinite(y).all(), f"{tag}: non-finite output"
+    assert e["rel_max"] < max(1e-4, 4 * noise["rel_max"])
+    assert e["rms_rel"] < max(1e-4, 4 * noise["rms_rel"])
+
+
+@pytest.mark.parametrize("precision", ["split", "f32"])
+@pytest.mark.parametrize("case,xscale,wscale", [("base", 1.0, 1.0), ("x1e-3", 1e-3, 1.0), ("x1e3", 1e3, 1.0), ("x3e4", 3e4, 1.0),
+                                                ("w1e-3", 1.0, 1e-3), ("w1e2", 1.0, 1e2), ("w1e-3_x3e4", 3e4, 1e-3)])
+def test_decoder_dynamic_range(precision, case, xscale, wscale):
+    """HeteroDecoder (four 3 x 3 convolutions + BatchNorm + ReLU, two 1 x 1 heads) on inputs / convolution weights far from unit
+    scale (the BatchNorm statistics stay, so the scale change is not normalised away)."""
+    import numpy as np
+    import hmvit_amd
+    from oracle import decoder_oracle as DO
+    params = DO.make_params()
+    sd = DO.random_state_dict(params, 5)
+    for k in sd:
+        if k.endswith(".weight") and sd[k].dim() == 4:
+            sd[k] = sd[k] * wscale
+    x = torch.from_numpy(np.random.RandomState(11).standard_normal((3, 1, 256, 12, 10)).astype(np.float32)) * xscale
+    mode = torch.tensor([[1], [0], [1]])
+    truth = DO.hetero_decoder(x, mode, sd, params, dtype=torch.float64)
+    ref32 = DO.hetero_decoder(x, mode, sd, params)
+    net = hmvit_amd.HeteroDecoder(params, precision=precision)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    psm, rm = net(x.cuda(), mode.cuda(), use_upsample=False)
+    _report(f"decoder:{precision}:{case}:psm", psm.cpu(), truth[0], ref32[0])
+    _report(f"decoder:{precision}:{case}:rm", rm.cpu(), truth[1], ref32[1])
+
+
+@pytest.mark.parametrize("precision", ["split", "f32"])
+@pytest.mark.parametrize("case,wscale,pscale", [("base", 1.0, 1.0), ("w1e-2", 1e-2, 1.0), ("w30", 30.0, 1.0), ("intensity_1e4", 1.0, 1e4)])
+def test_pointpillar_dynamic_range(precision, case, wscale, pscale):
+    """PointPillar encoder with its convolution weights (not the BatchNorm affine / statistics) scaled, and with the point
+    intensity channel scaled (raw LiDAR intensities are not always in [0, 1])."""
+    import hmvit_amd
+    from oracle import pointpillar_oracle as PO
+    nx, ny = 64, 48
+    args = PO.make_args(nx, ny)
+    sd = PO.random_state_dict(args, 9)
+    for k in sd:
+        if k.endswith(".weight") and sd[k].dim() == 4:
+            sd[k] = sd[k] * wscale
+    vf, vc, vn = PO.synthetic_pillars(2, 400, nx, ny, args, 4)
+    vf = vf.clone()
+    vf[:, :, 3] *= pscale
+    truth = PO.point_pillar_features(vf, vc, vn, sd, args, 2, dtype=torch.float64)
+    ref32 = PO.point_pillar_features(vf, vc, vn, sd, args, 2)
+    net = hmvit_amd.PointPillar(args, precision=precision)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    net.set_return_features()
+    batch = {"processed_lidar": {"voxel_features": vf.cuda(), "voxel_coords": vc.cuda(), "voxel_num_points": vn.cuda()}}
+    _report(f"pointpillar:{precision}:{case}", net(batch).cpu(), truth, ref32)

@@ -201,3 +201,101 @@ def test_ddp_wraps_the_module_over_rccl():
                 assert rel_max_err(a.grad, b.grad) < 1e-4, n     # f32 atomics: summation order differs run to run
     finally:
         dist.destroy_process_group()
+
+
+def test_backward_matches_oracle_autograd_five_agents_64x176():
+    """BASELINE configs[4]'s fusion at a size where every scheduling path of the training kernels is live:
+    5 agents 10110 (camera and LiDAR types, camera-type collaborators), C = 256, window 8, 64 x 176 px = 176 windows per agent,
+    against torch.autograd through the oracle on the CPU (about a minute, ~15 GB)."""
+    C, w, L, H, W = 256, 8, 5, 64, 176
+    cfg = O.make_config(C, w, L, voxel=0.4, downsample=2)
+    sd = O.random_state_dict(cfg, seed=45)
+    scene = O.synthetic_scene(L, C, H, W, [1, 0, 1, 1, 0], seed=46, tx_step=6.0, ty_step=-4.0)
+    gy = torch.randn(1, C, H, W, generator=torch.Generator().manual_seed(47))
+    y_ref, gx_ref, gp_ref = _oracle_grads(cfg, sd, scene, gy)
+    net = _net(cfg, sd).eval()
+    x = scene[0].cuda().requires_grad_(True)
+    y = net(x, *[t.cuda() for t in scene[1:]])
+    assert rel_max_err(y.detach().cpu(), y_ref) < 1e-4
+    (y * gy.cuda()).sum().backward()
+    worst = _check_grads(net, gp_ref, x.grad, gx_ref)
+    print("\nworst parameter-gradient errors (64x176, 5 agents):", sorted(worst.items(), key=lambda kv: -kv[1])[:3])
+
+
+@pytest.mark.parametrize("gscale", [1e-4, 1e-6, 1e4])
+def test_backward_is_independent_of_the_scale_of_the_loss(gscale):
+    """the backward products run on split-f16 operands, and real loss gradients (focal loss normalised by the
+    positives) arrive at 1e-4 ... 1e-7, far below f16's comfortable range.  The upstream gradient is renormalised by a power
+    of two inside FusionTrainFunction.backward (exact: the pass is linear in it), so the parity must not depend on its scale."""
+    C, w, L, H, W = 64, 4, 3, 16, 24
+    cfg = O.make_config(C, w, L, voxel=0.4, downsample=4)
+    sd = O.random_state_dict(cfg, seed=5)
+    scene = O.synthetic_scene(L, C, H, W, [0, 1, 0], n_valid=3, seed=6, tx_step=3.0, ty_step=-2.0)
+    gy = torch.randn(1, C, H, W, generator=torch.Generator().manual_seed(7)) * gscale
+    _, gx_ref, gp_ref = _oracle_grads(cfg, sd, scene, gy.double().float())
+    net = _net(cfg, sd).eval()
+    x = scene[0].cuda().requires_grad_(True)
+    y = net(x, *[t.cuda() for t in scene[1:]])
+    (y * gy.cuda()).sum().backward()
+    _check_grads(net, gp_ref, x.grad, gx_ref)
+
+
+def test_cfg2_gradient_is_consistent_with_finite_differences():
+    """The train step at the headline size (5 x 200 x 704 x 256, where the persistent split attention with its saved
+    log-sum-exp, k_warp_adjoint and the batched column sums run at full occupancy) cannot be checked against the CPU oracle's
+    autograd in reasonable time, so it is checked against itself: the directional derivative <grad L, d> along three random
+    parameter directions d (and one input direction) against the central difference (L(theta + eps d) - L(theta - eps d)) / 2 eps
+    of the exact-f32 inference forward, L = <y, g> accumulated in float64.  1e-2."""
+    import hmvit_amd
+    from hmvit_amd import synthetic as S
+    c = dict(L=5, C=256, H=200, W=704, window=8, modes=[1, 0, 1, 1, 0])
+    cfg = S.make_config(c["C"], c["window"], c["L"], voxel=0.4, downsample=1)
+    net = S.seeded_fusion(cfg, precision="f32", seed=0).cuda().eval()
+    scene = [t.cuda() for t in S.synthetic_scene(c["L"], c["C"], c["H"], c["W"], c["modes"], seed=3)]
+    g = torch.randn(1, c["C"], c["H"], c["W"], device="cuda", generator=torch.Generator(device="cuda").manual_seed(9))
+
+    def loss_value():
+        with torch.no_grad():
+            return float((net(*scene).double() * g.double()).sum())
+
+    net.force_autograd = True
+    x = scene[0].clone().requires_grad_(True)
+    y = net(x, *scene[1:])
+    (y * g).sum().backward()
+    net.force_autograd = False
+    base = float((y.detach().double() * g.double()).sum())
+    # the training forward and the inference forward are the same function (to f32 round-off)
+    assert abs(loss_value() - base) <= 1e-5 * float((y.detach().abs().double() * g.abs().double()).sum())
+    params = [(n, p) for n, p in net.named_parameters() if p.grad is not None and float(p.grad.abs().max()) > 0]
+    assert len(params) > 40
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    for trial in range(3):
+        dirs = {n: torch.randn(p.shape, device="cuda", generator=gen) * p.detach().abs().mean().clamp_min(1e-3) for n, p in params}
+        analytic = sum(float((p.grad.double() * dirs[n].double()).sum()) for n, p in params)
+        eps = 2e-3
+        with torch.no_grad():
+            for n, p in params:
+                p.add_(eps * dirs[n])
+            up = loss_value()
+            for n, p in params:
+                p.sub_(2 * eps * dirs[n])
+            down = loss_value()
+            for n, p in params:
+                p.add_(eps * dirs[n])
+        fd = (up - down) / (2 * eps)
+        print(f"\ncfg2 directional derivative {trial}: analytic {analytic:.6e}  central difference {fd:.6e}")
+        assert abs(fd - analytic) <= 1e-2 * max(abs(analytic), abs(fd)), (trial, analytic, fd)
+    # one direction in the input
+    d = torch.randn(scene[0].shape, device="cuda", generator=gen)
+    analytic = float((x.grad.double() * d.double()).sum())
+    eps = 1e-2
+    with torch.no_grad():
+        x0 = scene[0]
+        scene[0] = x0 + eps * d
+        up = loss_value()
+        scene[0] = x0 - eps * d
+        down = loss_value()
+        scene[0] = x0
+    fd = (up - down) / (2 * eps)
+    print(f"\ncfg2 directional derivative (input): analytic {analytic:.6e}  central difference {fd:.6e}")
+    assert abs(fd - analytic) <= 1e-2 * max(abs(analytic), abs(fd))

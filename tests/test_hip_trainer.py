@@ -10,13 +10,14 @@ pytestmark = pytest.mark.gpu
 
 class _Args:
     grid, agents, small, precision, seed, frames, train_lidar_backbone = [128, 96], 3, True, "f32", 0, 4, False
+    val_frames, camera_ratio, ego_mode, camera_image = 0, 0.0, "mixed", 64
 
 
 def test_train_loop_learns_saves_and_resumes(tmp_path):
     import hmvit_amd  # noqa: F401
     from hmvit_amd import trainer as T
     hypes = T.default_hypes(epoches=3)
-    cfg, model, pre, post, ds = T.build(_Args)
+    cfg, model, pre, post, ds, _ = T.build(_Args)
     model = model.cuda()
     before = {k: v.detach().clone() for k, v in model.state_dict().items()}
     res = T.train(model, ds, pre, hypes, saved_path=str(tmp_path))
@@ -34,7 +35,7 @@ def test_train_loop_learns_saves_and_resumes(tmp_path):
     assert moved("cls_head.weight") == 0
     assert sorted(os.listdir(tmp_path)) == ["net_epoch1.pth", "net_epoch2.pth", "net_epoch3.pth"]
     # resume: a fresh model picks up epoch 3's weights (train_utils.py:40-75)
-    _, fresh, _, _, _ = T.build(_Args)
+    _, fresh, _, _, _, _ = T.build(_Args)
     epoch, fresh = T.load_saved_model(str(tmp_path), fresh)
     assert epoch == 3
     for k, v in fresh.state_dict().items():
@@ -221,7 +222,7 @@ def test_whole_model_trains_with_unfrozen_encoder():
     class A(_Args):
         train_lidar_backbone = True
     hypes = T.default_hypes(epoches=1)
-    cfg, model, pre, post, ds = T.build(A)
+    cfg, model, pre, post, ds, _ = T.build(A)
     model = model.cuda()
     before = {k: v.detach().clone() for k, v in model.state_dict().items()}
     res = T.train(model, ds, pre, hypes)
@@ -255,3 +256,40 @@ def test_two_rank_ddp_training_on_one_gpu():
     res = json.loads(line)
     assert res["world_size"] == 2 and res["steps"] >= 3
     assert all(l == l for l in res["epoch_loss"]) and res["epoch_loss"][-1] < res["epoch_loss"][0]
+
+
+def test_mixed_camera_lidar_five_agent_train_loop_with_validation():
+    """BASELINE configs[4] in one process: 5 agents per scene, modality rolled per agent (camera_to_lidar_ratio 0.5, ego_mode
+    mixed, basedataset.py:193-200), the batch of mixed/intermediate_fusion_dataset.py:398-415 (camera / intrinsic / extrinsic next
+    to processed_lidar), CVT lift in the camera slot (frozen, --fix_camera_backbone), frozen PointPillar, the fusion and the tail
+    training on the HIP backward kernels, a validation pass every epoch (train_camera.py:201-220) that flips eval() / train()."""
+    import hmvit_amd  # noqa: F401
+    from hmvit_amd import trainer as T
+
+    class A(_Args):
+        agents, frames, val_frames, camera_ratio = 5, 4, 2, 0.5
+    hypes = T.default_hypes(epoches=3)
+    cfg, model, pre, post, ds, val = T.build(A)
+    rolled = [ds.roll_modes(i) for i in range(len(ds))]
+    assert any(0 in m for m in rolled) and any(1 in m for m in rolled) and any(m[0] == 0 for m in rolled) and any(m[0] == 1 for m in rolled), rolled
+    frame = ds[0]
+    assert frame["camera"].shape == (5, 4, 64, 64, 3) and frame["intrinsic"].shape == (5, 4, 3, 3) and frame["extrinsic"].shape == (5, 4, 4, 4)
+    model = model.cuda()
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    res = T.train(model, ds, pre, hypes, val_dataset=val)
+    assert len(res["epoch_loss"]) == 3 and len(res["val_loss"]) == 3
+    assert all(l == l for l in res["epoch_loss"] + res["val_loss"])                          # finite
+    assert res["epoch_loss"][-1] < res["epoch_loss"][0], res
+    after = model.state_dict()
+    moved = lambda k: float((after[k].float() - before[k].float()).abs().max())
+    # both agent types were in the scenes: the typed parameters of BOTH types moved (fusion on the HIP backward)
+    for t in (0, 1):
+        assert moved(f"fusion_net.hetero_fusion_block.window_attention.q_linears.{t}.weight") > 0
+        assert moved(f"fusion_net.hetero_fusion_block.grid_ffd.fn.net.{t}.0.weight") > 0
+    assert moved("fusion_net.hetero_fusion_block.grid_attention.relation_att") > 0
+    # camera and LiDAR egos both occurred: both typed decoders and both mlp_head branches trained
+    assert moved("decoder.lidar_cls_head.weight") > 0 and moved("decoder.camera_cls_head.weight") > 0
+    assert moved("fusion_net.mlp_head.net.0.0.weight") > 0 and moved("fusion_net.mlp_head.net.1.0.weight") > 0
+    # frozen encoders did not move
+    assert all(moved(k) == 0 for k in before if k.startswith(("lidar_encoder.", "camera_encoder.")) and "num_batches" not in k)
+    assert not model.training                  # validate() ran last: the model is left in eval mode, as in the reference loop

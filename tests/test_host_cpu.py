@@ -206,3 +206,56 @@ def test_generate_label_matches_reference_golden(pkg):
     # no valid box: every anchor negative, no positives
     lab = pp.generate_label(gt_box_center=np.zeros((4, 7), np.float32), anchors=anchors, mask=np.zeros(4))
     assert lab["pos_equal_one"].sum() == 0 and lab["neg_equal_one"].all()
+
+
+@pytest.mark.parametrize("wscale", [1.0, 1e-3, 1e2])
+def test_split_range_normalisation_is_exact_algebra(pkg, wscale):
+    """weights.stage_scales (HmvitStageScales): every factor is a power of two, every scaled operand's static bound sits in
+    (2^13, 2^14], and the scaled chain LN -> Q / K' / V' -> logits -> out-projection -> FFN reproduces the unscaled one exactly
+    (float64 emulation of what the split kernels do with the factors)."""
+    import math
+    from hmvit_amd import weights
+    cfg = O.make_config(256, 8, 3)
+    sd = O.random_state_dict(cfg, seed=3)
+    for k in sd:
+        if ("linears" in k or ".fn.net." in k) and sd[k].is_floating_point():
+            sd[k] = sd[k] * wscale
+    f = weights.fold_stage(sd, "hetero_fusion_block", "grid", 32, 8, torch.float32)
+    raw = {k: v.double() for k, v in f.items() if torch.is_tensor(v)}
+    sc, mul = weights.stage_scales(raw, planes_scaled=True)
+    flat = [sc["k_logit"]] + [v for k in ("c_q", "c_o", "c_1", "s_g", "k_2") for v in sc[k]] + \
+           [v for k in ("c_k", "c_v") for row in sc[k] for v in row]
+    assert all(math.frexp(v)[0] == 0.5 for v in flat), "every factor must be a power of two"
+    s = {k: raw[k] * mul[k].double() for k in mul}
+    C = 256
+    x = torch.randn(64, C, dtype=torch.float64) * 3 + 1
+    ln = lambda g, b: torch.nn.functional.layer_norm(x, (C,), g, b, 1e-5)
+    for t in range(2):
+        n, ns = ln(raw["ln_gamma"][t], raw["ln_beta"][t]), ln(s["ln_gamma"][t], s["ln_beta"][t])
+        assert float(ns.abs().max()) <= weights.TOP
+        for te in range(2):
+            q = n @ raw["w_q"][te].t() + raw["b_q"][te]
+            qs = (ns @ s["w_q"][te].t()) * sc["c_q"][te] + s["b_q"][te]
+            k = n @ raw["w_kv"][te, t, :C].t() + raw["b_kv"][te, t, :C]
+            ks = (ns @ s["w_kv"][te, t, :C].t()) * sc["c_k"][te][t] + s["b_kv"][te, t, :C]
+            v = n @ raw["w_kv"][te, t, C:].t() + raw["b_kv"][te, t, C:]
+            vs = (ns @ s["w_kv"][te, t, C:].t()) * sc["c_v"][te][t] + s["b_kv"][te, t, C:]
+            for a in (qs, ks, vs):
+                assert float(a.abs().max()) <= weights.TOP
+            logit, logit_s = q @ k.t(), (qs @ ks.t()) * sc["k_logit"]
+            assert float((logit - logit_s).abs().max()) <= 1e-12 * float(logit.abs().max())
+            # out-projection of ego type te on V' of source type t (a stand-in for the attention output)
+            o = v @ raw["w_o"][te].t() + raw["b_o"][te]
+            os_ = (vs @ s["w_o"][te].t() + s["b_o"][te]) * sc["c_o"][te]
+            assert float((o - os_).abs().max()) <= 1e-12 * float(o.abs().max())
+        nf, nfs = ln(raw["ffn_ln_gamma"][t], raw["ffn_ln_beta"][t]), ln(s["ffn_ln_gamma"][t], s["ffn_ln_beta"][t])
+        h = nf @ raw["w_1"][t].t() + raw["b_1"][t]
+        hs = (nfs @ s["w_1"][t].t() + s["b_1"][t]) * sc["c_1"][t]
+        assert float((h - hs).abs().max()) <= 1e-12 * float(h.abs().max())
+        g = torch.nn.functional.gelu(h)
+        assert float((g * sc["s_g"][t]).abs().max()) <= weights.TOP
+        y = x + g @ raw["w_2"][t].t() + raw["b_2"][t]
+        ys = (x * sc["k_2"][t] + s["b_2"][t] + (g * sc["s_g"][t]) @ s["w_2"][t].t()) / sc["k_2"][t]
+        assert float((y - ys).abs().max()) <= 1e-12 * float(y.abs().max())
+    bias_ratio = s["bias_frag"] / raw["bias_frag"]
+    assert float((bias_ratio * sc["k_logit"] - 1).abs().max()) == 0.0
