@@ -429,15 +429,25 @@ struct PcCursor {
     int started;
 };
 
+// Head group of a workgroup.  Default: the two head groups of a window alternate inside an XCD (an XCD step = wpx / NG windows x NG
+// head groups).  variant bit 0x800 ("head group per XCD"): XCD x works on head group x % NG only, so its workgroups cover twice
+// as many windows per step - in the dilated grid stages a 4 x 8 instead of a 2 x 8 window tile per lattice node, i.e. 45 instead
+// of 54 gathered pixels per 32 keys - and its L2 only ever holds that half of the K' / V' rows.
+__device__ __forceinline__ int pc_head_group(const AttnParams& p, int NG) {
+    return (p.variant & 0x800) ? (int)(blockIdx.x & 7) % NG : (int)(blockIdx.x >> 3) % NG;
+}
+
 // World-ordered list (p.sched, launch_attn_schedule): the list is cut into segments of sched_sub x (items per XCD step); XCD x
 // takes segments x, x + 8, ... and its workgroups walk a segment in sched_sub steps of consecutive items, so that what an
 // XCD's workgroups gather at any moment - for ALL egos - lies under the same few hundred pixels of ground.
 __device__ __forceinline__ bool pc_fetch_sched(const AttnParams& p, int X, int Y, int NG, PcCursor& cur, PcItem& it) {
     const int wpx = gridDim.x >> 3, x = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int tps = wpx / NG, t = j / NG, sub = p.sched_sub;
+    const bool hx = (p.variant & 0x800) != 0;
+    const int tps = hx ? wpx : wpx / NG, t = hx ? j : j / NG, sub = p.sched_sub;
+    const int lanes = hx ? 8 / NG : 8, lane0 = hx ? x / NG : x;          // XCDs sharing a head group, position among them
     while (true) {
-        if (!cur.started) { cur.trow = x; cur.tcol = 0; cur.started = 1; }
-        else if (++cur.tcol == sub) { cur.tcol = 0; cur.trow += 8; }
+        if (!cur.started) { cur.trow = lane0; cur.tcol = 0; cur.started = 1; }
+        else if (++cur.tcol == sub) { cur.tcol = 0; cur.trow += lanes; }
         if (cur.trow * sub * tps >= p.n_sched) return false;
         const int pos = (cur.trow * sub + cur.tcol) * tps + t;
         if (pos >= p.n_sched) continue;
@@ -455,7 +465,7 @@ __device__ __forceinline__ bool pc_fetch_sched(const AttnParams& p, int X, int Y
         it.ego = __builtin_amdgcn_readfirstlane(ego);
         it.wx = __builtin_amdgcn_readfirstlane(wx);
         it.wy = __builtin_amdgcn_readfirstlane(wy);
-        it.hg = __builtin_amdgcn_readfirstlane(j % NG);
+        it.hg = __builtin_amdgcn_readfirstlane(pc_head_group(p, NG));
         return true;
     }
 }
@@ -463,12 +473,13 @@ __device__ __forceinline__ bool pc_fetch_sched(const AttnParams& p, int X, int Y
 __device__ __forceinline__ bool pc_fetch(const AttnParams& p, int X, int Y, int NG, bool ego_fastest, PcCursor& cur, PcItem& it) {
     if (p.sched) return pc_fetch_sched(p, X, Y, NG, cur, it);
     const int wpx = gridDim.x >> 3, x = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int TH = wpx / NG / 8;                       // tile = TH x 8 windows
+    const bool hx = (p.variant & 0x800) != 0;          // head group per XCD (pc_head_group)
+    const int TH = (hx ? wpx : wpx / NG) / 8;          // tile = TH x 8 windows
     const int ntx = (X + TH - 1) / TH, nty = (Y + 7) / 8;
-    const int t = j / NG;
+    const int t = hx ? j : j / NG;
     while (true) {
         // advance by 8 list positions (by x for the first call): the fastest index first, carries into the others
-        int step = cur.started ? 8 : x;
+        int step = cur.started ? (hx ? 8 / NG : 8) : (hx ? x / NG : x);
         cur.started = 1;
         if (ego_fastest) {
             cur.ego += step;
@@ -497,7 +508,7 @@ __device__ __forceinline__ bool pc_fetch(const AttnParams& p, int X, int Y, int 
             it.ego = __builtin_amdgcn_readfirstlane(ego);
             it.wx = __builtin_amdgcn_readfirstlane(wx);
             it.wy = __builtin_amdgcn_readfirstlane(wy);
-            it.hg = __builtin_amdgcn_readfirstlane(j % NG);
+            it.hg = __builtin_amdgcn_readfirstlane(pc_head_group(p, NG));
             return true;
         }
     }
@@ -1196,7 +1207,7 @@ __global__ __launch_bounds__((HG * CW + HG * LWX) * 64) void k_attention_pc(Attn
     using SM = PcShared<HG, CW, LWX>;
     __shared__ __attribute__((aligned(16))) SM sm;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    pc_load_tables<HG, CW, LWX>(p, sm, (blockIdx.x >> 3) % (p.C / (HG * 32)));   // head group of this workgroup (pc_fetch)
+    pc_load_tables<HG, CW, LWX>(p, sm, pc_head_group(p, p.C / (HG * 32)));   // head group of this workgroup (pc_fetch)
     __syncthreads();
     // wave-uniform role split at the outermost level: the two loops have disjoint live ranges, so
     // the kernel's register count is the maximum of the two roles, not their sum
@@ -1720,7 +1731,7 @@ __global__ __launch_bounds__(512) void k_attention_pcs(AttnParams p) {
     using SM = PcSharedS;
     __shared__ __attribute__((aligned(16))) SM sm;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int hg = (blockIdx.x >> 3) % (p.C / SM::CH);
+    const int hg = pc_head_group(p, p.C / SM::CH);
     {
         const int n_rec = p.B * p.L * p.L * 8;
         for (int i = threadIdx.x; i < n_rec; i += blockDim.x) sm.ainv[i] = p.ainv[i];
@@ -1939,6 +1950,12 @@ int launch_attention(const AttnParams& p, int precision, hipStream_t st) {
         p.B * p.L * p.L <= PcSharedS::MAX_PAIRS) {
         AttnParams q = p;
         if (p.partition == HMVIT_PART_GRID) q.variant ^= 0x200;   // item order as for k_attention_pc
+        // head group per XCD: bit 0 grid stages, bit 1 local stages.  Measured at cfg2 (tools/probe/r03_attn_ab.sh): local stages
+        // 1660 -> 1593 us and 4.56 -> 4.13 GB fetched; the grid stages fetch 18 % less (11.3 -> 9.2 GB) but run 6 % SLOWER
+        // (2620 -> 2780 us: their time is not set by bytes), so only the local stages take it
+        int hgx = 2;
+        if (const char* e = HMVIT_ENV("HMVIT_ATTN_HGX")) hgx = atoi(e);
+        if ((8 % (p.C / PcSharedS::CH)) == 0 && ((p.partition == HMVIT_PART_GRID) ? (hgx & 1) : (hgx & 2))) q.variant |= 0x800;
         return launch_attn_pcs(q, st);
     }
     if (precision == HMVIT_PREC_F32 || precision == HMVIT_PREC_SPLIT) {   // f32 planes, exact-f32 MFMA

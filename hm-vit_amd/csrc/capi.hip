@@ -546,7 +546,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
     // World-ordered item list of the local stages (launch_attn_schedule): one list per forward, for the launches that run all
     // max_cav egos through a persistent kernel
     const int* sched = nullptr;
-    int sched_sub = 4;
+    int sched_sub = 2;
     if (const char* e = HMVIT_ENV("HMVIT_SCHED_SUB")) sched_sub = atoi(e);
     if (d->window == 8 && C > 64 && pl.max_cav > 1 && pl.max_cav <= 8 && d->skip_masked && sched_sub > 0 && d->H % 8 == 0 && d->W % 8 == 0) {
         AttnParams ap;

@@ -353,6 +353,29 @@ static void make_bwd_plan(const TrainPlan& pl, BwdPlan& bp) {
     bp.total = off;
 }
 
+#ifdef HMVIT_DBG_SUMS
+// debug aid (tools/probe/r03_grad_bisect.sh): order-independent fingerprint of a device buffer, printed from the host
+static void dbg_sum(const char* tag, int sidx, const float* p, size_t n, hipStream_t st) {
+    std::vector<float> h(n);
+    hipStreamSynchronize(st);
+    hipMemcpy(h.data(), p, n * 4, hipMemcpyDeviceToHost);
+    double s = 0, a = 0;
+    unsigned long long x = 0;
+    for (size_t i = 0; i < n; ++i) { s += h[i]; a += fabs((double)h[i]); unsigned u; memcpy(&u, &h[i], 4); x ^= (unsigned long long)u * (i + 1); }
+    fprintf(stderr, "DBG stage %d %-6s sum %.9e abs %.9e xor %016llx\n", sidx, tag, s, a, x);
+    if (sidx == 3 && (tag[0] == 'd' && tag[1] == 'q')) {
+        static int run = 0;
+        char name[64];
+        snprintf(name, sizeof(name), "/tmp/dbg_dq_%d.bin", run++);
+        FILE* f = fopen(name, "wb");
+        if (f) { fwrite(h.data(), 4, n, f); fclose(f); }
+    }
+}
+#define DBG_SUM(tag, p, n) dbg_sum(tag, sidx, p, n, st)
+#else
+#define DBG_SUM(tag, p, n) do {} while (0)
+#endif
+
 static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, float* d_x, const HmvitStageGrads* grads,
                           float* d_head_w1, float* d_head_b1, float* d_head_w2, float* d_head_b2, void* workspace,
                           size_t workspace_bytes, hipStream_t st) {
@@ -492,7 +515,11 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
             ab.bias_frag_neg = reinterpret_cast<const float*>(t->bias_frag_neg[s]);
             ab.d_out = T3; ab.dq = T4; ab.dkg = dkg; ab.d_bias_frag = gr.bias_frag;
             HMVIT_CHECK_HIP(hipMemsetAsync(dkg, 0, (size_t)B * n_ego * pl.max_cav * 2 * me * 4, st));
+            DBG_SUM("G", G, pl.A);
+            DBG_SUM("dO", T3, pl.A);
             HMVIT_TRY(launch_attention_bwd(ab, st));
+            DBG_SUM("dq", T4, (size_t)n_ego * me);
+            DBG_SUM("dkg", dkg, (size_t)B * n_ego * pl.max_cav * 2 * me);
             // biases are added after the gather: their gradients are column sums over the EGO pixels
             // (one launch per kMaxColsumJobs maps: 11 maps per ego at five agents)
             ColsumJobs cs;
@@ -523,6 +550,7 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
             wa.B = B; wa.L = L; wa.n_ego = n_ego; wa.n_src = pl.max_cav; wa.E = si.E; wa.C = C; wa.H = d->H; wa.W = d->W;
             for (int i = 0; i < pl.n_slots; ++i) wa.ego_e[i] = ab.f.ego_e[i];
             HMVIT_TRY(launch_warp_adjoint(wa, st));
+            DBG_SUM("dkv", dkv, (size_t)pl.n_slots * si.E * 2 * me);
         }
 
         // dxn (T1) = dq W_q + sum_e (dK'_e W_k,e + dV'_e W_v,e);  weight gradients against xn

@@ -594,8 +594,13 @@ int launch_layernorm_bwd(const float* x, const float* dy, const float* gamma, co
 // Two wavefronts per head: each takes two of the four 16-key tiles of a chunk (its dK / dV tiles are complete, its dQ is a partial
 // sum over its keys and meets the other wave's in LDS once at the end).  With one wave per head a workgroup had two waves and a
 // CU four - one per SIMD, so the gather of a chunk and its products never overlapped.
+// (No minimum-occupancy argument in the launch bounds.  With `__launch_bounds__(HG * 128, 2)` hipcc 7.2 held the window-8 instance
+// to 256 registers by spilling 8 of them to scratch, and that build was NOT deterministic: with masked keys in the scene, about
+// one backward pass in three differed from the next in a few dq / dK' rows (parameter gradients off by 1e-3 ... 1e-2, found by
+// tests/test_hip_train.py::test_backward_matches_oracle_autograd_five_agents_64x176; tools/probe/r03_grad_bisect.sh).  Without
+// the bound the same code takes 240 registers, no scratch, still two wavefronts per SIMD, and is bit-reproducible.)
 template <int WIN, int HG>
-__global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp) {
+__global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
     const AttnParams& p = bp.f;
     constexpr int N = WIN * WIN, NQT = N / 16, SPC = 64 / N, NB = (WIN == 8) ? 7 : 1;
     constexpr int CH = HG * 32, QS = CH + 2, KS = CH + 2;

@@ -21,17 +21,18 @@ def _net(cfg, sd):
     return net.cuda()
 
 
-def _oracle_grads(cfg, sd, scene, gy, drop_masks=None):
-    """Output, d/dx and d/dparam of <oracle(x), gy> by torch.autograd on the CPU."""
+def _oracle_grads(cfg, sd, scene, gy, drop_masks=None, dtype=torch.float32):
+    """Output, d/dx and d/dparam of <oracle(x), gy> by torch.autograd on the CPU (dtype=torch.float64: the yardstick run)."""
     x, pw, mode, rl, mask = scene
-    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
-    x = x.clone().requires_grad_(True)
-    y = O.hetero_fusion(x, pw, mode, rl, mask, sd, cfg, drop_masks=drop_masks)
-    (y * gy).sum().backward()
+    sd = {k: (v.to(dtype).clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    x = x.to(dtype).clone().requires_grad_(True)
+    y = O.hetero_fusion(x, pw, mode, rl, mask, sd, cfg, drop_masks=drop_masks, dtype=dtype)
+    (y * gy.to(dtype)).sum().backward()
     return y.detach(), x.grad, {k: v.grad for k, v in sd.items() if v.is_floating_point()}
 
 
-def _check_grads(net, ref_grads, x_grad, ref_x_grad, used_only=True):
+def _check_grads(net, ref_grads, x_grad, ref_x_grad, used_only=True, tol=None):
+    """tol: None = GRAD_TOL for every tensor, or {name: bound} (tensors missing from it: GRAD_TOL)."""
     assert rel_max_err(x_grad.cpu(), ref_x_grad) < GRAD_TOL
     worst = {}
     # A gradient that is zero in exact arithmetic comes out as round-off noise on both sides (the key bias when every source
@@ -47,7 +48,7 @@ def _check_grads(net, ref_grads, x_grad, ref_x_grad, used_only=True):
         assert p.grad is not None, name
         scale = max(float(ref.abs().max()), 1e-4 * gmax)
         worst[name] = float((p.grad.cpu().double() - ref.double()).abs().max()) / scale
-    bad = {k: v for k, v in worst.items() if not v < GRAD_TOL}
+    bad = {k: v for k, v in worst.items() if not v < (GRAD_TOL if tol is None else tol.get(k, GRAD_TOL))}
     assert not bad, bad
     return worst
 
@@ -212,14 +213,28 @@ def test_backward_matches_oracle_autograd_five_agents_64x176():
     sd = O.random_state_dict(cfg, seed=45)
     scene = O.synthetic_scene(L, C, H, W, [1, 0, 1, 1, 0], seed=46, tx_step=6.0, ty_step=-4.0)
     gy = torch.randn(1, C, H, W, generator=torch.Generator().manual_seed(47))
-    y_ref, gx_ref, gp_ref = _oracle_grads(cfg, sd, scene, gy)
+    # The yardstick is the oracle's autograd in FLOAT64; the same in float32 tells how far fp32 arithmetic itself is from it at
+    # this size (sums over 56 k tokens): a parameter gradient is held to max(1e-3, 3 x that distance).
+    y_ref, gx_ref, gp_ref = _oracle_grads(cfg, sd, scene, gy, dtype=torch.float64)
+    _, gx32, gp32 = _oracle_grads(cfg, sd, scene, gy)
+    gmax = max(float(g.abs().max()) for g in gp_ref.values() if g is not None)
+    noise = {k: float((gp32[k].double() - g).abs().max()) / max(float(g.abs().max()), 1e-4 * gmax)
+             for k, g in gp_ref.items() if g is not None and float(g.abs().max()) > 0}
     net = _net(cfg, sd).eval()
     x = scene[0].cuda().requires_grad_(True)
     y = net(x, *[t.cuda() for t in scene[1:]])
     assert rel_max_err(y.detach().cpu(), y_ref) < 1e-4
     (y * gy.cuda()).sum().backward()
-    worst = _check_grads(net, gp_ref, x.grad, gx_ref)
-    print("\nworst parameter-gradient errors (64x176, 5 agents):", sorted(worst.items(), key=lambda kv: -kv[1])[:3])
+    try:
+        worst = _check_grads(net, gp_ref, x.grad, gx_ref, tol={k: max(GRAD_TOL, 3 * v) for k, v in noise.items()})
+    finally:
+        w = {n: float((p.grad.cpu().double() - gp_ref[n]).abs().max()) / max(float(gp_ref[n].abs().max()), 1e-4 * gmax)
+             for n, p in net.named_parameters() if p.grad is not None and gp_ref.get(n) is not None and float(gp_ref[n].abs().max()) > 0}
+        top = sorted(w.items(), key=lambda kv: -kv[1])[:6]
+        print("\n64x176 / 5 agents, worst parameter gradients vs float64 autograd  [HIP | fp32 oracle]:")
+        for k, v in top:
+            print(f"   {k}: {v:.2e} | {noise[k]:.2e}")
+        print(f"   d/dx: {rel_max_err(x.grad.cpu(), gx_ref):.2e} | {rel_max_err(gx32, gx_ref):.2e}")
 
 
 @pytest.mark.parametrize("gscale", [1e-4, 1e-6, 1e4])
