@@ -121,6 +121,8 @@ _SIGNATURES = {
     "hmvit_bn_relu_tokens": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     "hmvit_cross_attention": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_void_p]),
     "hmvit_attention_bias": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]),
+    "hmvit_conv_range": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
+    "hmvit_absmax": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "hmvit_conv2d_ex": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 12 + [C.c_void_p]),
     "hmvit_conv2d_rowpack": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 10 + [C.c_void_p]),
     "hmvit_maxpool2d": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 8 + [C.c_void_p]),
@@ -160,3 +162,57 @@ def check(rc: int, what: str) -> None:
 def i32_array(values):
     arr = (C.c_int32 * len(values))(*[int(v) for v in values])
     return arr
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# range information of the split-mode convolutions (hmvit_conv_range, include/hmvit.h)
+# ---------------------------------------------------------------------------------------------------------------------
+_RANGE_BLOCKS = {}
+
+
+def _range_slot(device):
+    """A zeroed device slot (2 x int32; [0] = f32 bit pattern of max |.|).  Slots come from blocks of 64 that stay alive as long
+    as a tensor refers to one of theirs; a block is never reused, so a slot is written by exactly one producer chain."""
+    import torch
+    blk = _RANGE_BLOCKS.get(device)
+    if blk is None or blk[1] >= blk[0].shape[0]:
+        blk = [torch.zeros(64, 2, dtype=torch.int32, device=device), 0]
+        _RANGE_BLOCKS[device] = blk
+    i = blk[1]
+    blk[1] += 1
+    return blk[0][i]
+
+
+def conv_range(x, w_absmax: float, y, stream, share_out: bool = False):
+    """Before an HMVIT_PREC_SPLIT convolution x -> y: hand the library max |x| (the slot the producer of `x` left on the tensor,
+    or one measured here, once per tensor), max |w| (host value from weight preparation) and a fresh slot for max |y|, which
+    `y` then carries to its consumers.  share_out: several launches write `y` (channel windows of a concatenation)."""
+    xs = getattr(x, "_hmvit_absmax", None)
+    if xs is None:
+        xs = _range_slot(x.device)
+        check(lib.hmvit_absmax(x.data_ptr(), x.numel(), xs.data_ptr(), stream), "hmvit_absmax")
+        x._hmvit_absmax = xs
+    ys = getattr(y, "_hmvit_absmax", None) if share_out else None
+    if ys is None:
+        ys = _range_slot(y.device)
+        y._hmvit_absmax = ys
+    check(lib.hmvit_conv_range(xs.data_ptr(), float(w_absmax), ys.data_ptr()), "hmvit_conv_range")
+
+
+def prescale_weights(w):
+    """Split-mode convolution weights -> (w * s, -s) with s the power of two that puts max |w| into [2^13, 2^14): the multiply is
+    exact, and `-s` is the `w_absmax` argument that tells the kernel the weights are already scaled (hmvit_conv_range)."""
+    import math
+    wmax = float(w.abs().max())
+    if not (wmax > 0.0) or math.isinf(wmax) or math.isnan(wmax):
+        return w, 0.0
+    e = max(-40, min(40, math.frexp(wmax)[1] - 1))        # floor(log2 wmax), clamped like pow2_scale (csrc/common.hpp)
+    s = 2.0 ** (13 - e)
+    return w * s, -s
+
+
+def inherit_range(dst, src):
+    """`dst` holds a subset / copies of the values of `src` (max pooling of a non-negative map, a view): the same bound applies."""
+    r = getattr(src, "_hmvit_absmax", None)
+    if r is not None:
+        dst._hmvit_absmax = r

@@ -48,6 +48,9 @@ class _Conv:
             w, b = w * s[:, None, None, None], (b - bn.running_mean.detach().float()) * s + bn.bias.detach().float()
         co, ci, k, _ = w.shape
         self.cin, self.cout, self.k = _cpad(ci, prec), _cpad(co, prec), k
+        self.wmax = 0.0                      # range information of the split convolutions (hmvit_conv_range)
+        if prec == _lib.PREC_SPLIT:
+            w, self.wmax = _lib.prescale_weights(w)
         wp = torch.zeros(self.cout, k, k, self.cin, device=w.device)
         wp[:co, :, :, :ci] = w.permute(0, 2, 3, 1)
         self.w = wp.reshape(self.cout, -1).to(dt).contiguous()
@@ -64,6 +67,8 @@ class _Conv:
         Ho = (H + 2 * self.pad - self.k) // self.stride + 1
         Wo = (W + 2 * self.pad - self.k) // self.stride + 1
         y = torch.empty(n, Ho, Wo, self.cout, device=x.device, dtype=self.dt)
+        if self.prec == _lib.PREC_SPLIT:
+            _lib.conv_range(x, self.wmax, y, _stream())
         _lib.check(_lib.lib.hmvit_conv2d_ex(x.data_ptr(), self.w.data_ptr(), self.b.data_ptr(),
                                             residual.data_ptr() if residual is not None else None, y.data_ptr(), n, H, W, self.cin,
                                             self.cout, self.k, self.stride, self.pad, 1 if relu else 0, 1 if up2 else 0, 0,
@@ -83,6 +88,9 @@ class _StemConv:
         co, ci, k, _ = w.shape
         assert ci <= 4 and k <= 8 and conv.bias is None
         self.cout, self.k, self.stride, self.pad = _cpad(co, prec), k, conv.stride[0], conv.padding[0]
+        self.wmax = 0.0
+        if prec == _lib.PREC_SPLIT:
+            w, self.wmax = _lib.prescale_weights(w)
         wp = torch.zeros(self.cout, 8, 8, 4, device=w.device)
         wp[:co, :k, :k, :ci] = w.permute(0, 2, 3, 1)
         self.w = wp.reshape(self.cout, 256).to(dt).contiguous()
@@ -99,6 +107,8 @@ class _StemConv:
         xp = torch.zeros(n, Hp, Wp, 4, device=img_nhwc.device, dtype=self.dt)
         xp[:, self.pad:self.pad + H, self.pad:self.pad + W, :c] = img_nhwc
         y = torch.empty(n, Ho, Wo, self.cout, device=xp.device, dtype=self.dt)
+        if self.prec == _lib.PREC_SPLIT:
+            _lib.conv_range(xp, self.wmax, y, _stream())
         _lib.check(_lib.lib.hmvit_conv2d_rowpack(xp.data_ptr(), self.w.data_ptr(), self.b.data_ptr(), y.data_ptr(), n, Hp, Wp, Ho, Wo,
                                                  self.cout, 8, self.stride, 1, self.prec, _stream()), "conv2d_rowpack")
         return y
@@ -234,6 +244,7 @@ class ResnetEncoder(nn.Module):
         Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         y = torch.empty(n, Ho, Wo, C, device=x.device, dtype=dt)
         _lib.check(_lib.lib.hmvit_maxpool2d(x.data_ptr(), y.data_ptr(), n, H, W, C, 3, 2, 1, prec, _stream()), "maxpool2d")
+        _lib.inherit_range(y, x)                # a maximum over a post-ReLU map: the stem's bound holds
         x = y
         outs = []
         for li, blocks in enumerate(prep["layers"]):

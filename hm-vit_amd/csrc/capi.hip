@@ -871,12 +871,32 @@ int hmvit_pfn_scatter(const float* voxels, const int32_t* coords, const int32_t*
     return launch_pfn_scatter(p, precision, reinterpret_cast<hipStream_t>(stream));
 }
 
+// range information of the NEXT convolution call of this thread (HMVIT_PREC_SPLIT), consumed by that call
+static thread_local const unsigned* g_next_x_absmax = nullptr;
+static thread_local unsigned* g_next_y_absmax = nullptr;
+static thread_local float g_next_w_absmax = 0.f;
+static void take_conv_range(ConvParams& p) {
+    p.x_absmax = g_next_x_absmax; p.w_absmax = g_next_w_absmax; p.y_absmax = g_next_y_absmax;
+    g_next_x_absmax = nullptr; g_next_y_absmax = nullptr; g_next_w_absmax = 0.f;
+}
+int hmvit_conv_range(const void* x_absmax, float w_absmax, void* y_absmax) {
+    g_next_x_absmax = reinterpret_cast<const unsigned*>(x_absmax);
+    g_next_w_absmax = w_absmax;
+    g_next_y_absmax = reinterpret_cast<unsigned*>(y_absmax);
+    return HMVIT_OK;
+}
+int hmvit_absmax(const float* x, size_t n, void* slot, void* stream) {
+    HMVIT_CHECK_ARG(x && slot, "absmax: null pointer");
+    return launch_absmax(x, n, reinterpret_cast<unsigned*>(slot), reinterpret_cast<hipStream_t>(stream));
+}
+
 int hmvit_conv2d(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int Cin, int Cout,
                  int ksize, int stride, int pad, int relu, int y_ctot, int y_coff, int deconv_stride, int out_f32,
                  int precision, void* stream) {
     HMVIT_CHECK_ARG(x && w && y, "conv2d: null pointer");
     ConvParams p;
     memset(&p, 0, sizeof(p));
+    take_conv_range(p);
     p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = p.KW = ksize; p.stride = stride; p.pad = pad;
     p.relu = relu; p.y_ctot = y_ctot; p.y_coff = y_coff; p.deconv_s = deconv_stride; p.out_f32 = out_f32;
@@ -899,6 +919,7 @@ int hmvit_conv2d_ex(const void* x, const void* w, const float* bias, const void*
     HMVIT_CHECK_ARG(!(residual && out_f32 && precision == HMVIT_PREC_F16), "conv2d_ex: residual needs the precision's element type");
     ConvParams p;
     memset(&p, 0, sizeof(p));
+    take_conv_range(p);
     p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = p.KW = ksize; p.stride = stride; p.pad = pad;
     p.relu = relu; p.y_ctot = Cout; p.y_coff = 0; p.deconv_s = 0; p.out_f32 = out_f32;
@@ -913,6 +934,7 @@ int hmvit_conv2d_rowpack(const void* x, const void* w, const float* bias, void* 
     HMVIT_CHECK_ARG(x && w && y && N > 0 && Ho > 0 && Wo > 0 && Cout > 0 && krows > 0 && stride > 0, "conv2d_rowpack: bad argument");
     ConvParams p;
     memset(&p, 0, sizeof(p));
+    take_conv_range(p);
     p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.N = N; p.H = Hp; p.W = Wp; p.Cin = 4; p.Cout = Cout; p.KH = krows; p.KW = 8; p.stride = stride; p.pad = 0;
     p.relu = relu; p.y_ctot = Cout; p.y_coff = 0; p.Ho = Ho; p.Wo = Wo; p.rowpack = 1;

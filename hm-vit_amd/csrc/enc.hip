@@ -166,12 +166,17 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
     // split mode: range normalisation of both operands (ConvParams::absmax)
     float sx = 1.f, sw = 1.f, s_inv = 1.f;
     if constexpr (SPLIT) {
-        if (p.absmax) {
-            sx = pow2_scale(__uint_as_float(p.absmax[0]));
-            sw = pow2_scale(__uint_as_float(p.absmax[1]));
-            s_inv = pow2_inv(sx) * pow2_inv(sw);
+        if (p.x_absmax) {
+            sx = pow2_scale(__uint_as_float(p.x_absmax[0]));
+            if (p.w_absmax < 0.f) {            // the weights arrive pre-multiplied by the power of two -w_absmax: nothing to do at staging
+                s_inv = pow2_inv(sx) * pow2_inv(-p.w_absmax);
+            } else {
+                sw = pow2_scale(p.w_absmax > 0.f ? p.w_absmax : __uint_as_float(p.x_absmax[1]));
+                s_inv = pow2_inv(sx) * pow2_inv(sw);
+            }
         }
     }
+    const bool w_mul = sw != 1.f;
 
     // the rows this thread stages: decode (image, oy, ox) once
     int rn[RPT], roy[RPT], rox[RPT];
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
                 half4 h, l;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v = rw[SET][i][e] * sw;
+                    const float v = w_mul ? rw[SET][i][e] * sw : rw[SET][i][e];
                     h[e] = (half_t)v;
                     l[e] = (half_t)(v - (float)h[e]);
                 }
@@ -410,6 +415,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
     // one 16-byte store per run (8-byte stores are issue-bound, and this kernel is short of issue slots).
     const int s = p.deconv_s;
     const bool vec_ok = (p.Cout % 8 == 0) && (p.y_coff % 8 == 0) && (p.y_ctot % 8 == 0);
+    float ymax = 0.f;                      // max |y| of this lane's stores (ConvParams::y_absmax)
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * (CBM / 2) + i * 32 + r;
@@ -449,6 +455,10 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
+                    if constexpr (SPLIT) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ymax = fmaxf(ymax, fabsf(v[e]));
+                    }
                     if (p.out_f32 || sizeof(T) == 4) {
                         float* yp = reinterpret_cast<float*>(p.y) + o;
                         *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -473,11 +483,19 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
                         float ve = (SPLIT ? acc[i][j][8 * qq + e] * s_inv : acc[i][j][8 * qq + e]) + (p.bias ? p.bias[coe] : 0.f);
                         if (p.res) ve += (float)reinterpret_cast<const T*>(p.res)[pixe * p.Cout + coe];
                         if (p.relu) ve = fmaxf(ve, 0.f);
+                        if constexpr (SPLIT) ymax = fmaxf(ymax, fabsf(ve));
                         if (p.out_f32) reinterpret_cast<float*>(p.y)[oe] = ve;
                         else reinterpret_cast<T*>(p.y)[oe] = (T)ve;
                     }
                 }
             }
+    }
+    if constexpr (SPLIT) {
+        if (p.y_absmax) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
+            if (lane == 0 && ymax > 0.f) atomicMax(p.y_absmax, __float_as_uint(ymax));
+        }
     }
 }
 
@@ -559,16 +577,36 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
     // split mode: range normalisation of both operands (ConvParams::absmax)
     float sx = 1.f, sw = 1.f, s_inv = 1.f;
     if constexpr (SPLIT) {
-        if (p.absmax) {
-            sx = pow2_scale(__uint_as_float(p.absmax[0]));
-            sw = pow2_scale(__uint_as_float(p.absmax[1]));
-            s_inv = pow2_inv(sx) * pow2_inv(sw);
+        if (p.x_absmax) {
+            sx = pow2_scale(__uint_as_float(p.x_absmax[0]));
+            if (p.w_absmax < 0.f) {            // the weights arrive pre-multiplied by the power of two -w_absmax: nothing to do at staging
+                s_inv = pow2_inv(sx) * pow2_inv(-p.w_absmax);
+            } else {
+                sw = pow2_scale(p.w_absmax > 0.f ? p.w_absmax : __uint_as_float(p.x_absmax[1]));
+                s_inv = pow2_inv(sx) * pow2_inv(sw);
+            }
         }
     }
+    const bool w_mul = sw != 1.f;
     int4v rp[NPP], rw[RPW];                        // 16-byte pieces: 8 halves, or 4 floats (SPLIT)
     auto put = [&](T* dst, const int4v& piece, float sc) {   // one piece into its LDS row (SPLIT: scaled, as hi / lo halves)
         if constexpr (SPLIT) {
             const float4v f = __builtin_bit_cast(float4v, piece) * sc;
+            half4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[e] = (half_t)f[e];
+                l[e] = (half_t)(f[e] - (float)h[e]);
+            }
+            *reinterpret_cast<half4*>(dst) = h;
+            *reinterpret_cast<half4*>(dst + 32) = l;
+        } else {
+            *reinterpret_cast<half8*>(dst) = __builtin_bit_cast(half8, piece);
+        }
+    };
+    auto put_plain = [&](T* dst, const int4v& piece) {      // the same without the scale (pre-scaled weights)
+        if constexpr (SPLIT) {
+            const float4v f = __builtin_bit_cast(float4v, piece);
             half4 h, l;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -600,7 +638,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const int c = tid + 256 * i;
-            put(Ws[buf] + stage_row<SPLIT>(c) * LS + (c & 7) * PE, rw[i], sw);
+            if (w_mul) put(Ws[buf] + stage_row<SPLIT>(c) * LS + (c & 7) * PE, rw[i], sw);
+            else put_plain(Ws[buf] + stage_row<SPLIT>(c) * LS + (c & 7) * PE, rw[i]);
         }
     };
 
@@ -658,6 +697,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
     }
 
     // ---- epilogue (k_conv's vector path): lane (r, hi) owns pixel wm * 64 + i * 32 + r and channels 16 qq + 8 hi .. + 7 ----
+    float ymax = 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int pix = wm * 64 + i * 32 + r;
@@ -686,6 +726,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
+                if constexpr (SPLIT) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ymax = fmaxf(ymax, fabsf(v[e]));
+                }
                 const size_t o = opix * p.y_ctot + p.y_coff + co;
                 if (p.out_f32 || SPLIT) {
                     float* yp = reinterpret_cast<float*>(p.y) + o;
@@ -698,6 +742,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
                     *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.y) + o) = h;
                 }
             }
+    }
+    if constexpr (SPLIT) {
+        if (p.y_absmax) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
+            if (lane == 0 && ymax > 0.f) atomicMax(p.y_absmax, __float_as_uint(ymax));
+        }
     }
 }
 
@@ -744,14 +795,26 @@ int launch_maxpool(const void* x, void* y, int N, int H, int W, int C, int ksize
     return HMVIT_OK;
 }
 
-// split mode: max |x| and max |w| of one convolution, as f32 bit patterns (non-negative floats order like unsigned integers)
+// max |a| as an f32 bit pattern (non-negative floats order like unsigned integers), atomicMax into slot[which(blockIdx.y)]:
+// the range information of the split-mode convolutions when their caller did not provide it
 __global__ __launch_bounds__(256) void k_absmax2(const float* __restrict__ x, size_t nx, const float* __restrict__ w, size_t nw,
                                                  unsigned* __restrict__ slot) {
     const bool is_w = blockIdx.y != 0;
     const float* a = is_w ? w : x;
     const size_t n = is_w ? nw : nx, n4 = n / 4;
+    if (a == nullptr || n == 0) return;
     float m = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {            // four 16-byte loads in flight per thread
+        const float4 v0 = reinterpret_cast<const float4*>(a)[i], v1 = reinterpret_cast<const float4*>(a)[i + stride];
+        const float4 v2 = reinterpret_cast<const float4*>(a)[i + 2 * stride], v3 = reinterpret_cast<const float4*>(a)[i + 3 * stride];
+        m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))),
+                           fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w)))));
+        m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(v2.x), fabsf(v2.y)), fmaxf(fabsf(v2.z), fabsf(v2.w))),
+                           fmaxf(fmaxf(fabsf(v3.x), fabsf(v3.y)), fmaxf(fabsf(v3.z), fabsf(v3.w)))));
+    }
+    for (; i < n4; i += stride) {
         const float4 v = reinterpret_cast<const float4*>(a)[i];
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
@@ -761,31 +824,41 @@ __global__ __launch_bounds__(256) void k_absmax2(const float* __restrict__ x, si
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slot + (is_w ? 1 : 0), __float_as_uint(m));
 }
-// ring of result slots: a launch takes the next one (stream-ordered use: zeroed, filled, read by its own three stream operations)
+int launch_absmax(const float* x, size_t n, unsigned* slot, hipStream_t st) {
+    if (n == 0) return HMVIT_OK;
+    const unsigned blocks = (unsigned)std::min<size_t>(1024, std::max<size_t>(1, (n / 16 + 255) / 256));
+    hipLaunchKernelGGL(k_absmax2, dim3(blocks, 1), dim3(256), 0, st, x, n, nullptr, (size_t)0, slot);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+// ring of result slots of the fallback pass: a launch takes the next one (stream-ordered use: zeroed, filled, read by its own
+// three stream operations)
 constexpr int kAbsmaxSlots = 4096;
 __device__ unsigned g_conv_absmax[kAbsmaxSlots][2];
 
 int launch_conv(const ConvParams& p_in, int precision, hipStream_t st) {
     ConvParams p = p_in;
-    p.absmax = nullptr;
-    if (precision == HMVIT_PREC_SPLIT) {
+    if (precision != HMVIT_PREC_SPLIT) {
+        p.x_absmax = nullptr; p.y_absmax = nullptr;
+    } else if (!p.x_absmax) {
+        // no range information from the caller (hmvit_conv_range): measure max |x| (and max |w| unless given) here - one more pass
+        // over the input; the convolutional modules of hm-vit_amd chain the information instead (pointpillar.py, decoder.py, camera.py)
         static std::atomic<unsigned> next_slot{0};
         static unsigned* bases[64] = {};      // per device: the symbol's address is looked up once (not during a graph capture)
         int dev = 0;
         HMVIT_CHECK_HIP(hipGetDevice(&dev));
         HMVIT_CHECK_ARG(dev >= 0 && dev < 64, "conv: device ordinal %d", dev);
         if (!bases[dev]) HMVIT_CHECK_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&bases[dev]), HIP_SYMBOL(g_conv_absmax)));
-        unsigned* base = bases[dev];
-        unsigned* slot = base + 2 * (next_slot.fetch_add(1) % kAbsmaxSlots);
+        unsigned* slot = bases[dev] + 2 * (next_slot.fetch_add(1) % kAbsmaxSlots);
         const size_t nx = ((size_t)p.N * p.H * p.W * p.Cin) >> (p.up2 ? 2 : 0);
         const int ncols = p.deconv_s ? p.deconv_s * p.deconv_s * p.Cout : p.Cout;
-        const size_t nw = (size_t)ncols * (p.rowpack ? p.KH * 32 : p.KH * p.KW * p.Cin);
+        const size_t nw = p.w_absmax != 0.f ? 0 : (size_t)ncols * (p.rowpack ? p.KH * 32 : p.KH * p.KW * p.Cin);
         HMVIT_CHECK_HIP(hipMemsetAsync(slot, 0, 2 * sizeof(unsigned), st));
-        const unsigned blocks = (unsigned)std::min<size_t>(2048, std::max<size_t>(1, (std::max(nx, nw) / 4 + 255) / 256));
-        hipLaunchKernelGGL(k_absmax2, dim3(blocks, 2), dim3(256), 0, st, reinterpret_cast<const float*>(p.x), nx,
+        const unsigned blocks = (unsigned)std::min<size_t>(1024, std::max<size_t>(1, (std::max(nx, nw) / 16 + 255) / 256));
+        hipLaunchKernelGGL(k_absmax2, dim3(blocks, nw ? 2 : 1), dim3(256), 0, st, reinterpret_cast<const float*>(p.x), nx,
                            reinterpret_cast<const float*>(p.w), nw, slot);
         HMVIT_CHECK_LAUNCH();
-        p.absmax = slot;
+        p.x_absmax = slot;
     }
     const bool f32_maps = precision == HMVIT_PREC_F32 || precision == HMVIT_PREC_SPLIT;   // element type of x / w / residual
     const int bk = f32_maps ? ConvCfg<float>::BK : ConvCfg<half_t>::BK;

@@ -143,13 +143,19 @@ struct ConvParams {
     const void* res;          // optional residual (N, Ho, Wo, Cout) in the precision's element type, added before the ReLU
     int no_patch;             // 1: never take the patch-in-LDS 3 x 3 kernel (A/B checks of the two kernels against each other)
     int up2;                  // 1: the input is the nearest-neighbour x2 upsampling of x (N, H/2, W/2, Cin); H, W are the upsampled sizes
-    const unsigned* absmax;   // split mode (set by launch_conv): device (|x|max, |w|max) as f32 bit patterns; both operands are
-                              // brought to [2^13, 2^14) by a power of two on their way into LDS and the product is scaled back
+    // split mode: both operands are brought to [2^13, 2^14) by a power of two on their way into LDS and the product is scaled back.
+    const unsigned* x_absmax; // device, f32 bit pattern of max |x| (an upper bound is as good): written by the producer of x
+                              // (ConvParams::y_absmax of the convolution before, hmvit_absmax) or, when null, by a pass that
+                              // launch_conv runs itself
+    float w_absmax;           // > 0: max |w| (host value); < 0: weights pre-multiplied by the power of two -w_absmax; 0: measured
+    unsigned* y_absmax;       // optional, device, zeroed by the caller: atomicMax of |y| over everything this launch stores
     int rowpack;              // 1: few-channel stem.  x is a physically zero-padded (N, H, W, 4) map, output pixel (oy, ox) reads
                               // rows oy*stride .. + KH - 1 and pixels ox*stride .. + 7 of it; w is (Ncols, KH * 32) with
                               // k = ky * 32 + px * 4 + ci; Ho, Wo are given, pad / KW / Cin are not used
 };
 int launch_conv(const ConvParams& p, int precision, hipStream_t st);
+// atomicMax of max |x| (f32 bit pattern) into slot[0]; the caller zeroes the slot
+int launch_absmax(const float* x, size_t n, unsigned* slot, hipStream_t st);
 // max pooling on NHWC maps (the 3x3 / stride 2 / pad 1 stage of a ResNet stem)
 int launch_maxpool(const void* x, void* y, int N, int H, int W, int C, int ksize, int stride, int pad, int precision, hipStream_t st);
 

@@ -599,6 +599,9 @@ int launch_layernorm_bwd(const float* x, const float* dy, const float* gamma, co
 // one backward pass in three differed from the next in a few dq / dK' rows (parameter gradients off by 1e-3 ... 1e-2, found by
 // tests/test_hip_train.py::test_backward_matches_oracle_autograd_five_agents_64x176; tools/probe/r03_grad_bisect.sh).  Without
 // the bound the same code takes 240 registers, no scratch, still two wavefronts per SIMD, and is bit-reproducible.)
+// (Measured: the bounded, spilling build runs a launch in 6.6 ms at cfg2, this one in 8.3 ms - hipcc schedules for one wavefront per
+// SIMD when no occupancy is promised - and every attempt to get under 256 registers with the bound in place (fewer bias
+// accumulators, later operand loads) still left 28-96 bytes of scratch.  Correct first: tools/probe/r03_bwd_ab.sh.)
 template <int WIN, int HG>
 __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
     const AttnParams& p = bp.f;
@@ -656,11 +659,15 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
         }
     }
     // (the bias fragments themselves are re-read from global per tile pair: 14 fragment registers sets spilled the kernel)
-    float4v dbias[NB];
+    // bias-gradient accumulators: a wave's two key tiles (kt = 2 khalf, 2 khalf + 1) meet only NBW = 5 of the 7 tile offsets qt - kt + 3
+    // (window 8): offsets [2, 6] for khalf 0, [0, 4] for khalf 1 - eight registers less than all seven (and with them the kernel
+    // stays inside 256 registers at two waves per SIMD without spilling)
+    constexpr int NBW = (WIN == 8) ? 5 : 1;
+    float4v dbias[NBW];
     const float* biasT_g = p.bias_frag + ((size_t)head * NB * 64 + lane) * 4;
     const float* biasN_g = bp.bias_frag_neg + ((size_t)head * NB * 64 + lane) * 4;
 #pragma unroll
-    for (int v = 0; v < NB; ++v) {
+    for (int v = 0; v < NBW; ++v) {
         dbias[v] = (float4v)(0.f);
     }
     float4v dq_acc[NQT][2];
@@ -794,7 +801,7 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
                     float4v dsT;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dsT[r] = expf(sT[r] + maddT[r] - lseT) * (dpT[r] - dT);
-                    dbias[bvT] += dsT;
+                    dbias[(WIN == 8) ? bvT - (kt < 2 ? 2 : 0) : 0] += dsT;
                     {   // dQ^T += K^T dS^T over this tile's 16 keys: the lane's four values ARE the operand of v_mfma_f32_16x16x16_f16
                         half4 dsh, dsl;
                         split4(dsT[0], dsT[1], dsT[2], dsT[3], dsh, dsl);
@@ -895,11 +902,12 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
         for (int dt = 0; dt < 2; ++dt)
             *reinterpret_cast<float4*>(o + dt * 16) = make_float4(dq_acc[qt][dt][0], dq_acc[qt][dt][1], dq_acc[qt][dt][2], dq_acc[qt][dt][3]);
     }
+    const int vbase = (WIN == 8) ? (khalf == 0 ? 2 : 0) : 0;
 #pragma unroll
-    for (int v = 0; v < NB; ++v)
+    for (int v = 0; v < NBW; ++v)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (dbias[v][r] != 0.f) unsafeAtomicAdd(bp.d_bias_frag + ((size_t)(head * NB + v) * 64 + lane) * 4 + r, dbias[v][r]);
+            if (dbias[v][r] != 0.f) unsafeAtomicAdd(bp.d_bias_frag + ((size_t)(head * NB + vbase + v) * 64 + lane) * 4 + r, dbias[v][r]);
 }
 
 template <int WIN, int HG>

@@ -99,8 +99,11 @@ class HeteroDecoder(nn.Module):
             if bn is not None:
                 s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
                 w, b = w * s[:, None, None, None], (b - bn.running_mean.detach().float()) * s + bn.bias.detach().float()
+            wmax = 0.0
+            if prec == _lib.PREC_SPLIT:
+                w, wmax = _lib.prescale_weights(w)              # exact power-of-two multiple, undone in the kernel's epilogue
             return dict(w=w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous(), b=b.contiguous(),
-                        cin=w.shape[1], cout=w.shape[0], k=w.shape[2], pad=c.padding[0])
+                        cin=w.shape[1], cout=w.shape[0], k=w.shape[2], pad=c.padding[0], wmax=wmax)
 
         prep = {}
         for t, name in ((0, "camera"), (1, "lidar")):
@@ -180,6 +183,8 @@ class HeteroDecoder(nn.Module):
                 cur = tok.to(dt)
                 for layer in prep[t]["convs"]:
                     y = torch.empty(n, H, W, layer["cout"], device=dev, dtype=dt)
+                    if prec == _lib.PREC_SPLIT:
+                        _lib.conv_range(cur, layer["wmax"], y, stream)
                     _lib.check(_lib.lib.hmvit_conv2d(cur.data_ptr(), layer["w"].data_ptr(), layer["b"].data_ptr(),
                                                      y.data_ptr(), n, H, W, layer["cin"], layer["cout"], layer["k"], 1,
                                                      layer["pad"], 1, layer["cout"], 0, 0, 0, prec, stream), "conv2d")
@@ -187,6 +192,8 @@ class HeteroDecoder(nn.Module):
                 for head, dst in (("cls", psm), ("reg", rm)):
                     layer = prep[t][head]
                     y = torch.empty(n, H, W, layer["cout"], device=dev, dtype=torch.float32)
+                    if prec == _lib.PREC_SPLIT:
+                        _lib.conv_range(cur, layer["wmax"], y, stream)
                     _lib.check(_lib.lib.hmvit_conv2d(cur.data_ptr(), layer["w"].data_ptr(), layer["b"].data_ptr(),
                                                      y.data_ptr(), n, H, W, layer["cin"], layer["cout"], 1, 1, 0, 0,
                                                      layer["cout"], 0, 0, 1, prec, stream), "conv2d(head)")

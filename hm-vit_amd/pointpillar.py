@@ -119,16 +119,22 @@ class PointPillar(nn.Module):
             if bn is not None:
                 s, sh = self._fold_bn(bn)
                 w, b = w * s[:, None, None, None], b * s + sh
+            wmax = 0.0
+            if prec == _lib.PREC_SPLIT:
+                w, wmax = _lib.prescale_weights(w)              # exact power-of-two multiple, undone in the kernel's epilogue
             return dict(w=w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous(), b=b.contiguous(),
-                        cin=w.shape[1], cout=w.shape[0], k=w.shape[2], stride=c.stride[0], pad=c.padding[0])
+                        cin=w.shape[1], cout=w.shape[0], k=w.shape[2], stride=c.stride[0], pad=c.padding[0], wmax=wmax)
 
         def deconv(c, bn):
             w = c.weight.detach().float()                       # (Cin, Cout, s, s)
             s, sh = self._fold_bn(bn)
             w = w * s[None, :, None, None]
             us = c.stride[0]
+            wmax = 0.0
+            if prec == _lib.PREC_SPLIT:
+                w, wmax = _lib.prescale_weights(w)
             return dict(w=w.permute(2, 3, 1, 0).reshape(us * us * w.shape[1], w.shape[0]).to(dt).contiguous(),
-                        b=sh.contiguous(), cin=w.shape[0], cout=w.shape[1], us=us)
+                        b=sh.contiguous(), cin=w.shape[0], cout=w.shape[1], us=us, wmax=wmax)
 
         pfn = self.pillar_vfe.pfn_layers[0]
         s, sh = self._fold_bn(pfn.norm)
@@ -155,6 +161,8 @@ class PointPillar(nn.Module):
     def _conv(x, layer, N, H, W, out, ctot, coff, relu, out_f32, prec, stream):
         Ho = (H + 2 * layer["pad"] - layer["k"]) // layer["stride"] + 1
         Wo = (W + 2 * layer["pad"] - layer["k"]) // layer["stride"] + 1
+        if prec == _lib.PREC_SPLIT:
+            _lib.conv_range(x, layer["wmax"], out, stream)       # max |x| from x's producer, max |out| for its consumers
         _lib.check(_lib.lib.hmvit_conv2d(x.data_ptr(), layer["w"].data_ptr(), layer["b"].data_ptr(), out.data_ptr(), N, H,
                                          W, layer["cin"], layer["cout"], layer["k"], layer["stride"], layer["pad"],
                                          int(relu), ctot, coff, 0, int(out_f32), prec, stream), "hmvit_conv2d")
@@ -217,6 +225,8 @@ class PointPillar(nn.Module):
                     cat = torch.empty(n_agents, H * us, W * us, ctot, device=dev, dtype=dt)
                     Hc, Wc = H * us, W * us
                 assert (H * us, W * us) == (Hc, Wc), "up-sampled maps must share one size"
+                if prec == _lib.PREC_SPLIT:
+                    _lib.conv_range(x, de["wmax"], cat, stream, share_out=True)
                 _lib.check(_lib.lib.hmvit_conv2d(x.data_ptr(), de["w"].data_ptr(), de["b"].data_ptr(), cat.data_ptr(),
                                                  n_agents, H, W, de["cin"], de["cout"], 1, 1, 0, 1, ctot, coff, us, 0, prec,
                                                  stream), "hmvit_conv2d(deconv)")

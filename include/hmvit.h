@@ -366,6 +366,17 @@ int hmvit_conv2d(const void* x, const void* w, const float* bias, void* y, int N
                  int ksize, int stride, int pad, int relu, int y_ctot, int y_coff, int deconv_stride, int out_f32,
                  int precision, void* stream);
 
+/* Range information for the NEXT hmvit_conv2d / _ex / _rowpack call of the calling thread in HMVIT_PREC_SPLIT (consumed by it).
+ * The split convolutions scale both operands into f16's comfortable range by powers of two taken from max |x| and max |w|:
+ *   x_absmax  device pointer to the f32 bit pattern of max |x| (any upper bound works), e.g. the y_absmax slot of the
+ *             convolution that produced x, or a slot filled by hmvit_absmax; NULL: the library measures it (an extra pass);
+ *   w_absmax  > 0: max |w| as a host value (known when the weights are prepared); < 0: the weights were pre-multiplied by the
+ *             power of two -w_absmax when they were prepared (nothing left to do while staging them); 0: measured by the library;
+ *   y_absmax  device slot, zeroed by the caller, that receives atomicMax(|y|) over everything the call stores, or NULL.
+ * hmvit_absmax: atomicMax(max |x|) into a zeroed slot. */
+int hmvit_conv_range(const void* x_absmax, float w_absmax, void* y_absmax);
+int hmvit_absmax(const float* x, size_t n, void* slot, void* stream);
+
 /* hmvit_conv2d with a residual operand and an up-sampled input (camera branch):
  *   residual (N, Ho, Wo, Cout) in the precision's element type or NULL: y = act(conv(x) + bias + residual), the tail of a
  *   torchvision BasicBlock / Bottleneck (`out += identity; out = relu(out)`, used by resnet_ms.py:27-38 and

@@ -267,7 +267,7 @@ def test_mixed_camera_lidar_five_agent_train_loop_with_validation():
     from hmvit_amd import trainer as T
 
     class A(_Args):
-        agents, frames, val_frames, camera_ratio = 5, 4, 2, 0.5
+        agents, frames, val_frames, camera_ratio, seed = 5, 4, 2, 0.5, 1      # seed 1: the four frames hold camera AND LiDAR egos
     hypes = T.default_hypes(epoches=3)
     cfg, model, pre, post, ds, val = T.build(A)
     rolled = [ds.roll_modes(i) for i in range(len(ds))]
