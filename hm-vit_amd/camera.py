@@ -232,7 +232,9 @@ class ResnetEncoder(nn.Module):
 
     def forward(self, input_images):
         if self.training:
-            raise RuntimeError("hmvit_amd.ResnetEncoder folds BatchNorm statistics: call .eval() (inference only)")
+            # batch-statistics BatchNorm + gradients: the training-mode layer functions (hm-vit_amd/camera_train.py)
+            from .camera_train import resnet_encoder_forward
+            return resnet_encoder_forward(self, input_images)
         if not input_images.is_cuda:
             raise RuntimeError("hm-vit_amd has no CPU path: pass CUDA tensors")
         prec = _PREC[self.precision]
@@ -307,7 +309,8 @@ class CrossViewModule(nn.Module):
         """batch: 'inputs' (b, l, n, ...) only for its leading shape, 'intrinsic' (b, l, n, 3, 3), 'extrinsic' (b, l, n, 4, 4),
         'features': list of (b, l, n, C, h, w).  Returns (b, l, dim, H, W)."""
         if self.training:
-            raise RuntimeError("hmvit_amd.CrossViewModule: eval mode only")
+            from .camera_train import cross_view_module_forward
+            return cross_view_module_forward(self, batch)
         b, l, n = batch["inputs"].shape[:3]
         prec = _PREC[self.precision]
         dt = torch.float16 if prec == _lib.PREC_F16 else torch.float32
@@ -350,6 +353,10 @@ class CvtCameraEncoder(nn.Module):
         return [_Conv(dec[i], dec[i + 1], prec, dt) for i in range(0, len(dec), 3)]
 
     def forward(self, batch_camera):
+        if self.training:
+            # train_camera.py without --fix_camera_backbone: ResNet, cross-view lift and decoder on the autograd tape
+            from .camera_train import cvt_camera_encoder_forward
+            return cvt_camera_encoder_forward(self, batch_camera)
         cam = batch_camera["camera"]
         n_agents = cam.shape[0]
         prec = _PREC[self.precision]

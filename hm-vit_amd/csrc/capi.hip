@@ -1051,6 +1051,37 @@ int hmvit_cross_attention(const void* q, const void* k, const void* v, float* ou
                                   reinterpret_cast<const float*>(v), out, n_agents, n_cam, Q, K, heads, dim_head, nullptr, st);
 }
 
+/* ---- training-mode operators of the camera lift (cvt_modules.py:95-165 under autograd; hm-vit_amd/camera_train.py) ---- */
+int hmvit_cross_attention_train(const float* q, const float* k, const float* v, float* out, float* lse, int n_agents, int n_cam, int Q,
+                                int K, int heads, int dim_head, void* stream) {
+    HMVIT_CHECK_ARG(q && k && v && out && lse && n_agents > 0 && n_cam > 0 && Q > 0 && K > 0 && heads > 0, "cross_attention_train: bad argument");
+    return launch_cross_attention(q, k, v, out, n_agents, n_cam, Q, K, heads, dim_head, nullptr, reinterpret_cast<hipStream_t>(stream), lse);
+}
+int hmvit_cross_attention_backward(const float* q, const float* k, const float* v, const float* out, const float* lse, const float* d_out,
+                                   float* dq, float* dk, float* dv, int n_agents, int n_cam, int Q, int K, int heads, int dim_head,
+                                   void* stream) {
+    HMVIT_CHECK_ARG(q && k && v && out && lse && d_out && dq && dk && dv && n_agents > 0 && n_cam > 0, "cross_attention_backward: bad argument");
+    return launch_cross_attention_bwd(q, k, v, out, lse, d_out, dq, dk, dv, n_agents, n_cam, Q, K, heads, dim_head,
+                                      reinterpret_cast<hipStream_t>(stream));
+}
+int hmvit_layernorm_backward(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta, int M, int C,
+                             void* stream) {
+    HMVIT_CHECK_ARG(x && dy && gamma && dx && dgamma && dbeta && M > 0, "layernorm_backward: bad argument");
+    AgentTypes ty;
+    memset(&ty, 0, sizeof(ty));
+    return launch_layernorm_bwd(x, dy, gamma, ty, 1, nullptr, dx, dgamma, dbeta, M, C, reinterpret_cast<hipStream_t>(stream));
+}
+int hmvit_gelu(const float* pre, float* y, size_t n, void* stream) {
+    HMVIT_CHECK_ARG(pre && y, "gelu: null pointer");
+    DropCfg none = {0ull, 0u, 0.f};
+    return launch_gelu_drop(pre, y, n, none, reinterpret_cast<hipStream_t>(stream));
+}
+int hmvit_gelu_backward(const float* pre, const float* dy, float* dx, size_t n, void* stream) {
+    HMVIT_CHECK_ARG(pre && dy && dx, "gelu_backward: null pointer");
+    DropCfg none = {0ull, 0u, 0.f};
+    return launch_gelu_bwd(pre, dy, dx, n, none, reinterpret_cast<hipStream_t>(stream));
+}
+
 int hmvit_attention_bias(const float* q, const float* k, const float* v, const float* bias, float* out, int batch, int Q, int K,
                          int heads, int dim_head, void* stream) {
     HMVIT_CHECK_ARG(q && k && v && bias && out && batch > 0 && Q > 0 && K > 0 && heads > 0, "attention_bias: bad argument");

@@ -655,6 +655,14 @@ int hmvit_bn_train_stats(const float* x, float* sums, int M, int C, void* stream
     return launch_bn(a, 0, 0, reinterpret_cast<hipStream_t>(stream));
 }
 
+int hmvit_bn_train_stats_centered(const float* x, const float* pivot, float* sums, int M, int C, void* stream) {
+    HMVIT_CHECK_ARG(x && pivot && sums, "bn_train_stats_centered: null pointer");
+    BnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.mean = pivot; a.out = sums; a.M = M; a.C = C;
+    return launch_bn(a, 0, 0, reinterpret_cast<hipStream_t>(stream));
+}
+
 int hmvit_bn_train_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,
                          int M, int C, int relu, void* stream) {
     HMVIT_CHECK_ARG(x && mean && rstd && gamma && beta && y, "bn_train_apply: null pointer");

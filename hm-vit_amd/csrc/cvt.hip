@@ -119,7 +119,8 @@ __device__ __forceinline__ float xlane_sum4(float v) {
 
 __global__ __launch_bounds__(256) void k_cross_attention(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, float* __restrict__ out, int n_cam, int Q,
-                                                         int K, int heads, float scale, const float* __restrict__ bias) {
+                                                         int K, int heads, float scale, const float* __restrict__ bias,
+                                                         float* __restrict__ lse) {
     constexpr int D = 32, KS = D + 1;
     __shared__ float Ks[64 * KS], Vs[64 * KS];
     const int b = blockIdx.z, head = blockIdx.y;
@@ -195,7 +196,10 @@ __global__ __launch_bounds__(256) void k_cross_attention(const float* __restrict
             m_run = m_new;
         }
     }
-    const float inv = 1.f / xlane_sum4(l_part);
+    const float l_sum = xlane_sum4(l_part);
+    const float inv = 1.f / l_sum;
+    // training: the row's log-sum-exp (logits in scaled units, q . k / sqrt(d)) lets the backward pass rebuild the probabilities
+    if (lse && valid && g == 0) lse[((size_t)b * heads + head) * Q + qi] = m_run + logf(l_sum);
     if (valid) {
         // o_acc[dt][r] = O^T[d = dt * 16 + 4 g + r][query l]
         float* op = out + (((size_t)b * Q + qi) * HD + head * D + 4 * g);
@@ -206,12 +210,197 @@ __global__ __launch_bounds__(256) void k_cross_attention(const float* __restrict
 }
 
 int launch_cross_attention(const float* q, const float* k, const float* v, float* out, int b, int n_cam, int Q, int K, int heads,
-                           int dim_head, const float* bias, hipStream_t st) {
+                           int dim_head, const float* bias, hipStream_t st, float* lse) {
     HMVIT_CHECK_ARG(dim_head == 32, "cross_attention: dim_head=%d (32)", dim_head);
     HMVIT_CHECK_ARG(!bias || n_cam == 1, "cross_attention: a logit bias needs n_cam = 1 (got %d)", n_cam);
     if (b <= 0 || Q <= 0) return HMVIT_OK;
     hipLaunchKernelGGL(k_cross_attention, dim3(cdiv(Q, 64), heads, b), dim3(256), 0, st, q, k, v, out, n_cam, Q, K, heads,
-                       1.f / sqrtf((float)dim_head), bias);
+                       1.f / sqrtf((float)dim_head), bias, lse);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward pass of the joint-softmax cross attention (training of the camera lift, cvt_modules.py:95-165 under autograd).
+//   P[q, (cam, k)] = exp(s Q_cam[q] . K_cam[k] - lse[q]),   D[q] = dO[q] . O[q]
+//   dV[cam, k] = sum_q P dO[q],   dS = P (dO[q] . V[cam, k] - D[q]) s,   dQ_cam[q] = sum_k dS K_cam[k],   dK_cam[k] = sum_q dS Q_cam[q]
+// Two launches, neither with atomics: k_cross_attention_bwd_dq owns 64 queries of one head and walks every key tile,
+// k_cross_attention_bwd_dkv owns 64 keys of one camera and walks every query tile; both rebuild the 64 x 64 tile of P / dS from
+// the saved log-sum-exp (thread (tq, tk) = 4 x 4 query-key pairs, f32 FMAs over the 32 channels out of LDS) and contract it
+// through LDS.  Correctness first: plain f32 FMAs, about a third of the f32 vector peak.
+// ------------------------------------------------------------------------------------------
+namespace {
+constexpr int XB_D = 32, XB_T = 64, XB_LS = XB_D + 1;
+
+// tile rows [r0, r0 + 64) of a (rows, heads * 32) matrix -> LDS (64 x 33), zero beyond n_rows
+__device__ __forceinline__ void xb_load_tile(float* dst, const float* __restrict__ src, int r0, int n_rows, int HD, int head, float mul) {
+    const int row = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 8;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (r0 + row < n_rows) {
+        const float* p = src + (size_t)(r0 + row) * HD + head * XB_D + c0;
+        a = *reinterpret_cast<const float4*>(p);
+        b = *reinterpret_cast<const float4*>(p + 4);
+    }
+    float* d = dst + row * XB_LS + c0;
+    d[0] = a.x * mul; d[1] = a.y * mul; d[2] = a.z * mul; d[3] = a.w * mul; d[4] = b.x * mul; d[5] = b.y * mul; d[6] = b.z * mul; d[7] = b.w * mul;
+}
+
+// P and dS of the 4 x 4 pairs (queries 4 tq + i, keys 4 tk + j) of a 64 x 64 tile
+__device__ __forceinline__ void xb_tile_probs(const float* Qs, const float* dOs, const float* Ks, const float* Vs, const float* lse_s,
+                                              const float* d_s, int tq, int tk, int q_valid, int k_valid, float scale,
+                                              float (&P)[4][4], float (&dS)[4][4]) {
+    float s[4][4], dp[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[i][j] = dp[i][j] = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < XB_D; ++c) {
+        float qv[4], ov[4], kv[4], vv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { qv[i] = Qs[(4 * tq + i) * XB_LS + c]; ov[i] = dOs[(4 * tq + i) * XB_LS + c]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { kv[j] = Ks[(4 * tk + j) * XB_LS + c]; vv[j] = Vs[(4 * tk + j) * XB_LS + c]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[i][j] = fmaf(qv[i], kv[j], s[i][j]);
+                dp[i][j] = fmaf(ov[i], vv[j], dp[i][j]);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = (4 * tq + i < q_valid) && (4 * tk + j < k_valid);
+            const float p = ok ? __expf(s[i][j] * scale - lse_s[4 * tq + i]) : 0.f;
+            P[i][j] = p;
+            dS[i][j] = p * (dp[i][j] - d_s[4 * tq + i]) * scale;
+        }
+}
+}  // namespace
+
+// grid (Q / 64, heads, b): dq (b, n_cam, Q, HD)
+__global__ __launch_bounds__(256) void k_cross_attention_bwd_dq(const float* __restrict__ q, const float* __restrict__ k,
+                                                                const float* __restrict__ v, const float* __restrict__ out,
+                                                                const float* __restrict__ lse, const float* __restrict__ d_out,
+                                                                float* __restrict__ dq, int n_cam, int Q, int K, int heads, float scale) {
+    __shared__ float Qs[XB_T * XB_LS], dOs[XB_T * XB_LS], Ks[XB_T * XB_LS], Vs[XB_T * XB_LS], Ss[XB_T * (XB_T + 1)];
+    __shared__ float lse_s[XB_T], d_s[XB_T];
+    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * XB_T, HD = heads * XB_D;
+    const int tid = threadIdx.x, tq = tid >> 4, tk = tid & 15;
+    const int q_valid = min(XB_T, Q - q0);
+    xb_load_tile(dOs, d_out + (size_t)b * Q * HD, q0, Q, HD, head, 1.f);
+    xb_load_tile(Ss, out + (size_t)b * Q * HD, q0, Q, HD, head, 1.f);          // O, only for D
+    __syncthreads();
+    if (tid < XB_T) {
+        float d = 0.f;
+        for (int c = 0; c < XB_D; ++c) d = fmaf(dOs[tid * XB_LS + c], Ss[tid * XB_LS + c], d);
+        d_s[tid] = d;
+        lse_s[tid] = tid < q_valid ? lse[((size_t)b * heads + head) * Q + q0 + tid] : 0.f;
+    }
+    const int orow = tid >> 2, oc0 = (tid & 3) * 8;       // output role: query row, 8 channels
+    for (int cam = 0; cam < n_cam; ++cam) {
+        __syncthreads();
+        xb_load_tile(Qs, q + (size_t)(b * n_cam + cam) * Q * HD, q0, Q, HD, head, 1.f);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int k0 = 0; k0 < K; k0 += XB_T) {
+            __syncthreads();
+            xb_load_tile(Ks, k + (size_t)(b * n_cam + cam) * K * HD, k0, K, HD, head, 1.f);
+            xb_load_tile(Vs, v + ((size_t)b * n_cam + cam) * K * HD, k0, K, HD, head, 1.f);
+            __syncthreads();
+            float P[4][4], dS[4][4];
+            xb_tile_probs(Qs, dOs, Ks, Vs, lse_s, d_s, tq, tk, q_valid, min(XB_T, K - k0), scale, P, dS);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Ss[(4 * tq + i) * (XB_T + 1) + 4 * tk + j] = dS[i][j];
+            __syncthreads();
+            for (int kk = 0; kk < XB_T; ++kk) {
+                const float ds = Ss[orow * (XB_T + 1) + kk];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(ds, Ks[kk * XB_LS + oc0 + e], acc[e]);
+            }
+        }
+        if (orow < q_valid) {
+            float* o = dq + ((size_t)(b * n_cam + cam) * Q + q0 + orow) * HD + head * XB_D + oc0;
+            *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+    }
+}
+
+// grid (K / 64, heads * n_cam, b): dk (b, n_cam, K, HD), dv (b, n_cam * K, HD)
+__global__ __launch_bounds__(256) void k_cross_attention_bwd_dkv(const float* __restrict__ q, const float* __restrict__ k,
+                                                                 const float* __restrict__ v, const float* __restrict__ out,
+                                                                 const float* __restrict__ lse, const float* __restrict__ d_out,
+                                                                 float* __restrict__ dk, float* __restrict__ dv, int n_cam, int Q, int K,
+                                                                 int heads, float scale) {
+    __shared__ float Qs[XB_T * XB_LS], dOs[XB_T * XB_LS], Ks[XB_T * XB_LS], Vs[XB_T * XB_LS], Ss[XB_T * (XB_T + 1)], Ps[XB_T * (XB_T + 1)];
+    __shared__ float lse_s[XB_T], d_s[XB_T];
+    const int b = blockIdx.z, head = blockIdx.y % heads, cam = blockIdx.y / heads, k0 = blockIdx.x * XB_T, HD = heads * XB_D;
+    const int tid = threadIdx.x, tq = tid >> 4, tk = tid & 15;
+    const int k_valid = min(XB_T, K - k0);
+    xb_load_tile(Ks, k + (size_t)(b * n_cam + cam) * K * HD, k0, K, HD, head, 1.f);
+    xb_load_tile(Vs, v + ((size_t)b * n_cam + cam) * K * HD, k0, K, HD, head, 1.f);
+    const int orow = tid >> 2, oc0 = (tid & 3) * 8;       // output role: key row, 8 channels
+    float acck[8], accv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acck[e] = accv[e] = 0.f;
+    for (int q0 = 0; q0 < Q; q0 += XB_T) {
+        __syncthreads();
+        const int q_valid = min(XB_T, Q - q0);
+        xb_load_tile(Qs, q + (size_t)(b * n_cam + cam) * Q * HD, q0, Q, HD, head, 1.f);
+        xb_load_tile(dOs, d_out + (size_t)b * Q * HD, q0, Q, HD, head, 1.f);
+        xb_load_tile(Ss, out + (size_t)b * Q * HD, q0, Q, HD, head, 1.f);      // O (row stride XB_LS inside Ss), only for D
+        __syncthreads();
+        if (tid < XB_T) {
+            float d = 0.f;
+            for (int c = 0; c < XB_D; ++c) d = fmaf(dOs[tid * XB_LS + c], Ss[tid * XB_LS + c], d);
+            d_s[tid] = d;
+            lse_s[tid] = tid < q_valid ? lse[((size_t)b * heads + head) * Q + q0 + tid] : 0.f;
+        }
+        __syncthreads();
+        float P[4][4], dS[4][4];
+        xb_tile_probs(Qs, dOs, Ks, Vs, lse_s, d_s, tq, tk, q_valid, k_valid, scale, P, dS);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Ss[(4 * tq + i) * (XB_T + 1) + 4 * tk + j] = dS[i][j];
+                Ps[(4 * tq + i) * (XB_T + 1) + 4 * tk + j] = P[i][j];
+            }
+        __syncthreads();
+        for (int qq = 0; qq < XB_T; ++qq) {
+            const float ds = Ss[qq * (XB_T + 1) + orow], pp = Ps[qq * (XB_T + 1) + orow];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                acck[e] = fmaf(ds, Qs[qq * XB_LS + oc0 + e], acck[e]);
+                accv[e] = fmaf(pp, dOs[qq * XB_LS + oc0 + e], accv[e]);
+            }
+        }
+    }
+    if (orow < k_valid) {
+        const size_t row = ((size_t)(b * n_cam + cam) * K + k0 + orow) * HD + head * XB_D + oc0;
+        *reinterpret_cast<float4*>(dk + row) = make_float4(acck[0], acck[1], acck[2], acck[3]);
+        *reinterpret_cast<float4*>(dk + row + 4) = make_float4(acck[4], acck[5], acck[6], acck[7]);
+        *reinterpret_cast<float4*>(dv + row) = make_float4(accv[0], accv[1], accv[2], accv[3]);
+        *reinterpret_cast<float4*>(dv + row + 4) = make_float4(accv[4], accv[5], accv[6], accv[7]);
+    }
+}
+
+int launch_cross_attention_bwd(const float* q, const float* k, const float* v, const float* out, const float* lse, const float* d_out,
+                               float* dq, float* dk, float* dv, int b, int n_cam, int Q, int K, int heads, int dim_head, hipStream_t st) {
+    HMVIT_CHECK_ARG(dim_head == 32, "cross_attention_bwd: dim_head=%d (32)", dim_head);
+    if (b <= 0 || Q <= 0 || K <= 0) return HMVIT_OK;
+    const float scale = 1.f / sqrtf((float)dim_head);
+    hipLaunchKernelGGL(k_cross_attention_bwd_dq, dim3(cdiv(Q, 64), heads, b), dim3(256), 0, st, q, k, v, out, lse, d_out, dq, n_cam, Q, K,
+                       heads, scale);
+    hipLaunchKernelGGL(k_cross_attention_bwd_dkv, dim3(cdiv(K, 64), heads * n_cam, b), dim3(256), 0, st, q, k, v, out, lse, d_out, dk, dv,
+                       n_cam, Q, K, heads, scale);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }

@@ -339,7 +339,10 @@ struct CvtEmbedParams {
 int launch_cvt_embed(const CvtEmbedParams& p, hipStream_t st);
 int launch_bn_relu_tokens(const float* x, const float* scale, const float* shift, float* y, int n, int C, int P, hipStream_t st);
 int launch_cross_attention(const float* q, const float* k, const float* v, float* out, int b, int n_cam, int Q, int K, int heads,
-                           int dim_head, const float* bias, hipStream_t st);
+                           int dim_head, const float* bias, hipStream_t st, float* lse = nullptr);
+// backward of the joint-softmax cross attention: dq (b, n_cam, Q, HD), dk (b, n_cam, K, HD), dv (b, n_cam K, HD)
+int launch_cross_attention_bwd(const float* q, const float* k, const float* v, const float* out, const float* lse, const float* d_out,
+                               float* dq, float* dk, float* dv, int b, int n_cam, int Q, int K, int heads, int dim_head, hipStream_t st);
 int launch_cross_attention_f16(const half_t* q, const half_t* k, const half_t* v, float* out, int b, int n_cam, int Q, int K,
                                int heads, int dim_head, hipStream_t st);
 

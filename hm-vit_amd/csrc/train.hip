@@ -401,6 +401,9 @@ __global__ __launch_bounds__(256) void k_bn_reduce(BnArgs a, int rows_per_wg) {
         if (BWD) {
             const float4 m4 = *reinterpret_cast<const float4*>(a.mean + c), r4 = *reinterpret_cast<const float4*>(a.rstd + c);
             mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w; rs[0] = r4.x; rs[1] = r4.y; rs[2] = r4.z; rs[3] = r4.w;
+        } else if (a.mean) {   // forward, second pass: sums of (x - pivot) and (x - pivot)^2 (no cancellation in the variance)
+            const float4 m4 = *reinterpret_cast<const float4*>(a.mean + c);
+            mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w;
         }
         for (int m = m_begin + rg; m < m_end; m += 4) {
             const size_t o = (size_t)m * a.C + c;
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(256) void k_bn_reduce(BnArgs a, int rows_per_wg) {
                 for (int e = 0; e < 4; ++e) { s0[e] += g[e]; s1[e] = fmaf(g[e], (x[e] - mu[e]) * rs[e], s1[e]); }
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { s0[e] += x[e]; s1[e] = fmaf(x[e], x[e], s1[e]); }
+                for (int e = 0; e < 4; ++e) { const float d = x[e] - mu[e]; s0[e] += d; s1[e] = fmaf(d, d, s1[e]); }
             }
         }
     }

@@ -93,11 +93,11 @@ class Conv3x3(torch.autograd.Function):
 
 
 class BnRelu(torch.autograd.Function):
-    """Training-mode BatchNorm2d + ReLU on an NHWC map.  Returns (y, batch mean, biased batch variance); the statistics are
-    not differentiable outputs (the caller updates the running buffers with them)."""
+    """Training-mode BatchNorm2d (+ ReLU unless relu=False) on an NHWC map.  Returns (y, batch mean, biased batch variance); the
+    statistics are not differentiable outputs (the caller updates the running buffers with them)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, relu=True):
         x = x.contiguous()
         C = x.shape[-1]
         M = x.numel() // C
@@ -106,13 +106,21 @@ class BnRelu(torch.autograd.Function):
             sums = torch.zeros(2 * C, device=dev, dtype=torch.float32)
             _lib.check(_lib.lib.hmvit_bn_train_stats(x.data_ptr(), sums.data_ptr(), M, C, _stream(dev)), "bn_train_stats")
             mean = sums[:C] / M
-            var = (sums[C:] / M - mean * mean).clamp_min(0.0)
+            # second pass around the mean: E[x^2] - mean^2 cancels catastrophically for channels whose |mean| dwarfs their spread
+            # (behind a convolution bias; padded points of the PFN) and the clamp would hide it
+            sums2 = torch.zeros(2 * C, device=dev, dtype=torch.float32)
+            _lib.check(_lib.lib.hmvit_bn_train_stats_centered(x.data_ptr(), mean.contiguous().data_ptr(), sums2.data_ptr(), M, C, _stream(dev)),
+                       "bn_train_stats_centered")
+            r = sums2[:C] / M
+            mean = mean + r
+            var = (sums2[C:] / M - r * r).clamp_min(0.0)
             rstd = torch.rsqrt(var + eps)
             y = torch.empty_like(x)
             g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
             _lib.check(_lib.lib.hmvit_bn_train_apply(x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), b.data_ptr(),
-                                                     y.data_ptr(), M, C, 1, _stream(dev)), "bn_train_apply")
+                                                     y.data_ptr(), M, C, 1 if relu else 0, _stream(dev)), "bn_train_apply")
         ctx.save_for_backward(x, y, mean, rstd, g)
+        ctx.relu = bool(relu)
         ctx.mark_non_differentiable(mean, var)
         return y, mean, var
 
@@ -127,9 +135,9 @@ class BnRelu(torch.autograd.Function):
             sums = torch.zeros(2 * C, device=dev, dtype=torch.float32)
             dx = torch.empty_like(x)
             _lib.check(_lib.lib.hmvit_bn_train_backward(x.data_ptr(), y.data_ptr(), dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                                        g.data_ptr(), sums.data_ptr(), dx.data_ptr(), M, C, 1, _stream(dev)),
-                       "bn_train_backward")
-        return dx, sums[C:].clone(), sums[:C].clone(), None
+                                                        g.data_ptr(), sums.data_ptr(), dx.data_ptr(), M, C, 1 if ctx.relu else 0,
+                                                        _stream(dev)), "bn_train_backward")
+        return dx, sums[C:].clone(), sums[:C].clone(), None, None
 
 
 class Conv1x1(torch.autograd.Function):
@@ -175,10 +183,10 @@ class Conv1x1(torch.autograd.Function):
         return dx, dw[:co].reshape(co, ci, 1, 1).contiguous(), db[:co].contiguous()
 
 
-def bn_relu_module(x, bn: torch.nn.BatchNorm2d):
-    """``bn`` (train mode) + ReLU on an NHWC map through ``BnRelu``, with ``nn.BatchNorm2d``'s running-statistics update
-    (momentum, unbiased variance, ``num_batches_tracked``)."""
-    y, mean, var = BnRelu.apply(x, bn.weight, bn.bias, bn.eps)
+def bn_relu_module(x, bn: torch.nn.BatchNorm2d, relu: bool = True):
+    """``bn`` (train mode) + ReLU (unless relu=False) on an NHWC map through ``BnRelu``, with ``nn.BatchNorm2d``'s running-statistics
+    update (momentum, unbiased variance, ``num_batches_tracked``)."""
+    y, mean, var = BnRelu.apply(x, bn.weight, bn.bias, bn.eps, relu)
     if bn.track_running_stats and bn.running_mean is not None:
         with torch.no_grad():
             M = x.numel() // x.shape[-1]

@@ -281,15 +281,15 @@ def build(args):
     camera_encoder = None
     mixed = args.camera_ratio > 0 or args.ego_mode == "camera"
     if mixed:
-        # camera agents: the CVT lift in the model's camera slot, producing the LiDAR branch's (256, ny / 4, nx / 4) BEV map; it
-        # runs frozen (train_camera.py's --fix_camera_backbone: the camera encoders have no backward pass yet)
+        # camera agents: the CVT lift in the model's camera slot, producing the LiDAR branch's (256, ny / 4, nx / 4) BEV map; frozen
+        # (train_camera.py's --fix_camera_backbone) unless --train_camera_backbone puts it on the tape (hm-vit_amd/camera_train.py)
         from . import synthetic as S
         from .camera import CvtCameraEncoder
         camera_encoder = CvtCameraEncoder(S.camera_config(args.camera_image, 18, bev_h=args.grid[1] // 2, bev_w=args.grid[0] // 2),
                                           precision="f32" if args.precision == "f32" else "f16")
     model = BevformerPointPillarHetero(cfg, camera_encoder=camera_encoder, precision=args.precision)
-    if mixed:
-        model.fix_camera_backbone()
+    if mixed and not getattr(args, "train_camera_backbone", False):
+        model.fix_camera_backbone()                     # train_camera.py --fix_camera_backbone (the default here: faster steps)
     if not args.train_lidar_backbone:
         model.fix_lidar_backbone()
     pre = SpVoxelPreprocessor(R.preprocess_params(cfg), train=True)
@@ -313,6 +313,8 @@ def main(argv=None):
                     help="camera_to_lidar_ratio of the modality roll (basedataset.py:193-200); > 0 puts the CVT lift in the camera slot")
     ap.add_argument("--ego_mode", default="mixed", choices=["mixed", "lidar", "camera"])
     ap.add_argument("--camera_image", type=int, default=64, help="camera image size of the synthetic frames")
+    ap.add_argument("--train_camera_backbone", action="store_true",
+                    help="do NOT freeze the camera encoder: ResNet, cross-view lift and decoder train too (hm-vit_amd/camera_train.py)")
     ap.add_argument("--train_lidar_backbone", action="store_true",
                     help="do NOT freeze the LiDAR encoder: PointPillar trains too (hm-vit_amd/encoder_train.py)")
     ap.add_argument("--model_dir", default=None, help="folder with net_epoch%%d.pth to resume from / save into")

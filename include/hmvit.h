@@ -279,6 +279,9 @@ int hmvit_gemm_tn(const float* dy, const float* a, float* dw, float* dbias, int 
  *   backward: g = dy [y > 0] (relu) or dy; sums[c] += sum g = dbeta, sums[C + c] += sum g xhat = dgamma (zero-fill first);
  *             dx = gamma rstd (g - dbeta / M - xhat dgamma / M) */
 int hmvit_bn_train_stats(const float* x, float* sums, int M, int C, void* stream);
+/* the same sums of (x - pivot[c]): with pivot = the batch mean of a first pass, sums[C + c] / M - (sums[c] / M)^2 is the variance without
+ * the cancellation of E[x^2] - mean^2 (channels whose |mean| dwarfs their spread, e.g. behind a convolution bias) */
+int hmvit_bn_train_stats_centered(const float* x, const float* pivot, float* sums, int M, int C, void* stream);
 int hmvit_bn_train_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,
                          int M, int C, int relu, void* stream);
 int hmvit_bn_train_backward(const float* x, const float* y, const float* dy, const float* mean, const float* rstd, const float* gamma,
@@ -464,6 +467,23 @@ int hmvit_bn_relu_tokens(const float* x, const float* scale, const float* shift,
  * Q and K to be multiples of 64. */
 int hmvit_cross_attention(const void* q, const void* k, const void* v, float* out, int n_agents, int n_cam, int Q, int K,
                           int heads, int dim_head, int precision, void* stream);
+
+/* ---- training-mode operators of the camera lift (cvt_modules.py:95-165 and resnet_ms.py under autograd) ----
+ * hmvit_cross_attention_train: hmvit_cross_attention in exact f32 that also returns lse (n_agents, heads, Q), the log-sum-exp of
+ *   every query row over the keys of all cameras (logits q . k / sqrt(dim_head)).
+ * hmvit_cross_attention_backward: d_out (n_agents, Q, HD) -> dq (n_agents, n_cam, Q, HD), dk (n_agents, n_cam, K, HD),
+ *   dv (n_agents, n_cam K, HD); the probabilities are rebuilt from lse; every output element is written (no accumulation).
+ * hmvit_layernorm_backward: nn.LayerNorm(C), C in {64, 128, 256}: dx (M, C) written, dgamma / dbeta (C) ACCUMULATED (zero-fill).
+ * hmvit_gelu / hmvit_gelu_backward: erf GELU and dx = dy gelu'(pre), elementwise f32. */
+int hmvit_cross_attention_train(const float* q, const float* k, const float* v, float* out, float* lse, int n_agents, int n_cam, int Q,
+                                int K, int heads, int dim_head, void* stream);
+int hmvit_cross_attention_backward(const float* q, const float* k, const float* v, const float* out, const float* lse, const float* d_out,
+                                   float* dq, float* dk, float* dv, int n_agents, int n_cam, int Q, int K, int heads, int dim_head,
+                                   void* stream);
+int hmvit_layernorm_backward(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta, int M, int C,
+                             void* stream);
+int hmvit_gelu(const float* pre, float* y, size_t n, void* stream);
+int hmvit_gelu_backward(const float* pre, const float* dy, float* dx, size_t n, void* stream);
 
 /* Softmax attention with an additive logit bias, f32: q (batch, Q, heads * 32), k / v (batch, K, heads * 32),
  * bias (heads, Q, K) -> out (batch, Q, heads * 32); logits q . k / sqrt(32) + bias.  The self-attention that closes FAXModule

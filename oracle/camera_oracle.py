@@ -25,7 +25,8 @@ _EXPANSION = {18: 1, 34: 1, 50: 4, 101: 4, 152: 4}
 
 
 def _bn(x, sd, p, eps=1e-5):
-    return F.batch_norm(x, sd[f"{p}.running_mean"], sd[f"{p}.running_var"], sd[f"{p}.weight"], sd[f"{p}.bias"], False, 0.0, eps)
+    tr = CO.BN_TRAINING[0]          # training-mode restatement: batch statistics + running-buffer update (cvt_oracle.batch_statistics)
+    return F.batch_norm(x, sd[f"{p}.running_mean"], sd[f"{p}.running_var"], sd[f"{p}.weight"], sd[f"{p}.bias"], tr, 0.1 if tr else 0.0, eps)
 
 
 def resnet_features(images: Tensor, sd: Dict[str, Tensor], num_layers: int, prefix: str = "encoder") -> List[Tensor]:

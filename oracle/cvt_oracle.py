@@ -36,8 +36,22 @@ def bev_grid(bev_height, bev_width, h_meters, w_meters, offset, n_decoder_blocks
     return g.reshape(3, h, w)
 
 
+# training-mode restatement (tests of the camera branch's backward pass): BatchNorm on batch statistics, running buffers of the
+# state dict updated in place with nn.BatchNorm2d's default momentum 0.1 - switched on by the tests through batch_statistics()
+BN_TRAINING = [False]
+
+
+class batch_statistics:
+    def __enter__(self):
+        BN_TRAINING[0] = True
+
+    def __exit__(self, *a):
+        BN_TRAINING[0] = False
+
+
 def _bn_relu_conv(x, sd, p):
-    y = F.batch_norm(x, sd[f"{p}.0.running_mean"], sd[f"{p}.0.running_var"], sd[f"{p}.0.weight"], sd[f"{p}.0.bias"], False, 0.0, 1e-5)
+    y = F.batch_norm(x, sd[f"{p}.0.running_mean"], sd[f"{p}.0.running_var"], sd[f"{p}.0.weight"], sd[f"{p}.0.bias"],
+                     BN_TRAINING[0], 0.1 if BN_TRAINING[0] else 0.0, 1e-5)
     return F.conv2d(F.relu(y), sd[f"{p}.2.weight"])
 
 
@@ -78,7 +92,7 @@ def cross_view_attention(x, grid, feature, I_inv, E_inv, sd: Dict[str, Tensor], 
     """CrossViewAttention.forward (cvt_modules.py:216-280).  x (b, dim, H, W); grid (3, H, W) = BEVEmbedding.grid;
     feature (b, n, feat_dim, h, w); I_inv (b, n, 3, 3); E_inv (b, n, 4, 4)."""
     b, n, feat_dim, h, w = feature.shape
-    pixel = generate_grid(h, w)[None]
+    pixel = generate_grid(h, w)[None].to(x.dtype)
     pixel[:, :, 0] *= cfg["image_width"]
     pixel[:, :, 1] *= cfg["image_height"]
     c = E_inv[..., -1:]
@@ -92,7 +106,7 @@ def cross_view_attention(x, grid, feature, I_inv, E_inv, sd: Dict[str, Tensor], 
     d_embed = F.conv2d(d_flat, sd["img_embed.weight"])
     img_embed = d_embed - c_embed
     img_embed = img_embed / (img_embed.norm(dim=1, keepdim=True) + 1e-7)
-    world = grid[:2]
+    world = grid[:2].to(x.dtype)
     w_embed = F.conv2d(world[None], sd["bev_embed.weight"], sd["bev_embed.bias"])
     bev_embed = w_embed - c_embed
     bev_embed = bev_embed / (bev_embed.norm(dim=1, keepdim=True) + 1e-7)

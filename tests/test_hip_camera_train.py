@@ -1,0 +1,171 @@
+"""GPU tests of the camera branch's TRAINING path (hm-vit_amd/camera_train.py; VERDICT r2 missing #1): ResNet trunk, cross-view
+lift (joint-softmax cross attention with its HIP backward) and up-sampling decoder under ``train()`` against the CPU
+restatement of the same modules (oracle/camera_oracle.py, BatchNorm switched to batch statistics) differentiated by
+torch.autograd in FLOAT64: outputs, every parameter gradient, the input gradient where there is one, and the running statistics."""
+import pytest
+import torch
+
+from conftest import rel_max_err
+from oracle import camera_oracle as CAM
+from oracle import cvt_oracle as CO
+
+pytestmark = pytest.mark.gpu
+
+
+def _f64(sd):
+    return {k: (v.double().clone() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+
+
+def _leaf(sd):
+    return {k: (v.requires_grad_(True) if (v.is_floating_point() and "running_" not in k) else v) for k, v in sd.items()}
+
+
+def _compare_grads(named_params, ref_sd, prefix_map=lambda k: k, tol=2e-3, report=None):
+    gmax = max(float(v.grad.abs().max()) for v in ref_sd.values() if getattr(v, "grad", None) is not None)
+    worst = {}
+    for name, p in named_params:
+        ref = ref_sd[prefix_map(name)]
+        if getattr(ref, "grad", None) is None:
+            continue
+        assert p.grad is not None, name
+        scale = max(float(ref.grad.abs().max()), 1e-4 * gmax)
+        worst[name] = float((p.grad.cpu().double() - ref.grad).abs().max()) / scale
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+    print(f"\n{report or 'gradients'}: {len(worst)} parameter tensors, worst", [(k, f"{v:.1e}") for k, v in top])
+    bad = {k: v for k, v in worst.items() if not v < tol}
+    assert not bad, bad
+    return worst
+
+
+def test_cross_attention_backward_kernel():
+    """hmvit_cross_attention_train / _backward against torch autograd (float64) of softmax over all cameras' keys."""
+    from hmvit_amd.camera_train import CrossAttnFn
+    g = torch.Generator().manual_seed(3)
+    b, n, Q, K, heads, d = 2, 3, 80, 100, 4, 32          # Q, K not multiples of 64: ragged tiles
+    q = torch.randn(b, n, Q, heads * d, generator=g)
+    k = torch.randn(b, n, K, heads * d, generator=g)
+    v = torch.randn(b, n * K, heads * d, generator=g)
+    go = torch.randn(b, Q, heads * d, generator=g)
+    qr, kr, vr = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    qh = qr.reshape(b, n, Q, heads, d).permute(0, 3, 1, 2, 4)
+    kh = kr.reshape(b, n, K, heads, d).permute(0, 3, 1, 2, 4)
+    vh = vr.reshape(b, n * K, heads, d).permute(0, 2, 1, 3)
+    dot = d ** -0.5 * torch.einsum("bmnqd,bmnkd->bmnqk", qh, kh).permute(0, 1, 3, 2, 4).reshape(b, heads, Q, n * K)
+    ref = torch.einsum("bmqk,bmkd->bmqd", dot.softmax(-1), vh).permute(0, 2, 1, 3).reshape(b, Q, heads * d)
+    (ref * go.double()).sum().backward()
+    qc, kc, vc = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    out = CrossAttnFn.apply(qc, kc, vc, heads, d)
+    (out * go.cuda()).sum().backward()
+    assert rel_max_err(out.detach().cpu(), ref.detach()) < 1e-5
+    for name, a, r in (("dq", qc, qr), ("dk", kc, kr), ("dv", vc, vr)):
+        assert rel_max_err(a.grad.cpu(), r.grad) < 1e-5, name
+
+
+def test_cvt_camera_encoder_training_matches_float64_autograd():
+    """The whole camera branch in training mode (ResNet-18 trunk on 64 x 64 images, two cross-view levels with two Bottlenecks
+    each, decoder with two x2 up-samplings): output, parameter gradients and BatchNorm running statistics against the oracle
+    restatement with batch-statistics BatchNorm under float64 autograd."""
+    from hmvit_amd.camera import CvtCameraEncoder
+    ccfg = CAM.make_config(image=64, num_layers=18)
+    ccfg["cvm"]["bev_embedding"].update(bev_height=32, bev_width=32)
+    csd = CAM.random_state_dict(ccfg, seed=21)
+    net = CvtCameraEncoder(ccfg, precision="f32")
+    missing, unexpected = net.load_state_dict(csd, strict=False)
+    assert not unexpected and all("num_batches_tracked" in k for k in missing)
+    net = net.cuda().train()
+    batch = CAM.synthetic_batch(2, ccfg, seed=22)
+    ref_sd = _leaf(_f64(csd))
+    with CO.batch_statistics():
+        ref = CAM.camera_encoder({k: v.double() for k, v in batch.items()}, ref_sd, ccfg)
+    go = torch.randn(ref.shape, generator=torch.Generator().manual_seed(23))
+    (ref * go.double()).sum().backward()
+
+    out = net({k: v.cuda() for k, v in batch.items()})
+    assert out.shape == ref.shape and out.requires_grad
+    assert rel_max_err(out.detach().cpu(), ref.detach()) < 1e-4
+    (out * go.cuda()).sum().backward()
+    # Gradients against float64 autograd.  The branch has 30 ReLUs behind BatchNorms on batch statistics of 8 images; a
+    # pre-activation within round-off of zero flips its mask between any two arithmetic orders, and one flip moves the gradients
+    # of everything in front of it by up to a per cent (the fp32 run of the oracle itself sits 1e-3 ... 2e-3 from float64 on some
+    # trunk tensors, with other flips than the HIP path's; a flip in ResNet layer 3 shows in every tensor of the stem and of
+    # layers 1-2, i.e. in almost half of all tensors; one in the decoder shows everywhere).  So the bound is statistical: all
+    # gradients taken together (relative L2 over their concatenation) to 5e-3, the median tensor to 2e-3, none beyond 5e-2 - and
+    # the single layers are held to tight bounds, where no mask can flip, in test_camera_training_layers_match_float64 below.
+    err, num, den = {}, 0.0, 0.0
+    nmax = max(float(v.grad.norm()) for v in ref_sd.values() if getattr(v, "grad", None) is not None)
+    for name, p in net.named_parameters():
+        r = ref_sd[name]
+        if getattr(r, "grad", None) is None:
+            continue
+        assert p.grad is not None, name
+        d = (p.grad.cpu().double() - r.grad).norm()
+        num, den = num + float(d) ** 2, den + float(r.grad.norm()) ** 2
+        # (a convolution bias in front of a batch-statistics BatchNorm has gradient zero in exact arithmetic: absolute floor)
+        err[name] = float(d / r.grad.norm().clamp_min(1e-6 * nmax))
+    vals = sorted(err.values())
+    top = sorted(err.items(), key=lambda kv: -kv[1])[:5]
+    total = (num / den) ** 0.5
+    print(f"\ncamera branch: {len(err)} parameter gradients vs float64 autograd: all together {total:.1e}; per tensor 40th percentile "
+          f"{vals[int(0.4 * len(vals))]:.1e}, median {vals[len(vals) // 2]:.1e}, worst", [(k, f"{v:.1e}") for k, v in top])
+    assert len(err) > 150
+    assert total < 5e-3 and vals[len(vals) // 2] < 2e-3 and vals[-1] < 5e-2, (total, top)
+    # running statistics moved exactly as nn.BatchNorm2d moves them
+    for name, buf in net.named_buffers():
+        if "running_" in name:
+            assert rel_max_err(buf.cpu(), ref_sd[name]) < 1e-4, name
+    # and eval() afterwards serves the folded inference kernels again
+    net.eval()
+    with torch.no_grad():
+        y = net({k: v.cuda() for k, v in batch.items()})
+    assert y.shape == ref.shape and not y.requires_grad
+
+
+def test_camera_training_layers_match_float64():
+    """The building blocks of hm-vit_amd/camera_train.py one by one, where no ReLU mask can flip: Linear (ragged K / N), LayerNorm,
+    GELU, strided 3 x 3 convolution, strided 1 x 1 convolution and BatchNorm without ReLU - outputs and all gradients against
+    torch in float64."""
+    import torch.nn.functional as F
+    from hmvit_amd import camera_train as CT
+    from hmvit_amd import tail_train as TT
+    g = torch.Generator().manual_seed(7)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+
+    def check(name, outs, refs, tol=2e-5):
+        for i, (a, r) in enumerate(zip(outs, refs)):
+            assert rel_max_err(a.detach().cpu() if a.is_cuda else a, r.detach()) < tol, (name, i)
+
+    # Linear: K = 147 (the unfolded 7 x 7 stem), N = 64, with bias
+    x, w, b, gy = rnd(300, 147), rnd(64, 147) * 0.1, rnd(64), rnd(300, 64)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    (F.linear(xr, wr, br) * gy.double()).sum().backward()
+    xc, wc, bc = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    y = CT.LinearFn.apply(xc, wc, bc)
+    (y * gy.cuda()).sum().backward()
+    check("linear", [y, xc.grad, wc.grad, bc.grad], [F.linear(xr, wr, br), xr.grad, wr.grad, br.grad])
+    # LayerNorm(128) and GELU
+    x, w, b, gy = rnd(200, 128) * 2 + 0.5, 1 + 0.1 * rnd(128), 0.1 * rnd(128), rnd(200, 128)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    (F.gelu(F.layer_norm(xr, (128,), wr, br, 1e-5)) * gy.double()).sum().backward()
+    xc, wc, bc = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    y = CT.GeluFn.apply(CT.LayerNormFn.apply(xc, wc, bc, 1e-5))
+    (y * gy.cuda()).sum().backward()
+    check("ln+gelu", [y, xc.grad, wc.grad, bc.grad], [F.gelu(F.layer_norm(xr, (128,), wr, br, 1e-5)), xr.grad, wr.grad, br.grad])
+    # 3 x 3 / stride 2 convolution -> BatchNorm (batch statistics, no ReLU) -> strided 1 x 1 convolution, NHWC on the HIP side
+    conv = torch.nn.Conv2d(32, 64, 3, 2, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(64)
+    ds = torch.nn.Conv2d(64, 32, 1, 2, bias=False)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.1 * rnd(64)); bn.bias.copy_(0.1 * rnd(64))
+    import copy
+    conv_r, bn_r, ds_r = (copy.deepcopy(m).double().train() for m in (conv, bn, ds))
+    x, gy = rnd(2, 32, 12, 10), rnd(2, 32, 3, 3)
+    xr = x.double().requires_grad_(True)
+    ref = ds_r(bn_r(conv_r(xr)))
+    (ref * gy.double()).sum().backward()
+    conv, bn, ds = conv.cuda().train(), bn.cuda().train(), ds.cuda().train()
+    xc = x.cuda().permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    y = CT.conv1x1(TT.bn_relu_module(CT.conv3x3(xc, conv), bn, relu=False), ds, 2)
+    (y * gy.cuda().permute(0, 2, 3, 1)).sum().backward()
+    check("conv-bn-conv", [y.permute(0, 3, 1, 2), xc.grad.permute(0, 3, 1, 2), conv.weight.grad, bn.weight.grad, bn.bias.grad, ds.weight.grad],
+          [ref, xr.grad, conv_r.weight.grad, bn_r.weight.grad, bn_r.bias.grad, ds_r.weight.grad], tol=5e-5)
+    assert rel_max_err(bn.running_var.cpu(), bn_r.running_var) < 1e-5 and rel_max_err(bn.running_mean.cpu(), bn_r.running_mean) < 1e-5

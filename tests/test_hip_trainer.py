@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 class _Args:
     grid, agents, small, precision, seed, frames, train_lidar_backbone = [128, 96], 3, True, "f32", 0, 4, False
-    val_frames, camera_ratio, ego_mode, camera_image = 0, 0.0, "mixed", 64
+    val_frames, camera_ratio, ego_mode, camera_image, train_camera_backbone = 0, 0.0, "mixed", 64, False
 
 
 def test_train_loop_learns_saves_and_resumes(tmp_path):
@@ -293,3 +293,29 @@ def test_mixed_camera_lidar_five_agent_train_loop_with_validation():
     # frozen encoders did not move
     assert all(moved(k) == 0 for k in before if k.startswith(("lidar_encoder.", "camera_encoder.")) and "num_batches" not in k)
     assert not model.training                  # validate() ran last: the model is left in eval mode, as in the reference loop
+
+
+def test_mixed_batch_trains_the_camera_encoder_too():
+    """train_camera.py without --fix_camera_backbone on a mixed batch: the CVT camera encoder (ResNet trunk, cross-view lift,
+    decoder) is on the tape next to the fusion and the tail; one epoch moves parameters of every part of it and its BatchNorm
+    running statistics, and the loss stays finite."""
+    import hmvit_amd  # noqa: F401
+    from hmvit_amd import trainer as T
+
+    class A(_Args):
+        agents, frames, val_frames, camera_ratio, seed, train_camera_backbone = 3, 3, 1, 0.6, 1, True
+    hypes = T.default_hypes(epoches=1)
+    cfg, model, pre, post, ds, val = T.build(A)
+    assert any(0 in ds.roll_modes(i) for i in range(len(ds)))
+    model = model.cuda()
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    res = T.train(model, ds, pre, hypes, val_dataset=val)
+    assert all(l == l for l in res["epoch_loss"] + res["val_loss"])
+    after = model.state_dict()
+    moved = lambda k: float((after[k].float() - before[k].float()).abs().max())
+    for k in ("camera_encoder.encoder.encoder.conv1.weight", "camera_encoder.encoder.encoder.layer2.0.conv1.weight",
+              "camera_encoder.encoder.encoder.layer4.1.bn2.weight", "camera_encoder.cvm.cross_views.0.cross_attend.to_q.1.weight",
+              "camera_encoder.cvm.cross_views.1.img_embed.weight", "camera_encoder.cvm.bev_embedding.learned_features",
+              "camera_encoder.cvm.layers.0.0.conv2.weight", "camera_encoder.decoder.decoder.0.weight",
+              "camera_encoder.encoder.encoder.bn1.running_mean", "fusion_net.hetero_fusion_block.window_attention.q_linears.0.weight"):
+        assert moved(k) > 0, k
