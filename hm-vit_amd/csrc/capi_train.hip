@@ -31,6 +31,7 @@ struct StageInfo {
 
 struct TrainPlan {
     int B, L, C, H, W, P, mlp, heads, n_slots, max_cav, E_max, n_stages;
+    int only_stage;      // -1: the whole HeteroFusion; 0 / 1: one stage of the block on its own (HmvitFusionTrainDesc::only_stage)
     size_t A;            // floats of one (n_slots, P, C) activation
     size_t stage_floats; // floats saved per stage
     // offsets (floats) inside one stage's record
@@ -44,10 +45,12 @@ int make_train_plan(const HmvitFusionTrainDesc* t, TrainPlan& pl) {
     HMVIT_TRY(check_desc(d));
     HMVIT_CHECK_ARG(d->precision == HMVIT_PREC_F32, "training runs in the exact-f32 mode (precision=%d)", d->precision);
     HMVIT_CHECK_ARG(!d->parallel, "training: architect_mode 'parallel' is not built (the shipped yaml is sequential)");
-    HMVIT_CHECK_ARG(d->apply_head == 1, "training: only HeteroFusion (apply_head = 1) is built");
+    pl.only_stage = t->only_stage >= 1 && t->only_stage <= 2 ? t->only_stage - 1 : -1;
+    HMVIT_CHECK_ARG(t->only_stage >= 0 && t->only_stage <= 2, "only_stage=%d (0 = whole fusion, 1 = window stage, 2 = grid stage)", t->only_stage);
+    HMVIT_CHECK_ARG(d->apply_head == (pl.only_stage < 0 ? 1 : 0), "training: HeteroFusion (apply_head = 1), or one stage of the block (apply_head = 0)");
     HMVIT_CHECK_ARG(t->drop_p >= 0.f && t->drop_p < 1.f, "drop_p=%f out of [0, 1)", t->drop_p);
     pl.B = d->B; pl.L = d->L; pl.C = d->C; pl.H = d->H; pl.W = d->W; pl.P = d->H * d->W; pl.mlp = d->mlp_dim;
-    pl.heads = d->heads; pl.n_slots = d->B * d->L; pl.n_stages = 2 * d->num_iters;
+    pl.heads = d->heads; pl.n_slots = d->B * d->L; pl.n_stages = pl.only_stage < 0 ? 2 * d->num_iters : 1;
     HMVIT_CHECK_ARG(pl.n_slots <= kMaxSlots, "B*L=%d exceeds %d agent slots per call", pl.n_slots, kMaxSlots);
     pl.max_cav = 0;
     for (int b = 0; b < d->B; ++b) pl.max_cav = d->record_len[b] > pl.max_cav ? d->record_len[b] : pl.max_cav;
@@ -74,7 +77,7 @@ int make_train_plan(const HmvitFusionTrainDesc* t, TrainPlan& pl) {
 
 StageInfo stage_info(const HmvitFusionDesc* d, const TrainPlan& pl, int st) {
     StageInfo si;
-    si.last = st == pl.n_stages - 1;
+    si.last = pl.only_stage < 0 && st == pl.n_stages - 1;      // only HeteroFusion's last stage is pruned to ego 0
     si.n_ego = si.last ? 1 : pl.max_cav;
     si.E = 0;
     for (int t = 0; t < HMVIT_NUM_TYPES; ++t) { si.e_of_type[t] = -1; si.e_type[t] = 0; }
@@ -200,7 +203,7 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
         set_error("workspace too small: %zu < %zu bytes", d->workspace_bytes, scratch);
         return HMVIT_ENOMEM;
     }
-    HMVIT_CHECK_ARG(d->head_w1 && d->head_b1 && d->head_w2 && d->head_b2, "mlp_head weights are null");
+    HMVIT_CHECK_ARG(pl.only_stage >= 0 || (d->head_w1 && d->head_b1 && d->head_w2 && d->head_b2), "mlp_head weights are null");
     const int B = d->B, L = d->L, C = d->C, P = pl.P, mlp = pl.mlp;
     const size_t me = (size_t)P * C;
     float* S = reinterpret_cast<float*>(t->saved);
@@ -211,7 +214,7 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
     HMVIT_TRY(launch_pair_affines(d->pairwise_t, ainv, pl.n_slots * L, d->H, d->W, d->discrete_ratio, d->downsample_rate, st));
 
     for (int sidx = 0; sidx < pl.n_stages; ++sidx) {
-        const int s = sidx & 1;
+        const int s = pl.only_stage < 0 ? (sidx & 1) : pl.only_stage;
         const HmvitStageWeights& wt = d->stage[s];
         const StageInfo si = stage_info(d, pl, sidx);
         float* R = S + (size_t)sidx * pl.stage_floats;
@@ -298,6 +301,15 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
                 HMVIT_TRY(launch_add_drop(x1 + slot * me, tmp + slot * me, x_out + slot * me, me, di, st));
             }
         }
+    }
+    if (pl.only_stage >= 0) {
+        // one stage of the block on its own (the parallel block's branches, hetero_fusion.py:459-470): every agent's map goes
+        // back as (B, L, C, H, W); padded slots, which no later step reads, are zero
+        float* xf = S + pl.o_xfin;
+        HMVIT_CHECK_HIP(hipMemsetAsync(d->out, 0, pl.A * 4, st));
+        for (int b = 0; b < B; ++b)
+            HMVIT_TRY(launch_transpose(xf + (size_t)b * L * me, d->out + (size_t)b * L * me, pl.max_cav, P, C, st));
+        return HMVIT_OK;
     }
     // mlp_head on the ego map (no norm, no residual, dropout 0; bevformer_point_pillar_hetero.py:37,47-48)
     {
@@ -386,7 +398,7 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
     make_bwd_plan(pl, bp);
     HMVIT_CHECK_ARG(d_out && d_x && grads && workspace && t->saved, "backward: null pointer");
     HMVIT_CHECK_ARG(t->bias_frag_neg[0] && t->bias_frag_neg[1], "backward: bias_frag_neg is null");
-    HMVIT_CHECK_ARG(d_head_w1 && d_head_b1 && d_head_w2 && d_head_b2, "backward: mlp_head gradient buffers are null");
+    HMVIT_CHECK_ARG(pl.only_stage >= 0 || (d_head_w1 && d_head_b1 && d_head_w2 && d_head_b2), "backward: mlp_head gradient buffers are null");
     if (workspace_bytes < bp.total * 4) {
         set_error("backward workspace too small: %zu < %zu bytes", workspace_bytes, bp.total * 4);
         return HMVIT_ENOMEM;
@@ -410,12 +422,18 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
         HMVIT_TRY(launch_transpose(reinterpret_cast<const float*>(wt.w_1), base + bp.wt_1, T, mlp, C, st));   // (mlp, C) -> (C, mlp)
         HMVIT_TRY(launch_transpose(reinterpret_cast<const float*>(wt.w_2), base + bp.wt_2, T, C, mlp, st));   // (C, mlp) -> (mlp, C)
     }
-    HMVIT_TRY(launch_transpose(reinterpret_cast<const float*>(d->head_w1), WT + bp.wt_h1, T, C, C, st));
-    HMVIT_TRY(launch_transpose(reinterpret_cast<const float*>(d->head_w2), WT + bp.wt_h2, T, C, C, st));
+    if (pl.only_stage < 0) {
+        HMVIT_TRY(launch_transpose(reinterpret_cast<const float*>(d->head_w1), WT + bp.wt_h1, T, C, C, st));
+        HMVIT_TRY(launch_transpose(reinterpret_cast<const float*>(d->head_w2), WT + bp.wt_h2, T, C, C, st));
+    }
 
     // ---- mlp_head ----
     HMVIT_CHECK_HIP(hipMemsetAsync(G, 0, pl.A * 4, st));
-    {
+    if (pl.only_stage >= 0) {
+        // single stage: d_out is (B, L, C, H, W), the gradient of every agent's map
+        for (int b = 0; b < B; ++b)
+            HMVIT_TRY(launch_transpose(d_out + (size_t)b * L * me, G + (size_t)b * L * me, pl.max_cav, C, P, st));
+    } else {
         float* dy = T1;                 // (B, P, C)
         float* dh = T2;
         const float* xf = S + pl.o_xfin;
@@ -443,7 +461,7 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
     }
 
     for (int sidx = pl.n_stages - 1; sidx >= 0; --sidx) {
-        const int s = sidx & 1;
+        const int s = pl.only_stage < 0 ? (sidx & 1) : pl.only_stage;
         const HmvitStageWeights& wt = d->stage[s];
         const HmvitStageGrads& gr = grads[s];
         const StageInfo si = stage_info(d, pl, sidx);

@@ -64,7 +64,7 @@ def folded_for_training(module, block_types=None, head_types=None) -> List[torch
     return out, neg
 
 
-def _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, out, saved, workspace):
+def _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, out, saved, workspace, only_stage=0):
     blk = module._block_cfg
     B, L, C, H, W = x.shape
     t = _lib.FusionTrainDesc()
@@ -72,7 +72,8 @@ def _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, 
     d.B, d.L, d.C, d.H, d.W = B, L, C, H, W
     d.heads, d.dim_head = C // blk["dim_head"], blk["dim_head"]
     d.window, d.mlp_dim, d.num_iters = blk["window_size"], blk["mlp_dim"], module.num_iters
-    d.precision, d.apply_head, d.skip_masked = _lib.PREC_F32, 1, 1
+    d.precision, d.apply_head, d.skip_masked = _lib.PREC_F32, (1 if only_stage == 0 else 0), 1
+    t.only_stage = only_stage
     d.self_identity = 1            # checked by fusion_forward_with_grad: pairwise_t_matrix[b, i, i] = I
     d.discrete_ratio, d.downsample_rate = float(module.discrete_ratio), float(module.downsample_rate)
     keep = (_lib.i32_array(mode_h), _lib.i32_array(rl_h), _lib.i32_array(mask_h))
@@ -95,35 +96,39 @@ def _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, 
 
 
 class FusionTrainFunction(torch.autograd.Function):
-    """y = HeteroFusion(x) with gradients for x and for the folded weights.  Inputs after ``ctx_args`` are tensors only."""
+    """y = HeteroFusion(x) with gradients for x and for the folded weights.  Inputs after ``ctx_args`` are tensors only.
+    ``host`` = (mode, record_len, mask) host lists, optionally followed by ``only_stage`` (1 = the window stage, 2 = the grid stage of
+    the block on its own: y is (B, L, C, H, W), every agent an ego, no mlp_head - the branches of the parallel block)."""
 
     @staticmethod
     def forward(ctx, module, host, drop_p, seed, x, pw, neg0, neg1, *folded):
+        only_stage = host[3] if len(host) > 3 else 0
+        host = host[:3]
         mode_h, rl_h, mask_h = host
         x = x.detach().to(torch.float32).contiguous()
         pw = pw.detach().to(device=x.device, dtype=torch.float32).contiguous()
         folded = [f.detach().contiguous() for f in folded]
         neg = [neg0.detach().contiguous(), neg1.detach().contiguous()]
         B, L, C, H, W = x.shape
-        out = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)
-        probe, keep0 = _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, out, None, None)
+        out = torch.empty((B, C, H, W) if only_stage == 0 else (B, L, C, H, W), device=x.device, dtype=torch.float32)
+        probe, keep0 = _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, out, None, None, only_stage)
         need = _lib.lib.hmvit_fusion_train_saved_bytes(ctypes.byref(probe))
         if need == 0:
             _lib.check(-22, "hmvit_fusion_train_saved_bytes")
         saved = torch.empty(need, dtype=torch.uint8, device=x.device)
         blk = module._block_cfg
         scratch = torch.empty(4 * B * L * H * W * max(C, blk["mlp_dim"]), dtype=torch.uint8, device=x.device)
-        t, keep = _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, out, saved, scratch)
+        t, keep = _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, out, saved, scratch, only_stage)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib.hmvit_fusion_train_forward(ctypes.byref(t), ctypes.c_void_p(stream)), "hmvit_fusion_train_forward")
-        ctx.launch = (module, host, drop_p, seed, x, pw, neg, folded, saved)
+        ctx.launch = (module, host + (only_stage,), drop_p, seed, x, pw, neg, folded, saved)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         module, host, drop_p, seed, x, pw, neg, folded, saved = ctx.launch
-        mode_h, rl_h, mask_h = host
+        mode_h, rl_h, mask_h, only_stage = host
         d_out = d_out.detach().to(torch.float32).contiguous()
         # The backward kernels form their products on split-f16 operands (x = hi + lo, two f16 halves): gradients of a real loss
         # reach this point at 1e-4 ... 1e-7 (focal loss normalised by the positives), where the lo half falls under f16's
@@ -134,7 +139,7 @@ class FusionTrainFunction(torch.autograd.Function):
         k = k.clamp(-100.0, 100.0)
         d_out = d_out * torch.exp2(k)
         unscale = torch.exp2(-k)
-        t, keep = _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, None, saved, None)
+        t, keep = _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, None, saved, None, only_stage)
         need = _lib.lib.hmvit_fusion_backward_workspace_bytes(ctypes.byref(t))
         if need == 0:
             _lib.check(-22, "hmvit_fusion_backward_workspace_bytes")
@@ -167,8 +172,6 @@ def fusion_forward_with_grad(module, x, pairwise_t_matrix, mode, record_len, mas
         raise ValueError(f"{module._block_cfg['architect_mode']} not implemented")        # hetero_fusion.py:472
     if x.dim() != 5:
         raise ValueError("x must be (B, L, C, H, W)")
-    if module._block_cfg["architect_mode"] != "sequential":
-        raise NotImplementedError("training is built for architect_mode 'sequential' (the shipped yaml)")
     B, L = x.shape[:2]
     pw = pairwise_t_matrix.to(device=x.device, dtype=torch.float32)
     if tuple(pw.shape) != (B, L, L, 4, 4):
@@ -185,9 +188,45 @@ def fusion_forward_with_grad(module, x, pairwise_t_matrix, mode, record_len, mas
     folded, neg = folded_for_training(module, block_types={int(v) for v in mode_h},
                                       head_types={int(mode_h[b * L]) for b in range(B)})
     drop_p = float(module._block_cfg["drop_out"]) if module.training else 0.0
-    seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if drop_p > 0 else 0
+    new_seed = lambda: int(torch.randint(0, 2 ** 62, (1,)).item()) if drop_p > 0 else 0
+    if module._block_cfg["architect_mode"] == "parallel":
+        return _parallel_forward_with_grad(module, x, pw, (mode_h, rl_h, mask_h), folded, neg, drop_p, new_seed)
+    seed = new_seed()
     module.last_dropout = (drop_p, seed)
     return FusionTrainFunction.apply(module, (mode_h, rl_h, mask_h), drop_p, seed, x, pw, neg[0], neg[1], *folded)
+
+
+def _parallel_forward_with_grad(module, x, pw, host, folded, neg, drop_p, new_seed):
+    """architect_mode 'parallel' on the tape (hetero_fusion.py:459-470, bevformer_point_pillar_hetero.py:39-49): per iteration the
+    window and the grid stage both start from the block input - each ONE call of the training kernels in their single-stage form
+    (HmvitFusionTrainDesc::only_stage) - and are merged by SplitAttn (fusion_modules/split_attn.py:32-67): global average pool,
+    two small Linears around a LayerNorm + ReLU, a two-way softmax per channel, a weighted sum (Linears / LayerNorm on libhmvit
+    through camera_train's Functions, the rest elementwise torch); then mlp_head (typed Linear - GELU - Linear) on the ego row."""
+    from .camera_train import GeluFn, LayerNormFn, LinearFn
+    mode_h = host[0]
+    B, L, C, H, W = x.shape
+    sa = module.hetero_fusion_block.split_attn
+    seeds = []
+    cur = x.to(torch.float32)
+    for _ in range(module.num_iters):
+        branches = []
+        for which in (1, 2):
+            seed = new_seed()
+            seeds.append(seed)
+            branches.append(FusionTrainFunction.apply(module, host + (which,), drop_p, seed, cur, pw, neg[0], neg[1], *folded))
+        a, b = branches
+        gap = (a + b).mean((3, 4)).reshape(B * L, C)
+        g = torch.relu(LayerNormFn.apply(LinearFn.apply(gap, sa.fc1.weight, None), sa.bn1.weight, sa.bn1.bias, sa.bn1.eps))
+        w = torch.softmax(LinearFn.apply(g, sa.fc2.weight, None).reshape(B, L, 2, C), dim=2)
+        cur = a * w[:, :, 0, :, None, None] + b * w[:, :, 1, :, None, None]
+    module.last_dropout = (drop_p, seeds)
+    outs = []
+    for bi in range(B):
+        net = module.mlp_head.net[int(mode_h[bi * L])]
+        tok = cur[bi, 0].reshape(C, H * W).t()
+        y = LinearFn.apply(GeluFn.apply(LinearFn.apply(tok, net[0].weight, net[0].bias)), net[3].weight, net[3].bias)
+        outs.append(y.t().reshape(C, H, W))
+    return torch.stack(outs)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -253,6 +253,11 @@ typedef struct HmvitFusionTrainDesc {
     size_t saved_bytes;              /* >= hmvit_fusion_train_saved_bytes                                                  */
     const void* bias_frag_neg[2];    /* per stage, device (heads, NB, 64, 4) f32: bias_frag of the table with negated
                                         offsets (table flipped along its first axis); read by the backward pass only       */
+    int32_t only_stage;              /* 0: HeteroFusion (fwd.apply_head = 1).  1 / 2: ONE stage of the block on its own - the window
+                                        (local) or the grid (global) stage - with fwd.apply_head = 0: out and d_out are
+                                        (B, L, C, H, W), every agent runs as an ego, no mlp_head (its gradient pointers may be
+                                        NULL).  The branches of architect_mode 'parallel' (hetero_fusion.py:459-470) train
+                                        through this form; their SplitAttn merge is host-side autograd (hm-vit_amd/train.py)  */
 } HmvitFusionTrainDesc;
 
 size_t hmvit_fusion_train_saved_bytes(const HmvitFusionTrainDesc* desc);
