@@ -35,7 +35,8 @@ struct TrainPlan {
     size_t A;            // floats of one (n_slots, P, C) activation
     size_t stage_floats; // floats saved per stage
     // offsets (floats) inside one stage's record
-    size_t o_x, o_xn, o_q, o_kv, o_o, o_lse, o_x1, o_xn2, o_pre, o_h;
+    // (round 3: the normalised rows and the FFN activations are no longer kept - the backward recomputes them from x / x' / pre)
+    size_t o_x, o_q, o_kv, o_o, o_lse, o_x1, o_pre;
     // offsets (floats) of the tail of the saved area
     size_t o_xfin, o_hpre, o_hh, o_ainv, total_floats;
 };
@@ -62,9 +63,9 @@ int make_train_plan(const HmvitFusionTrainDesc* t, TrainPlan& pl) {
     pl.A = tok * pl.C;
     size_t off = 0;
     auto carve = [&](size_t n) { size_t o = off; off = (off + n + 63) / 64 * 64; return o; };
-    pl.o_x = carve(pl.A); pl.o_xn = carve(pl.A); pl.o_q = carve(pl.A);
+    pl.o_x = carve(pl.A); pl.o_q = carve(pl.A);
     pl.o_kv = carve(tok * pl.E_max * 2 * pl.C); pl.o_o = carve(pl.A); pl.o_lse = carve(tok * pl.heads);
-    pl.o_x1 = carve(pl.A); pl.o_xn2 = carve(pl.A); pl.o_pre = carve(tok * pl.mlp); pl.o_h = carve(tok * pl.mlp);
+    pl.o_x1 = carve(pl.A); pl.o_pre = carve(tok * pl.mlp);
     pl.stage_floats = off;
     off = pl.stage_floats * pl.n_stages;
     pl.o_xfin = carve(pl.A);
@@ -156,9 +157,10 @@ void fill_attn(const HmvitFusionDesc* d, const TrainPlan& pl, const StageInfo& s
 
 // LayerNorm of slots [0, n) of every sample (contiguous per sample)
 int ln_slots(const float* x, float* y, const float* g, const float* be, const HmvitFusionDesc* d, const TrainPlan& pl, int n,
-             hipStream_t st) {
+             hipStream_t st, int only_b = -1) {
     const size_t me = (size_t)pl.P * pl.C;
     for (int b = 0; b < d->B; ++b) {
+        if (only_b >= 0 && b != only_b) continue;
         AgentTypes ty;
         memset(&ty, 0, sizeof(ty));
         for (int i = 0; i < n; ++i) ty.t[i] = (int8_t)d->mode[b * d->L + i];
@@ -220,8 +222,10 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
         float* R = S + (size_t)sidx * pl.stage_floats;
         float* x_in = R + pl.o_x;
         float* x_out = (sidx + 1 < pl.n_stages) ? S + (size_t)(sidx + 1) * pl.stage_floats + pl.o_x : S + pl.o_xfin;
-        float *xn = R + pl.o_xn, *q = R + pl.o_q, *kv = R + pl.o_kv, *o = R + pl.o_o, *lse = R + pl.o_lse, *x1 = R + pl.o_x1,
-              *xn2 = R + pl.o_xn2, *pre = R + pl.o_pre, *h = R + pl.o_h;
+        float *q = R + pl.o_q, *kv = R + pl.o_kv, *o = R + pl.o_o, *lse = R + pl.o_lse, *x1 = R + pl.o_x1, *pre = R + pl.o_pre;
+        // transient rows live in the one scratch buffer, each dead before the next is written (stream order): LN(x), the
+        // out-projection, LN(x'), the FFN activations
+        float *xn = tmp, *xn2 = tmp, *h = tmp;
         const int n_ego = si.n_ego;
 
         HMVIT_TRY(ln_slots(x_in, xn, wt.ln_gamma, wt.ln_beta, d, pl, pl.max_cav, st));
@@ -272,8 +276,8 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
                 HMVIT_TRY(launch_add_drop(x_in + off, tmp + off, x1 + off, me, di, st));
             }
         }
-        HMVIT_TRY(ln_slots(x1, xn2, wt.ffn_ln_gamma, wt.ffn_ln_beta, d, pl, n_ego, st));
         for (int b = 0; b < B; ++b) {
+            HMVIT_TRY(ln_slots(x1, xn2, wt.ffn_ln_gamma, wt.ffn_ln_beta, d, pl, n_ego, st, b));
             Jobs j1(st);
             for (int i = 0; i < n_ego; ++i) {
                 const int slot = b * L + i, ty = d->mode[slot];
@@ -291,14 +295,14 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
             for (int i = 0; i < n_ego; ++i) {
                 const int slot = b * L + i, ty = d->mode[slot];
                 HMVIT_TRY(j2.add(h + (size_t)slot * P * mlp, reinterpret_cast<const float*>(wt.w_2) + (size_t)ty * C * mlp, wt.b_2 + ty * C,
-                                 nullptr, tmp + slot * me, P, C, mlp));
+                                 nullptr, x_out + slot * me, P, C, mlp));
             }
             HMVIT_TRY(j2.flush());
             for (int i = 0; i < n_ego; ++i) {
                 const int slot = b * L + i;
                 DropCfg di = drop_cfg(t, sidx, 2);
                 di.seed += 0x51ED270B1ull * (unsigned long long)(slot + 1);
-                HMVIT_TRY(launch_add_drop(x1 + slot * me, tmp + slot * me, x_out + slot * me, me, di, st));
+                HMVIT_TRY(launch_add_drop(x1 + slot * me, x_out + slot * me, x_out + slot * me, me, di, st));   // in place
             }
         }
     }
@@ -349,7 +353,7 @@ static void make_bwd_plan(const TrainPlan& pl, BwdPlan& bp) {
     const size_t big = pl.A > tok * pl.mlp ? pl.A : tok * pl.mlp;
     size_t off = 0;
     auto carve = [&](size_t n) { size_t o = off; off = (off + n + 63) / 64 * 64; return o; };
-    bp.o_G = carve(pl.A); bp.o_T1 = carve(big); bp.o_T2 = carve(big); bp.o_T3 = carve(pl.A); bp.o_T4 = carve(pl.A);
+    bp.o_G = carve(pl.A); bp.o_T1 = carve(big); bp.o_T2 = carve(big); bp.o_T3 = carve(big); bp.o_T4 = carve(pl.A);
     bp.o_dkg = carve((size_t)pl.B * pl.max_cav * pl.max_cav * 2 * pl.P * pl.C);
     bp.o_dkv = carve(tok * pl.E_max * 2 * pl.C);
     const size_t T = HMVIT_NUM_TYPES, C = pl.C, mlp = pl.mlp;
@@ -466,8 +470,10 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
         const HmvitStageGrads& gr = grads[s];
         const StageInfo si = stage_info(d, pl, sidx);
         const float* R = S + (size_t)sidx * pl.stage_floats;
-        const float *x_in = R + pl.o_x, *xn = R + pl.o_xn, *q = R + pl.o_q, *kv = R + pl.o_kv, *o = R + pl.o_o, *lse = R + pl.o_lse,
-                    *x1 = R + pl.o_x1, *xn2 = R + pl.o_xn2, *pre = R + pl.o_pre, *h = R + pl.o_h;
+        const float *x_in = R + pl.o_x, *q = R + pl.o_q, *kv = R + pl.o_kv, *o = R + pl.o_o, *lse = R + pl.o_lse,
+                    *x1 = R + pl.o_x1, *pre = R + pl.o_pre;
+        // recomputed into T3 where a weight gradient needs them (T3 is otherwise dO, which does not exist yet / any more)
+        float *xn = T3, *xn2 = T3, *h = T3;
         const float* wts = WT + (size_t)s * bp.wt_stage;
         const int n_ego = si.n_ego;
 
@@ -478,6 +484,9 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
                 DropCfg di = drop_cfg(t, sidx, 2);
                 di.seed += 0x51ED270B1ull * (unsigned long long)(slot + 1);
                 HMVIT_TRY(launch_add_drop(nullptr, G + slot * me, T1 + slot * me, me, di, st));            // df
+                DropCfg dh = drop_cfg(t, sidx, 1);
+                dh.seed += 0x51ED270B1ull * (unsigned long long)(slot + 1);
+                HMVIT_TRY(launch_gelu_drop(pre + (size_t)slot * P * mlp, h + (size_t)slot * P * mlp, (size_t)P * mlp, dh, st));
             }
             Jobs j1(st);
             TnJobs tn(st);
@@ -495,6 +504,7 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
                 float* dpre = T2 + (size_t)slot * P * mlp;
                 HMVIT_TRY(launch_gelu_bwd(pre + (size_t)slot * P * mlp, dpre, dpre, (size_t)P * mlp, di, st));
             }
+            HMVIT_TRY(ln_slots(x1, xn2, wt.ffn_ln_gamma, wt.ffn_ln_beta, d, pl, n_ego, st, b));
             Jobs j2(st);
             for (int i = 0; i < n_ego; ++i) {
                 const int slot = b * L + i, ty = d->mode[slot];
@@ -532,7 +542,7 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
             fill_attn(d, pl, si, s, q, kv, const_cast<float*>(o), const_cast<float*>(lse), ainv, ab.f);
             ab.bias_frag_neg = reinterpret_cast<const float*>(t->bias_frag_neg[s]);
             ab.d_out = T3; ab.dq = T4; ab.dkg = dkg; ab.d_bias_frag = gr.bias_frag;
-            HMVIT_CHECK_HIP(hipMemsetAsync(dkg, 0, (size_t)B * n_ego * pl.max_cav * 2 * me * 4, st));
+            // (k_attention_bwd writes every key row of every (ego, source < max_cav) pair, zeros where nothing is visible)
             DBG_SUM("G", G, pl.A);
             DBG_SUM("dO", T3, pl.A);
             HMVIT_TRY(launch_attention_bwd(ab, st));
@@ -573,6 +583,7 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
 
         // dxn (T1) = dq W_q + sum_e (dK'_e W_k,e + dV'_e W_v,e);  weight gradients against xn
         {
+            HMVIT_TRY(ln_slots(x_in, xn, wt.ln_gamma, wt.ln_beta, d, pl, pl.max_cav, st));
             TnJobs tn(st);
             // pass 0: first term of every slot (no accumulate), later passes accumulate through the residual input
             const int n_terms = 1 + 2 * si.E;

@@ -199,14 +199,6 @@ __device__ __forceinline__ void mma_chunk_op(float16v& acc, const half_t* buf, c
     if constexpr (SP) mma_chunk_split<KK, DEPTH>(acc, buf, a.hi, a.lo, lane);
     else mma_chunk<KK, DEPTH>(acc, buf, a.hi, lane);
 }
-// x -> (hi, lo) f16 pair (a macro: vector elements cannot bind to references)
-#define split_h(x, H, L)                     \
-    do {                                     \
-        const float _x = (x);                \
-        const half_t _h = (half_t)_x;        \
-        (H) = _h;                            \
-        (L) = (half_t)(_x - (float)_h);      \
-    } while (0)
 
 __device__ __forceinline__ float pair_sum(float v) { return xor32_sum(v); }
 

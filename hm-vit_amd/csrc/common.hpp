@@ -16,6 +16,14 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+// x -> (hi, lo) f16 pair (a macro: vector elements cannot bind to references)
+#define split_h(x, H, L)                     \
+    do {                                     \
+        const float _x = (x);                \
+        const half_t _h = (half_t)_x;        \
+        (H) = _h;                            \
+        (L) = (half_t)(_x - (float)_h);      \
+    } while (0)
 
 // Tuning / ablation switches read from the environment exist only in probe builds (`make PROBE=1` -> -DHMVIT_PROBE, used by
 // tools/probe and tests/tools): the shipped library never calls getenv and never takes a pointer out of the environment.

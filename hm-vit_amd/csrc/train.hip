@@ -609,13 +609,17 @@ template <int WIN, int HG>
 __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
     const AttnParams& p = bp.f;
     constexpr int N = WIN * WIN, NQT = N / 16, SPC = 64 / N, NB = (WIN == 8) ? 7 : 1;
-    constexpr int CH = HG * 32, QS = CH + 2, KS = CH + 2;
+    constexpr int CH = HG * 32, QS = CH + 8, KS = CH + 8;             // halves per LDS row (16-byte aligned, conflict-free b128 reads)
     constexpr int THREADS = HG * 128;
     constexpr int TPK = CH / 8, KPP = THREADS / TPK;
-    __shared__ __attribute__((aligned(16))) float Qs[N * QS];
-    __shared__ __attribute__((aligned(16))) float dOs[N * QS];
-    __shared__ __attribute__((aligned(16))) float Ks[64 * KS];
-    __shared__ __attribute__((aligned(16))) float Vs[64 * KS];
+    // every tile is kept as (hi, lo) f16 halves, split ONCE by the thread that stages it (round 3; the f32 tiles of round 2 were
+    // re-split by every wave for every key tile: the kernel was bound by those conversions, not by its matrix products).  Operands
+    // along the channels are 16-byte row reads; operands along the rows (the 16 x 16 x 16 products over keys / queries) come out
+    // of the same row-major tiles through ds_read_b64_tr_b16.
+    __shared__ __attribute__((aligned(16))) half_t Qh[N * QS], Ql[N * QS], dOh[N * QS], dOl[N * QS];
+    __shared__ __attribute__((aligned(16))) half_t KVs[4 * 64 * KS];
+    half_t *Kh = KVs, *Kl = KVs + 64 * KS, *Vh = KVs + 2 * 64 * KS, *Vl = KVs + 3 * 64 * KS;
+    static_assert(sizeof(KVs) >= (size_t)HG * NQT * 2 * 64 * 16, "the dQ exchange at the end reuses the key / value tiles");
     __shared__ float maskadd[64];
     __shared__ float Dl[N][HG], Lse[N][HG];
 
@@ -643,11 +647,16 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
             int row, col;
             token_pixel(p.partition, WIN, X, Y, wx, wy, n, row, col);
             const size_t o = (size_t)(row * W + col) * C + ch0 + cl;
+            half8 qh_, ql_, dh_, dl_;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                Qs[n * QS + cl + e] = qplane[o + e] + bq[cl + e];
-                dOs[n * QS + cl + e] = doplane[o + e];
+                split_h(qplane[o + e] + bq[cl + e], qh_[e], ql_[e]);
+                split_h(doplane[o + e], dh_[e], dl_[e]);
             }
+            *reinterpret_cast<half8*>(Qh + n * QS + cl) = qh_;
+            *reinterpret_cast<half8*>(Ql + n * QS + cl) = ql_;
+            *reinterpret_cast<half8*>(dOh + n * QS + cl) = dh_;
+            *reinterpret_cast<half8*>(dOl + n * QS + cl) = dl_;
         }
         for (int i = tid; i < N * HG; i += THREADS) {
             const int n = i / HG, hh = i - n * HG;
@@ -658,7 +667,8 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
 #pragma unroll 8
             for (int e = 0; e < 32; ++e) d = fmaf(doplane[o + e], oplane[o + e], d);
             Dl[n][hh] = d;
-            Lse[n][hh] = p.lse[((size_t)(b * L + ego) * P + row * W + col) * heads + hg * HG + hh];
+            // kept times log2(e): the probabilities are rebuilt with v_exp_f32 (a base-2 exponential)
+            Lse[n][hh] = p.lse[((size_t)(b * L + ego) * P + row * W + col) * heads + hg * HG + hh] * 1.4426950408889634f;
         }
     }
     // (the bias fragments themselves are re-read from global per tile pair: 14 fragment registers sets spilled the kernel)
@@ -726,11 +736,16 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
                             }
                     }
                 }
+                half8 kh_, kl_, vh_, vl_;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    Ks[kk * KS + cl + e] = kvv[0][e];
-                    Vs[kk * KS + cl + e] = kvv[1][e];
+                    split_h(kvv[0][e], kh_[e], kl_[e]);
+                    split_h(kvv[1][e], vh_[e], vl_[e]);
                 }
+                *reinterpret_cast<half8*>(Kh + kk * KS + cl) = kh_;
+                *reinterpret_cast<half8*>(Kl + kk * KS + cl) = kl_;
+                *reinterpret_cast<half8*>(Vh + kk * KS + cl) = vh_;
+                *reinterpret_cast<half8*>(Vl + kk * KS + cl) = vl_;
                 if (cl == 0) maskadd[kk] = visible ? 0.f : -INFINITY;
                 any_visible |= visible ? 1 : 0;
             }
@@ -738,40 +753,37 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
         any_visible = __syncthreads_or(any_visible);
 
         if (any_visible) {
-            auto split8 = [](const float* src, half8& h, half8& l) {        // 8 consecutive f32 of an LDS row -> hi / lo halves
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float x = src[e];
-                    h[e] = (half_t)x;
-                    l[e] = (half_t)(x - (float)h[e]);
-                }
-            };
             auto split4 = [](float a, float b, float c, float d, half4& h, half4& l) {
                 const float v[4] = {a, b, c, d};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    h[e] = (half_t)v[e];
-                    l[e] = (half_t)(v[e] - (float)h[e]);
-                }
+                for (int e = 0; e < 4; ++e) split_h(v[e], h[e], l[e]);
             };
+            // rows row0 .. row0 + 3, column col0 + lq of a row-major f16 tile as one operand of v_mfma_f32_16x16x16_f16
+            // (ds_read_b64_tr_b16: lane l of a 16-lane group points at row row0 + (l >> 2), columns col0 + 4 (l & 3) .. + 3 and
+            // receives column l of the 4 x 16 block; tests/test_hip_ops.py::test_tr16_lane_mapping)
+            auto col4 = [&](const half_t* tile, int stride, int row0, int col0) {
+                const half_t* a = tile + (row0 + (lq >> 2)) * stride + col0 + 4 * (lq & 3);
+                const fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(a));
+                return half4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            };
+            constexpr float LOG2E = 1.4426950408889634f;
             // (the key tile index stays a compile-time constant: it selects the bias fragment)
             auto key_tile = [&](auto kt_c) {
                 constexpr int kt = decltype(kt_c)::value;
-                // operands of key tile kt: rows (kt*16 + lq) x k (4 ks + g), and the "row 4g + r, column lq" form of K
+                // operands of key tile kt: rows (kt*16 + lq) x channels 8 g .. 8 g + 7, and the "row 4g + r, column lq" form of K.
                 // The four products over the 32 channels of a head (S^T, dP^T, S, dP) run on split-f16 operands (three
                 // v_mfma_f32_16x16x32_f16 instead of eight v_mfma_f32_16x16x4_f32: lane (l, g) supplies channels 8 g .. 8 g + 7 of
                 // row l, the accumulator layout is the same), and so do the products over the 16 keys / queries of a tile (v_mfma_f32_16x16x16_f16).
-                half8 kh, kl, vh, vl;
-                float kfd[4][2];
-                split8(Ks + (kt * 16 + lq) * KS + hoff + 8 * g, kh, kl);
-                split8(Vs + (kt * 16 + lq) * KS + hoff + 8 * g, vh, vl);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) kfd[r][dt] = Ks[(kt * 16 + 4 * g + r) * KS + hoff + dt * 16 + lq];
+                const half8 kh = *reinterpret_cast<const half8*>(Kh + (kt * 16 + lq) * KS + hoff + 8 * g);
+                const half8 kl = *reinterpret_cast<const half8*>(Kl + (kt * 16 + lq) * KS + hoff + 8 * g);
+                const half8 vh = *reinterpret_cast<const half8*>(Vh + (kt * 16 + lq) * KS + hoff + 8 * g);
+                const half8 vl = *reinterpret_cast<const half8*>(Vl + (kt * 16 + lq) * KS + hoff + 8 * g);
                 half4 kdh[2], kdl[2];
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) split4(kfd[0][dt], kfd[1][dt], kfd[2][dt], kfd[3][dt], kdh[dt], kdl[dt]);
+                for (int dt = 0; dt < 2; ++dt) {
+                    kdh[dt] = col4(Kh, KS, kt * 16 + 4 * g, hoff + dt * 16);
+                    kdl[dt] = col4(Kl, KS, kt * 16 + 4 * g, hoff + dt * 16);
+                }
                 const float4v maddT = *reinterpret_cast<const float4v*>(maskadd + kt * 16 + 4 * g);
                 const float maddN = maskadd[kt * 16 + lq];
                 float4v dk_acc[2], dv_acc[2];
@@ -780,17 +792,10 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
 
 #pragma unroll
                 for (int qt = 0; qt < NQT; ++qt) {
-                    float qfd[4][2], dofd[4][2];
-                    half8 qh, ql, doh, dol;
-                    split8(Qs + (qt * 16 + lq) * QS + hoff + 8 * g, qh, ql);
-                    split8(dOs + (qt * 16 + lq) * QS + hoff + 8 * g, doh, dol);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) {
-                            qfd[r][dt] = Qs[(qt * 16 + 4 * g + r) * QS + hoff + dt * 16 + lq];
-                            dofd[r][dt] = dOs[(qt * 16 + 4 * g + r) * QS + hoff + dt * 16 + lq];
-                        }
+                    const half8 qh = *reinterpret_cast<const half8*>(Qh + (qt * 16 + lq) * QS + hoff + 8 * g);
+                    const half8 ql = *reinterpret_cast<const half8*>(Ql + (qt * 16 + lq) * QS + hoff + 8 * g);
+                    const half8 doh = *reinterpret_cast<const half8*>(dOh + (qt * 16 + lq) * QS + hoff + 8 * g);
+                    const half8 dol = *reinterpret_cast<const half8*>(dOl + (qt * 16 + lq) * QS + hoff + 8 * g);
                     const int bvT = (WIN == 8) ? (qt - kt + 3) : 0, bvN = (WIN == 8) ? (kt - qt + 3) : 0;
                     // ---- T orientation: rows = keys 4g + r, column = query lq ----
                     float4v sT = *reinterpret_cast<const float4v*>(biasT_g + bvT * 256), dpT = (float4v)(0.f);
@@ -803,7 +808,8 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
                     const float lseT = Lse[qt * 16 + lq][wave], dT = Dl[qt * 16 + lq][wave];
                     float4v dsT;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dsT[r] = expf(sT[r] + maddT[r] - lseT) * (dpT[r] - dT);
+                    for (int r = 0; r < 4; ++r)
+                        dsT[r] = __builtin_amdgcn_exp2f(fmaf(sT[r], LOG2E, maddT[r] - lseT)) * (dpT[r] - dT);
                     dbias[(WIN == 8) ? bvT - (kt < 2 ? 2 : 0) : 0] += dsT;
                     {   // dQ^T += K^T dS^T over this tile's 16 keys: the lane's four values ARE the operand of v_mfma_f32_16x16x16_f16
                         half4 dsh, dsl;
@@ -826,7 +832,7 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
                     float4v pN, dsN;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        pN[r] = expf(sN[r] + maddN - Lse[qt * 16 + 4 * g + r][wave]);
+                        pN[r] = __builtin_amdgcn_exp2f(fmaf(sN[r], LOG2E, maddN - Lse[qt * 16 + 4 * g + r][wave]));
                         dsN[r] = pN[r] * (dpN[r] - Dl[qt * 16 + 4 * g + r][wave]);
                     }
                     {   // dV += P^T dO, dK += dS^T Q over this tile's 16 queries
@@ -835,9 +841,8 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
                         split4(dsN[0], dsN[1], dsN[2], dsN[3], sh, sl);
 #pragma unroll
                         for (int dt = 0; dt < 2; ++dt) {
-                            half4 oh, ol, qh4, ql4;
-                            split4(dofd[0][dt], dofd[1][dt], dofd[2][dt], dofd[3][dt], oh, ol);
-                            split4(qfd[0][dt], qfd[1][dt], qfd[2][dt], qfd[3][dt], qh4, ql4);
+                            const half4 oh = col4(dOh, QS, qt * 16 + 4 * g, hoff + dt * 16), ol = col4(dOl, QS, qt * 16 + 4 * g, hoff + dt * 16);
+                            const half4 qh4 = col4(Qh, QS, qt * 16 + 4 * g, hoff + dt * 16), ql4 = col4(Ql, QS, qt * 16 + 4 * g, hoff + dt * 16);
                             dv_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(pl, oh, dv_acc[dt], 0, 0, 0);
                             dv_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(ph, ol, dv_acc[dt], 0, 0, 0);
                             dv_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(ph, oh, dv_acc[dt], 0, 0, 0);
@@ -872,13 +877,34 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
                 key_tile(std::integral_constant<int, 2>{});
                 key_tile(std::integral_constant<int, 3>{});
             }
+        } else {
+            // a chunk without a visible key: its gathered-key gradients are zero.  Written here so that the caller does not have
+            // to clear the whole (ego, source) gradient buffer first (7 GB per stage at cfg2)
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kk = (2 * khalf + kt2) * 16 + 4 * g + r;
+                    const int src = chunk * SPC + kk / N, n = kk % N;
+                    if (src < p.n_src) {
+                        int row, col;
+                        token_pixel(p.partition, WIN, X, Y, wx, wy, n, row, col);
+                        float* dst = bp.dkg + (((size_t)(b * p.n_ego + ego) * p.n_src + src) * 2) * P * C +
+                                     (size_t)(row * W + col) * C + head * 32 + lq;
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) {
+                            dst[dt * 16] = 0.f;
+                            dst[(size_t)P * C + dt * 16] = 0.f;
+                        }
+                    }
+                }
         }
         __syncthreads();
     }
 
     // the two key halves of a head meet: the second wave's partial dQ through LDS (the K tile is free after the last barrier)
     {
-        float4v* xch = reinterpret_cast<float4v*>(Ks);            // [head][qt][dt][lane]
+        float4v* xch = reinterpret_cast<float4v*>(KVs);           // [head][qt][dt][lane]
         if (khalf == 1) {
 #pragma unroll
             for (int qt = 0; qt < NQT; ++qt)
