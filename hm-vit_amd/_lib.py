@@ -91,6 +91,7 @@ _SIGNATURES = {
                               [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]),
     "hmvit_dropout_mask": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_float, C.c_void_p]),
     "hmvit_gemm_tn": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
+    "hmvit_linear16": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 2 + [C.c_void_p] * 2),
     "hmvit_bn_train_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "hmvit_bn_train_stats_centered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "hmvit_bn_train_apply": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),

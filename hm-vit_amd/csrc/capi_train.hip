@@ -39,6 +39,48 @@ struct TrainPlan {
     size_t o_x, o_q, o_kv, o_o, o_lse, o_x1, o_pre;
     // offsets (floats) of the tail of the saved area
     size_t o_xfin, o_hpre, o_hh, o_ainv, total_floats;
+    // x16 images of the forward's weight matrices (k_linear16; C = mlp = 256 only): same layout as the backward's transposed
+    // weights (WeightLayout), one float of storage per (hi, lo) pair; o_winv: one inverse scale per matrix
+    size_t o_img, o_winv;
+    bool lin16;
+};
+
+// (C, C) blocks of one set of weights: per stage q (T), kv (T, T, 2), o (T), w_1 (T), w_2 (T); then the head's two (T each)
+struct WeightLayout {
+    size_t q, kv, o, w1, w2, stage, h1, h2, total;
+};
+static WeightLayout weight_layout(int C, int mlp) {
+    const size_t T = HMVIT_NUM_TYPES;
+    WeightLayout wl;
+    size_t w = 0;
+    wl.q = w; w += T * C * C;
+    wl.kv = w; w += T * T * 2 * C * C;
+    wl.o = w; w += T * C * C;
+    wl.w1 = w; w += T * C * mlp;
+    wl.w2 = w; w += T * mlp * C;
+    wl.stage = w;
+    wl.h1 = 2 * w; wl.h2 = 2 * w + T * C * C;
+    wl.total = 2 * w + 2 * T * C * C;
+    return wl;
+}
+
+// which image goes with a weight pointer: the image areas mirror the weight arrays element for element
+struct ImgRegistry {
+    struct Entry { const float* w; size_t n_floats; const half_t* img; const float* inv; };
+    Entry e[16];
+    int n = 0;
+    void add(const float* w, size_t n_mat, const float* img_as_float, const float* inv) {
+        if (w && n < 16) e[n++] = Entry{w, n_mat * 65536, reinterpret_cast<const half_t*>(img_as_float), inv};
+    }
+    bool find(const float* w, const half_t*& img, const float*& inv) const {
+        for (int i = 0; i < n; ++i)
+            if (w >= e[i].w && w < e[i].w + e[i].n_floats && (size_t)(w - e[i].w) % 65536 == 0) {
+                img = e[i].img + 2 * (size_t)(w - e[i].w);
+                inv = e[i].inv + (size_t)(w - e[i].w) / 65536;
+                return true;
+            }
+        return false;
+    }
 };
 
 int make_train_plan(const HmvitFusionTrainDesc* t, TrainPlan& pl) {
@@ -72,6 +114,10 @@ int make_train_plan(const HmvitFusionTrainDesc* t, TrainPlan& pl) {
     pl.o_hpre = carve((size_t)pl.B * pl.P * pl.C);
     pl.o_hh = carve((size_t)pl.B * pl.P * pl.C);
     pl.o_ainv = carve((size_t)pl.n_slots * pl.L * 8);
+    pl.lin16 = pl.C == 256 && pl.mlp == 256;
+    const WeightLayout wl = weight_layout(pl.C, pl.mlp);
+    pl.o_img = carve(pl.lin16 ? wl.total : 0);
+    pl.o_winv = carve(pl.lin16 ? wl.total / 65536 : 0);
     pl.total_floats = off;
     return HMVIT_OK;
 }
@@ -92,10 +138,17 @@ StageInfo stage_info(const HmvitFusionDesc* d, const TrainPlan& pl, int st) {
 
 struct Jobs {
     GemmJobs jobs;
+    LinJobs lin;                 // jobs whose weight has an x16 image (ImgRegistry): k_linear16
+    const ImgRegistry* reg;
     bool a_f32, gelu, out_f32;
     hipStream_t st;
-    Jobs(hipStream_t s) : a_f32(false), gelu(false), out_f32(true), st(s) { jobs.n = 0; }
+    Jobs(hipStream_t s, const ImgRegistry* r = nullptr) : reg(r), a_f32(false), gelu(false), out_f32(true), st(s) { jobs.n = 0; lin.n = 0; }
     int flush() {
+        if (lin.n) {
+            const int rc = launch_linear16(lin, st);
+            lin.n = 0;
+            if (rc != HMVIT_OK) return rc;
+        }
         if (jobs.n == 0) return HMVIT_OK;
         // f32 operands and results; the products run as split f16 pairs (gemm.hip k_gemm_split: fp32-class accuracy, ~3x the
         // rate of the exact-f32 MFMA), -DHMVIT_TRAIN_EXACT_F32 restores the exact-f32 kernel
@@ -109,6 +162,27 @@ struct Jobs {
     }
     // y (M, N) = a (M, K) w^T (+ bias) (+ residual)
     int add(const float* a, const float* w, const float* bias, const float* residual, float* y, int M, int N, int K) {
+#ifndef HMVIT_TRAIN_EXACT_F32
+        const half_t* img;
+        const float* inv;
+        if (reg && N == 256 && K == 256 && reg->find(w, img, inv)) {
+            // products of the same rows (Q / K' / V' of a slot) share one pass over them
+            if (lin.n > 0 && !residual) {
+                LinJob& q = lin.j[lin.n - 1];
+                if (q.a == a && q.M == M && !q.residual && q.n_mat < kMaxLinMats) {
+                    q.wimg[q.n_mat] = img; q.w_inv[q.n_mat] = inv; q.bias[q.n_mat] = bias; q.y[q.n_mat] = y;
+                    ++q.n_mat;
+                    return HMVIT_OK;
+                }
+            }
+            if (lin.n == kMaxLinJobs) HMVIT_TRY(flush());
+            LinJob& q = lin.j[lin.n++];
+            memset(&q, 0, sizeof(q));
+            q.a = a; q.wimg[0] = img; q.w_inv[0] = inv; q.bias[0] = bias; q.y[0] = y; q.residual = residual;
+            q.M = M; q.n_mat = 1; q.ldy = N;
+            return HMVIT_OK;
+        }
+#endif
         GemmJob j;
         j.a = a; j.w = w; j.bias = bias; j.residual = residual; j.y = y;
         j.M = M; j.N = N; j.K = K; j.n_per_plane = N; j.plane_stride = 0;
@@ -215,6 +289,37 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
     HMVIT_TRY(launch_transpose(d->x, S + pl.o_x, pl.n_slots, C, P, st));
     HMVIT_TRY(launch_pair_affines(d->pairwise_t, ainv, pl.n_slots * L, d->H, d->W, d->discrete_ratio, d->downsample_rate, st));
 
+    // x16 images of this step's weights (they change every step): k_linear16 serves every Linear of the forward
+    ImgRegistry reg;
+    const ImgRegistry* regp = nullptr;
+    if (pl.lin16) {
+        const WeightLayout wl = weight_layout(C, mlp);
+        const int T = HMVIT_NUM_TYPES;
+        float* IMG = S + pl.o_img;
+        float* INV = S + pl.o_winv;
+        auto images = [&](const void* w, size_t off, int n_mat) -> int {
+            if (!w) return HMVIT_OK;
+            const float* wf = reinterpret_cast<const float*>(w);
+            reg.add(wf, n_mat, IMG + off, INV + off / 65536);
+            return launch_weight_images16(wf, reinterpret_cast<half_t*>(IMG + off), INV + off / 65536, n_mat, st);
+        };
+        for (int s = 0; s < 2; ++s) {
+            if (pl.only_stage >= 0 && s != pl.only_stage) continue;
+            const HmvitStageWeights& wt = d->stage[s];
+            const size_t base = (size_t)s * wl.stage;
+            HMVIT_TRY(images(wt.w_q, base + wl.q, T));
+            HMVIT_TRY(images(wt.w_kv, base + wl.kv, T * T * 2));
+            HMVIT_TRY(images(wt.w_o, base + wl.o, T));
+            HMVIT_TRY(images(wt.w_1, base + wl.w1, T));
+            HMVIT_TRY(images(wt.w_2, base + wl.w2, T));
+        }
+        if (pl.only_stage < 0) {
+            HMVIT_TRY(images(d->head_w1, wl.h1, T));
+            HMVIT_TRY(images(d->head_w2, wl.h2, T));
+        }
+        regp = &reg;
+    }
+
     for (int sidx = 0; sidx < pl.n_stages; ++sidx) {
         const int s = pl.only_stage < 0 ? (sidx & 1) : pl.only_stage;
         const HmvitStageWeights& wt = d->stage[s];
@@ -230,7 +335,7 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
 
         HMVIT_TRY(ln_slots(x_in, xn, wt.ln_gamma, wt.ln_beta, d, pl, pl.max_cav, st));
         {
-            Jobs jb(st);
+            Jobs jb(st, regp);
             for (int b = 0; b < B; ++b)
                 for (int l = 0; l < pl.max_cav; ++l) {
                     const int slot = b * L + l, ty = d->mode[slot];
@@ -260,7 +365,7 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
         }
         // x' = x + Dropout(a_linears(O)) on the ego slots
         for (int b = 0; b < B; ++b) {
-            Jobs jb(st);
+            Jobs jb(st, regp);
             for (int i = 0; i < n_ego; ++i) {
                 const int slot = b * L + i, ty = d->mode[slot];
                 HMVIT_TRY(jb.add(o + slot * me, reinterpret_cast<const float*>(wt.w_o) + (size_t)ty * C * C, wt.b_o + ty * C, nullptr,
@@ -278,7 +383,7 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
         }
         for (int b = 0; b < B; ++b) {
             HMVIT_TRY(ln_slots(x1, xn2, wt.ffn_ln_gamma, wt.ffn_ln_beta, d, pl, n_ego, st, b));
-            Jobs j1(st);
+            Jobs j1(st, regp);
             for (int i = 0; i < n_ego; ++i) {
                 const int slot = b * L + i, ty = d->mode[slot];
                 HMVIT_TRY(j1.add(xn2 + slot * me, reinterpret_cast<const float*>(wt.w_1) + (size_t)ty * mlp * C, wt.b_1 + ty * mlp, nullptr,
@@ -291,7 +396,7 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
                 di.seed += 0x51ED270B1ull * (unsigned long long)(slot + 1);
                 HMVIT_TRY(launch_gelu_drop(pre + (size_t)slot * P * mlp, h + (size_t)slot * P * mlp, (size_t)P * mlp, di, st));
             }
-            Jobs j2(st);
+            Jobs j2(st, regp);
             for (int i = 0; i < n_ego; ++i) {
                 const int slot = b * L + i, ty = d->mode[slot];
                 HMVIT_TRY(j2.add(h + (size_t)slot * P * mlp, reinterpret_cast<const float*>(wt.w_2) + (size_t)ty * C * mlp, wt.b_2 + ty * C,
@@ -320,7 +425,7 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
         float* xf = S + pl.o_xfin;
         float* hpre = S + pl.o_hpre;
         float* hh = S + pl.o_hh;
-        Jobs j1(st);
+        Jobs j1(st, regp);
         for (int b = 0; b < B; ++b) {
             const int slot = b * L, ty = d->mode[slot];
             HMVIT_TRY(j1.add(xf + slot * me, reinterpret_cast<const float*>(d->head_w1) + (size_t)ty * C * C, d->head_b1 + ty * C, nullptr,
@@ -329,7 +434,7 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
         HMVIT_TRY(j1.flush());
         DropCfg none = {0ull, 0u, 0.f};
         HMVIT_TRY(launch_gelu_drop(hpre, hh, (size_t)B * me, none, st));
-        Jobs j2(st);
+        Jobs j2(st, regp);
         for (int b = 0; b < B; ++b) {
             const int ty = d->mode[b * L];
             HMVIT_TRY(j2.add(hh + (size_t)b * me, reinterpret_cast<const float*>(d->head_w2) + (size_t)ty * C * C, d->head_b2 + ty * C, nullptr,
@@ -343,7 +448,7 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
 
 // ---- backward workspace layout (floats) ----
 struct BwdPlan {
-    size_t o_G, o_T1, o_T2, o_T3, o_T4, o_dkg, o_dkv, o_wt, total;
+    size_t o_G, o_T1, o_T2, o_T3, o_T4, o_dkg, o_dkv, o_wt, o_img, o_winv, total;
     // transposed weights inside o_wt, per stage s: q (T,C,C), kv (T,T,2,C,C), o (T,C,C), w1t (T,C,mlp), w2t (T,mlp,C); head: w1t, w2t
     size_t wt_stage, wt_q, wt_kv, wt_o, wt_1, wt_2, wt_h1, wt_h2;
 };
@@ -366,6 +471,9 @@ static void make_bwd_plan(const TrainPlan& pl, BwdPlan& bp) {
     bp.wt_stage = w;
     bp.wt_h1 = 2 * w; bp.wt_h2 = 2 * w + T * C * C;
     bp.o_wt = carve(2 * w + 2 * T * C * C);
+    // x16 images of the transposed weights (k_linear16), one float of storage per (hi, lo) pair, + one inverse scale per matrix
+    bp.o_img = carve(pl.lin16 ? 2 * w + 2 * T * C * C : 0);
+    bp.o_winv = carve(pl.lin16 ? (2 * w + 2 * T * C * C) / 65536 : 0);
     bp.total = off;
 }
 
@@ -430,6 +538,15 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
         HMVIT_TRY(launch_transpose(reinterpret_cast<const float*>(d->head_w1), WT + bp.wt_h1, T, C, C, st));
         HMVIT_TRY(launch_transpose(reinterpret_cast<const float*>(d->head_w2), WT + bp.wt_h2, T, C, C, st));
     }
+    ImgRegistry reg;
+    const ImgRegistry* regp = nullptr;
+    if (pl.lin16) {
+        // every block of WT is a (256, 256) matrix: one launch images them all (the head's blocks only when they were written)
+        const int n_mat = (int)((pl.only_stage < 0 ? bp.wt_h1 + 2 * (size_t)T * C * C : 2 * bp.wt_stage) / 65536);
+        HMVIT_TRY(launch_weight_images16(WT, reinterpret_cast<half_t*>(Wk + bp.o_img), Wk + bp.o_winv, n_mat, st));
+        reg.add(WT, n_mat, Wk + bp.o_img, Wk + bp.o_winv);
+        regp = &reg;
+    }
 
     // ---- mlp_head ----
     HMVIT_CHECK_HIP(hipMemsetAsync(G, 0, pl.A * 4, st));
@@ -444,7 +561,7 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
         const float* hpre = S + pl.o_hpre;
         const float* hh = S + pl.o_hh;
         HMVIT_TRY(launch_transpose(d_out, dy, B, C, P, st));
-        Jobs j1(st);
+        Jobs j1(st, regp);
         TnJobs tn(st);
         for (int b = 0; b < B; ++b) {
             const int ty = d->mode[b * L];
@@ -454,7 +571,7 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
         HMVIT_TRY(j1.flush());
         HMVIT_TRY(tn.flush());
         HMVIT_TRY(launch_gelu_bwd(hpre, dh, dh, (size_t)B * me, none, st));
-        Jobs j2(st);
+        Jobs j2(st, regp);
         for (int b = 0; b < B; ++b) {
             const int slot = b * L, ty = d->mode[slot];
             HMVIT_TRY(j2.add(dh + (size_t)b * me, WT + bp.wt_h1 + (size_t)ty * C * C, nullptr, nullptr, G + slot * me, P, C, C));
@@ -488,7 +605,7 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
                 dh.seed += 0x51ED270B1ull * (unsigned long long)(slot + 1);
                 HMVIT_TRY(launch_gelu_drop(pre + (size_t)slot * P * mlp, h + (size_t)slot * P * mlp, (size_t)P * mlp, dh, st));
             }
-            Jobs j1(st);
+            Jobs j1(st, regp);
             TnJobs tn(st);
             for (int i = 0; i < n_ego; ++i) {
                 const int slot = b * L + i, ty = d->mode[slot];
@@ -505,7 +622,7 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
                 HMVIT_TRY(launch_gelu_bwd(pre + (size_t)slot * P * mlp, dpre, dpre, (size_t)P * mlp, di, st));
             }
             HMVIT_TRY(ln_slots(x1, xn2, wt.ffn_ln_gamma, wt.ffn_ln_beta, d, pl, n_ego, st, b));
-            Jobs j2(st);
+            Jobs j2(st, regp);
             for (int i = 0; i < n_ego; ++i) {
                 const int slot = b * L + i, ty = d->mode[slot];
                 HMVIT_TRY(j2.add(T2 + (size_t)slot * P * mlp, wts + bp.wt_1 + (size_t)ty * C * mlp, nullptr, nullptr, T1 + slot * me, P, C, mlp));
@@ -525,7 +642,7 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
                 di.seed += 0x51ED270B1ull * (unsigned long long)(slot + 1);
                 HMVIT_TRY(launch_add_drop(nullptr, G + slot * me, T1 + slot * me, me, di, st));            // da
             }
-            Jobs j1(st);
+            Jobs j1(st, regp);
             TnJobs tn(st);
             for (int i = 0; i < n_ego; ++i) {
                 const int slot = b * L + i, ty = d->mode[slot];
@@ -588,7 +705,7 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
             // pass 0: first term of every slot (no accumulate), later passes accumulate through the residual input
             const int n_terms = 1 + 2 * si.E;
             for (int term = 0; term < n_terms; ++term) {
-                Jobs jb(st);
+                Jobs jb(st, regp);
                 for (int b = 0; b < B; ++b)
                     for (int l = 0; l < pl.max_cav; ++l) {
                         const int slot = b * L + l, ty = d->mode[slot];
@@ -674,6 +791,27 @@ int hmvit_gemm_tn(const float* dy, const float* a, float* dw, float* dbias, int 
     GemmTnJob& j = jobs.j[0];
     j.dy = dy; j.a = a; j.dw = dw; j.dbias = dbias; j.M = M; j.N = N; j.K = K; j.ld_dy = ld_dy; j.ld_a = ld_a;
     return launch_gemm_tn(jobs, reinterpret_cast<hipStream_t>(stream));
+}
+
+int hmvit_linear16(const float* a, const float* w, const float* bias, const float* residual, float* y, int M, int n_mat,
+                   float* image_ws, void* stream) {
+    HMVIT_CHECK_ARG(a && w && y && image_ws && M > 0 && n_mat >= 1 && n_mat <= kMaxLinMats, "linear16: bad argument");
+    HMVIT_CHECK_ARG(!residual || n_mat == 1, "linear16: a residual goes with a single matrix%s", "");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float* inv = image_ws + (size_t)65536 * n_mat;
+    HMVIT_TRY(launch_weight_images16(w, reinterpret_cast<half_t*>(image_ws), inv, n_mat, st));
+    LinJobs jobs;
+    memset(&jobs, 0, sizeof(jobs));
+    jobs.n = 1;
+    LinJob& j = jobs.j[0];
+    j.a = a; j.residual = residual; j.M = M; j.n_mat = n_mat; j.ldy = 256 * n_mat;
+    for (int m = 0; m < n_mat; ++m) {
+        j.wimg[m] = reinterpret_cast<const half_t*>(image_ws) + (size_t)m * 2 * 65536;
+        j.w_inv[m] = inv + m;
+        j.bias[m] = bias ? bias + 256 * m : nullptr;
+        j.y[m] = y + 256 * m;
+    }
+    return launch_linear16(jobs, st);
 }
 
 int hmvit_bn_train_stats(const float* x, float* sums, int M, int C, void* stream) {

@@ -1180,6 +1180,153 @@ __global__ __launch_bounds__(X16_THREADS, 2) void k_ln_qkv16(QkvParams p) {
     if (X16_DEPHASE && !grp_b) wg_barrier();
 }
 
+// ------------------------------------------------------------------------------------------
+// k_linear16: y_m = a W_m^T (+ bias_m) (+ residual), a (M, 256) f32, up to three (256, 256) matrices per job - the skinny GEMMs of
+// the training path (capi_train.hip).  k_ln_qkv16 without the LayerNorm: 128 rows per workgroup, every row read once, all 256
+// n_mat output columns formed from the same operand registers, weight chunks through the three-slot LDS-DMA ring.  The generic tile
+// kernel it replaces (gemm.hip k_gemm_split, 128 x 128 tiles) fetched every row of `a` twice and the weights once per tile: 1.5 GB
+// fetched for 0.7 GB of rows per launch, 0.73 ms where the bytes take 0.3 ms (profiles/r03_train_pmc.txt).
+// Range: the row is scaled per token to [2^13, 2^14) before the hi / lo split (pow2_scale), the image carries the matrix at a
+// power of two (launch_weight_images16): exact, and gradients of any magnitude keep their low halves.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_lin16(float* stg, float* y, int ldy, int c, const float4v (&v)[2], int tk, int g, int lane, int tok_w, int M) {
+    float* d = stg + tk * X16_STG_ROW + 32 * (c & 1) + 4 * g;
+    *reinterpret_cast<float4*>(d) = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
+    *reinterpret_cast<float4*>(d + 16) = make_float4(v[1][0], v[1][1], v[1][2], v[1][3]);
+    if (c & 1) {
+        float* yo = y + (size_t)tok_w * ldy + 64 * (c >> 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int token = 4 * k + (lane >> 4), piece = lane & 15;
+            const float4 q = *reinterpret_cast<const float4*>(stg + token * X16_STG_ROW + piece * 4);
+            if (tok_w + token < M) *reinterpret_cast<float4*>(yo + (size_t)token * ldy + piece * 4) = q;
+        }
+    }
+}
+
+__global__ __launch_bounds__(X16_THREADS, 2) void k_linear16(LinJobs jobs) {
+    constexpr int C = 256, NCH = 8;                 // chunks (32 output rows) per matrix
+    __shared__ __attribute__((aligned(16))) half_t smem[X16_RING * X16_CHUNK + 2 * kMaxLinMats * C + 2 * X16_WAVES * X16_STG_WAVE];
+    float* bs = reinterpret_cast<float*>(smem + X16_RING * X16_CHUNK);
+    const LinJob& J = jobs.j[blockIdx.y];
+    const int M = J.M;
+    if ((int)blockIdx.x * X16_TOKENS >= M) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tk = lane & 15, g = lane >> 4;
+    const int tok_w = blockIdx.x * X16_TOKENS + wave * 16, tok = tok_w + tk;
+    float* stg = reinterpret_cast<float*>(smem + X16_RING * X16_CHUNK + 2 * kMaxLinMats * C) + wave * X16_STG_WAVE;
+    for (int i = threadIdx.x; i < J.n_mat * C; i += X16_THREADS) bs[i] = J.bias[i / C] ? J.bias[i / C][i % C] : 0.f;
+    const int n_chunks = J.n_mat * NCH;
+    auto chunk_ptr = [&](int i) -> const half_t* { return J.wimg[i / NCH] + (size_t)(i % NCH) * X16_CHUNK; };
+    auto slot = [&](int i) -> half_t* { return smem + (i % X16_RING) * X16_CHUNK; };
+    // step protocol and the one-barrier skew of waves 4-7: see tail16_body
+    const bool grp_b = X16_DEPHASE && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >= 4;
+    const bool full_wave = tok_w + 16 <= M;
+    stage_chunk16(chunk_ptr(0), slot(0));
+    stage_chunk16(chunk_ptr(1), slot(1));
+    if (grp_b) stage_chunk16(chunk_ptr(2), slot(2));
+    float4v x[16];
+    const int tok_c = min(tok, M - 1);
+    {
+        const float* xp = J.a + (size_t)tok_c * C + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float4 f = *reinterpret_cast<const float4*>(xp + 16 * t);
+            x[t][0] = f.x; x[t][1] = f.y; x[t][2] = f.z; x[t][3] = f.w;
+        }
+    }
+    dma_wait();
+    __syncthreads();
+    if (grp_b) wg_barrier();
+    half8 ah[8], al[8];
+    const float s_tok = pow2_scale(row_absmax16(x));
+    rows_to_operands16(x, ah, al, s_tok);
+    const float inv_tok = pow2_inv(s_tok);
+    // the residual rows take the registers of `a`, in the accumulator layout (channel 16 t + 4 g + r of the lane's token)
+    if (J.residual) {
+        const float* rp = J.residual + (size_t)tok_c * J.ldy + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float4 f = *reinterpret_cast<const float4*>(rp + 16 * t);
+            x[t][0] = f.x; x[t][1] = f.y; x[t][2] = f.z; x[t][3] = f.w;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) x[t] = (float4v)(0.f);
+    }
+    auto flushes = [](int k) { return k >= 0 && (k & 1) != 0; };
+    for (int mat = 0; mat < J.n_mat; ++mat) {
+        const float cm = inv_tok * J.w_inv[mat][0];
+        const float* bm = bs + mat * C + 4 * g;
+        const bool res = mat == 0;
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) {
+            const int c = mat * NCH + t;
+            auto ring_wait = [&](bool flush_since) {
+                if (c + 2 < n_chunks && full_wave) { if (flush_since) ring_wait_newest8(); else ring_wait_newest4(); }
+                else dma_wait();
+            };
+            float4v acc[2] = {(float4v)(0.f), (float4v)(0.f)};
+            mma_proj16(acc, slot(c), ah, al, lane);
+            if constexpr (X16_DEPHASE) {
+                if (grp_b) ring_wait(flushes(c - 1));
+                wg_barrier();
+            }
+            float4v v[2];
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bm + 32 * t + 16 * T);
+                const float4v r4 = res ? x[2 * t + T] : (float4v)(0.f);
+                v[T][0] = fmaf(acc[T][0], cm, b4.x) + r4[0];
+                v[T][1] = fmaf(acc[T][1], cm, b4.y) + r4[1];
+                v[T][2] = fmaf(acc[T][2], cm, b4.z) + r4[2];
+                v[T][3] = fmaf(acc[T][3], cm, b4.w) + r4[3];
+            }
+            store_lin16(stg, J.y[mat], J.ldy, t, v, tk, g, lane, tok_w, M);
+            const int ahead = c + 2 + (grp_b ? 1 : 0);
+            if (ahead < n_chunks) stage_chunk16(chunk_ptr(ahead), slot(ahead));
+            if (!grp_b) ring_wait(flushes(c));
+            wg_barrier();
+        }
+    }
+    if (X16_DEPHASE && !grp_b) wg_barrier();
+}
+
+// (256, 256) f32 matrices -> x16 split images at a power of two: one workgroup per matrix (absmax, then the fragments;
+// weights.py weight_image16 is the host-side statement of the layout)
+__global__ __launch_bounds__(1024) void k_weight_image16(const float* __restrict__ w, half_t* __restrict__ img, float* __restrict__ w_inv) {
+    constexpr int C = 256;
+    __shared__ float red[16];
+    const float* W = w + (size_t)blockIdx.x * C * C;
+    half_t* I = img + (size_t)blockIdx.x * 2 * C * C;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < C * C / 4; i += 1024) {
+        const float4 f = reinterpret_cast<const float4*>(W)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(f.x), fabsf(f.y))), fmaxf(fabsf(f.z), fabsf(f.w)));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = red[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+    const float sc = pow2_scale(m);
+    if (threadIdx.x == 0) w_inv[blockIdx.x] = pow2_inv(sc);
+    // fragment (T, s): lane (l, g) holds W[16 T + l][32 s + 16 (j >> 2) + 4 g + (j & 3)], hi fragment then lo fragment
+    for (int f = threadIdx.x; f < 16 * 8 * 64; f += 1024) {
+        const int lane = f & 63, s = (f >> 6) & 7, T = f >> 9;
+        const float* row = W + (size_t)(16 * T + (lane & 15)) * C + 32 * s + 4 * (lane >> 4);
+        const float4 f0 = *reinterpret_cast<const float4*>(row), f1 = *reinterpret_cast<const float4*>(row + 16);
+        const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+        half8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split_h(v[j] * sc, h[j], l[j]);
+        half_t* dst = I + ((size_t)(T * 8 + s) * 2) * 512 + lane * 8;
+        *reinterpret_cast<half8*>(dst) = h;
+        *reinterpret_cast<half8*>(dst + 512) = l;
+    }
+}
+
 // TAIL: 0 = stage tail only (x'' stored), 1 = + next stage's LayerNorm / Q / K' / V', 2 = + mlp_head (output (C, P) map).
 // OUTPROJ / LN / RESID as in out_ffn_body; OUT_NCHW (TAIL 0): x'' goes to a (C, P) map (the stand-alone mlp_head launch).
 template <bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW, int TAIL, bool XN, bool A16>
@@ -1613,6 +1760,29 @@ int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, int split
         case 256: return split ? launch_out_ffn_c<256, true>(p, n_jobs, variant, st) : launch_out_ffn_c<256, false>(p, n_jobs, variant, st);
         default: set_error("out_ffn: C=%d unsupported", C); return HMVIT_EINVAL;
     }
+}
+
+int launch_linear16(const LinJobs& jobs, hipStream_t st) {
+    if (jobs.n == 0) return HMVIT_OK;
+    int max_m = 0;
+    for (int i = 0; i < jobs.n; ++i) {
+        const LinJob& j = jobs.j[i];
+        HMVIT_CHECK_ARG(j.a && j.M > 0 && j.n_mat >= 1 && j.n_mat <= kMaxLinMats && j.ldy >= 256 && j.ldy % 4 == 0, "linear16: bad job %d", i);
+        HMVIT_CHECK_ARG(!j.residual || j.n_mat == 1, "linear16: a residual goes with a single matrix (job %d)", i);
+        for (int m = 0; m < j.n_mat; ++m) HMVIT_CHECK_ARG(j.wimg[m] && j.w_inv[m] && j.y[m], "linear16: null pointer (job %d, matrix %d)", i, m);
+        max_m = j.M > max_m ? j.M : max_m;
+    }
+    hipLaunchKernelGGL(k_linear16, dim3(cdiv(max_m, X16_TOKENS), jobs.n), dim3(X16_THREADS), 0, st, jobs);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+int launch_weight_images16(const float* w, half_t* img, float* w_inv, int n_mat, hipStream_t st) {
+    if (n_mat <= 0) return HMVIT_OK;
+    HMVIT_CHECK_ARG(w && img && w_inv, "weight_images16: null pointer%s", "");
+    hipLaunchKernelGGL(k_weight_image16, dim3(n_mat), dim3(1024), 0, st, w, img, w_inv);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
 }
 
 #ifdef HMVIT_PROBE

@@ -44,6 +44,28 @@ struct GemmJobs {
 int launch_gemm(const GemmJobs& jobs, bool a_f32, bool gelu, bool out_f32, int precision,
                 hipStream_t st);
 
+// ---- chain.hip: Linear(256 -> 256 n_mat) on f32 rows with split-f16 products ("x16" tiles: every row of `a` is read once, all output
+// columns are formed in the same workgroup; the training path's skinny GEMMs).  Weights come as x16 split images built on the device
+// by launch_weight_images16 (per-matrix power-of-two scale, its inverse in w_inv); activations are scaled per token inside.
+constexpr int kMaxLinMats = 3, kMaxLinJobs = 16;
+struct LinJob {
+    const float* a;                      // (M, 256) f32 rows
+    const half_t* wimg[kMaxLinMats];     // images of the (256, 256) matrices W: y_m = a W_m^T
+    const float* w_inv[kMaxLinMats];     // device scalars written by launch_weight_images16
+    const float* bias[kMaxLinMats];      // (256) or null
+    float* y[kMaxLinMats];               // (M, ldy) f32
+    const float* residual;               // (M, ldy) f32 or null: added to y[0] (may alias it)
+    int M, n_mat, ldy;
+};
+struct LinJobs {
+    LinJob j[kMaxLinJobs];
+    int n;
+};
+int launch_linear16(const LinJobs& jobs, hipStream_t st);
+// n_mat row-major (256, 256) f32 matrices, contiguous -> n_mat images (65536 (hi, lo) pairs each, same byte offsets as the
+// matrices) + n_mat inverse scales
+int launch_weight_images16(const float* w, half_t* img, float* w_inv, int n_mat, hipStream_t st);
+
 // ---- chain.hip (f16 mode: register-resident token chains) ----
 constexpr int kMaxChainJobs = 16;
 struct QkvJob {

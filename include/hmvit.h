@@ -278,6 +278,13 @@ int hmvit_dropout_mask(float* mask, size_t n, uint64_t seed, uint32_t salt, floa
  * products run on split-f16 operands (fp32-class accuracy).  dw / dbias are ACCUMULATED into (atomics). */
 int hmvit_gemm_tn(const float* dy, const float* a, float* dw, float* dbias, int M, int N, int K, int ld_dy, int ld_a, void* stream);
 
+/* y (M, 256 n_mat) = a (M, 256) W^T (+ bias) (+ residual), W (256 n_mat, 256) row-major f32, n_mat <= 3: the training path's
+ * skinny Linear (torch.nn.Linear forward, hetero_fusion.py:142-152 / base_transformer.py:129-192 under train()), products on
+ * split-f16 operands with per-token and per-matrix power-of-two scaling (exact; any magnitude of a / W).  `image_ws` takes the
+ * weights' device-built operand images: 65536 n_mat + 64 floats.  residual (M, 256), n_mat == 1 only, may alias y. */
+int hmvit_linear16(const float* a, const float* w, const float* bias, const float* residual, float* y, int M, int n_mat,
+                   float* image_ws, void* stream);
+
 /* nn.BatchNorm2d on batch statistics + ReLU over NHWC maps viewed as (M = N H W, C), C % 4 == 0, f32:
  *   stats:    sums[c] += sum_m x[m][c], sums[C + c] += sum_m x[m][c]^2   (zero-fill sums first; the caller forms mean / rstd)
  *   apply:    y = relu?(gamma (x - mean) rstd + beta)

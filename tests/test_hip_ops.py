@@ -201,3 +201,35 @@ def test_window_attention_operator(lib, precision, C, window, partition):
               "window_attention")
     err = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
     assert err < {"f32": 2e-5, "f16": 3e-3, "split": 2e-5}[precision], err
+
+
+@pytest.mark.parametrize("M,n_mat,bias,res,a_scale,w_scale", [
+    (1000, 1, True, False, 1.0, 1.0), (129, 1, True, True, 1.0, 1.0), (4096, 3, True, False, 1.0, 1.0), (300, 2, False, False, 1.0, 1.0),
+    (640, 1, True, True, 1e-7, 1.0), (640, 1, True, False, 3e5, 1e-4), (640, 3, False, False, 1.0, 300.0)])
+def test_linear16_matches_float64(lib, M, n_mat, bias, res, a_scale, w_scale):
+    """hmvit_linear16 (the training path's skinny Linear: x16 tiles, split-f16 products, per-token / per-matrix power-of-two
+    scaling) against torch.nn.functional.linear in float64: fp32 round-off class whatever the magnitudes (1e-7 rows are
+    back-propagated gradients, 3e5 un-normalised residual streams), ragged M, up to three matrices over one pass of the rows."""
+    torch.manual_seed(M + n_mat)
+    a = (torch.randn(M, 256, device="cuda") * a_scale)
+    a[::7] *= 50.0                                              # rows of very different magnitude next to each other
+    w = torch.randn(256 * n_mat, 256, device="cuda") * w_scale / 16
+    b = torch.randn(256 * n_mat, device="cuda") * a_scale * w_scale if bias else None
+    r = torch.randn(M, 256, device="cuda") * a_scale * w_scale if res else None
+    y = torch.full((M, 256 * n_mat), float("nan"), device="cuda")
+    ws = torch.empty(65536 * n_mat + 64, device="cuda")
+    lib.check(lib.lib.hmvit_linear16(a.data_ptr(), w.data_ptr(), b.data_ptr() if bias else None, r.data_ptr() if res else None,
+                                     y.data_ptr(), M, n_mat, ws.data_ptr(), _stream()), "linear16")
+    ref = torch.nn.functional.linear(a.double(), w.double(), b.double() if bias else None)
+    if res:
+        ref = ref + r.double()
+    err = ((y.double() - ref).abs().max() / ref.abs().max()).item()
+    row_err = ((y.double() - ref).abs().amax(1) / ref.abs().amax(1)).max().item()    # every row against its own magnitude
+    print(f"\nlinear16 M={M} n_mat={n_mat} a_scale={a_scale:g} w_scale={w_scale:g}: rel-max {err:.2e}, worst row {row_err:.2e}")
+    assert torch.isfinite(y).all()
+    assert err < 2e-6 and row_err < 5e-6
+    if res:                                                      # the residual may alias the output (accumulation in place)
+        y2 = r.clone()
+        lib.check(lib.lib.hmvit_linear16(a.data_ptr(), w.data_ptr(), b.data_ptr() if bias else None, y2.data_ptr(), y2.data_ptr(),
+                                         M, n_mat, ws.data_ptr(), _stream()), "linear16")
+        assert torch.equal(y2, y)
