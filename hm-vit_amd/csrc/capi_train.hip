@@ -161,7 +161,18 @@ struct Jobs {
         return rc;
     }
     // y (M, N) = a (M, K) w^T (+ bias) (+ residual)
-    int add(const float* a, const float* w, const float* bias, const float* residual, float* y, int M, int N, int K) {
+    // (ln_g, ln_b): y = LayerNorm(a) w^T ... - only where can_fuse_ln(w) said so (the x16 kernel normalises the rows in registers)
+    bool can_fuse_ln(const float* w, int N, int K) const {
+#ifndef HMVIT_TRAIN_EXACT_F32
+        const half_t* img;
+        const float* inv;
+        return reg && N == 256 && K == 256 && reg->find(w, img, inv);
+#else
+        return false;
+#endif
+    }
+    int add(const float* a, const float* w, const float* bias, const float* residual, float* y, int M, int N, int K,
+            const float* ln_g = nullptr, const float* ln_b = nullptr) {
 #ifndef HMVIT_TRAIN_EXACT_F32
         const half_t* img;
         const float* inv;
@@ -169,7 +180,7 @@ struct Jobs {
             // products of the same rows (Q / K' / V' of a slot) share one pass over them
             if (lin.n > 0 && !residual) {
                 LinJob& q = lin.j[lin.n - 1];
-                if (q.a == a && q.M == M && !q.residual && q.n_mat < kMaxLinMats) {
+                if (q.a == a && q.M == M && !q.residual && q.n_mat < kMaxLinMats && q.ln_gamma == ln_g) {
                     q.wimg[q.n_mat] = img; q.w_inv[q.n_mat] = inv; q.bias[q.n_mat] = bias; q.y[q.n_mat] = y;
                     ++q.n_mat;
                     return HMVIT_OK;
@@ -179,10 +190,11 @@ struct Jobs {
             LinJob& q = lin.j[lin.n++];
             memset(&q, 0, sizeof(q));
             q.a = a; q.wimg[0] = img; q.w_inv[0] = inv; q.bias[0] = bias; q.y[0] = y; q.residual = residual;
-            q.M = M; q.n_mat = 1; q.ldy = N;
+            q.M = M; q.n_mat = 1; q.ldy = N; q.ln_gamma = ln_g; q.ln_beta = ln_b;
             return HMVIT_OK;
         }
 #endif
+        if (ln_g) { set_error("training: LayerNorm fusion asked of the generic GEMM%s", ""); return HMVIT_EINVAL; }
         GemmJob j;
         j.a = a; j.w = w; j.bias = bias; j.residual = residual; j.y = y;
         j.M = M; j.N = N; j.K = K; j.n_per_plane = N; j.plane_stride = 0;
@@ -333,20 +345,25 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
         float *xn = tmp, *xn2 = tmp, *h = tmp;
         const int n_ego = si.n_ego;
 
-        HMVIT_TRY(ln_slots(x_in, xn, wt.ln_gamma, wt.ln_beta, d, pl, pl.max_cav, st));
         {
             Jobs jb(st, regp);
+            // with the x16 Linear the LayerNorm happens on the rows' way into the products (the normalised rows are not written)
+            const bool fuse = jb.can_fuse_ln(reinterpret_cast<const float*>(wt.w_q), C, C);
+            if (!fuse) HMVIT_TRY(ln_slots(x_in, xn, wt.ln_gamma, wt.ln_beta, d, pl, pl.max_cav, st));
+            const float* rows = fuse ? x_in : xn;
             for (int b = 0; b < B; ++b)
                 for (int l = 0; l < pl.max_cav; ++l) {
                     const int slot = b * L + l, ty = d->mode[slot];
+                    const float* lg = fuse ? wt.ln_gamma + ty * C : nullptr;
+                    const float* lb = fuse ? wt.ln_beta + ty * C : nullptr;
                     if (l < n_ego)
-                        HMVIT_TRY(jb.add(xn + slot * me, reinterpret_cast<const float*>(wt.w_q) + (size_t)ty * C * C, nullptr, nullptr,
-                                         q + slot * me, P, C, C));
+                        HMVIT_TRY(jb.add(rows + slot * me, reinterpret_cast<const float*>(wt.w_q) + (size_t)ty * C * C, nullptr, nullptr,
+                                         q + slot * me, P, C, C, lg, lb));
                     for (int e = 0; e < si.E; ++e) {
                         const float* w = reinterpret_cast<const float*>(wt.w_kv) + (size_t)(si.e_type[e] * HMVIT_NUM_TYPES + ty) * 2 * C * C;
                         float* y = kv + (size_t)(slot * si.E + e) * 2 * me;
-                        HMVIT_TRY(jb.add(xn + slot * me, w, nullptr, nullptr, y, P, C, C));                       // K'
-                        HMVIT_TRY(jb.add(xn + slot * me, w + (size_t)C * C, nullptr, nullptr, y + me, P, C, C));  // V'
+                        HMVIT_TRY(jb.add(rows + slot * me, w, nullptr, nullptr, y, P, C, C, lg, lb));                       // K'
+                        HMVIT_TRY(jb.add(rows + slot * me, w + (size_t)C * C, nullptr, nullptr, y + me, P, C, C, lg, lb));  // V'
                     }
                 }
             HMVIT_TRY(jb.flush());
@@ -382,12 +399,14 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
             }
         }
         for (int b = 0; b < B; ++b) {
-            HMVIT_TRY(ln_slots(x1, xn2, wt.ffn_ln_gamma, wt.ffn_ln_beta, d, pl, n_ego, st, b));
             Jobs j1(st, regp);
+            const bool fuse = j1.can_fuse_ln(reinterpret_cast<const float*>(wt.w_1), mlp, C);
+            if (!fuse) HMVIT_TRY(ln_slots(x1, xn2, wt.ffn_ln_gamma, wt.ffn_ln_beta, d, pl, n_ego, st, b));
             for (int i = 0; i < n_ego; ++i) {
                 const int slot = b * L + i, ty = d->mode[slot];
-                HMVIT_TRY(j1.add(xn2 + slot * me, reinterpret_cast<const float*>(wt.w_1) + (size_t)ty * mlp * C, wt.b_1 + ty * mlp, nullptr,
-                                 pre + (size_t)slot * P * mlp, P, mlp, C));
+                HMVIT_TRY(j1.add((fuse ? x1 : xn2) + slot * me, reinterpret_cast<const float*>(wt.w_1) + (size_t)ty * mlp * C, wt.b_1 + ty * mlp,
+                                 nullptr, pre + (size_t)slot * P * mlp, P, mlp, C, fuse ? wt.ffn_ln_gamma + ty * C : nullptr,
+                                 fuse ? wt.ffn_ln_beta + ty * C : nullptr));
             }
             HMVIT_TRY(j1.flush());
             for (int i = 0; i < n_ego; ++i) {
@@ -659,6 +678,7 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
             fill_attn(d, pl, si, s, q, kv, const_cast<float*>(o), const_cast<float*>(lse), ainv, ab.f);
             ab.bias_frag_neg = reinterpret_cast<const float*>(t->bias_frag_neg[s]);
             ab.d_out = T3; ab.dq = T4; ab.dkg = dkg; ab.d_bias_frag = gr.bias_frag;
+            ab.probe = 0;
             // (k_attention_bwd writes every key row of every (ego, source < max_cav) pair, zeros where nothing is visible)
             DBG_SUM("G", G, pl.A);
             DBG_SUM("dO", T3, pl.A);

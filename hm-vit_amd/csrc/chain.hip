@@ -1036,6 +1036,34 @@ __device__ __forceinline__ void ln_to_operands16(const float4v (&x)[16], const f
     }
 }
 
+// LayerNorm of the token held by 4 lanes, in place (f32 rows; k_linear16 scales and splits them afterwards)
+__device__ __forceinline__ void ln_rows16(float4v (&x)[16], const float* __restrict__ lg, const float* __restrict__ lb, int g) {
+    constexpr int C = 256;
+    float sm = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) sm += (x[t][0] + x[t][1]) + (x[t][2] + x[t][3]);
+    const float mean = quad_sum(sm) * (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = x[t][r] - mean;
+            q = fmaf(d, d, q);
+        }
+    const float rstd = rsqrtf(quad_sum(q) * (1.f / C) + 1e-5f);
+    const float shift = -mean * rstd;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const float4 ga = *reinterpret_cast<const float4*>(lg + 16 * t + 4 * g);
+        const float4 be = *reinterpret_cast<const float4*>(lb + 16 * t + 4 * g);
+        x[t][0] = fmaf(x[t][0], rstd, shift) * ga.x + be.x;
+        x[t][1] = fmaf(x[t][1], rstd, shift) * ga.y + be.y;
+        x[t][2] = fmaf(x[t][2], rstd, shift) * ga.z + be.z;
+        x[t][3] = fmaf(x[t][3], rstd, shift) * ga.w + be.w;
+    }
+}
+
 // two projected row tiles (32 channels 32 c .. 32 c + 31) of the wave's 16 tokens -> f32 plane, through the wave's staging rows:
 // chunks (2 k, 2 k + 1) fill 64 channels = 256 bytes per token, then 4 store instructions write 4 x (4 tokens x 256 bytes)
 __device__ __forceinline__ void store_proj16(float* stg, float* y, int c, const float4v (&acc)[2], float cm, int tk, int g, int lane, int tok_w, int P) {
@@ -1206,15 +1234,21 @@ __device__ __forceinline__ void store_lin16(float* stg, float* y, int ldy, int c
 
 __global__ __launch_bounds__(X16_THREADS, 2) void k_linear16(LinJobs jobs) {
     constexpr int C = 256, NCH = 8;                 // chunks (32 output rows) per matrix
-    __shared__ __attribute__((aligned(16))) half_t smem[X16_RING * X16_CHUNK + 2 * kMaxLinMats * C + 2 * X16_WAVES * X16_STG_WAVE];
+    __shared__ __attribute__((aligned(16))) half_t smem[X16_RING * X16_CHUNK + 2 * (kMaxLinMats + 2) * C + 2 * X16_WAVES * X16_STG_WAVE];
     float* bs = reinterpret_cast<float*>(smem + X16_RING * X16_CHUNK);
+    float* lnp = bs + kMaxLinMats * C;              // gamma, beta
     const LinJob& J = jobs.j[blockIdx.y];
     const int M = J.M;
     if ((int)blockIdx.x * X16_TOKENS >= M) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tk = lane & 15, g = lane >> 4;
     const int tok_w = blockIdx.x * X16_TOKENS + wave * 16, tok = tok_w + tk;
-    float* stg = reinterpret_cast<float*>(smem + X16_RING * X16_CHUNK + 2 * kMaxLinMats * C) + wave * X16_STG_WAVE;
+    float* stg = reinterpret_cast<float*>(smem + X16_RING * X16_CHUNK + 2 * (kMaxLinMats + 2) * C) + wave * X16_STG_WAVE;
     for (int i = threadIdx.x; i < J.n_mat * C; i += X16_THREADS) bs[i] = J.bias[i / C] ? J.bias[i / C][i % C] : 0.f;
+    if (J.ln_gamma)
+        for (int i = threadIdx.x; i < C; i += X16_THREADS) {
+            lnp[i] = J.ln_gamma[i];
+            lnp[C + i] = J.ln_beta[i];
+        }
     const int n_chunks = J.n_mat * NCH;
     auto chunk_ptr = [&](int i) -> const half_t* { return J.wimg[i / NCH] + (size_t)(i % NCH) * X16_CHUNK; };
     auto slot = [&](int i) -> half_t* { return smem + (i % X16_RING) * X16_CHUNK; };
@@ -1238,6 +1272,7 @@ __global__ __launch_bounds__(X16_THREADS, 2) void k_linear16(LinJobs jobs) {
     __syncthreads();
     if (grp_b) wg_barrier();
     half8 ah[8], al[8];
+    if (J.ln_gamma) ln_rows16(x, lnp, lnp + C, g);
     const float s_tok = pow2_scale(row_absmax16(x));
     rows_to_operands16(x, ah, al, s_tok);
     const float inv_tok = pow2_inv(s_tok);
@@ -1769,6 +1804,7 @@ int launch_linear16(const LinJobs& jobs, hipStream_t st) {
         const LinJob& j = jobs.j[i];
         HMVIT_CHECK_ARG(j.a && j.M > 0 && j.n_mat >= 1 && j.n_mat <= kMaxLinMats && j.ldy >= 256 && j.ldy % 4 == 0, "linear16: bad job %d", i);
         HMVIT_CHECK_ARG(!j.residual || j.n_mat == 1, "linear16: a residual goes with a single matrix (job %d)", i);
+        HMVIT_CHECK_ARG((j.ln_gamma == nullptr) == (j.ln_beta == nullptr), "linear16: LayerNorm needs gamma and beta (job %d)", i);
         for (int m = 0; m < j.n_mat; ++m) HMVIT_CHECK_ARG(j.wimg[m] && j.w_inv[m] && j.y[m], "linear16: null pointer (job %d, matrix %d)", i, m);
         max_m = j.M > max_m ? j.M : max_m;
     }

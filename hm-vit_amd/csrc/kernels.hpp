@@ -55,6 +55,8 @@ struct LinJob {
     const float* bias[kMaxLinMats];      // (256) or null
     float* y[kMaxLinMats];               // (M, ldy) f32
     const float* residual;               // (M, ldy) f32 or null: added to y[0] (may alias it)
+    const float* ln_gamma;               // (256) or null: the rows are LayerNorm-ed (eps 1e-5) on their way into the products,
+    const float* ln_beta;                //   i.e. y = LN(a) W^T: the normalised rows are never written
     int M, n_mat, ldy;
 };
 struct LinJobs {
@@ -264,8 +266,9 @@ struct AttnBwdParams {
     const float* d_out;       // (B, L, P, C) gradient of O
     float* dq;                // (B, L, P, C) gradient of the (un-biased) q planes, ego slots
     float* dkg;               // (B, n_ego, n_src, 2, P, C): gradient of the gathered K / V keys of every (ego, source) pair,
-                              // indexed by EGO pixel; zero-filled by the caller
+                              // indexed by EGO pixel; every key row of every pair is written (zeros where nothing is visible)
     float* d_bias_frag;       // (heads, NB, 64, 4) accumulated into
+    int probe;                // probe builds (HMVIT_BWD_PROBE): 1 = skip the products, 2 = skip the tap loads, 3 = skip the prologue's dot products
 };
 int launch_attention_bwd(const AttnBwdParams& p, hipStream_t st);
 // adjoint of the bilinear key gather: dkv[(b, src), e, plane, s, :] = sum over egos of variant e and ego pixels u whose taps

@@ -664,6 +664,9 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
             token_pixel(p.partition, WIN, X, Y, wx, wy, n, row, col);
             const size_t o = (size_t)(row * W + col) * C + ch0 + hh * 32;
             float d = 0.f;
+#ifdef HMVIT_PROBE
+            if (bp.probe != 3)
+#endif
 #pragma unroll 8
             for (int e = 0; e < 32; ++e) d = fmaf(doplane[o + e], oplane[o + e], d);
             Dl[n][hh] = d;
@@ -720,6 +723,12 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
                         t = make_taps(a, col, row, H, W);
                     }
                     visible = (t.roi != 0.f) && (p.cav[b * L + src] != 0);
+#ifdef HMVIT_PROBE
+                    if (visible && bp.probe == 2) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) kvv[0][e] = kvv[1][e] = 0.01f * (float)(e + cl);
+                    } else
+#endif
                     if (visible) {
                         const int ts = p.mode[b * L + src];
                         const float* kpl = kvplanes + ((size_t)((b * L + src) * p.E + ev) * 2) * P * C + ch0 + cl;
@@ -751,6 +760,9 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
             }
         }
         any_visible = __syncthreads_or(any_visible);
+#ifdef HMVIT_PROBE
+        if (bp.probe == 1) any_visible = 0;
+#endif
 
         if (any_visible) {
             auto split4 = [](float a, float b, float c, float d, half4& h, half4& l) {
@@ -953,6 +965,13 @@ int launch_attention_bwd(const AttnBwdParams& p, hipStream_t st) {
     HMVIT_CHECK_ARG(p.f.C == 64 || p.f.C == 128 || p.f.C == 256, "attention_bwd: C=%d unsupported", p.f.C);
     HMVIT_CHECK_ARG(p.f.lse && p.f.out && p.d_out && p.dq && p.dkg && p.d_bias_frag && p.bias_frag_neg, "attention_bwd: null pointer");
     if (p.f.n_ego <= 0 || p.f.B <= 0) return HMVIT_OK;
+#ifdef HMVIT_PROBE
+    if (const char* e = HMVIT_ENV("HMVIT_BWD_PROBE")) {
+        AttnBwdParams q = p;
+        q.probe = atoi(e);
+        return q.f.window == 8 ? launch_attn_bwd_t<8, 2>(q, st) : launch_attn_bwd_t<4, 2>(q, st);
+    }
+#endif
     return p.f.window == 8 ? launch_attn_bwd_t<8, 2>(p, st) : launch_attn_bwd_t<4, 2>(p, st);
 }
 
