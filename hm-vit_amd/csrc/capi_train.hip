@@ -764,7 +764,7 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
 }  // namespace hmvit
 
 #ifdef HMVIT_PROBE
-namespace hmvit { int debug_x16_trace(unsigned long long* host, int n); }
+namespace hmvit { int debug_x16_trace(unsigned long long* host, int n); int debug_bwd_trace(unsigned long long* host, int n); }
 #endif
 using namespace hmvit;
 
@@ -873,6 +873,7 @@ int hmvit_bn_train_backward(const float* x, const float* y, const float* dy, con
 
 #ifdef HMVIT_PROBE
 int hmvit_debug_x16_trace(unsigned long long* host, int n) { return hmvit::debug_x16_trace(host, n); }
+int hmvit_debug_bwd_trace(unsigned long long* host, int n) { return hmvit::debug_bwd_trace(host, n); }
 #endif
 
 }  // extern "C"

@@ -605,6 +605,23 @@ int launch_layernorm_bwd(const float* x, const float* dy, const float* gamma, co
 // (Measured: the bounded, spilling build runs a launch in 6.6 ms at cfg2, this one in 8.3 ms - hipcc schedules for one wavefront per
 // SIMD when no occupancy is promised - and every attempt to get under 256 registers with the bound in place (fewer bias
 // accumulators, later operand loads) still left 28-96 bytes of scratch.  Correct first: tools/probe/r03_bwd_ab.sh.)
+#ifdef HMVIT_PROBE
+// cycle stamps of one workgroup (lane 0 of every wave): [wave][0 start, 1 prologue done, 2 + 3 c gather issued+staged, 3 + 3 c gather
+// barrier passed, 4 + 3 c products + stores done, ..., 30 dq stored]; hmvit_debug_bwd_trace (tools/probe/bwd_trace.py)
+__device__ unsigned long long g_bwd_trace[8 * 32];
+#define BWD_STAMP(slot)                                                                              \
+    do {                                                                                             \
+        if (blockIdx.x == 2001 && blockIdx.y == 1 && (threadIdx.x & 63) == 0 && (slot) < 32)         \
+            g_bwd_trace[(threadIdx.x >> 6) * 32 + (slot)] = __builtin_readcyclecounter();            \
+    } while (0)
+int debug_bwd_trace(unsigned long long* host, int n) {
+    HMVIT_CHECK_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bwd_trace), sizeof(unsigned long long) * (n < 256 ? n : 256)));
+    return HMVIT_OK;
+}
+#else
+#define BWD_STAMP(slot) do {} while (0)
+#endif
+
 template <int WIN, int HG>
 __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
     const AttnParams& p = bp.f;
@@ -639,6 +656,7 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
     const float* doplane = bp.d_out + (size_t)(b * L + ego) * P * C;
     const float* kvplanes = reinterpret_cast<const float*>(p.kv);
 
+    BWD_STAMP(0);
     // ---- query tile (+ bias), dO tile, D and lse ----
     {
         const float* bq = p.b_q + te * C + ch0;
@@ -692,6 +710,7 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) dq_acc[qt][dt] = (float4v)(0.f);
     __syncthreads();
+    BWD_STAMP(1);
 
     const int hoff = wave * 32;
     const int n_chunks = (p.n_src + SPC - 1) / SPC;
@@ -759,7 +778,9 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
                 any_visible |= visible ? 1 : 0;
             }
         }
+        BWD_STAMP(2 + 3 * chunk);
         any_visible = __syncthreads_or(any_visible);
+        BWD_STAMP(3 + 3 * chunk);
 #ifdef HMVIT_PROBE
         if (bp.probe == 1) any_visible = 0;
 #endif
@@ -911,6 +932,7 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
                     }
                 }
         }
+        BWD_STAMP(4 + 3 * chunk);
         __syncthreads();
     }
 
@@ -943,6 +965,7 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
         for (int dt = 0; dt < 2; ++dt)
             *reinterpret_cast<float4*>(o + dt * 16) = make_float4(dq_acc[qt][dt][0], dq_acc[qt][dt][1], dq_acc[qt][dt][2], dq_acc[qt][dt][3]);
     }
+    BWD_STAMP(30);
     const int vbase = (WIN == 8) ? (khalf == 0 ? 2 : 0) : 0;
 #pragma unroll
     for (int v = 0; v < NBW; ++v)
