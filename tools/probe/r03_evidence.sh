@@ -21,6 +21,7 @@ for p in f32 split f16; do timeout 600 python tests/tools/ap_replay.py --precisi
  python tests/tools/encoder_bench.py 2>&1 | grep PointPillar;
  python tests/tools/camera_bench.py f16 split f32 2>&1 | grep Cvt) > profiles/r03_model.txt; echo "model rc=$?"
 bash tools/probe/r03_attn_prof.sh final > profiles/r03_attention_per_stage.txt 2>&1
+bash tools/probe/r03_train_pmc.sh > gpurun_out/r03/train_pmc.log 2>&1; cp gpurun_out/r03/train_pmc.txt profiles/r03_train_pmc.txt; cp gpurun_out/r03/train_kernel_stats.csv profiles/r03_train_kernel_stats.csv
 grep -E "^range\[" gpurun_out/r03/gputest.log > profiles/r03_range.txt
 cp profiles/r03_* profiles/pmc_traffic.json gpurun_out/r03/profiles/
 cut -c1-400 profiles/r03_bench.json; cat profiles/r03_train.txt profiles/r03_model.txt
