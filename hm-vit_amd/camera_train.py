@@ -62,7 +62,7 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        dy = dy.contiguous()
+        dy, un = _lib.grad_pow2(dy)                      # split-f16 products: run on dy 2^k, results times 2^-k (exact)
         M, K = x.shape
         w2 = weight.detach().reshape(weight.shape[0], -1)
         N = w2.shape[0]
@@ -82,7 +82,8 @@ class LinearFn(torch.autograd.Function):
             db = torch.zeros(Np, device=dev, dtype=torch.float32)
             _lib.check(_lib.lib.hmvit_gemm_tn(dy4.data_ptr(), x4.data_ptr(), dw.data_ptr(), db.data_ptr(), M, Np, Kp, Np, Kp, _stream(dev)),
                        "gemm_tn")
-        return dx, dw[:N, :K].reshape(weight.shape).contiguous(), db[:N].contiguous() if ctx.has_bias else None
+        return (dx * un if dx is not None else None, dw[:N, :K].reshape(weight.shape).contiguous() * un,
+                db[:N].contiguous() * un if ctx.has_bias else None)
 
 
 class LayerNormFn(torch.autograd.Function):

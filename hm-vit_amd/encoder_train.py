@@ -48,6 +48,7 @@ class Deconv(torch.autograd.Function):
         n, H, W, _ = x.shape
         M, K = n * H * W, s * s * co
         dev = x.device
+        dy, un = _lib.grad_pow2(dy)                      # split-f16 products: run on dy 2^k, results times 2^-k (exact)
         dys = dy.reshape(n, H, s, W, s, co).permute(0, 1, 3, 2, 4, 5).reshape(M, K).contiguous()      # [(a, b, co)] per input pixel
         with torch.cuda.device(dev):
             wm = weight.detach().permute(0, 2, 3, 1).reshape(ci, K).contiguous()                         # (ci, (a, b, co))
@@ -56,7 +57,7 @@ class Deconv(torch.autograd.Function):
                                              _stream(dev)), "linear(deconv dgrad)")
             dw = torch.zeros(K, ci, device=dev, dtype=torch.float32)
             _lib.check(_lib.lib.hmvit_gemm_tn(dys.data_ptr(), x.data_ptr(), dw.data_ptr(), None, M, K, ci, K, ci, _stream(dev)), "gemm_tn")
-        return dx, dw.view(s, s, co, ci).permute(3, 2, 0, 1).contiguous()
+        return dx * un, dw.view(s, s, co, ci).permute(3, 2, 0, 1).contiguous() * un
 
 
 class LinearNoBias(torch.autograd.Function):
@@ -84,14 +85,14 @@ class LinearNoBias(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (xp,) = ctx.saved_tensors
-        dy = dy.contiguous()
+        dy, un = _lib.grad_pow2(dy)
         M, Kp = xp.shape
         N = dy.shape[1]
         dw = torch.zeros(N, Kp, device=dy.device, dtype=torch.float32)
         with torch.cuda.device(dy.device):
             _lib.check(_lib.lib.hmvit_gemm_tn(dy.data_ptr(), xp.data_ptr(), dw.data_ptr(), None, M, N, Kp, N, Kp, _stream(dy.device)),
                        "gemm_tn")
-        return None, dw[:, :ctx.K].contiguous()
+        return None, dw[:, :ctx.K].contiguous() * un
 
 
 def pfn_features(vf, vc, vn, voxel_size, lidar_range):

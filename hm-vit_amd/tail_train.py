@@ -57,7 +57,7 @@ class Conv3x3(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        dy = dy.contiguous()
+        dy, un = _lib.grad_pow2(dy)                      # split-f16 products: run on dy 2^k, results times 2^-k (exact)
         co, ci = weight.shape[:2]
         n, H, W, _ = x.shape
         dev = x.device
@@ -88,8 +88,8 @@ class Conv3x3(torch.autograd.Function):
                     tap = ky * 3 + kx
                     _lib.check(_lib.lib.hmvit_gemm_tn(dyp.data_ptr(), a.data_ptr(), dw[tap].data_ptr(),
                                                       db.data_ptr() if tap == 0 else None, Mp, co, ci, co, ci, st), "gemm_tn")
-        return (dx if ctx.needs_input_grad[0] else None, dw.view(3, 3, co, ci).permute(2, 3, 0, 1).contiguous(),
-                db if ctx.has_bias else None, None)
+        return (dx * un if ctx.needs_input_grad[0] else None, dw.view(3, 3, co, ci).permute(2, 3, 0, 1).contiguous() * un,
+                db * un if ctx.has_bias else None, None)
 
 
 class BnRelu(torch.autograd.Function):
@@ -159,7 +159,7 @@ class Conv1x1(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        dy = dy.contiguous()
+        dy, un = _lib.grad_pow2(dy)
         co, ci = weight.shape[:2]
         M = x.numel() // ci
         dev = x.device
@@ -180,7 +180,7 @@ class Conv1x1(torch.autograd.Function):
             db = torch.zeros(cq, device=dev, dtype=torch.float32)
             _lib.check(_lib.lib.hmvit_gemm_tn(dy4.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), M, cq, ci, cq, ci,
                                               _stream(dev)), "gemm_tn")
-        return dx, dw[:co].reshape(co, ci, 1, 1).contiguous(), db[:co].contiguous()
+        return dx * un, dw[:co].reshape(co, ci, 1, 1).contiguous() * un, db[:co].contiguous() * un
 
 
 def bn_relu_module(x, bn: torch.nn.BatchNorm2d, relu: bool = True):

@@ -134,11 +134,7 @@ class FusionTrainFunction(torch.autograd.Function):
         # reach this point at 1e-4 ... 1e-7 (focal loss normalised by the positives), where the lo half falls under f16's
         # 2^-24 floor.  The backward pass is LINEAR in d_out, so it runs on d_out 2^k (max |.| brought to [2^9, 2^10)) and every
         # result is multiplied by 2^-k: exact, and independent of the scale of the loss.  No host synchronisation.
-        amax = d_out.abs().max()
-        k = torch.where(torch.isfinite(amax) & (amax > 0), 9.0 - torch.floor(torch.log2(amax.clamp_min(1e-38))), torch.zeros_like(amax))
-        k = k.clamp(-100.0, 100.0)
-        d_out = d_out * torch.exp2(k)
-        unscale = torch.exp2(-k)
+        d_out, unscale = _lib.grad_pow2(d_out)
         t, keep = _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, None, saved, None, only_stage)
         need = _lib.lib.hmvit_fusion_backward_workspace_bytes(ctypes.byref(t))
         if need == 0:

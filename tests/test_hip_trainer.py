@@ -69,11 +69,13 @@ def _tail_reference(dec, x, modes):
     return torch.stack(psm), torch.stack(rm)
 
 
+@pytest.mark.parametrize("gscale", [1.0, 1e-6])
 @pytest.mark.parametrize("modes", [[[1, 1], [1, 0]], [[0, 1], [1, 1], [0, 0]]])
-def test_tail_training_kernels_match_torch_modules(modes):
+def test_tail_training_kernels_match_torch_modules(modes, gscale):
     """The detection tail in training mode on libhmvit (conv3x3 / BatchNorm on batch statistics + ReLU / 1x1 heads, forward and
     backward, hm-vit_amd/tail_train.py) against the same torch modules under torch autograd: outputs, input gradient, every
-    parameter gradient and the running statistics."""
+    parameter gradient and the running statistics.  gscale 1e-6: the upstream gradient at the magnitude a normalised focal loss
+    hands back - the split-f16 products of the backward must not lose their low halves there (_lib.grad_pow2)."""
     import copy
     import hmvit_amd
     from oracle import decoder_oracle as DO
@@ -88,7 +90,7 @@ def test_tail_training_kernels_match_torch_modules(modes):
     B = len(modes)
     mode = torch.tensor(modes)
     x = torch.randn(B, 1, 256, 12, 10)
-    gp, gr = torch.randn(B, 2, 12, 10), torch.randn(B, 14, 12, 10)
+    gp, gr = torch.randn(B, 2, 12, 10) * gscale, torch.randn(B, 14, 12, 10) * gscale
     outs = []
     for m, torch_modules, conv in ((net, False, lambda t: t.cuda()), (ref, True, lambda t: t.double())):
         xi = conv(x).clone().requires_grad_(True)
