@@ -3,7 +3,7 @@
 and of the camera branch ``FaxFusedTransformer`` assembles (``opencood/models/fax_fused_transformer.py:12-64``:
 ``ResnetEncoder`` -> ``FAXModule`` -> up-sampling ``NaiveDecoder``), with the same constructor dicts, ``state_dict`` names and
 the encoder-slot contract of the HM-ViT model (``set_return_features()``, ``forward(batch_camera) -> (N, 256, H, W)``,
-SURVEY 8f-4).  Eval mode only, no CPU path.
+SURVEY 8f-4).  No CPU path; train() mode runs hm-vit_amd/fax_train.py (HIP forward + backward on the autograd tape).
 
 Kernels: the positional embeddings (``hmvit_cvt_embed``), BatchNorm + ReLU + layout (``hmvit_bn_relu_tokens``), LayerNorm and
 every Linear / 1x1 convolution (``hmvit_layernorm`` / ``hmvit_linear``), the windowed cross attention on
@@ -156,7 +156,10 @@ class CrossViewSwapAttention(nn.Module):
 
     def forward(self, index, x, bev, feature, I_inv, E_inv):
         if self.training:
-            raise NotImplementedError("hm-vit_amd CrossViewSwapAttention: eval mode only")
+            if not torch.is_grad_enabled():
+                raise RuntimeError("hmvit_amd.CrossViewSwapAttention: train() mode under no_grad; call eval() for inference")
+            from .fax_train import cross_view_swap_attention_forward
+            return cross_view_swap_attention_forward(self, index, x, bev, feature, I_inv, E_inv)
         if not x.is_cuda:
             raise RuntimeError("hm-vit_amd has no CPU path: pass CUDA tensors")
         b, n, feat_dim, h, w = feature.shape
@@ -223,7 +226,8 @@ class Attention(nn.Module):
 
     def forward(self, x):
         if self.training:
-            raise NotImplementedError("hm-vit_amd Attention: eval mode only")
+            from .fax_train import self_attention_forward
+            return self_attention_forward(self, x)
         b, dim, h, w = x.shape
         if h * w != self.rel_pos_indices.shape[0]:
             raise ValueError(f"Attention: map {h}x{w} does not match window_size {self.window_size}")
@@ -284,7 +288,8 @@ class FAXModule(nn.Module):
 
     def _forward(self, batch):
         if self.training:
-            raise RuntimeError("hmvit_amd.FAXModule: eval mode only")
+            from .fax_train import fax_module_forward
+            return fax_module_forward(self, batch)
         b, l, n = batch["camera"].shape[:3]
         prec = _PREC[self.precision]
         dt = torch.float16 if prec == _lib.PREC_F16 else torch.float32
@@ -343,6 +348,12 @@ class FaxCameraEncoder(nn.Module):
     def forward(self, batch_camera):
         if not self.return_features:
             raise NotImplementedError("FaxCameraEncoder serves the HM-ViT camera slot: call set_return_features() first")
+        if self.training:
+            # un-frozen camera backbone (train_camera.py:109-120): HIP forward + backward on the autograd tape
+            if not torch.is_grad_enabled():
+                raise RuntimeError("hmvit_amd.FaxCameraEncoder: train() mode under no_grad; call eval() for inference")
+            from .fax_train import fax_camera_encoder_forward
+            return fax_camera_encoder_forward(self, batch_camera)
         cam = batch_camera["camera"]
         prec = _PREC[self.precision]
         dt = torch.float16 if prec == _lib.PREC_F16 else torch.float32

@@ -5,7 +5,9 @@ level loop of FAXModule (:448-525).  TEST INFRASTRUCTURE ONLY.
 Parity: CrossViewSwapAttention, Attention and the down-sampling block are PINNED by tests/golden/g16_fax.npz (the reference
 modules imported with torchvision stubbed).  The ResNetBottleNeck layers of FAXModule are torchvision's Bottleneck (absent,
 version unpinned): restated from its published definition in oracle/camera_oracle.py, so the assembled module is parity
-UNPINNED at those layers, exactly like the CVT branch.  Eval mode: BatchNorm uses running statistics, Dropout is the identity."""
+UNPINNED at those layers, exactly like the CVT branch.  Eval mode: BatchNorm uses running statistics, Dropout is the identity;
+under ``cvt_oracle.batch_statistics()`` the BatchNorms use batch statistics and update their running buffers (the training-mode
+restatement the gradient tests differentiate, in float64).  Every function follows the dtype of its inputs."""
 from __future__ import annotations
 
 from typing import Dict, List
@@ -15,7 +17,13 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor
 
+from . import cvt_oracle as CO
 from .cvt_oracle import generate_grid
+
+
+def _bn(x, sd, p):
+    tr = CO.BN_TRAINING[0]
+    return F.batch_norm(x, sd[f"{p}.running_mean"], sd[f"{p}.running_var"], sd[f"{p}.weight"], sd[f"{p}.bias"], tr, 0.1 if tr else 0.0, 1e-5)
 
 
 def bev_grids(bev_height, bev_width, h_meters, w_meters, offset, upsample_scales) -> List[Tensor]:
@@ -58,8 +66,7 @@ def cross_win_attention(q, k, v, skip, sd: Dict[str, Tensor], p: str, heads: int
 
 
 def _bn_relu_conv(x, sd, p):
-    y = F.batch_norm(x, sd[f"{p}.0.running_mean"], sd[f"{p}.0.running_var"], sd[f"{p}.0.weight"], sd[f"{p}.0.bias"], False, 0.0, 1e-5)
-    return F.conv2d(F.relu(y), sd[f"{p}.2.weight"])
+    return F.conv2d(F.relu(_bn(x, sd, f"{p}.0")), sd[f"{p}.2.weight"])
 
 
 def _pad_divisible(x, win_h, win_w):
@@ -86,7 +93,8 @@ def cross_view_swap_attention(x, grid, feature, I_inv, E_inv, sd: Dict[str, Tens
     _, dim, H, W = x.shape
     heads, dim_head = cfg["heads"][index], cfg["dim_head"][index]
     qw, fw = cfg["q_win_size"][index], cfg["feat_win_size"][index]
-    pixel = generate_grid(h, w)[None]
+    pixel = generate_grid(h, w)[None].to(x.dtype)
+    grid = grid.to(x.dtype)
     pixel[:, :, 0] *= cfg["image_width"]
     pixel[:, :, 1] *= cfg["image_height"]
     c = E_inv[..., -1:].reshape(b * n, 4, 1, 1)
@@ -162,9 +170,9 @@ def downsample_block(x, sd: Dict[str, Tensor], p: str):
     y = F.conv2d(x, sd[f"{q}.0.weight"], None, 1, 1)
     y = F.pixel_unshuffle(y, 2)
     y = F.conv2d(y, sd[f"{q}.2.weight"], None, 1, 1)
-    y = F.relu(F.batch_norm(y, sd[f"{q}.3.running_mean"], sd[f"{q}.3.running_var"], sd[f"{q}.3.weight"], sd[f"{q}.3.bias"], False, 0.0, 1e-5))
+    y = F.relu(_bn(y, sd, f"{q}.3"))
     y = F.conv2d(y, sd[f"{q}.5.weight"])
-    return F.batch_norm(y, sd[f"{q}.6.running_mean"], sd[f"{q}.6.running_var"], sd[f"{q}.6.weight"], sd[f"{q}.6.bias"], False, 0.0, 1e-5)
+    return _bn(y, sd, f"{q}.6")
 
 
 def fax_module(features: List[Tensor], intrinsic, extrinsic, sd: Dict[str, Tensor], cfg: dict):
