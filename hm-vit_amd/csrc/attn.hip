@@ -1772,6 +1772,148 @@ static int launch_attn_t(const AttnParams& p, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Generic shapes: any window (N = window^2 <= 256 tokens) and any dim_head <= 64 (hetero_fusion.py:187-277 takes both from the
+// yaml; the shipped configs use 8 and 32, which the MFMA kernels above serve).  Plain f32 FMAs, one thread per query, one
+// workgroup per (window, head, ego): keys in chunks of 64 gathered into LDS (same taps, biases and visibility rule as k_attention),
+// online softmax per thread.  Correct for every shape the reference accepts, two orders of magnitude slower than the MFMA kernels:
+// a fallback, not a tuned path.  The relative-position bias arrives dense: (heads, N, N) (weights.py bias_dense).
+// ------------------------------------------------------------------------------------------
+constexpr int ANY_KC = 64;
+template <int DHM>
+__global__ __launch_bounds__(256) void k_attention_any(AttnParams p) {
+    __shared__ float Ks[ANY_KC][DHM + 1], Vs[ANY_KC][DHM + 1], maskadd[ANY_KC];
+    const int WIN = p.window, N = WIN * WIN, DH = p.dim_head, C = p.C, H = p.H, W = p.W, L = p.L, P = H * W;
+    const int heads = C / DH, X = H / WIN, Y = W / WIN;
+    const int win = blockIdx.x / heads, head = blockIdx.x - win * heads;
+    const int ego = blockIdx.y, b = blockIdx.z;
+    const int wx = win / Y, wy = win - wx * Y;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int te = p.mode[b * L + ego], ev = p.ego_e[b * L + ego];
+    const int ch0 = head * DH;
+    const float kl = p.k_logit != 0.f ? p.k_logit : 1.f;
+    const float* qplane = reinterpret_cast<const float*>(p.q) + (size_t)(b * L + ego) * P * C;
+    const float* kvplanes = reinterpret_cast<const float*>(p.kv);
+    const bool active = tid < N;
+
+    float q[DHM], o[DHM];
+#pragma unroll
+    for (int d = 0; d < DHM; ++d) q[d] = o[d] = 0.f;
+    int qrow = 0, qcol = 0;
+    if (active) {
+        token_pixel(p.partition, WIN, X, Y, wx, wy, tid, qrow, qcol);
+        const float* a = p.ainv + ((size_t)(b * L + ego) * L + ego) * 8;
+        const float* bq = p.b_q + te * C + ch0;
+        if (a[6] != 0.f) {
+            const float* src = qplane + (size_t)(qrow * W + qcol) * C + ch0;
+#pragma unroll
+            for (int d = 0; d < DHM; ++d)
+                if (d < DH) q[d] = src[d] + bq[d];
+        } else {
+            const Taps t = make_taps(a, qcol, qrow, H, W);
+#pragma unroll
+            for (int d = 0; d < DHM; ++d)
+                if (d < DH) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc = fmaf(t.w[k], qplane[(size_t)t.idx[k] * C + ch0 + d], acc);
+                    q[d] = acc + bq[d];
+                }
+        }
+    }
+    float m_run = -INFINITY, l_run = 0.f;
+    const float* bias = p.bias_frag + ((size_t)head * N + (active ? tid : 0)) * N;     // row of this query
+
+    const int n_keys = p.n_src * N;
+    for (int k0 = 0; k0 < n_keys; k0 += ANY_KC) {
+        // gather: key kk = tid % 64, channels d = tid / 64, + nthr / 64, ...
+        int any_visible = 0;
+        {
+            const int kk = tid % ANY_KC, key = k0 + kk;
+            bool visible = false;
+            Taps t;
+            bool ident = false;
+            int self_idx = 0, src = 0;
+            if (key < n_keys) {
+                src = key / N;
+                int row, col;
+                token_pixel(p.partition, WIN, X, Y, wx, wy, key - src * N, row, col);
+                const float* a = p.ainv + ((size_t)(b * L + src) * L + ego) * 8;
+                ident = a[6] != 0.f;
+                self_idx = row * W + col;
+                t.roi = 1.f;
+                if (!ident) t = make_taps(a, col, row, H, W);
+                visible = (t.roi != 0.f) && (p.cav[b * L + src] != 0);
+            }
+            const int ts = p.mode[b * L + src];
+            const float* kpl = kvplanes + ((size_t)((b * L + src) * p.E + ev) * 2) * P * C + ch0;
+            const float* bk = p.b_kv + (size_t)(te * HMVIT_NUM_TYPES + ts) * 2 * C + ch0;
+            for (int d = tid / ANY_KC; d < DHM; d += nthr / ANY_KC) {     // channels DH .. DHM - 1 are zero padding
+                float kvv[2] = {0.f, 0.f};
+                if (visible && d < DH) {
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        const float* plane = kpl + (size_t)pl * P * C + d;
+                        float acc;
+                        if (ident) {
+                            acc = plane[(size_t)self_idx * C];
+                        } else {
+                            acc = t.w[0] * plane[(size_t)t.idx[0] * C];
+#pragma unroll
+                            for (int k = 1; k < 4; ++k) acc = fmaf(t.w[k], plane[(size_t)t.idx[k] * C], acc);
+                        }
+                        kvv[pl] = acc + bk[pl * C + d];
+                    }
+                }
+                Ks[kk][d] = kvv[0];
+                Vs[kk][d] = kvv[1];
+            }
+            if (tid < ANY_KC) maskadd[kk] = visible ? 0.f : -INFINITY;
+            any_visible = visible ? 1 : 0;
+        }
+        any_visible = __syncthreads_or(any_visible);
+        if ((any_visible || !p.skip_masked) && active) {
+            const int kmax = min(ANY_KC, n_keys - k0);
+            for (int kk = 0; kk < kmax; ++kk) {
+                float s = 0.f;
+#pragma unroll
+                for (int d = 0; d < DHM; ++d) s = fmaf(q[d], Ks[kk][d], s);       // channels >= DH hold zeros on the query side
+                const int kn = (k0 + kk) % N;
+                s = s * kl + bias[kn] + maskadd[kk];
+                const float m_new = fmaxf(m_run, s);
+                if (m_new == -INFINITY) continue;
+                const float alpha = expf(m_run - m_new), e = expf(s - m_new);
+                l_run = l_run * alpha + e;
+#pragma unroll
+                for (int d = 0; d < DHM; ++d) o[d] = fmaf(e, Vs[kk][d], o[d] * alpha);
+                m_run = m_new;
+            }
+        }
+        __syncthreads();
+    }
+    if (active) {
+        const float inv = 1.f / l_run;
+        float* op = reinterpret_cast<float*>(p.out) + (size_t)(b * L + ego) * P * C + (size_t)(qrow * W + qcol) * C + ch0;
+#pragma unroll
+        for (int d = 0; d < DHM; ++d)
+            if (d < DH) op[d] = o[d] * inv;
+        if (p.lse) p.lse[((size_t)(b * L + ego) * P + qrow * W + qcol) * heads + head] = m_run + logf(l_run);
+    }
+}
+
+static int launch_attn_any(const AttnParams& p, hipStream_t st) {
+    const int N = p.window * p.window, DH = p.dim_head;
+    HMVIT_CHECK_ARG(N <= 256, "attention (generic): window=%d gives %d tokens per window (at most 256)", p.window, N);
+    HMVIT_CHECK_ARG(DH >= 1 && DH <= 64 && p.C % DH == 0, "attention (generic): dim_head=%d unsupported (1 .. 64, a divisor of C=%d)", DH, p.C);
+    const int threads = N <= 64 ? 64 : (N + 63) / 64 * 64;
+    dim3 grid((p.H / p.window) * (p.W / p.window) * (p.C / DH), p.n_ego, p.B);
+    if (DH <= 16) hipLaunchKernelGGL(k_attention_any<16>, grid, dim3(threads), 0, st, p);
+    else if (DH <= 32) hipLaunchKernelGGL(k_attention_any<32>, grid, dim3(threads), 0, st, p);
+    else hipLaunchKernelGGL(k_attention_any<64>, grid, dim3(threads), 0, st, p);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // Which (ego, window, source) tiles have any visible key?  One wave per window, lane = key: the same tap
 // arithmetic as the loader (make_taps' nearest-pixel ROI test x the agent-validity mask).  In the local stage of
 // cfg2 a third of the (ego, source != ego, window) tiles lie entirely outside the source's field of view; the
@@ -1939,12 +2081,19 @@ int launch_tile_vis(const AttnParams& p, unsigned* vis_mask, const unsigned char
 }
 
 int launch_attention(const AttnParams& p, int precision, hipStream_t st) {
-    HMVIT_CHECK_ARG(p.window == 4 || p.window == 8, "attention: window=%d unsupported (4 or 8)", p.window);
-    HMVIT_CHECK_ARG(p.C == 64 || p.C == 128 || p.C == 256, "attention: C=%d unsupported (64, 128, 256)", p.C);
-    HMVIT_CHECK_ARG(p.H % p.window == 0 && p.W % p.window == 0, "attention: %dx%d not divisible by window %d",
+    HMVIT_CHECK_ARG(p.window >= 1 && p.H % p.window == 0 && p.W % p.window == 0, "attention: %dx%d not divisible by window %d",
                     p.H, p.W, p.window);
     HMVIT_CHECK_ARG(p.B * p.L <= kMaxSlots, "attention: B*L=%d exceeds %d per launch", p.B * p.L, kMaxSlots);
     if (p.n_ego <= 0 || p.B <= 0) return HMVIT_OK;
+    const int dim_head = p.dim_head ? p.dim_head : 32;
+    if ((p.window != 4 && p.window != 8) || dim_head != 32) {
+        HMVIT_CHECK_ARG(precision == HMVIT_PREC_F32, "attention: window=%d / dim_head=%d run in the exact-f32 mode only (generic kernel)",
+                        p.window, dim_head);
+        AttnParams q = p;
+        q.dim_head = dim_head;
+        return launch_attn_any(q, st);
+    }
+    HMVIT_CHECK_ARG(p.C == 64 || p.C == 128 || p.C == 256, "attention: C=%d unsupported (64, 128, 256)", p.C);
     const bool w8 = p.window == 8;
     if (precision == HMVIT_PREC_SPLIT && w8 && p.C >= 128 && p.self_identity && p.n_src <= 8 &&
         p.B * p.L * p.L <= PcSharedS::MAX_PAIRS) {

@@ -34,10 +34,15 @@ int check_desc(const HmvitFusionDesc* d) {
     HMVIT_CHECK_ARG(d != nullptr, "desc is null");
     HMVIT_CHECK_ARG(d->B > 0 && d->L > 0 && d->L <= HMVIT_MAX_AGENTS, "B=%d L=%d out of range (L <= %d)", d->B,
                     d->L, HMVIT_MAX_AGENTS);
-    HMVIT_CHECK_ARG(d->dim_head == 32, "dim_head=%d unsupported (32)", d->dim_head);
-    HMVIT_CHECK_ARG(d->C == d->heads * d->dim_head, "C=%d != heads*dim_head=%d", d->C, d->heads * d->dim_head);
+    HMVIT_CHECK_ARG(d->dim_head >= 1 && d->C == d->heads * d->dim_head, "C=%d != heads*dim_head=%d*%d", d->C, d->heads, d->dim_head);
     HMVIT_CHECK_ARG(d->C == 64 || d->C == 128 || d->C == 256, "C=%d unsupported (64, 128, 256)", d->C);
-    HMVIT_CHECK_ARG(d->window == 4 || d->window == 8, "window_size=%d unsupported (4 or 8)", d->window);
+    // the tuned kernels serve window 4 / 8 with dim_head 32 (the shipped yamls); anything else the reference accepts runs on the
+    // generic exact-f32 attention kernel: inference, HMVIT_PREC_F32 only (bias_frag then carries the dense (heads, N, N) bias)
+    const bool generic_shape = (d->window != 4 && d->window != 8) || d->dim_head != 32;
+    HMVIT_CHECK_ARG(d->window >= 1 && d->window * d->window <= 256, "window_size=%d unsupported (window^2 <= 256)", d->window);
+    HMVIT_CHECK_ARG(!generic_shape || (d->precision == HMVIT_PREC_F32 && d->dim_head <= 64),
+                    "window_size=%d / dim_head=%d: generic shapes run with precision HMVIT_PREC_F32 and dim_head <= 64 only", d->window,
+                    d->dim_head);
     HMVIT_CHECK_ARG(d->H > 0 && d->W > 0 && d->H % d->window == 0 && d->W % d->window == 0,
                     "BEV %dx%d must be divisible by window_size %d", d->H, d->W, d->window);
     HMVIT_CHECK_ARG(d->mlp_dim > 0 && d->mlp_dim % 64 == 0, "mlp_dim=%d must be a multiple of 64", d->mlp_dim);
@@ -266,7 +271,7 @@ static int fusion_forward(const HmvitFusionDesc* d, hipStream_t st, PhaseTimer* 
                 ap.ainv = ainv; ap.out = ob;
                 ap.B = B; ap.L = L; ap.n_ego = n_ego; ap.n_src = n_src; ap.E = E; ap.C = C; ap.H = d->H; ap.W = d->W;
                 ap.window = d->window; ap.partition = s == 0 ? HMVIT_PART_WINDOW : HMVIT_PART_GRID;
-                ap.skip_masked = d->skip_masked;
+                ap.skip_masked = d->skip_masked; ap.dim_head = d->dim_head;
                 for (int i = 0; i < pl.n_slots; ++i) {
                     ap.mode[i] = (int8_t)d->mode[i];
                     ap.cav[i] = (int8_t)(d->cav_mask[i] != 0);

@@ -88,6 +88,8 @@ int make_train_plan(const HmvitFusionTrainDesc* t, TrainPlan& pl) {
     HMVIT_TRY(check_desc(d));
     HMVIT_CHECK_ARG(d->precision == HMVIT_PREC_F32, "training runs in the exact-f32 mode (precision=%d)", d->precision);
     HMVIT_CHECK_ARG(!d->parallel, "training: architect_mode 'parallel' is not built (the shipped yaml is sequential)");
+    HMVIT_CHECK_ARG((d->window == 4 || d->window == 8) && d->dim_head == 32, "training: window_size=%d / dim_head=%d (4 or 8, 32)", d->window,
+                    d->dim_head);
     pl.only_stage = t->only_stage >= 1 && t->only_stage <= 2 ? t->only_stage - 1 : -1;
     HMVIT_CHECK_ARG(t->only_stage >= 0 && t->only_stage <= 2, "only_stage=%d (0 = whole fusion, 1 = window stage, 2 = grid stage)", t->only_stage);
     HMVIT_CHECK_ARG(d->apply_head == (pl.only_stage < 0 ? 1 : 0), "training: HeteroFusion (apply_head = 1), or one stage of the block (apply_head = 0)");

@@ -203,7 +203,7 @@ struct AttnParams {
     const void* kv;           // (B, L, E, 2, P, C)
     const float* b_q;         // (T, C)
     const float* b_kv;        // (T_ego, T_src, 2C)
-    const float* bias_frag;   // (heads, NB, 64, 4)
+    const float* bias_frag;   // (heads, NB, 64, 4); generic shapes (window not 4 / 8, or dim_head != 32): dense (heads, N, N) bias, N = window^2
     const float* ainv;        // (B, L_src, L_ego, 8): sampling map of pairwise_t[b, src, ego]
     void* out;                // (B, L, P, C)
     int B, L, n_ego, n_src, E, C, H, W, window, partition, skip_masked;
@@ -218,6 +218,8 @@ struct AttnParams {
     int n_sched, sched_sub;   // sched_sub: steps per list segment (pc_fetch_sched)
     float k_logit;            // f32-plane kernels: logits formed from the planes * k_logit = natural units (HmvitStageScales;
                               // 0 is read as 1: descriptors that never heard of it)
+    int dim_head;             // channels per head (0 is read as 32); anything but 32, or a window other than 4 / 8, takes the generic
+                              // exact-f32 kernel k_attention_any (f32 planes only)
     int8_t mode[kMaxSlots];   // (B, L)
     int8_t cav[kMaxSlots];    // (B, L)
     int8_t ego_e[kMaxSlots];  // (B, L): K/V variant used by ego (b, i)

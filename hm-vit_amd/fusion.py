@@ -211,6 +211,14 @@ class _FusionBase(nn.Module):
                               f"precision {precision!r} falls back to the exact-f32 kernels", stacklevel=3)
                 self._warned_mlp = True
             precision = "f32"
+        if precision != "f32" and weights.generic_shape(blk["window_size"], blk["dim_head"]):
+            # the tuned kernels are built for window 4 / 8 and dim_head 32 (the shipped yamls); every other shape the reference accepts
+            # runs the generic exact-f32 attention kernel between the un-fused exact-f32 Linears - correct, far slower
+            if not getattr(self, "_warned_shape", False):
+                warnings.warn(f"hmvit_amd: window_size={blk['window_size']} / dim_head={blk['dim_head']}: precision {precision!r} falls "
+                              f"back to the generic exact-f32 kernels (tuned kernels: window 4 / 8, dim_head 32)", stacklevel=3)
+                self._warned_shape = True
+            precision = "f32"
         prec = _PRECISIONS[precision]
         x = x.detach().to(torch.float32).contiguous()
         pw = pairwise_t_matrix.detach().to(device=x.device, dtype=torch.float32).contiguous()

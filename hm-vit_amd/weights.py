@@ -43,6 +43,23 @@ def bias_fragments(table: torch.Tensor, window: int, keep_graph: bool = False) -
     return frag.permute(3, 0, 1, 2).contiguous()
 
 
+def bias_dense(table: torch.Tensor, window: int, keep_graph: bool = False) -> torch.Tensor:
+    """table ((2w-1)^2, heads) -> (heads, N, N) f32, N = w^2: bias[h][q][k] = table[(i_q - i_k + w - 1)(2w - 1) + (j_q - j_k + w - 1)][h]
+    (hetero_fusion.py:82-109, 227-233) - the layout of the generic attention kernel (any window, any dim_head: csrc/attn.hip
+    k_attention_any), where `bias_frag` of HmvitStageWeights carries this tensor instead of MFMA fragments."""
+    w = window
+    n = torch.arange(w * w)
+    i, j = n // w, n % w
+    idx = (i[:, None] - i[None, :] + w - 1) * (2 * w - 1) + (j[:, None] - j[None, :] + w - 1)       # (N, N) [q][k]
+    dense = (table if keep_graph else table.detach()).float()[idx.to(table.device)]                   # (N, N, heads)
+    return dense.permute(2, 0, 1).contiguous()
+
+
+def generic_shape(window: int, dim_head: int) -> bool:
+    """True for the shapes only the generic exact-f32 attention kernel serves (the tuned kernels: window 4 / 8, dim_head 32)."""
+    return window not in (4, 8) or dim_head != 32
+
+
 def store_row_order(r):
     """Channel (inside a 32-channel tile) computed by MFMA output row r of the projections whose results
     go to memory as f16 (img_q / img_kv).  An accumulator lane (token m, half hi) owns rows 8 j + 4 hi + i;
@@ -211,7 +228,12 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
             w_kv[te, ts, C:] = torch.einsum("hpq,hpc->hqc", rel_msg[e], wv).reshape(C, C)
             b_kv[te, ts, C:] = torch.einsum("hpq,hp->hq", rel_msg[e], bv).reshape(C)
     raw["w_kv"], raw["b_kv"] = w_kv, b_kv
-    raw["bias_frag"] = bias_fragments(sd[f"{att}.relative_position_bias_table.weight"], window, keep_graph) * (LOG2E if log2e else 1.0)
+    if generic_shape(window, dim_head):
+        if f16 or split or keep_graph:
+            raise ValueError(f"window_size={window} / dim_head={dim_head}: generic shapes run in the exact-f32 inference mode only")
+        raw["bias_frag"] = bias_dense(sd[f"{att}.relative_position_bias_table.weight"], window)
+    else:
+        raw["bias_frag"] = bias_fragments(sd[f"{att}.relative_position_bias_table.weight"], window, keep_graph) * (LOG2E if log2e else 1.0)
     raw["w_o"] = stack(f"{att}.a_linears.{{t}}.0.weight")
     raw["b_o"] = stack(f"{att}.a_linears.{{t}}.0.bias")
     raw["ffn_ln_gamma"] = stack(f"{prefix}{which}_ffd.norm.net.{{t}}.weight")

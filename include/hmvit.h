@@ -68,7 +68,9 @@ extern "C" {
  *                                     e = t_ego*2 + t_src  (hetero_fusion.py:154-185,221-223,263-264)
  *   b_kv      (T_ego, T_src, 2C) f32  the same maps applied to the k / v biases
  *   bias_frag (heads, NB, 64, 4) f32  relative-position bias in MFMA accumulator order,
- *                                     NB = 7 (window 8) or 1 (window 4), hetero_fusion.py:82-109,227-233
+ *                                     NB = 7 (window 8) or 1 (window 4), hetero_fusion.py:82-109,227-233.
+ *                                     Generic shapes (window not 4 / 8, up to 16; or dim_head != 32, up to 64; HMVIT_PREC_F32,
+ *                                     inference only): the dense bias (heads, N, N), N = window^2, [h][query][key]
  *   w_o, b_o  (T, C, C), (T, C)       a_linears[t][0], hetero_fusion.py:142-152
  *   ffn_ln_*  (T, C)            f32   {window,grid}_ffd.norm, base_transformer.py:129-136
  *   w_1,b_1   (T, mlp, C),(T, mlp)    {window,grid}_ffd.fn.net[t][0], base_transformer.py:180-192

@@ -421,3 +421,32 @@ def test_full_size_forward_is_bit_reproducible(precision):
         y0 = net(*scene).clone()
         for _ in range(7):
             assert torch.equal(net(*scene), y0)
+
+
+@pytest.mark.parametrize("C,dim_head,window,H,W,arch", [
+    (64, 16, 4, 16, 24, "sequential"),      # dim_head 16 on the tuned window
+    (128, 64, 8, 16, 32, "sequential"),     # dim_head 64
+    (64, 32, 2, 12, 20, "sequential"),      # window 2
+    (128, 32, 16, 32, 48, "sequential"),    # window 16: 256 tokens per window
+    (64, 8, 6, 24, 36, "parallel"),         # window 6, dim_head 8, parallel block
+])
+def test_fusion_generic_window_and_dim_head(C, dim_head, window, H, W, arch):
+    """Shapes outside the tuned kernels' window 4 / 8 and dim_head 32 (the reference takes both from the yaml,
+    hetero_fusion.py:187-277): the generic exact-f32 attention kernel (csrc/attn.hip k_attention_any) between the un-fused exact-f32
+    Linears, against the oracle; a module asked for another precision falls back to it with a warning; training raises."""
+    import warnings
+    cfg = O.make_config(C, window, 3, voxel=0.4, downsample=4, dim_head=dim_head, arch=arch)
+    sd = O.random_state_dict(cfg, seed=41)
+    scene = O.synthetic_scene(3, C, H, W, [1, 0, 1], n_valid=3, seed=42, tx_step=4.0, ty_step=-3.0, yaw_step=0.3)
+    ref = O.hetero_fusion(*scene, sd, cfg)
+    y = _fusion(cfg, sd, "f32")(*_cuda(*scene)).cpu()
+    assert rel_max_err(y, ref) < 2e-5
+    net = _fusion(cfg, sd, "split")
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        y2 = net(*_cuda(*scene)).cpu()
+    assert any("generic exact-f32" in str(w.message) for w in rec)
+    assert torch.equal(y2, y)
+    net.train()
+    with pytest.raises(ValueError, match="generic shapes"):
+        net(*_cuda(*scene))
