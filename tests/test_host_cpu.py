@@ -45,6 +45,16 @@ def test_descriptor_validation_without_gpu(pkg):
     d.window, d.H = 4, 18
     assert _lib.lib.hmvit_fusion_workspace_bytes(ctypes.byref(d)) == 0
     assert b"divisible" in _lib.lib.hmvit_last_error()
+    # generic shapes (window not 4 / 8, dim_head != 32) are served by the exact-f32 mode only
+    d.window, d.H, d.precision = 2, 16, _lib.PREC_F32
+    assert _lib.lib.hmvit_fusion_workspace_bytes(ctypes.byref(d)) > 0
+    d.heads, d.dim_head = 4, 16
+    assert _lib.lib.hmvit_fusion_workspace_bytes(ctypes.byref(d)) > 0
+    d.precision = _lib.PREC_SPLIT
+    assert _lib.lib.hmvit_fusion_workspace_bytes(ctypes.byref(d)) == 0
+    assert b"generic shapes" in _lib.lib.hmvit_last_error()
+    d.precision, d.window = _lib.PREC_F32, 17
+    assert _lib.lib.hmvit_fusion_workspace_bytes(ctypes.byref(d)) == 0
 
 
 def test_state_dict_names_match_reference(pkg):
@@ -126,6 +136,15 @@ def test_bias_fragments_layout(pkg):
                     for r in range(4):
                         q, k = qt * 16 + (lane & 15), kt * 16 + 4 * (lane >> 4) + r
                         assert torch.equal(frag[:, v, lane, r], full[:, q, k])
+
+
+def test_bias_dense_layout(pkg):
+    """The generic attention kernel's bias: (heads, N, N) [h][query][key] = the reference's table lookup (hetero_fusion.py:227-233)."""
+    from hmvit_amd import weights
+    for w in (2, 3, 6, 16):
+        table = torch.randn((2 * w - 1) ** 2, 5)
+        assert torch.equal(weights.bias_dense(table, w), table[O.relative_position_index(w)].permute(2, 0, 1))
+    assert weights.generic_shape(6, 32) and weights.generic_shape(8, 16) and not weights.generic_shape(8, 32) and not weights.generic_shape(4, 32)
 
 
 def test_voxelizer_oracle_properties():
