@@ -226,10 +226,13 @@ def test_fax_camera_encoder_training_matches_float64_autograd():
         gk = ".".join(k.split(".")[:3]) if k.startswith("fax.") else ".".join(k.split(".")[:2])
         groups.setdefault(gk, []).append(v)
     print("   per group (median):", {k: f"{sorted(v)[len(v) // 2]:.1e}" for k, v in groups.items()})
-    # (seen: every tensor 2-4e-3 from float64 - the signature of one flipped mask at the end of the branch, which reaches
-    # everything in front of it; a wrong term shows at 0.1-1 on the tensors behind it.  The FAX-specific pieces are held to
-    # tight bounds one by one in test_fax_training_layers_match_float64.)
-    assert total < 8e-3 and vals[len(vals) // 2] < 8e-3 and vals[-1] < 5e-2, (total, top)
+    # Seen over repeated runs (tools/probe/r03_flaky.sh): every tensor 2.4e-3, 4.2-4.8e-3 or 5.5e-3 from float64 - one, two, ... flipped
+    # ReLU masks near the end of the branch (the final map alone holds 11 activations within 1e-5 of zero and disagrees with the
+    # float64 forward on 0-1 of its 524 288 masks per run: tools/probe/r03_fax_flips.py); one unit of one channel of the last
+    # BatchNorm moves that layer's weight gradient by ~1 / sqrt(2048 x 256) ~ 1.4e-3 and everything in front of it likewise.  A
+    # wrong term shows at 0.1-1 on the tensors behind it; the FAX-specific pieces are held to tight bounds one by one in
+    # test_fax_training_layers_match_float64, the forward output to 1e-4 above (measured 6.5e-6).
+    assert total < 2e-2 and vals[len(vals) // 2] < 2e-2 and vals[-1] < 5e-2, (total, top)
     for name, buf in net.named_buffers():
         if "running_" in name:
             assert rel_max_err(buf.cpu(), ref_sd[name]) < 1e-4, name
