@@ -1848,21 +1848,22 @@ __global__ __launch_bounds__(256) void k_attention_any(AttnParams p) {
             const float* kpl = kvplanes + ((size_t)((b * L + src) * p.E + ev) * 2) * P * C + ch0;
             const float* bk = p.b_kv + (size_t)(te * HMVIT_NUM_TYPES + ts) * 2 * C + ch0;
             for (int d = tid / ANY_KC; d < DHM; d += nthr / ANY_KC) {     // channels DH .. DHM - 1 are zero padding
+                // (no divergent region around the tap loads: an invisible key, or a padding channel, loads pixel 0 / channel 0 and the
+                // result is selected afterwards - see k_attention_bwd in train.hip for what a divergent gather did at two workgroups per CU)
                 float kvv[2] = {0.f, 0.f};
-                if (visible && d < DH) {
+                const bool live = visible && d < DH;
+                const int dd = d < DH ? d : 0;
 #pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) {
-                        const float* plane = kpl + (size_t)pl * P * C + d;
-                        float acc;
-                        if (ident) {
-                            acc = plane[(size_t)self_idx * C];
-                        } else {
-                            acc = t.w[0] * plane[(size_t)t.idx[0] * C];
+                for (int pl = 0; pl < 2; ++pl) {
+                    const float* plane = kpl + (size_t)pl * P * C + dd;
+                    const int i0 = live ? (ident ? self_idx : t.idx[0]) : 0;
+                    float acc = (ident ? 1.f : t.w[0]) * plane[(size_t)i0 * C];
 #pragma unroll
-                            for (int k = 1; k < 4; ++k) acc = fmaf(t.w[k], plane[(size_t)t.idx[k] * C], acc);
-                        }
-                        kvv[pl] = acc + bk[pl * C + d];
+                    for (int k = 1; k < 4; ++k) {
+                        const int ik = (live && !ident) ? t.idx[k] : 0;
+                        acc = fmaf((live && !ident) ? t.w[k] : 0.f, plane[(size_t)ik * C], acc);
                     }
+                    kvv[pl] = live ? acc + bk[pl * C + dd] : 0.f;
                 }
                 Ks[kk][d] = kvv[0];
                 Vs[kk][d] = kvv[1];

@@ -270,7 +270,7 @@ struct AttnBwdParams {
     float* dkg;               // (B, n_ego, n_src, 2, P, C): gradient of the gathered K / V keys of every (ego, source) pair,
                               // indexed by EGO pixel; every key row of every pair is written (zeros where nothing is visible)
     float* d_bias_frag;       // (heads, NB, 64, 4) accumulated into
-    int probe;                // probe builds (HMVIT_BWD_PROBE): 1 = skip the products, 2 = skip the tap loads, 3 = skip the prologue's dot products
+    int probe;                // probe builds (HMVIT_BWD_PROBE): 1 = skip the products, 3 = skip the prologue's dot products
 };
 int launch_attention_bwd(const AttnBwdParams& p, hipStream_t st);
 // adjoint of the bilinear key gather: dkv[(b, src), e, plane, s, :] = sum over egos of variant e and ego pixels u whose taps

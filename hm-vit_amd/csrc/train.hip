@@ -597,14 +597,14 @@ int launch_layernorm_bwd(const float* x, const float* dy, const float* gamma, co
 // Two wavefronts per head: each takes two of the four 16-key tiles of a chunk (its dK / dV tiles are complete, its dQ is a partial
 // sum over its keys and meets the other wave's in LDS once at the end).  With one wave per head a workgroup had two waves and a
 // CU four - one per SIMD, so the gather of a chunk and its products never overlapped.
-// (No minimum-occupancy argument in the launch bounds.  With `__launch_bounds__(HG * 128, 2)` hipcc 7.2 held the window-8 instance
-// to 256 registers by spilling 8 of them to scratch, and that build was NOT deterministic: with masked keys in the scene, about
-// one backward pass in three differed from the next in a few dq / dK' rows (parameter gradients off by 1e-3 ... 1e-2, found by
-// tests/test_hip_train.py::test_backward_matches_oracle_autograd_five_agents_64x176; tools/probe/r03_grad_bisect.sh).  Without
-// the bound the same code takes 240 registers, no scratch, still two wavefronts per SIMD, and is bit-reproducible.)
-// (Measured: the bounded, spilling build runs a launch in 6.6 ms at cfg2, this one in 8.3 ms - hipcc schedules for one wavefront per
-// SIMD when no occupancy is promised - and every attempt to get under 256 registers with the bound in place (fewer bias
-// accumulators, later operand loads) still left 28-96 bytes of scratch.  Correct first: tools/probe/r03_bwd_ab.sh.)
+// Occupancy (round 3).  Left to itself hipcc allocated this kernel 256 VGPRs + 96 AGPRs - ONE wavefront per SIMD, four per CU - and
+// with `__launch_bounds__(.., 2)` it spilled.  The registers were not operands: (i) every token's store address, precomputed
+// outside the chunk loop and kept alive (cured by taking the lane coordinates through an opaque asm copy where the addresses are
+// formed); (ii) the fragments of all four query tiles of both orientations at once, the Q / dO tiles being loop-invariant (cured by
+// two passes over the query tiles, each tile pair behind a compiler fence).  Now 254 VGPRs, no AGPRs, no scratch: two wavefronts per
+// SIMD = two workgroups per CU, 7.3 -> 5.3 ms per launch at cfg2.  Two workgroups per CU also exposed the divergent gather (below).
+// (History: an earlier `(.., 2)` build that spilled 8 VGPRs was not reproducible from run to run - tools/probe/r03_grad_bisect.sh -
+// which was blamed on the spills; it was the same divergent gather.)
 #ifdef HMVIT_PROBE
 // cycle stamps of one workgroup (lane 0 of every wave): [wave][0 start, 1 prologue done, 2 + 3 c gather issued+staged, 3 + 3 c gather
 // barrier passed, 4 + 3 c products + stores done, ..., 30 dq stored]; hmvit_debug_bwd_trace (tools/probe/bwd_trace.py)
@@ -623,7 +623,7 @@ int debug_bwd_trace(unsigned long long* host, int n) {
 #endif
 
 template <int WIN, int HG>
-__global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
+__global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp) {
     const AttnParams& p = bp.f;
     constexpr int N = WIN * WIN, NQT = N / 16, SPC = 64 / N, NB = (WIN == 8) ? 7 : 1;
     constexpr int CH = HG * 32, QS = CH + 8, KS = CH + 8;             // halves per LDS row (16-byte aligned, conflict-free b128 reads)
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
     __shared__ __attribute__((aligned(16))) half_t KVs[4 * 64 * KS];
     half_t *Kh = KVs, *Kl = KVs + 64 * KS, *Vh = KVs + 2 * 64 * KS, *Vl = KVs + 3 * 64 * KS;
     static_assert(sizeof(KVs) >= (size_t)HG * NQT * 2 * 64 * 16, "the dQ exchange at the end reuses the key / value tiles");
-    __shared__ float maskadd[64];
+    __shared__ __attribute__((aligned(16))) float maskadd[64];
     __shared__ float Dl[N][HG], Lse[N][HG];
 
     const int C = p.C, H = p.H, W = p.W, L = p.L, P = H * W;
@@ -718,10 +718,12 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
         // ---- gather 64 keys x CH channels of K and V (as the forward does) ----
         int any_visible = 0;
         {
-            const int cl = (tid % TPK) * 8;
+            int tid_o = tid;
+            asm volatile("" : "+v"(tid_o));
+            const int cl = (tid_o % TPK) * 8;
 #pragma unroll 1
             for (int pass = 0; pass < 64 / KPP; ++pass) {
-                const int kk = pass * KPP + tid / TPK;
+                const int kk = pass * KPP + tid_o / TPK;
                 const int src = chunk * SPC + kk / N;
                 const int n = kk % N;
                 float kvv[2][8];
@@ -742,26 +744,33 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
                         t = make_taps(a, col, row, H, W);
                     }
                     visible = (t.roi != 0.f) && (p.cav[b * L + src] != 0);
-#ifdef HMVIT_PROBE
-                    if (visible && bp.probe == 2) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) kvv[0][e] = kvv[1][e] = 0.01f * (float)(e + cl);
-                    } else
-#endif
-                    if (visible) {
+                    if (__any(visible)) {     // wave-uniform: a wave none of whose keys is visible loads nothing
+                        // Every lane loads (pixel 0 where the key is invisible) and the result is selected afterwards: NO divergent region.
+                        // With `if (visible) { loads }` the kernel was not reproducible at two workgroups per CU - one backward pass in
+                        // two differed in keys at the edge of a source's field of view, where visibility differs between the lanes of a
+                        // wave (tools/probe/bwd_repro.py, r03_bwd_occ.sh; the same source at one workgroup per CU was reproducible).
                         const int ts = p.mode[b * L + src];
                         const float* kpl = kvplanes + ((size_t)((b * L + src) * p.E + ev) * 2) * P * C + ch0 + cl;
                         const float* bk = p.b_kv + (size_t)(te * HMVIT_NUM_TYPES + ts) * 2 * C + ch0 + cl;
+                        int ix[4];
 #pragma unroll
-                        for (int pl = 0; pl < 2; ++pl)
+                        for (int k = 0; k < 4; ++k) ix[k] = visible ? t.idx[k] : 0;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                float acc = 0.f;
+                        for (int pl = 0; pl < 2; ++pl) {
+                            float acc[8];
 #pragma unroll
-                                for (int k = 0; k < 4; ++k)
-                                    acc = fmaf(t.w[k], kpl[(size_t)pl * P * C + (size_t)t.idx[k] * C + e], acc);
-                                kvv[pl][e] = acc + bk[pl * C + e];
+                            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float4* s4 = reinterpret_cast<const float4*>(kpl + (size_t)pl * P * C + (size_t)ix[k] * C);
+                                const float4 r0 = s4[0], r1 = s4[1];
+                                const float wk = t.w[k];
+                                acc[0] = fmaf(wk, r0.x, acc[0]); acc[1] = fmaf(wk, r0.y, acc[1]); acc[2] = fmaf(wk, r0.z, acc[2]); acc[3] = fmaf(wk, r0.w, acc[3]);
+                                acc[4] = fmaf(wk, r1.x, acc[4]); acc[5] = fmaf(wk, r1.y, acc[5]); acc[6] = fmaf(wk, r1.z, acc[6]); acc[7] = fmaf(wk, r1.w, acc[7]);
                             }
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) kvv[pl][e] = visible ? acc[e] + bk[pl * C + e] : 0.f;
+                        }
                     }
                 }
                 half8 kh_, kl_, vh_, vl_;
@@ -825,6 +834,7 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
 
 #pragma unroll
                 for (int qt = 0; qt < NQT; ++qt) {
+                    asm volatile("" ::: "memory");
                     const half8 qh = *reinterpret_cast<const half8*>(Qh + (qt * 16 + lq) * QS + hoff + 8 * g);
                     const half8 ql = *reinterpret_cast<const half8*>(Ql + (qt * 16 + lq) * QS + hoff + 8 * g);
                     const half8 doh = *reinterpret_cast<const half8*>(dOh + (qt * 16 + lq) * QS + hoff + 8 * g);
@@ -854,6 +864,16 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
                             dq_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(kdh[dt], dsh, dq_acc[qt][dt], 0, 0, 0);
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int qt = 0; qt < NQT; ++qt) {
+                    asm volatile("" ::: "memory");
+                    const half8 qh = *reinterpret_cast<const half8*>(Qh + (qt * 16 + lq) * QS + hoff + 8 * g);
+                    const half8 ql = *reinterpret_cast<const half8*>(Ql + (qt * 16 + lq) * QS + hoff + 8 * g);
+                    const half8 doh = *reinterpret_cast<const half8*>(dOh + (qt * 16 + lq) * QS + hoff + 8 * g);
+                    const half8 dol = *reinterpret_cast<const half8*>(dOl + (qt * 16 + lq) * QS + hoff + 8 * g);
+                    const int bvN = (WIN == 8) ? (kt - qt + 3) : 0;
                     // ---- N orientation: rows = queries 4g + r, column = key lq ----
                     float4v sN = *reinterpret_cast<const float4v*>(biasN_g + bvN * 256), dpN = (float4v)(0.f);
                     sN = __builtin_amdgcn_mfma_f32_16x16x32_f16(ql, kh, sN, 0, 0, 0);
@@ -884,17 +904,20 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
                             dk_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(sh, qh4, dk_acc[dt], 0, 0, 0);
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 // ---- store: lane holds keys kt*16 + 4g + r, channel head*32 + dt*16 + lq ----
+                int g_o = g, lq_o = lq;
+                asm volatile("" : "+v"(g_o), "+v"(lq_o));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int kk = kt * 16 + 4 * g + r;
+                    const int kk = kt * 16 + 4 * g_o + r;
                     const int src = chunk * SPC + kk / N, n = kk % N;
                     if (src < p.n_src) {
                         int row, col;
                         token_pixel(p.partition, WIN, X, Y, wx, wy, n, row, col);
                         float* dst = bp.dkg + (((size_t)(b * p.n_ego + ego) * p.n_src + src) * 2) * P * C +
-                                     (size_t)(row * W + col) * C + head * 32 + lq;
+                                     (size_t)(row * W + col) * C + head * 32 + lq_o;
 #pragma unroll
                         for (int dt = 0; dt < 2; ++dt) {
                             dst[dt * 16] = dk_acc[dt][r];
@@ -913,17 +936,19 @@ __global__ __launch_bounds__(HG * 128) void k_attention_bwd(AttnBwdParams bp) {
         } else {
             // a chunk without a visible key: its gathered-key gradients are zero.  Written here so that the caller does not have
             // to clear the whole (ego, source) gradient buffer first (7 GB per stage at cfg2)
+            int g_o = g, lq_o = lq;
+            asm volatile("" : "+v"(g_o), "+v"(lq_o));
 #pragma unroll
             for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int kk = (2 * khalf + kt2) * 16 + 4 * g + r;
+                    const int kk = (2 * khalf + kt2) * 16 + 4 * g_o + r;
                     const int src = chunk * SPC + kk / N, n = kk % N;
                     if (src < p.n_src) {
                         int row, col;
                         token_pixel(p.partition, WIN, X, Y, wx, wy, n, row, col);
                         float* dst = bp.dkg + (((size_t)(b * p.n_ego + ego) * p.n_src + src) * 2) * P * C +
-                                     (size_t)(row * W + col) * C + head * 32 + lq;
+                                     (size_t)(row * W + col) * C + head * 32 + lq_o;
 #pragma unroll
                         for (int dt = 0; dt < 2; ++dt) {
                             dst[dt * 16] = 0.f;
