@@ -278,3 +278,25 @@ def test_split_range_normalisation_is_exact_algebra(pkg, wscale):
         assert float((y - ys).abs().max()) <= 1e-12 * float(y.abs().max())
     bias_ratio = s["bias_frag"] / raw["bias_frag"]
     assert float((bias_ratio * sc["k_logit"] - 1).abs().max()) == 0.0
+
+
+def test_grad_pow2_is_an_exact_rescaling(pkg):
+    """_lib.grad_pow2 (every backward function whose products run on split-f16 operands calls it): the gradient times a power of two
+    that brings its largest magnitude into [2^9, 2^10), and the factor that undoes it - exact for any magnitude, identity for zeros
+    and non-finite input."""
+    from hmvit_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    for scale in (1.0, 1e-7, 3e-5, 4e4, 2.0 ** -60, 2.0 ** 40):
+        dy = torch.randn(7, 33, generator=g) * scale
+        s, un = _lib.grad_pow2(dy)
+        m = float(s.abs().max())
+        assert 2.0 ** 9 <= m < 2.0 ** 10, (scale, m)
+        assert torch.equal(s * un, dy)                       # power of two: no rounding in either direction
+        k = float(torch.log2(un))
+        assert k == round(k)
+    z = torch.zeros(4, 4)
+    s, un = _lib.grad_pow2(z)
+    assert torch.equal(s, z) and float(un) == 1.0
+    bad = torch.tensor([1.0, float("inf")])
+    s, un = _lib.grad_pow2(bad)
+    assert float(un) == 1.0 and torch.equal(s, bad)
