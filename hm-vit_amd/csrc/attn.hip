@@ -230,17 +230,30 @@ __global__ __launch_bounds__(HG * 64, (sizeof(T) == 2 ? 2 : 1)) void k_attention
                     const float* a = p.ainv + ((size_t)(b * L + src) * L + ego) * 8;
                     const bool ident = a[6] != 0.f;
                     Taps t;
-                    if (ident) {
+                    if (ident) {                       // the key's own pixel with weight 1: the same four-tap arithmetic gives it back exactly
                         t.roi = 1.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { t.idx[k] = row * W + col; t.w[k] = k == 0 ? 1.f : 0.f; }
                     } else {
                         t = make_taps(a, col, row, H, W);
                     }
                     visible = (t.roi != 0.f) && (p.cav[b * L + src] != 0);
-                    if (visible) {
+                    // No divergent region around the tap loads (train.hip k_attention_bwd: a gather behind `if (visible)` was not
+                    // reproducible at two workgroups per CU): a wave without a visible key skips, which is wave-uniform; otherwise every
+                    // lane loads - pixel 0 where its key is invisible - and the result is selected afterwards.
+                    if (__any(visible)) {
                         const int ts = p.mode[b * L + src];
                         const T* kpl = kvplanes + ((size_t)((b * L + src) * p.E + ev) * 2) * P * C + ch0;
                         const float* bk = p.b_kv + (size_t)(te * HMVIT_NUM_TYPES + ts) * 2 * C + ch0;
-                        sample8<T, 2>(kpl, (size_t)P * C, C, cl, t, ident, row * W + col, bk, C, kvv);
+                        if (!visible) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) t.idx[k] = 0;
+                        }
+                        sample8<T, 2>(kpl, (size_t)P * C, C, cl, t, false, 0, bk, C, kvv);
+                        if (!visible) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) kvv[0][e] = kvv[1][e] = 0.f;
+                        }
                     }
                 }
                 store8_lds<T>(Ks + kk * KS + cl, kvv[0]);
