@@ -206,16 +206,36 @@ def conv_range(x, w_absmax: float, y, stream, share_out: bool = False):
     """Before an HMVIT_PREC_SPLIT convolution x -> y: hand the library max |x| (the slot the producer of `x` left on the tensor,
     or one measured here, once per tensor), max |w| (host value from weight preparation) and a fresh slot for max |y|, which
     `y` then carries to its consumers.  share_out: several launches write `y` (channel windows of a concatenation)."""
-    xs = getattr(x, "_hmvit_absmax", None)
+    xs = range_of(x)
     if xs is None:
         xs = _range_slot(x.device)
         check(lib.hmvit_absmax(x.data_ptr(), x.numel(), xs.data_ptr(), stream), "hmvit_absmax")
-        x._hmvit_absmax = xs
-    ys = getattr(y, "_hmvit_absmax", None) if share_out else None
+        set_range(x, xs)
+    ys = range_of(y) if share_out else None
     if ys is None:
         ys = _range_slot(y.device)
-        y._hmvit_absmax = ys
+        set_range(y, ys)
     check(lib.hmvit_conv_range(xs.data_ptr(), float(w_absmax), ys.data_ptr()), "hmvit_conv_range")
+
+
+def set_range(t, slot):
+    """Attach an absmax slot to a tensor, stamped with the tensor's storage address: a bound is only as good as the bytes it was
+    measured on.  (The library's own kernels write `t` through raw pointers, which torch's version counter does not see, so the
+    stamp is re-taken by whoever writes: conv_range for an output, the stand-alone absmax pass for an input.)"""
+    t._hmvit_absmax = (slot, t.data_ptr(), t._version)
+
+
+def range_of(t):
+    """The slot attached to `t`, or None when there is none or the tensor was modified in place by torch / re-pointed since
+    (a stale bound would overflow f16 or drop the low halves of a split convolution silently)."""
+    r = getattr(t, "_hmvit_absmax", None)
+    if r is None:
+        return None
+    slot, ptr, version = r
+    if ptr != t.data_ptr() or version != t._version:
+        t._hmvit_absmax = None
+        return None
+    return slot
 
 
 def prescale_weights(w):
@@ -232,6 +252,6 @@ def prescale_weights(w):
 
 def inherit_range(dst, src):
     """`dst` holds a subset / copies of the values of `src` (max pooling of a non-negative map, a view): the same bound applies."""
-    r = getattr(src, "_hmvit_absmax", None)
+    r = range_of(src)
     if r is not None:
-        dst._hmvit_absmax = r
+        set_range(dst, r)

@@ -249,7 +249,10 @@ __global__ __launch_bounds__(HG * 64, (sizeof(T) == 2 ? 2 : 1)) void k_attention
 #pragma unroll
                             for (int k = 0; k < 4; ++k) t.idx[k] = 0;
                         }
-                        sample8<T, 2>(kpl, (size_t)P * C, C, cl, t, false, 0, bk, C, kvv);
+                        // identity source for every lane of the wave (wave-uniform): one direct read per plane instead of four
+                        // loads of the same pixel; mixed waves (window 4: several sources per chunk) take the tap path
+                        const bool wave_ident = __all(ident);
+                        sample8<T, 2>(kpl, (size_t)P * C, C, cl, t, wave_ident, t.idx[0], bk, C, kvv);
                         if (!visible) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) kvv[0][e] = kvv[1][e] = 0.f;
@@ -1404,8 +1407,13 @@ __device__ __forceinline__ void pcs_loader_loop(const AttnParams& p, PcSharedS& 
         const int ixa[4] = {ix.x, ix.y, ix.z, ix.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+#ifdef HMVIT_EXP_PCS_NOLOAD
+            R[pass][0][k] = tok_load4f(G.rs_kv, -1 - (ixa[k] & 1), cl_bytes, 0);
+            R[pass][1][k] = tok_load4f(G.rs_kv, -1 - (ixa[k] & 1), cl_bytes, plane_bytes);
+#else
             R[pass][0][k] = tok_load4f(G.rs_kv, G.valid ? ixa[k] : -1, cl_bytes, 0);
             R[pass][1][k] = tok_load4f(G.rs_kv, G.valid ? ixa[k] : -1, cl_bytes, plane_bytes);
+#endif
         }
     };
     // identity half chunk: the ego's own rows; the first half also brings the whole 64-row query tile
@@ -1633,7 +1641,11 @@ __device__ __forceinline__ void pcs_compute_loop(const AttnParams& p, PcSharedS&
             }
             const bool any_visible = (vis_or & 1) != 0;
             const bool all_visible = (vis_and & 2) != 0;
+#ifdef HMVIT_EXP_PCS_NOMATH
+            if (false) {
+#else
             if (any_visible || !p.skip_masked) {
+#endif
                 float4v madd[2];
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) madd[kt] = (float4v)(0.f);

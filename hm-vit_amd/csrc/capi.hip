@@ -553,7 +553,8 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
     const int* sched = nullptr;
     int sched_sub = 2;
     if (const char* e = HMVIT_ENV("HMVIT_SCHED_SUB")) sched_sub = atoi(e);
-    if (d->window == 8 && C > 64 && pl.max_cav > 1 && pl.max_cav <= 8 && d->skip_masked && sched_sub > 0 && d->H % 8 == 0 && d->W % 8 == 0) {
+    if (d->window == 8 && C > 64 && pl.max_cav > 1 && pl.max_cav <= 8 && d->skip_masked && sched_sub > 0 && d->H % 8 == 0 && d->W % 8 == 0 &&
+        B <= 128 && d->H / 8 <= 1024 && d->W / 8 <= 1024) {   // the packed item word's field widths (launch_attn_schedule); larger scenes keep the tile order
         AttnParams ap;
         memset(&ap, 0, sizeof(ap));
         ap.ainv = ainv; ap.B = B; ap.L = L; ap.n_ego = pl.max_cav; ap.H = d->H; ap.W = d->W;
@@ -898,10 +899,10 @@ int hmvit_absmax(const float* x, size_t n, void* slot, void* stream) {
 int hmvit_conv2d(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int Cin, int Cout,
                  int ksize, int stride, int pad, int relu, int y_ctot, int y_coff, int deconv_stride, int out_f32,
                  int precision, void* stream) {
-    HMVIT_CHECK_ARG(x && w && y, "conv2d: null pointer");
     ConvParams p;
     memset(&p, 0, sizeof(p));
-    take_conv_range(p);
+    take_conv_range(p);   // first: an early return must not leave the range of this call to the next one
+    HMVIT_CHECK_ARG(x && w && y, "conv2d: null pointer");
     p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = p.KW = ksize; p.stride = stride; p.pad = pad;
     p.relu = relu; p.y_ctot = y_ctot; p.y_coff = y_coff; p.deconv_s = deconv_stride; p.out_f32 = out_f32;
@@ -919,12 +920,12 @@ int hmvit_conv2d(const void* x, const void* w, const float* bias, void* y, int N
 /* Conv2d + folded BatchNorm with the two extras a ResNet / the up-sampling decoder need. */
 int hmvit_conv2d_ex(const void* x, const void* w, const float* bias, const void* residual, void* y, int N, int H, int W, int Cin,
                     int Cout, int ksize, int stride, int pad, int relu, int upsample2, int out_f32, int precision, void* stream) {
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    take_conv_range(p);   // first: an early return must not leave the range of this call to the next one
     HMVIT_CHECK_ARG(x && w && y, "conv2d_ex: null pointer");
     HMVIT_CHECK_ARG(!(upsample2 & 1) || (H % 2 == 0 && W % 2 == 0), "conv2d_ex: upsampled size %dx%d must be even", H, W);
     HMVIT_CHECK_ARG(!(residual && out_f32 && precision == HMVIT_PREC_F16), "conv2d_ex: residual needs the precision's element type");
-    ConvParams p;
-    memset(&p, 0, sizeof(p));
-    take_conv_range(p);
     p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = p.KW = ksize; p.stride = stride; p.pad = pad;
     p.relu = relu; p.y_ctot = Cout; p.y_coff = 0; p.deconv_s = 0; p.out_f32 = out_f32;
@@ -936,10 +937,10 @@ int hmvit_conv2d_ex(const void* x, const void* w, const float* bias, const void*
 
 int hmvit_conv2d_rowpack(const void* x, const void* w, const float* bias, void* y, int N, int Hp, int Wp, int Ho, int Wo, int Cout,
                          int krows, int stride, int relu, int precision, void* stream) {
-    HMVIT_CHECK_ARG(x && w && y && N > 0 && Ho > 0 && Wo > 0 && Cout > 0 && krows > 0 && stride > 0, "conv2d_rowpack: bad argument");
     ConvParams p;
     memset(&p, 0, sizeof(p));
-    take_conv_range(p);
+    take_conv_range(p);   // first: an early return must not leave the range of this call to the next one
+    HMVIT_CHECK_ARG(x && w && y && N > 0 && Ho > 0 && Wo > 0 && Cout > 0 && krows > 0 && stride > 0, "conv2d_rowpack: bad argument");
     p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.N = N; p.H = Hp; p.W = Wp; p.Cin = 4; p.Cout = Cout; p.KH = krows; p.KW = 8; p.stride = stride; p.pad = 0;
     p.relu = relu; p.y_ctot = Cout; p.y_coff = 0; p.Ho = Ho; p.Wo = Wo; p.rowpack = 1;

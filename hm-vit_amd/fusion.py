@@ -361,8 +361,8 @@ class HeteroFusion(_FusionBase):
         # eval mode, grad mode on, input off the tape.  The reference would still record a graph here whenever a parameter
         # requires grad (their default state), e.g. an eval-mode fine-tune behind a frozen encoder; this module treats the call
         # as inference (the fused launch, no 40 GB of saved activations) and says so once
-        if not _FusionBase._warned_eval_grad and any(p.requires_grad for p in self.parameters()):
-            _FusionBase._warned_eval_grad = True
+        if not self.__dict__.get("_warned_eval_grad", False) and any(p.requires_grad for p in self.parameters()):
+            self._warned_eval_grad = True          # per instance: every module that drops a backward pass says so once
             warnings.warn("hmvit_amd.HeteroFusion: eval-mode call with grad mode on and an input that does not require grad runs as "
                           "INFERENCE (no autograd graph, parameters get no gradient).  Wrap inference in torch.no_grad() to "
                           "silence this; set `module.force_autograd = True` (or train(), or x.requires_grad_()) to record the "

@@ -76,20 +76,46 @@ def test_fusion_g6_cfg1_full_size(precision):
     assert float((y.double().mean((0, 2, 3)) - g["chan_mean"]).abs().max()) / scale < TOL[precision]
 
 
-def _check_full_size(g, y, tol):
+def full_size_report(g, y):
+    """Error statistics of a full-size output against a full-size golden (25 x 44 sub-grid of every channel + rows 0 / 199):
+    rel-max, rms-relative and the 99.9-percentile of the element-wise relative error |d| / max(|ref|, 1e-3 rms ref) -
+    the last one is what bounds small-magnitude outputs, which a max-norm cannot see."""
+    ref = torch.cat([g["out_sub"].flatten(), g["out_rows"].flatten()]).double()
+    got = torch.cat([y[:, :, 3::8, 5::16].flatten(), y[:, :, [0, 199], :].flatten()]).double()
+    d = (got - ref).abs()
+    rms = ref.pow(2).mean().sqrt()
+    elem = d / ref.abs().clamp_min(1e-3 * rms)
+    k = max(1, int(round(0.999 * elem.numel())))
+    return dict(rel_max=float(d.max() / float(g["abs_max"])), rms_rel=float(d.pow(2).mean().sqrt() / rms),
+                p999=float(elem.kthvalue(k).values))
+
+
+# 99.9-percentile of the element-wise relative error |d| / max(|ref|, 1e-3 rms): the fp32-class modes are held to 1e-3 (the
+# reference's own fp32 run sits at 2-3e-4 of float64 by this measure: an output 1000 x below the rms of its map carries the
+# absolute round-off of its neighbours); `mixed` and `f16` round attention operands / everything to f16 and are what they are
+# by this measure (measured 2e-3 / 0.25) - they are the side modes, bounded here so that a regression shows
+P999 = {"f32": 1e-3, "split": 1e-3, "mixed": 5e-3, "f16": 0.5}
+
+
+def _check_full_size(g, y, tol, tag="", p999=None):
     scale = float(g["abs_max"])
+    e = full_size_report(g, y)
+    print(f"\nfull-size[{tag}] rel-max {e['rel_max']:.2e} rms-rel {e['rms_rel']:.2e} p99.9 {e['p999']:.2e}")
     assert float((y[:, :, 3::8, 5::16] - g["out_sub"]).abs().max()) / scale < tol
     assert float((y[:, :, [0, 199], :] - g["out_rows"]).abs().max()) / scale < tol
+    assert e["rms_rel"] < tol                   # rms-relative at the same bound as the max norm
+    assert e["p999"] < (10 * tol if p999 is None else p999)
     y64 = y.double()
     assert float((y64.mean((0, 2, 3)) - g["chan_mean"]).abs().max()) / scale < tol
     assert float(((y64 * y64).mean((0, 2, 3)) - g["chan_sqmean"]).abs().max() / g["chan_sqmean"].max()) < 2 * tol
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-@pytest.mark.parametrize("name", ["g12_fusion_cfg2.npz", "g13_fusion_cfg3.npz"])
+@pytest.mark.parametrize("name", ["g12_fusion_cfg2.npz", "g13_fusion_cfg3.npz", "g18_fusion_cfg4.npz"])
 def test_fusion_full_size_goldens(precision, name):
-    """BASELINE configs[1] / configs[2] at the HEADLINE size (5 agents, 200x704, C=256, window 8, 0.4 m/px): the
-    reference's own forward (tests/golden/make_goldens.py g12 / g13), sub-sampled + two full rows + channel moments.
+    """BASELINE configs[1] / configs[2] / configs[3] (type patterns 11111 / 10110 / 00000) at the HEADLINE size (5 agents,
+    200x704, C=256, window 8, 0.4 m/px): the reference's own forward (tests/golden/make_goldens.py g12 / g13 / g18),
+    sub-sampled + two full rows + channel moments.
     This is the only place the persistent schedule, the reachability tables and the 32-bit plane offsets are checked
     at the size bench.py runs."""
     g = load_golden(name)
@@ -97,7 +123,7 @@ def test_fusion_full_size_goldens(precision, name):
     net = _fusion(g["cfg"], sd, precision)
     scene = _cuda(*O.synthetic_scene(**g["scene"]))
     y = net(*scene).cpu()
-    _check_full_size(g, y, TOL[precision])
+    _check_full_size(g, y, TOL[precision], f"{name[:3]}:{precision}", P999[precision])
     if precision != "f32":
         # dead-work elimination (masked key tiles, unreachable windows) is exact at full size too
         net.skip_masked = False

@@ -59,17 +59,43 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("precision", ["split", "f32"])
+# a size where every scheduling path is live (persistent attention, world-ordered schedule, reachability tables, 440 chain
+# workgroups): 5 agents 10110, 64 x 176 (the float64 oracle needs ~1 min per case on the CPU)
+BIG = dict(L=5, H=64, W=176, modes=(1, 0, 1, 1, 0))
+BIG_CASES = {
+    "big_base": dict(BIG),
+    "big_x3e4_outliers": dict(BIG, xscale=3e4, outliers=400),
+    "big_w1e2": dict(BIG, wscale=1e2),
+    "big_w1e-3_x1e3": dict(BIG, wscale=1e-3, xscale=1e3),
+}
+CASES.update(BIG_CASES)
+_truth_cache = {}
+
+
+def _truth(case):
+    """float64 truth + the fp32 oracle's own distance from it; computed once per case for all precisions."""
+    if case not in _truth_cache:
+        kw = dict(CASES[case])
+        cfg = O.make_config(256, 8, kw.get("L", 3))
+        sd = scaled_state_dict(cfg, 1, kw.pop("wscale", 1.0))
+        scene = stress_scene(**kw)
+        truth = O.hetero_fusion(*scene, sd, cfg, dtype=torch.float64)
+        noise = error_report(O.hetero_fusion(*scene, sd, cfg), truth)
+        _truth_cache.clear()        # one entry at a time: the big cases hold 100 MB each
+        _truth_cache[case] = (cfg, sd, scene, truth, noise)
+    return _truth_cache[case]
+
+
 @pytest.mark.parametrize("case", list(CASES))
+@pytest.mark.parametrize("precision", ["split", "mixed", "f32"])
 def test_fusion_dynamic_range(precision, case):
+    """`mixed` (split products in the Linears, attention operands rounded once to f16) is held to the same bound wherever the
+    scale of the operands is all that changes: its static power-of-two scales must keep the f16 planes in range.  Where the
+    WEIGHTS grow (w10, w1e2) the logits grow with their square and the softmax sharpens: rounding Q / K' to f16 then costs
+    2^-11 of a logit of several hundred - the data dependence that keeps `mixed` from being the headline.  Those
+    cases must stay finite and within 0.1; the measured figures are printed (6.9e-4 / 3.9e-2 / 5.0e-2 in round 4)."""
     import hmvit_amd
-    kw = dict(CASES[case])
-    cfg = O.make_config(256, 8, 3)
-    sd = scaled_state_dict(cfg, 1, kw.pop("wscale", 1.0))
-    scene = stress_scene(**kw)
-    truth = O.hetero_fusion(*scene, sd, cfg, dtype=torch.float64)
-    ref32 = O.hetero_fusion(*scene, sd, cfg)
-    noise = error_report(ref32, truth)
+    cfg, sd, scene, truth, noise = _truth(case)
     net = hmvit_amd.HeteroFusion(cfg, precision=precision)
     net.load_state_dict(sd, strict=True)
     net = net.cuda().eval()
@@ -78,6 +104,9 @@ def test_fusion_dynamic_range(precision, case):
     e = error_report(y, truth)
     print(f"\nrange[{precision}:{case}] rel-max {e['rel_max']:.2e} rms-rel {e['rms_rel']:.2e} p99.9 {e['p999']:.2e}"
           f"   (fp32 oracle vs float64: {noise['rel_max']:.2e} / {noise['rms_rel']:.2e} / {noise['p999']:.2e})")
+    if precision == "mixed" and CASES[case].get("wscale", 1.0) >= 10.0:
+        assert e["rel_max"] < 0.1
+        return
     assert e["rel_max"] < max(1e-4, 4 * noise["rel_max"])
     assert e["rms_rel"] < max(1e-4, 4 * noise["rms_rel"])
 

@@ -77,9 +77,9 @@ def test_g6_fusion_cfg1_full_size():
 
 
 @pytest.mark.skipif(not os.environ.get("HMVIT_SLOW"), reason="full-size oracle run: ~3 min and ~20 GB; set HMVIT_SLOW=1")
-@pytest.mark.parametrize("name", ["g12_fusion_cfg2.npz", "g13_fusion_cfg3.npz"])
+@pytest.mark.parametrize("name", ["g12_fusion_cfg2.npz", "g13_fusion_cfg3.npz", "g18_fusion_cfg4.npz"])
 def test_full_size_goldens(name):
-    """The oracle against the reference's forward at the headline size (BASELINE configs[1] / [2])."""
+    """The oracle against the reference's forward at the headline size (BASELINE configs[1] / [2] / [3])."""
     g = load_golden(name)
     sd = O.random_state_dict(g["cfg"], g["seed_weights"])
     y = O.hetero_fusion(*O.synthetic_scene(**g["scene"]), sd, g["cfg"])

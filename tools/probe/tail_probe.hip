@@ -1,0 +1,93 @@
+// Probe (round 4): what bounds the x16 split tails?  One 512-thread workgroup per CU walks 48 chunks of 32 KB through a 3-slot
+// LDS ring exactly as tail16_body does (LDS-DMA two chunks ahead, one workgroup barrier per chunk), and each wave optionally
+// (a) reads the 32 fragments back (ds_read_b128), (b) feeds them to the 48 MFMAs of a projection chunk.  Variants: start chunk
+// staggered per workgroup, nt policy, 16 / 32 tokens per wave (2 accumulator sets sharing each fragment).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+constexpr int CHUNK_BYTES = 32768, N_CHUNKS = 48;
+
+template <int MODE, int TOK, bool STAGGER, bool NT>
+__global__ __launch_bounds__(512, 2) void k_tail(const char* __restrict__ w, float* out, int iters) {
+    __shared__ __attribute__((aligned(16))) char ring[3 * CHUNK_BYTES];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ring;
+    const int c0 = STAGGER ? (blockIdx.x * 7) % N_CHUNKS : 0;
+    auto issue = [&](int c) {
+        const char* src = w + (size_t)((c + c0) % N_CHUNKS) * CHUNK_BYTES;
+        const unsigned slot = lds_base + (c % 3) * CHUNK_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece0 = (i * 8 + wave) * 64;
+            const uint4* g = reinterpret_cast<const uint4*>(src) + piece0 + lane;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(slot + piece0 * 16);
+            unsigned keep;
+            if (NT)
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+            else
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+        }
+    };
+    half8 ah[8], al[8], bh[8], bl[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { ah[s] = (half8)(_Float16)(lane * 0.01f + s); al[s] = (half8)(_Float16)(0.001f * s); bh[s] = ah[s] + (_Float16)1; bl[s] = al[s]; }
+    float4v acc[2] = {(float4v)(0.f), (float4v)(0.f)}, acc2[2] = {(float4v)(0.f), (float4v)(0.f)};
+    const int total = iters * N_CHUNKS;
+    issue(0); issue(1);
+    for (int c = 0; c < total; ++c) {
+        if (c + 2 < total) { issue(c + 2); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (MODE >= 1) {
+            const half8* f = reinterpret_cast<const half8*>(ring + (c % 3) * CHUNK_BYTES) + lane;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const half8 v = f[k * 64];
+                const int T = k / 16, s = (k % 16) / 2;
+                if (MODE == 1) { acc[T][0] += (float)v[0]; }
+                else if ((k & 1) == 0) {
+                    acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v, al[s], acc[T], 0, 0, 0);
+                    acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v, ah[s], acc[T], 0, 0, 0);
+                    if (TOK == 32) {
+                        acc2[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v, bl[s], acc2[T], 0, 0, 0);
+                        acc2[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v, bh[s], acc2[T], 0, 0, 0);
+                    }
+                } else {
+                    acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v, ah[s], acc[T], 0, 0, 0);
+                    if (TOK == 32) acc2[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v, bh[s], acc2[T], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const float r = acc[0][0] + acc[1][1] + acc2[0][2] + acc2[1][3];
+    if (r == 12345.f) out[0] = r;
+}
+template <typename K>
+void run(const char* name, K k, const char* w, float* out, int tok) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int iters = 20;
+    hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, w, out, 2);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, w, out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double chunks = (double)iters * N_CHUNKS;
+    printf("%-58s %.3f ms  %.0f ns/chunk  %.1f GB/s per CU  (%.2f TB/s chip)  tokens/CU/us %.1f\n", name, ms, ms * 1e6 / chunks,
+           chunks * CHUNK_BYTES / ms / 1e6, chunks * CHUNK_BYTES * 256 / ms / 1e9, 8.0 * tok * iters / (ms * 1e3));
+}
+int main() {
+    char* w; hipMalloc(&w, (size_t)N_CHUNKS * CHUNK_BYTES); hipMemset(w, 0, (size_t)N_CHUNKS * CHUNK_BYTES);
+    float* out; hipMalloc(&out, 1024);
+    run("stream only", k_tail<0, 16, false, false>, w, out, 16);
+    run("stream only, staggered start", k_tail<0, 16, true, false>, w, out, 16);
+    run("stream only, nt", k_tail<0, 16, false, true>, w, out, 16);
+    run("stream + readback", k_tail<1, 16, false, false>, w, out, 16);
+    run("stream + readback + 48 MFMA (16 tok/wave)", k_tail<2, 16, false, false>, w, out, 16);
+    run("stream + readback + 48 MFMA (16 tok/wave), staggered", k_tail<2, 16, true, false>, w, out, 16);
+    run("stream + readback + 96 MFMA (32 tok/wave)", k_tail<2, 32, false, false>, w, out, 32);
+    run("stream + readback + 96 MFMA (32 tok/wave), staggered", k_tail<2, 32, true, false>, w, out, 32);
+    return 0;
+}
