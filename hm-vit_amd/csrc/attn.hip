@@ -16,6 +16,7 @@
 //   f16 mode: v_mfma_f32_16x16x32_f16; V^T fragments come from ds_read_b64_tr_b16.
 //   f32 mode: v_mfma_f32_16x16x4_f32 (exact f32), element-granular operands, no transposes.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -1302,6 +1303,11 @@ struct PcSharedS {
 __device__ __forceinline__ uint4v tok_load4f(int4v rs, int token, int off_bytes, int soff) {
     return llvm_struct_buffer_load_b128(rs, token, off_bytes, soff, 0);
 }
+__device__ unsigned llvm_struct_buffer_load_b32(int4v rsrc, int vindex, int voffset, int soffset, int aux) __asm(
+    "llvm.amdgcn.struct.buffer.load.i32");
+__device__ __forceinline__ unsigned tok_load1(int4v rs, int token, int off_bytes, int soff) {
+    return llvm_struct_buffer_load_b32(rs, token, off_bytes, soff, 0);
+}
 
 struct PcGatherS {
     PcItem it;
@@ -1402,6 +1408,9 @@ __device__ __forceinline__ void pcs_loader_loop(const AttnParams& p, PcSharedS& 
     bool any = false, allv = true;
 
     auto issueG = [&](int pass, const PcGatherS& G) {
+#ifdef HMVIT_EXP_PCS_NOLOADER
+        return;
+#endif
         const int j = pass * KPW + kj;
         const int4 ix = *reinterpret_cast<const int4*>(sm.tidx[lw][G.slot][j]);
         const int ixa[4] = {ix.x, ix.y, ix.z, ix.w};
@@ -1418,6 +1427,9 @@ __device__ __forceinline__ void pcs_loader_loop(const AttnParams& p, PcSharedS& 
     };
     // identity half chunk: the ego's own rows; the first half also brings the whole 64-row query tile
     auto issueI = [&](int pass, const PcGatherS& G) {
+#ifdef HMVIT_EXP_PCS_NOLOADER
+        return;
+#endif
         int row, col;
         token_pixel(p.partition, 8, X, Y, G.it.wx, G.it.wy, G.half * 32 + pass * KPP + kin, row, col);
         const int tok = row * p.W + col;
@@ -1450,6 +1462,9 @@ __device__ __forceinline__ void pcs_loader_loop(const AttnParams& p, PcSharedS& 
     auto blendG = [&](int pass, const PcGatherS& G) {
         const int kk = pass * KPP + kin;
         const int j = pass * KPW + kj;
+#ifdef HMVIT_EXP_PCS_NOLOADER
+        { const bool v_ = sm.tvis[lw][G.slot][j] != 0; any |= v_; allv &= v_; return; }
+#endif
         const float4 wt = *reinterpret_cast<const float4*>(sm.tw[lw][G.slot][j]);
         float k4[4];
         blend4(R[pass][0], wt, *reinterpret_cast<const float4*>(&sm.bkv[G.tsel][0][cl]), k4);
@@ -1463,6 +1478,9 @@ __device__ __forceinline__ void pcs_loader_loop(const AttnParams& p, PcSharedS& 
     };
     auto blendI = [&](int pass, const PcGatherS& G) {
         const int kk = pass * KPP + kin;
+#ifdef HMVIT_EXP_PCS_NOLOADER
+        return;
+#endif
         float k4[4];
         add4(R[pass][0][0], *reinterpret_cast<const float4*>(&sm.bkv[G.tsel][0][cl]), k4);
         store_split4(sm.Kh[G.kvbuf] + kk * KS + cl, sm.Kl[G.kvbuf] + kk * KS + cl, k4);
@@ -1781,8 +1799,544 @@ __global__ __launch_bounds__(512) void k_attention_pcs(AttnParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_attention_pcs2 (round 4): the same persistent producer / consumer kernel with the LOADER role rebuilt around what the
+// round-4 role ablations measured (tools/probe/run_libs.sh; four attention launches of a cfg2 forward: 6.11 ms as shipped,
+// 5.09 ms with the loader's instruction stream alone - no tap memory traffic, no compute role -, 3.48 ms with the compute
+// role alone, 1.32 ms with both roles reduced to their bookkeeping): the kernel was bound by the loader wave's INSTRUCTION
+// stream, not by memory - per 32-key step ~20 exposed LDS round trips (tap weights, biases, visibility, indices, each read
+// right where it was used behind a scheduling fence), 32 v_mov_b64 + a near-full vmcnt wait at the loop head (the identity /
+// general / last-gather variants of the loop body kept the 128 tap registers from being updated in place), a divergent
+// mask store per pass, and per-step descriptor look-ups in LDS.  Here:
+//   * ONE loop body for every gather.  The ego's own half chunks are gathers like any other whose table entries say
+//     "tap 0 = the key's own pixel, weight 1, taps 1-3 out of range" (index -1 returns zeros without a memory access, and
+//     1 x + 0 0 + 0 0 + 0 0 + b is exact); the end of the list is a gather through an empty descriptor.  The 128 tap
+//     registers are loop-carried in place: vmcnt(24) before each pass, nothing else;
+//   * Q does not pass through the loader or LDS any more: a compute wave reads its head's 64 x 32 f32 query block straight
+//     from the plane (8 loads per lane, requested one item ahead), adds the bias and splits it in registers.  70 KB of LDS
+//     and a fifth of the loader's tile stores go away;
+//   * per ITEM, not per step: the tap tables of all of the item's half chunks (indices, weights, -inf masks, any / all flags),
+//     built one item ahead by the 64 lanes of each loader wave for the wave's own 8 keys per half chunk (two table sets by
+//     item parity; only the owning wave ever touches its rows, so program order is the only synchronisation); agent types,
+//     K' / V' variant and validity of the item's sources are packed into scalars once;
+//   * per STEP: one batch of LDS reads (4 x weights of the gather being blended, 4 x indices of the gather being requested,
+//     2 x bias, 1 x mask row), ONE wait, then 4 x [blend + split + store pass p, request pass p of the next gather]; the
+//     mask row and the flags reach the consumer's buffer through one 9-lane store.
+// The compute role is k_attention_pcs's, minus the Q tile.
+// ------------------------------------------------------------------------------------------
+struct PcShared2 {
+    static constexpr int HG = 4, CH = 128, KEYS = 32;
+    static constexpr int KS = CH + 8, VS = CH + 16;   // halves per LDS row
+    static constexpr int TPK = CH / 4;             // loader lanes per key row (4 f32 channels each)
+    static constexpr int KPW = 64 / TPK;           // keys per loader wave and pass (2)
+    static constexpr int LWG = 4, CWG = 4;
+    static constexpr int KPP = LWG * KPW;          // keys per pass (8)
+    static constexpr int NP = KEYS / KPP;          // passes per half chunk (4)
+    static constexpr int NK = NP * KPW;            // keys owned by one loader wave (8)
+    static constexpr int NS = 16;                  // half-chunk slots per item: 2 x n_src, n_src <= 8
+    static constexpr int MAX_PAIRS = 128;
+    half_t Kh[2][KEYS * KS], Kl[2][KEYS * KS];
+    half_t Vh[2][KEYS * VS], Vl[2][KEYS * VS];
+    float maskadd[2][KEYS];
+    int vis[2][LWG];
+    float ainv[MAX_PAIRS * 8];
+    float bkv[HMVIT_NUM_TYPES * HMVIT_NUM_TYPES][2][CH];
+    float bq[HMVIT_NUM_TYPES][CH];
+    int mode[kMaxSlots], cav[kMaxSlots], ego_e[kMaxSlots];
+    // item tables, [item parity][loader wave][slot = 2 chunk + half][key of the wave]
+    int tidx[2][LWG][NS][NK][4];
+    float tw[2][LWG][NS][NK][4];
+    float tmask[2][LWG][NS][16];                   // [0..7]: 0 / -inf per key, [8]: bit 0 some key visible, bit 1 all (int bits)
+    float qstage[CWG][8 * 64 * 4];                 // per compute wave: the next item's raw query block, landed by LDS-DMA
+    int iconst[kMaxSlots][2];                      // per (sample, ego): PcItemC, filled once per workgroup
+};
+
+// wave-uniform constants of an item: te | ev << 4 | self_vis << 8, and the (te, ts) pair of every chunk's source (4 bits each)
+struct PcItemC {
+    int tev;
+    unsigned tsel;
+};
+__device__ __forceinline__ void pcs2_fill_consts(const AttnParams& p, PcShared2& sm) {    // after mode / cav / ego_e are in LDS
+    const int L = p.L, i = threadIdx.x;
+    if (i < p.B * L && i < kMaxSlots) {
+        const int b = i / L, ego = i - b * L;
+        const int te = sm.mode[i], ev = sm.ego_e[i], sv = sm.cav[i];
+        unsigned ts = 0;
+        for (int c = 0; c < p.n_src && c < 8; ++c) ts |= (unsigned)(te * HMVIT_NUM_TYPES + sm.mode[b * L + pc_src(c, ego)]) << (4 * c);
+        sm.iconst[i][0] = te | (ev << 4) | ((sv != 0 ? 1 : 0) << 8);
+        sm.iconst[i][1] = (int)ts;
+    }
+}
+__device__ __forceinline__ PcItemC pcs2_item_consts(const AttnParams& p, const PcShared2& sm, const PcItem& it) {
+    const int2 v = *reinterpret_cast<const int2*>(sm.iconst[it.b * p.L + it.ego]);
+    PcItemC r;
+    r.tev = __builtin_amdgcn_readfirstlane(v.x);
+    r.tsel = __builtin_amdgcn_readfirstlane(v.y);
+    return r;
+}
+// half chunks to walk: both halves of the ego's own chunk, then the visible general ones: bit s = slot 2 chunk + half
+__device__ __forceinline__ unsigned pcs2_bits(const AttnParams& p, const PcItem& it, int X, int Y) {
+    const unsigned half_bits = ((1u << (2 * p.n_src)) - 1u) << 8;
+    return ((pc_item_vis(p, it, X, Y, true) & half_bits) >> 8) | 3u;
+}
+
+// tables of one item for this loader wave: lane = (slot in the round, key j of the wave)
+__device__ __forceinline__ void pcs2_tables(const AttnParams& p, PcShared2& sm, const PcItem& it, int par, int lw, int lane) {
+    using SM = PcShared2;
+    const int H = p.H, W = p.W, L = p.L, X = H / 8, Y = W / 8;
+    const int j = lane & 7, n_slots = 2 * p.n_src;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (r == 1 && n_slots <= 8) break;
+        const int s = (lane >> 3) + 8 * r;
+        if (s < n_slots) {
+            const int chunk = s >> 1, half = s & 1;
+            const int src = pc_src(chunk, it.ego);
+            const float* a = sm.ainv + ((it.b * L + src) * L + it.ego) * 8;
+            const int n = half * 32 + (j / SM::KPW) * SM::KPP + SM::KPW * lw + (j % SM::KPW);
+            int row, col;
+            token_pixel(p.partition, 8, X, Y, it.wx, it.wy, n, row, col);
+            const bool cav = sm.cav[it.b * L + src] != 0;
+            int ix[4];
+            float w[4];
+            bool vis;
+            if (a[6] != 0.f) {   // identity map (the ego itself, or a source at the same pose): the key's own pixel
+                ix[0] = row * W + col; ix[1] = ix[2] = ix[3] = -1;
+                w[0] = 1.f; w[1] = w[2] = w[3] = 0.f;
+                vis = cav;
+            } else {
+                const Taps t = make_taps(a, col, row, H, W);
+                vis = cav && t.roi != 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ix[k] = (t.w[k] != 0.f) ? t.idx[k] : -1;
+                    w[k] = t.w[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (!vis) ix[k] = -1;
+            *reinterpret_cast<int4*>(sm.tidx[par][lw][s][j]) = make_int4(ix[0], ix[1], ix[2], ix[3]);
+            *reinterpret_cast<float4*>(sm.tw[par][lw][s][j]) = make_float4(w[0], w[1], w[2], w[3]);
+            sm.tmask[par][lw][s][j] = vis ? 0.f : -INFINITY;
+            const unsigned bits8 = (unsigned)(__ballot(vis) >> (8 * (lane >> 3))) & 0xffu;
+            if (j == 0) sm.tmask[par][lw][s][8] = __int_as_float((bits8 != 0 ? 1 : 0) | (bits8 == 0xffu ? 2 : 0));
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read ordering
+}
+
+// wave-uniform description of one gather (half chunk `slot` of an item)
+struct PcGath2 {
+    int4v rs;                 // K' plane of the source, head group's channels (V' = + plane_bytes); rs.z = 0: nothing to load
+    int par, slot, buf, tsel;
+};
+__device__ __forceinline__ PcGath2 pcs2_gather(const AttnParams& p, const PcItem& it, const PcItemC& ic, int par, int slot, int g) {
+    const int L = p.L, P = p.H * p.W, C = p.C;
+    PcGath2 G;
+    G.par = par; G.slot = slot; G.buf = g & 1;
+    const int chunk = slot >> 1;
+    const int src = pc_src(chunk, it.ego), ev = (ic.tev >> 4) & 15;
+    G.tsel = (ic.tsel >> (4 * chunk)) & 15;
+    const float* kpl = reinterpret_cast<const float*>(p.kv) + ((size_t)((it.b * L + src) * p.E + ev) * 2) * P * C + it.hg * PcShared2::CH;
+    G.rs = token_rsrc(kpl, C * 4, P);
+    return G;
+}
+
+__device__ __forceinline__ void pcs2_loader_loop(const AttnParams& p, PcShared2& sm, int lw, int lane) {
+    using SM = PcShared2;
+    constexpr int KS = SM::KS, VS = SM::VS, TPK = SM::TPK, KPW = SM::KPW, NP = SM::NP, KPP = SM::KPP;
+    const int X = p.H / 8, Y = p.W / 8, NG = p.C / SM::CH;
+    const int plane_bytes = p.H * p.W * p.C * 4;
+    const int ltid = lw * 64 + lane;
+    const int cl = (ltid % TPK) * 4, cl_bytes = cl * 4;
+    const int kin = ltid / TPK;                  // key row of this lane inside a KPP-key pass
+    const int kj = kin % KPW;
+    const bool ego_fastest = (p.variant & 0x200) == 0;
+    // destination of this lane's share of the 9-lane mask / flag store: key j = lane of the wave sits in tile row
+    // (j / KPW) KPP + KPW lw + j % KPW; lane 8 carries the flags
+    const int mrow = (lane / KPW) * KPP + KPW * lw + (lane % KPW);
+
+    uint4v R[NP][2][4];      // the 32 tap loads of the gather in flight - the only state carried from a request to its blend
+
+    auto request = [&](int pass, const PcGath2& N, const int4 ix) {
+        const int ixa[4] = {ix.x, ix.y, ix.z, ix.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#ifdef HMVIT_EXP_PCS_NOLOAD
+            R[pass][0][k] = tok_load4f(N.rs, -1 - (ixa[k] & 1), cl_bytes, 0);
+            R[pass][1][k] = tok_load4f(N.rs, -1 - (ixa[k] & 1), cl_bytes, plane_bytes);
+#else
+            R[pass][0][k] = tok_load4f(N.rs, ixa[k], cl_bytes, 0);
+            R[pass][1][k] = tok_load4f(N.rs, ixa[k], cl_bytes, plane_bytes);
+#endif
+        }
+    };
+    auto blend4 = [&](const uint4v (&t)[4], const float4 w, const float4 b, bool ident, float (&o)[4]) {
+        const float bb[4] = {b.x, b.y, b.z, b.w};
+        if (ident) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned t0 = t[0][e];
+                o[e] = __builtin_bit_cast(float, t0) + bb[e];
+            }
+            return;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned t0 = t[0][e], t1 = t[1][e], t2 = t[2][e], t3 = t[3][e];
+            float acc = fmaf(w.x, __builtin_bit_cast(float, t0), bb[e]);
+            acc = fmaf(w.y, __builtin_bit_cast(float, t1), acc);
+            acc = fmaf(w.z, __builtin_bit_cast(float, t2), acc);
+            o[e] = fmaf(w.w, __builtin_bit_cast(float, t3), acc);
+        }
+    };
+
+    PcCursor cur = {0, 0, 0, 0, 0};
+    PcItem it, itn;
+    if (!pc_fetch(p, X, Y, NG, ego_fastest, cur, it)) { pc_wg_barrier(); return; }
+    unsigned rest = pcs2_bits(p, it, X, Y), restn = 0;
+    PcItemC ic = pcs2_item_consts(p, sm, it), icn = ic;
+    bool itn_valid = false;
+    int par = 0, g = 0;
+    pcs2_tables(p, sm, it, par, lw, lane);
+    PcGath2 G = pcs2_gather(p, it, ic, par, __builtin_ctz(rest), g);
+    rest &= rest - 1;
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass)
+        request(pass, G, *reinterpret_cast<const int4*>(sm.tidx[G.par][lw][G.slot][pass * KPW + kj]));
+
+#pragma unroll 1
+    while (true) {
+        // ---- the gather after G ----
+        bool nvalid = true;
+        if (rest == 0) {
+            nvalid = itn_valid;
+            if (itn_valid) { it = itn; ic = icn; rest = restn; par ^= 1; }
+        }
+        PcGath2 N = G;
+        if (nvalid) {
+            const int s = __builtin_ctz(rest);
+            rest &= rest - 1;
+            N = pcs2_gather(p, it, ic, par, s, g + 1);
+            if (s == 1) {
+                // G is the item's first half chunk: the last reader of the other table set (the blend of the previous item's
+                // last gather) is behind us - fetch the next item and build its tables now
+                itn_valid = pc_fetch(p, X, Y, NG, ego_fastest, cur, itn);
+                if (itn_valid) {
+                    restn = pcs2_bits(p, itn, X, Y);
+                    icn = pcs2_item_consts(p, sm, itn);
+                    pcs2_tables(p, sm, itn, par ^ 1, lw, lane);
+                }
+            }
+        } else {
+            N.rs.z = 0;      // empty descriptor: the requests of the closing step return zeros without touching memory
+        }
+        // ---- one step: blend G pass by pass while N is requested ----
+        // (the fields are wave-uniform by construction; saying so keeps the descriptor in SGPRs - without it hipcc wraps every
+        // one of the 32 requests in a waterfall loop)
+        N.rs.x = __builtin_amdgcn_readfirstlane(N.rs.x); N.rs.y = __builtin_amdgcn_readfirstlane(N.rs.y);
+        N.rs.z = __builtin_amdgcn_readfirstlane(N.rs.z); N.rs.w = __builtin_amdgcn_readfirstlane(N.rs.w);
+        N.par = __builtin_amdgcn_readfirstlane(N.par); N.slot = __builtin_amdgcn_readfirstlane(N.slot);
+        N.buf = __builtin_amdgcn_readfirstlane(N.buf); N.tsel = __builtin_amdgcn_readfirstlane(N.tsel);
+        float4 wt[NP];
+        int4 ixn[NP];
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
+            wt[pass] = *reinterpret_cast<const float4*>(sm.tw[G.par][lw][G.slot][pass * KPW + kj]);
+            ixn[pass] = *reinterpret_cast<const int4*>(sm.tidx[N.par][lw][N.slot][pass * KPW + kj]);
+        }
+        const float4 bK = *reinterpret_cast<const float4*>(&sm.bkv[G.tsel][0][cl]);
+        const float4 bV = *reinterpret_cast<const float4*>(&sm.bkv[G.tsel][1][cl]);
+        const float mk = sm.tmask[G.par][lw][G.slot][lane & 15];
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int kk = pass * KPP + kin;
+#ifndef HMVIT_EXP_PCS_NOLOADER
+            float k4[4];
+            blend4(R[pass][0], wt[pass], bK, false, k4);
+#ifndef HMVIT_EXP_PCS_NOSTORE
+            store_split4(sm.Kh[G.buf] + kk * KS + cl, sm.Kl[G.buf] + kk * KS + cl, k4);
+#else
+            if (k4[0] == 1.2345f) store_split4(sm.Kh[G.buf] + kk * KS + cl, sm.Kl[G.buf] + kk * KS + cl, k4);
+#endif
+            blend4(R[pass][1], wt[pass], bV, false, k4);
+#ifndef HMVIT_EXP_PCS_NOSTORE
+            store_split4(sm.Vh[G.buf] + kk * VS + cl, sm.Vl[G.buf] + kk * VS + cl, k4);
+#else
+            if (k4[0] == 1.2345f) store_split4(sm.Vh[G.buf] + kk * VS + cl, sm.Vl[G.buf] + kk * VS + cl, k4);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            request(pass, N, ixn[pass]);
+#endif
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (lane < 9) {
+            float* dst = lane < 8 ? &sm.maskadd[G.buf][mrow] : reinterpret_cast<float*>(&sm.vis[G.buf][lw]);
+            *dst = mk;
+        }
+        pc_wg_barrier();
+        if (!nvalid) break;
+        G = N; ++g;
+    }
+    pc_wg_barrier();   // the interval in which the compute waves consume the last gather
+}
+
+__device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2& sm, int wave, int lane) {
+    using SM = PcShared2;
+    constexpr int KS = SM::KS, VS = SM::VS, LWG = SM::LWG;
+    const float kl = p.k_logit != 0.f ? p.k_logit : 1.f;
+    const float LOG2E = 1.4426950408889634f * kl;
+    const int hl = wave;
+    const int C = p.C, H = p.H, W = p.W, L = p.L, P = H * W;
+    const int X = H / 8, Y = W / 8, NG = C / SM::CH;
+    const int lq = lane & 15, g = lane >> 4;
+    const bool ego_fastest = (p.variant & 0x200) == 0;
+    PcCursor cur = {0, 0, 0, 0, 0};
+    PcItem it, itn;
+    pc_wg_barrier();
+    if (!pc_fetch(p, X, Y, NG, ego_fastest, cur, it)) return;
+
+    // this wave's query block of an item: 4 tiles of 16 queries x the head's 32 channels, lane (lq, g) takes channels 8 g .. 8 g + 7.
+    // Requested one item ahead by LDS-DMA into the wave's own 8 KB (piece i = 2 qt + half: 64 lanes x 16 bytes), so that the
+    // block costs the compute role no registers while it waits
+    const unsigned qlds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)sm.qstage[hl];
+    auto request_q = [&](const PcItem& t) {
+        const float* qpl = reinterpret_cast<const float*>(p.q) + (size_t)(t.b * L + t.ego) * P * C + (t.hg * SM::HG + hl) * 32 + g * 8;
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            int row, col;
+            token_pixel(p.partition, 8, X, Y, t.wx, t.wy, qt * 16 + lq, row, col);
+            const float* a = qpl + (size_t)(row * W + col) * C;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const float* src = a + 4 * hf;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(qlds + (2 * qt + hf) * 1024);
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            }
+        }
+    };
+    request_q(it);
+
+    float4v biasf[7];
+    int bias_head = -1;
+    half8 qhh[4], qhl[4];
+    float m_run[4];          // running row maximum in exponent units: max(logit) * LOG2E (one rounding, shared by every element of the row)
+    float4v o_acc[4][2], l_acc[4];
+    const half8 ones = (half8)(half_t)1.0f;
+    int gstep = 0;
+    while (true) {
+        const bool nvalid = pc_fetch(p, X, Y, NG, ego_fastest, cur, itn);
+        const int head = it.hg * SM::HG + hl;
+        unsigned todo = pcs2_bits(p, it, X, Y);
+        const int h_last = 31 - __builtin_clz(todo);
+        if (head != bias_head) {
+#pragma unroll
+            for (int v = 0; v < 7; ++v)
+                biasf[v] = *reinterpret_cast<const float4v*>(p.bias_frag + ((size_t)(head * 7 + v) * 64 + lane) * 4);
+            bias_head = head;
+        }
+        {   // Q + b_q -> (hi, lo) operand halves; then the next item's block is requested into the same 8 KB.
+            // The 8 DMA pieces are older than the output stores of the previous item (8, + 4 log-sum-exp stores in the training
+            // forward): "all but the newest n" leaves those stores in flight (loads and stores share the in-order counter)
+            if (gstep == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (p.lse) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            const int te = sm.mode[it.b * L + it.ego];
+            const float4 b0 = *reinterpret_cast<const float4*>(&sm.bq[te][hl * 32 + g * 8]);
+            const float4 b1 = *reinterpret_cast<const float4*>(&sm.bq[te][hl * 32 + g * 8 + 4]);
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const float4 q4 = *reinterpret_cast<const float4*>(&sm.qstage[hl][((2 * qt + hf) * 64 + lane) * 4]);
+                    const float qq[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = qq[e] + bb[4 * hf + e];
+                        const half_t hh = (half_t)v;
+                        qhh[qt][4 * hf + e] = hh;
+                        qhl[qt][4 * hf + e] = (half_t)(v - (float)hh);
+                    }
+                }
+                m_run[qt] = -INFINITY;
+                l_acc[qt] = (float4v)(0.f);
+                o_acc[qt][0] = (float4v)(0.f);
+                o_acc[qt][1] = (float4v)(0.f);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the block is in registers before its LDS rows are requested again
+            __builtin_amdgcn_sched_barrier(0);
+            if (nvalid) request_q(itn);
+        }
+        while (todo) {
+            const int h = __builtin_ctz(todo);
+            todo &= todo - 1;
+            const int buf = gstep & 1;
+            int vis_or = 0, vis_and = 3;
+#pragma unroll
+            for (int w = 0; w < LWG; ++w) {
+                vis_or |= sm.vis[buf][w];
+                vis_and &= sm.vis[buf][w];
+            }
+            const bool any_visible = (vis_or & 1) != 0;
+            const bool all_visible = (vis_and & 2) != 0;
+#ifdef HMVIT_EXP_PCS_NOMATH
+            if (false) {
+#else
+            if (any_visible || !p.skip_masked) {
+#endif
+                float4v madd[2];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) madd[kt] = (float4v)(0.f);
+                if (!all_visible) {
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) madd[kt] = *reinterpret_cast<const float4v*>(sm.maskadd[buf] + kt * 16 + 4 * g);
+                }
+                half8 khh[2], khl[2], vhh[2], vhl[2];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    khh[kt] = *reinterpret_cast<const half8*>(sm.Kh[buf] + (kt * 16 + lq) * KS + hl * 32 + g * 8);
+                    khl[kt] = *reinterpret_cast<const half8*>(sm.Kl[buf] + (kt * 16 + lq) * KS + hl * 32 + g * 8);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    // V^T tile dt takes the head's channels 8 q4 + 4 dt + r (q4 = lq & 3) as its rows 4 q4 + r (as k_attention_pc)
+                    const int off = (4 * g + (lq >> 2)) * VS + hl * 32 + (lq & 3) * 8 + dt * 4;
+#pragma unroll
+                    for (int hlx = 0; hlx < 2; ++hlx) {
+                        const half_t* base = (hlx ? sm.Vl[buf] : sm.Vh[buf]) + off;
+                        const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base));
+                        const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base + 16 * VS));
+                        half8 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = (half_t)lo[e];
+                            v[4 + e] = (half_t)hi[e];
+                        }
+                        if (hlx) vhl[dt] = v; else vhh[dt] = v;
+                    }
+                }
+                // One 16-query tile against the 32 keys of the buffer.  HK (which half of the 64 key positions: bias tiles 2 HK + kt)
+                // and ALLV (every key visible: no mask) are compile-time so that the bias fragment is a plain MFMA C operand and
+                // the mask costs nothing when there is none: with run-time selects hipcc spent 24 of ~90 VALU instructions per
+                // tile on v_cndmask (round-4 ISA reading; the role is bound by its instruction stream, 4.2 ms of 6.0).
+                // Exponent: p = exp2(s c - M) as ONE fma per element, M = max(s) c rounded once per row (the same M enters
+                // alpha and every element, so its rounding cancels in the normalisation).
+                auto tile = [&](auto hk_c, auto allv_c, int qt_rt) {
+                    constexpr int HK = decltype(hk_c)::value;
+                    constexpr bool ALLV = decltype(allv_c)::value;
+#pragma unroll
+                    for (int qt = 0; qt < 4; ++qt) {
+                        float4v s[2];
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt) {
+                            const float4v b0 = biasf[qt - kt + 3], b1 = biasf[qt - kt + 1 >= 0 ? qt - kt + 1 : 0];
+                            float4v acc = (h & 1) ? b1 : b0;
+                            acc += madd[kt];
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(khl[kt], qhh[qt], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(khh[kt], qhl[qt], acc, 0, 0, 0);
+                            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(khh[kt], qhh[qt], acc, 0, 0, 0);
+                        }
+                        float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+                        mx = fmaxf(mx, fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+                        mx = max_over_lane_groups(mx);
+                        const float m_new = max_raw(m_run[qt], mx * LOG2E);
+                        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+                        const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_safe);
+                        half8 ph, pl;
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], LOG2E, -m_safe));
+                                const half_t eh = (half_t)e;
+                                ph[4 * kt + r] = eh;
+                                pl[4 * kt + r] = (half_t)(e - (float)eh);
+                            }
+                        m_run[qt] = m_new;
+                        o_acc[qt][0] *= alpha;
+                        o_acc[qt][1] *= alpha;
+                        l_acc[qt] *= alpha;
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) {
+                            o_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhl[dt], ph, o_acc[qt][dt], 0, 0, 0);
+                            o_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhh[dt], pl, o_acc[qt][dt], 0, 0, 0);
+                            o_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhh[dt], ph, o_acc[qt][dt], 0, 0, 0);
+                        }
+                        l_acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pl, l_acc[qt], 0, 0, 0);
+                        l_acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, ph, l_acc[qt], 0, 0, 0);
+                        if (qt & 1) __builtin_amdgcn_sched_barrier(0);   // two tiles in flight at a time: four overflow the register file
+                    }
+                };
+                using T_ = std::true_type;
+                using F_ = std::false_type;
+                tile(std::integral_constant<int, 0>{}, F_{}, 0);
+            }
+            if (h == h_last) {
+                float* outp = reinterpret_cast<float*>(p.out) + (size_t)(it.b * L + it.ego) * P * C;
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) {
+                    int row, col;
+                    token_pixel(p.partition, 8, X, Y, it.wx, it.wy, qt * 16 + lq, row, col);
+                    const float inv = 1.f / l_acc[qt][0];
+                    float* o = outp + (size_t)(row * W + col) * C + head * 32 + 8 * g;
+                    *reinterpret_cast<float4*>(o) = make_float4(o_acc[qt][0][0] * inv, o_acc[qt][0][1] * inv, o_acc[qt][0][2] * inv, o_acc[qt][0][3] * inv);
+                    *reinterpret_cast<float4*>(o + 4) = make_float4(o_acc[qt][1][0] * inv, o_acc[qt][1][1] * inv, o_acc[qt][1][2] * inv, o_acc[qt][1][3] * inv);
+                    if (p.lse && g == 0)
+                        p.lse[((size_t)(it.b * L + it.ego) * P + row * W + col) * (C / 32) + head] = m_run[qt] * 0.6931471805599453f + logf(l_acc[qt][0]);
+                }
+            }
+            pc_wg_barrier();
+            ++gstep;
+        }
+        if (!nvalid) break;
+        it = itn;
+    }
+}
+
+__global__ __launch_bounds__(512) void k_attention_pcs2(AttnParams p) {
+    using SM = PcShared2;
+    __shared__ __attribute__((aligned(16))) SM sm;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hg = pc_head_group(p, p.C / SM::CH);
+    {
+        const int n_rec = p.B * p.L * p.L * 8;
+        for (int i = threadIdx.x; i < n_rec; i += blockDim.x) sm.ainv[i] = p.ainv[i];
+        for (int i = threadIdx.x; i < HMVIT_NUM_TYPES * HMVIT_NUM_TYPES * 2 * SM::CH; i += blockDim.x) {
+            const int e = i / (2 * SM::CH), pl = (i / SM::CH) & 1, c = i % SM::CH;
+            sm.bkv[e][pl][c] = p.b_kv[(size_t)e * 2 * p.C + pl * p.C + hg * SM::CH + c];
+        }
+        for (int i = threadIdx.x; i < HMVIT_NUM_TYPES * SM::CH; i += blockDim.x)
+            sm.bq[i / SM::CH][i % SM::CH] = p.b_q[(i / SM::CH) * p.C + hg * SM::CH + (i % SM::CH)];
+        if (threadIdx.x < kMaxSlots) {
+            sm.mode[threadIdx.x] = p.mode[threadIdx.x];
+            sm.cav[threadIdx.x] = p.cav[threadIdx.x];
+            sm.ego_e[threadIdx.x] = p.ego_e[threadIdx.x];
+        }
+    }
+    __syncthreads();
+    pcs2_fill_consts(p, sm);
+    __syncthreads();
+    if (wave >= SM::CWG) {
+        __builtin_amdgcn_s_setprio(3);
+        pcs2_loader_loop(p, sm, wave - SM::CWG, threadIdx.x & 63);
+    } else {
+        pcs2_compute_loop(p, sm, wave, threadIdx.x & 63);
+    }
+}
+
 static int launch_attn_pcs(const AttnParams& p, hipStream_t st) {
-    hipLaunchKernelGGL(k_attention_pcs, dim3(256), dim3(512), 0, st, p);
+    if (HMVIT_ENV("HMVIT_PCS_OLD")) {       // probe builds: the round-2/3 kernel, for same-box A/B runs
+        hipLaunchKernelGGL(k_attention_pcs, dim3(256), dim3(512), 0, st, p);
+        HMVIT_CHECK_LAUNCH();
+        return HMVIT_OK;
+    }
+    hipLaunchKernelGGL(k_attention_pcs2, dim3(256), dim3(512), 0, st, p);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }
