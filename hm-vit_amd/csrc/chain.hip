@@ -1364,39 +1364,70 @@ __global__ __launch_bounds__(1024) void k_weight_image16(const float* __restrict
 
 // TAIL: 0 = stage tail only (x'' stored), 1 = + next stage's LayerNorm / Q / K' / V', 2 = + mlp_head (output (C, P) map).
 // OUTPROJ / LN / RESID as in out_ffn_body; OUT_NCHW (TAIL 0): x'' goes to a (C, P) map (the stand-alone mlp_head launch).
+//
+// PERSISTENT (round 4): a workgroup walks the 128-token tiles blockIdx.x + k gridDim.x of its job (k < 32; the launch sizes the
+// grid to about one workgroup per CU) with ONE uninterrupted chunk sequence: the weight ring keeps turning across tile
+// boundaries (the last steps of a tile request the first chunks of the next), group B stays one barrier behind group A from the
+// first tile to the last, and the attention rows of the next tile are requested into the (by then idle) residual registers
+// during the Q / K' / V' phase.  With one workgroup per CU and one tile per workgroup, 20-33 k of a tile's ~150 k cycles passed
+// before the first MFMA (inputs + the first two chunks arriving with nothing to overlap them); now only the first tile pays.
+// Tiles none of whose tokens a later stage reads (FfnJob::need) are dropped from the walk up front.
+constexpr int X16_MAX_TILES = 32;      // tiles per workgroup (bits of the live mask)
 template <bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW, int TAIL, bool XN, bool A16>
 __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams* qp) {
     constexpr int C = 256, NCH = 8, NH = 8;
     constexpr bool QKV = TAIL == 1, HEAD = TAIL == 2;
-    __shared__ __attribute__((aligned(16))) half_t smem[X16_RING * X16_CHUNK + 10 * C + 2 * X16_WAVES * X16_STG_WAVE];
-    float (*vec)[C] = reinterpret_cast<float (*)[C]>(smem + X16_RING * X16_CHUNK);   // b_o, ln g, ln b, b_1, b_2
+    __shared__ __attribute__((aligned(16))) half_t smem[X16_RING * X16_CHUNK + 14 * C + 2 * X16_WAVES * X16_STG_WAVE];
+    // layout: [7 vector rows][per-wave store staging][weight ring]: the rows and the staging sit below 64 KB, where the 16-bit
+    // offset field of the DS instructions reaches them from one base register (behind the ring every row position needed an
+    // address register of its own: 32 of them, spilled, for the LayerNorm parameters alone)
+    // rows: b_o, ln g, ln b, b_1, b_2, then [5], [6]: the next stage's LayerNorm (QKV) or mlp_head's b_1 / b_2 (HEAD)
+    constexpr int X16_VEC = 14 * C, X16_STG = 2 * X16_WAVES * X16_STG_WAVE;      // halves
+    half_t* ring = smem + X16_VEC + X16_STG;
+    float (*vec)[C] = reinterpret_cast<float (*)[C]>(smem);
     const FfnJob& J = p.job[blockIdx.y];
-    const int P = p.P;
-    if (J.need) {   // none of this workgroup's tokens is read by a later stage (k_window_need)
-        const int t = blockIdx.x * X16_TOKENS + (threadIdx.x & (X16_TOKENS - 1));
-        const int r = t / p.W, c = t - r * p.W;
-        const int live = (t < P) ? J.need[(r >> 3) * (p.W >> 3) + (c >> 3)] : 0;
-        if (!__syncthreads_or(live)) return;
-    }
+    const int P = p.P, n_tiles = (P + X16_TOKENS - 1) / X16_TOKENS;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tk = lane & 15, g = lane >> 4;
-    const int tok_w = blockIdx.x * X16_TOKENS + wave * 16, tok = tok_w + tk;
-    const bool valid = tok < P;
+    float* stg = reinterpret_cast<float*>(smem + 14 * C) + wave * X16_STG_WAVE;
+
+    // ---- the live tiles of this workgroup (thread = (tile k, 8-token run): W is a multiple of 8, so a run lies in one window) ----
+    unsigned live_mask;
+    {
+        unsigned* sl = reinterpret_cast<unsigned*>(smem + 14 * C);
+        if (threadIdx.x == 0) *sl = 0;
+        __syncthreads();
+        const int k = threadIdx.x >> 4, t = blockIdx.x + k * gridDim.x, tok0 = t * X16_TOKENS + (threadIdx.x & 15) * 8;
+        if (k < X16_MAX_TILES && t < n_tiles && tok0 < P) {
+            int live = 1;
+            if (J.need) {
+                const int r = tok0 / p.W, c = tok0 - r * p.W;
+                live = J.need[(r >> 3) * (p.W >> 3) + (c >> 3)];
+            }
+            if (live) atomicOr(sl, 1u << k);
+        }
+        __syncthreads();
+        live_mask = __builtin_amdgcn_readfirstlane(*sl);
+        __syncthreads();
+    }
+    if (live_mask == 0) return;
+
     const int ty = J.type;
-    float* stg = reinterpret_cast<float*>(smem + X16_RING * X16_CHUNK + 10 * C) + wave * X16_STG_WAVE;
+    const QkvJob* Qj = QKV ? &qp->job[blockIdx.y] : nullptr;
     for (int i = threadIdx.x; i < C; i += X16_THREADS) {
         vec[0][i] = OUTPROJ ? p.b_o[ty * C + i] : 0.f;
         vec[1][i] = LN ? p.ln_g[ty * C + i] : 1.f;
         vec[2][i] = LN ? p.ln_b[ty * C + i] : 0.f;
         vec[3][i] = p.b_1[ty * C + i];
         vec[4][i] = p.b_2[ty * C + i];
+        if constexpr (QKV) { vec[5][i] = qp->gamma[ty * C + i]; vec[6][i] = qp->beta[ty * C + i]; }
+        if constexpr (HEAD) { vec[5][i] = p.hb_1[ty * C + i]; vec[6][i] = p.hb_2[ty * C + i]; }
     }
-    // the whole launch as ONE chunk sequence: [out-projection 8] [FFN 16: W_1 tile, W_2 slice alternating] [tail: mlp_head 16 |
+    // a tile as ONE chunk sequence: [out-projection 8] [FFN 16: W_1 tile, W_2 slice alternating] [tail: mlp_head 16 |
     // next stage's Q / K' / V' 8 per matrix]
     constexpr int N_OUT = OUTPROJ ? NCH : 0, N_FFN = 2 * NH;
     const half_t* wo = OUTPROJ ? p.w_o + (size_t)ty * NCH * X16_CHUNK : nullptr;
     const half_t* wf = p.w_ffn + (size_t)ty * N_FFN * X16_CHUNK;
     const half_t* wh = HEAD ? p.w_head + (size_t)ty * N_FFN * X16_CHUNK : nullptr;
-    const QkvJob* Qj = QKV ? &qp->job[blockIdx.y] : nullptr;
     const int n_tail = QKV ? Qj->n_mat * NCH : (HEAD ? N_FFN : 0);
     const int n_total = N_OUT + N_FFN + n_tail;
     auto chunk_ptr = [&](int i) -> const half_t* {
@@ -1405,10 +1436,14 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
         if (i < N_FFN) return wf + (size_t)i * X16_CHUNK;
         i -= N_FFN;
         if constexpr (QKV) return Qj->w[i / NCH] + (size_t)(i % NCH) * X16_CHUNK;
-        else return wh + (size_t)i * X16_CHUNK;
+        else if constexpr (HEAD) return wh + (size_t)i * X16_CHUNK;
+        else return wf;                                  // TAIL 0: no chunk past the FFN (never reached)
     };
-    auto slot = [&](int i) -> half_t* { return smem + (i % X16_RING) * X16_CHUNK; };
-    int cc = 0;                                          // chunk of the current step
+    int gs3 = 0;                                         // (chunks of the tiles done so far) mod 3: the ring does not restart
+    auto slot = [&](int i) -> half_t* { return ring + ((gs3 + i) % X16_RING) * X16_CHUNK; };
+    int cc = 0;                                          // chunk of the current step, within the tile
+    bool has_next = false;                               // another live tile follows the current one
+    bool full_wave = true;
     // A step = [products of chunk cc] barrier [everything else: accumulate / GELU / stage + store, request a chunk] barrier.
     // The two wavefronts of a SIMD (w, w + 4) would run the same half at the same time and leave the matrix pipe idle during
     // every second half, so group B (waves 4-7) runs ONE BARRIER BEHIND group A (an extra barrier before its first step, one
@@ -1418,13 +1453,21 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
     // chunk k - 1, whose last reader finished in half 2k - 1) and confirms chunk k + 1 at the end of that half; B requests its
     // pieces of chunk k + 3 in its rest-half of step k (half 2k + 2: slot of chunk k, read until half 2k + 1) and confirms
     // chunk k + 1 at the end of its products of step k (half 2k + 1) - so every piece of chunk k + 1 is confirmed before the
-    // barrier that opens half 2k + 2.  vmcnt(n) = "all but the newest n operations": n counts the request made since (4) and,
-    // where a tile flush (4 stores) was issued since, those too; partial waves (a store instruction may be skipped) wait for all.
+    // barrier that opens half 2k + 2.  Chunk numbers run on across tiles (k + 2 / k + 3 past the tile's last chunk are the next
+    // tile's first ones).  vmcnt(n) = "all but the newest n operations": n counts the request made since (4) and, where a tile
+    // flush (4 stores) was issued since, those too; anything else a wave has in flight (the next tile's rows) is older than the
+    // request and only makes the wait stricter; partial waves (a store instruction may be skipped) wait for all.
     const bool grp_b = X16_DEPHASE && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >= 4;
-    const bool full_wave = tok_w + 16 <= P;
+    // `extra`: row loads this wave issued since the request it confirms (the next tile's attention rows / this tile's residual
+    // row): they stay in flight too, or every tile boundary would cost two memory latencies
+    int extra = 0;                                       // pending for this wave's next counted wait
     auto ring_wait = [&](bool flush_since) {
-        if (cc + 2 < n_total && full_wave) { if (flush_since) ring_wait_newest8(); else ring_wait_newest4(); }
-        else dma_wait();
+        if ((cc + 2 < n_total || has_next) && full_wave) {
+            if (extra == 0) { if (flush_since) ring_wait_newest8(); else ring_wait_newest4(); }
+            else if (extra <= 16) { if (flush_since) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+        } else dma_wait();
+        extra = 0;
     };
     auto step_begin = [&]() { X16_STAMP(cc, 0); };
     // end of the products of step cc; flush_prev: the rest-half of step cc - 1 stored a tile
@@ -1441,6 +1484,7 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
     auto step_end = [&](bool flush_now) {
         const int ahead = cc + 2 + (grp_b ? 1 : 0);
         if (ahead < n_total) stage_chunk16(chunk_ptr(ahead), slot(ahead));
+        else if (has_next) stage_chunk16(chunk_ptr(ahead - n_total), slot(ahead));
         X16_STAMP(cc, 4);
         if (!grp_b) ring_wait(flush_now);
         wg_barrier();
@@ -1453,219 +1497,242 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
 
     float4v xacc[16];
     half8 ah[8], al[8];
-    const int tok_c = min(tok, P - 1);
-    if constexpr (XN) {
-        const unsigned long long a = (unsigned long long)J.x;
-        int4v rs;
-        rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-        rs.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
-        rs.z = C * P * 4;
-        rs.w = 0x00020000;
-        const int voff = (4 * g * P + tok_c) * 4;
-#pragma unroll
-        for (int t = 0; t < 16; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) xacc[t][r] = llvm_raw_buffer_load_f32(rs, voff, (16 * t + r) * P * 4, 0);
-    } else {
-        const float* xp = J.x + (size_t)tok_c * C + 4 * g;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const float4 f = *reinterpret_cast<const float4*>(xp + 16 * t);
-            xacc[t][0] = f.x; xacc[t][1] = f.y; xacc[t][2] = f.z; xacc[t][3] = f.w;
-        }
-    }
+    bool have_o = false;                                 // xacc holds this tile's attention rows (requested during the tile before)
     // range normalisation (HmvitStageScales): uniform powers of two for the stage's own chain; the stand-alone mlp_head launch
     // (!OUTPROJ && !LN) multiplies the un-normalised row itself and takes per-token factors (head_token_scales)
-    float c_1 = p.c_1[ty], s_g = p.s_g[ty], k_2 = p.k_2[ty];
-    float b1_pre = 1.f;             // mlp_head only: the hidden accumulator starts from b_1 b1_pre = b_1 / c_1
-    const float c_o = p.c_o[ty];
-    // mlp_head on a raw row: operand scale from the row's own maximum, the hidden bound from |h| <= l1 max|x| + max|b_1|
-    auto head_token_scales = [&](float& s_tok) {
-        s_tok = 1.f; c_1 = 1.f; s_g = 1.f; k_2 = 1.f; b1_pre = 1.f;
-        if (p.dyn_head) {
-            const float r = row_absmax16(xacc);
-            s_tok = pow2_scale(r);
-            b1_pre = p.head.w1[ty] * s_tok;
-            c_1 = pow2_inv(b1_pre);
-            s_g = pow2_scale(fmaf(p.head.l1[ty], r, p.head.b1max[ty]));
-            k_2 = p.head.w2[ty] * s_g;
-        }
-    };
-    if constexpr (!OUTPROJ && !LN) {   // mlp_head: x itself is the operand
-        float s_tok;
-        head_token_scales(s_tok);
-        rows_to_operands16(xacc, ah, al, s_tok);
-    }
-    if constexpr (OUTPROJ && A16) {
-        // attention output (f16, exact operand: no lo half) of this token
-        const half_t* op = reinterpret_cast<const half_t*>(J.o) + (size_t)tok_c * C + 4 * g;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const half4 a = *reinterpret_cast<const half4*>(op + 32 * s);
-            const half4 b = *reinterpret_cast<const half4*>(op + 32 * s + 16);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { ah[s][j] = a[j]; ah[s][4 + j] = b[j]; }
-        }
-    } else if constexpr (OUTPROJ) {
-        // attention output (f32) of this token: slot j of k-step s <- channel 32 s + 16 (j >> 2) + 4 g + (j & 3)
-        const float* op = reinterpret_cast<const float*>(J.o) + (size_t)tok_c * C + 4 * g;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const float4 a = *reinterpret_cast<const float4*>(op + 32 * s);
-            const float4 b = *reinterpret_cast<const float4*>(op + 32 * s + 16);
-            const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) split_h(f[j], ah[s][j], al[s][j]);
-        }
-    }
+    const float c_1s = p.c_1[ty], s_gs = p.s_g[ty], k_2s = p.k_2[ty], c_o = p.c_o[ty];
+
     dma_wait();
     __syncthreads();
     if (grp_b) wg_barrier();
-
-    // ---- phase 1: x' = x + b_o + W_o . O, two 16-channel tiles per chunk ----
-    if constexpr (OUTPROJ) {
 #pragma unroll 1
-        for (int c = 0; c < N_OUT; ++c) {
-            step_begin();
-            float4v acc[2];                                          // starts from b_o / c_o (pre-divided on the host)
-#pragma unroll
-            for (int T = 0; T < 2; ++T) {
-                const float4 bo = *reinterpret_cast<const float4*>(&vec[0][32 * c + 16 * T + 4 * g]);
-                acc[T][0] = bo.x; acc[T][1] = bo.y; acc[T][2] = bo.z; acc[T][3] = bo.w;
+    do {
+        const int tile = blockIdx.x + __builtin_ctz(live_mask) * gridDim.x;
+        live_mask &= live_mask - 1;
+        has_next = live_mask != 0;
+        const int next_tile = has_next ? blockIdx.x + __builtin_ctz(live_mask) * gridDim.x : tile;
+        const int tok_w = tile * X16_TOKENS + wave * 16, tok = tok_w + tk;
+        const bool valid = tok < P;
+        full_wave = tok_w + 16 <= P;
+        const int tok_c = min(tok, P - 1);
+        cc = 0;
+        float c_1 = c_1s, s_g = s_gs, k_2 = k_2s;
+        float b1_pre = 1.f;             // mlp_head only: the hidden accumulator starts from b_1 b1_pre = b_1 / c_1
+        // mlp_head on a raw row: operand scale from the row's own maximum, the hidden bound from |h| <= l1 max|x| + max|b_1|
+        auto head_token_scales = [&](float& s_tok) {
+            s_tok = 1.f; c_1 = 1.f; s_g = 1.f; k_2 = 1.f; b1_pre = 1.f;
+            if (p.dyn_head) {
+                const float r = row_absmax16(xacc);
+                s_tok = pow2_scale(r);
+                b1_pre = p.head.w1[ty] * s_tok;
+                c_1 = pow2_inv(b1_pre);
+                s_g = pow2_scale(fmaf(p.head.l1[ty], r, p.head.b1max[ty]));
+                k_2 = p.head.w2[ty] * s_g;
             }
-            mma_proj16<!A16>(acc, slot(cc), ah, al, lane);          // f16 attention output: exact operand, no lo half
-            products_end(false);
+        };
+        // ---- operands of the out-projection: the tile's attention rows ----
+        if constexpr (OUTPROJ && A16) {
+            // attention output (f16, exact operand: no lo half) of this token
+            const half_t* op = reinterpret_cast<const half_t*>(J.o) + (size_t)tok_c * C + 4 * g;
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
-                if (t == c) { xacc[2 * t] = acc[0] * c_o + xacc[2 * t]; xacc[2 * t + 1] = acc[1] * c_o + xacc[2 * t + 1]; }
-            step_end(false);
-        }
-    }
-    if constexpr (LN) ln_to_operands16(xacc, vec[1], vec[2], g, ah, al);
-
-    // the row is carried as x k_2 while W_2's (scaled) products accumulate into it.  Stage chain: b_2 arrives as b_2 k_2;
-    // mlp_head (no residual, per-token k_2): b_2 at its true scale
+            for (int s = 0; s < 8; ++s) {
+                const half4 a = *reinterpret_cast<const half4*>(op + 32 * s);
+                const half4 b = *reinterpret_cast<const half4*>(op + 32 * s + 16);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const float4 b2 = *reinterpret_cast<const float4*>(&vec[4][16 * t + 4 * g]);
-        if constexpr (RESID) {
-            xacc[t][0] = fmaf(xacc[t][0], k_2, b2.x); xacc[t][1] = fmaf(xacc[t][1], k_2, b2.y);
-            xacc[t][2] = fmaf(xacc[t][2], k_2, b2.z); xacc[t][3] = fmaf(xacc[t][3], k_2, b2.w);
-        } else {
-            xacc[t][0] = b2.x * k_2; xacc[t][1] = b2.y * k_2; xacc[t][2] = b2.z * k_2; xacc[t][3] = b2.w * k_2;
-        }
-    }
-
-    // ---- phase 2: per hidden tile hc: h = GELU(W_1[hc] . xn + b_1[hc]);  x'' += W_2[:, hc] . h ----
-    // DYN (mlp_head on a raw row): per-token factors, b_1 at its true scale; otherwise b_1 arrives as b_1 / c_1
-    auto ffn_pass = [&](auto dyn_c) {
-        constexpr bool DYN = decltype(dyn_c)::value;
-#pragma unroll 1
-        for (int hc = 0; hc < NH; ++hc) {
-            step_begin();
-            float4v hacc[2];                                 // starts from b_1 / c_1
+                for (int j = 0; j < 4; ++j) { ah[s][j] = a[j]; ah[s][4 + j] = b[j]; }
+            }
+        } else if constexpr (OUTPROJ) {
+            // attention output (f32) of this token, in the residual row's layout: slot j of k-step s <- channel
+            // 32 s + 16 (j >> 2) + 4 g + (j & 3) = row tile 2 s + (j >> 2), element j & 3
+            if (!have_o) {
+                const float* op = reinterpret_cast<const float*>(J.o) + (size_t)tok_c * C + 4 * g;
 #pragma unroll
-            for (int T = 0; T < 2; ++T) {
-                const float4 b1 = *reinterpret_cast<const float4*>(&vec[3][32 * hc + 16 * T + 4 * g]);
-                if constexpr (DYN) {
-                    hacc[T][0] = b1.x * b1_pre; hacc[T][1] = b1.y * b1_pre; hacc[T][2] = b1.z * b1_pre; hacc[T][3] = b1.w * b1_pre;
-                } else {
-                    hacc[T][0] = b1.x; hacc[T][1] = b1.y; hacc[T][2] = b1.z; hacc[T][3] = b1.w;
+                for (int t = 0; t < 16; ++t) {
+                    const float4 f = *reinterpret_cast<const float4*>(op + 16 * t);
+                    xacc[t][0] = f.x; xacc[t][1] = f.y; xacc[t][2] = f.z; xacc[t][3] = f.w;
                 }
             }
-            mma_proj16(hacc, slot(cc), ah, al, lane);
-            products_end(false);
-            half8 hh, hl;                                    // hidden channel 32 hc + 16 (j >> 2) + 4 g + (j & 3) = hacc[j >> 2][j & 3]
-#pragma unroll
-            for (int j = 0; j < 8; ++j) split_h(gelu_f(hacc[j >> 2][j & 3] * c_1) * s_g, hh[j], hl[j]);
-            step_end(false);
-            step_begin();
-            mma_slice16(xacc, slot(cc), hh, hl, lane);
-            products_end(false);
-            step_end(false);
+            rows_to_operands16(xacc, ah, al, 1.f);
+            have_o = false;
         }
-    };
-    ffn_pass(std::integral_constant<bool, !OUTPROJ && !LN>{});
-    {
-        const float k_inv = pow2_inv(k_2);
+        // ---- the residual row ----
+        if constexpr (XN) {
+            const unsigned long long a = (unsigned long long)J.x;
+            int4v rs;
+            rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+            rs.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+            rs.z = C * P * 4;
+            rs.w = 0x00020000;
+            const int voff = (4 * g * P + tok_c) * 4;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) xacc[t] *= k_inv;
-    }
-
-    auto store_x = [&]() {
-        if (valid && !(QKV && J.pad)) {
-            if constexpr (OUT_NCHW) {
-                float* op = J.out + (size_t)(4 * g) * P + tok;
+            for (int t = 0; t < 16; ++t)
 #pragma unroll
-                for (int t = 0; t < 16; ++t)
+                for (int r = 0; r < 4; ++r) xacc[t][r] = llvm_raw_buffer_load_f32(rs, voff, (16 * t + r) * P * 4, 0);
+        } else {
+            const float* xp = J.x + (size_t)tok_c * C + 4 * g;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) op[(size_t)(16 * t + r) * P] = xacc[t][r];
-            } else {
-                float* op = J.out + (size_t)tok * C + 4 * g;
-#pragma unroll
-                for (int t = 0; t < 16; ++t) *reinterpret_cast<float4*>(op + 16 * t) = make_float4(xacc[t][0], xacc[t][1], xacc[t][2], xacc[t][3]);
+            for (int t = 0; t < 16; ++t) {
+                const float4 f = *reinterpret_cast<const float4*>(xp + 16 * t);
+                xacc[t][0] = f.x; xacc[t][1] = f.y; xacc[t][2] = f.z; xacc[t][3] = f.w;
             }
         }
-    };
-    if constexpr (TAIL == 0) store_x();
-
-    if constexpr (HEAD) {
-        float s_tok;
-        head_token_scales(s_tok);
-        rows_to_operands16(xacc, ah, al, s_tok);
-        // vec[3..4] are free: their last readers passed the barrier that ended phase 2
-        for (int i = threadIdx.x; i < C; i += X16_THREADS) {
-            vec[3][i] = p.hb_1[ty * C + i];
-            vec[4][i] = p.hb_2[ty * C + i];
+        if constexpr (!OUTPROJ && !LN) {   // mlp_head: x itself is the operand
+            float s_tok;
+            head_token_scales(s_tok);
+            rows_to_operands16(xacc, ah, al, s_tok);
         }
-        __syncthreads();
+        extra = XN ? 64 : 16;
+
+        // ---- phase 1: x' = x + b_o + W_o . O, two 16-channel tiles per chunk ----
+        if constexpr (OUTPROJ) {
+#pragma unroll 1
+            for (int c = 0; c < N_OUT; ++c) {
+                step_begin();
+                float4v acc[2];                                          // starts from b_o / c_o (pre-divided on the host)
+#pragma unroll
+                for (int T = 0; T < 2; ++T) {
+                    const float4 bo = *reinterpret_cast<const float4*>(&vec[0][32 * c + 16 * T + 4 * g]);
+                    acc[T][0] = bo.x; acc[T][1] = bo.y; acc[T][2] = bo.z; acc[T][3] = bo.w;
+                }
+                mma_proj16<!A16>(acc, slot(cc), ah, al, lane);          // f16 attention output: exact operand, no lo half
+                products_end(false);
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    if (t == c) { xacc[2 * t] = acc[0] * c_o + xacc[2 * t]; xacc[2 * t + 1] = acc[1] * c_o + xacc[2 * t + 1]; }
+                step_end(false);
+            }
+        }
+        if constexpr (LN) ln_to_operands16(xacc, vec[1], vec[2], g, ah, al);
+
+        // the row is carried as x k_2 while W_2's (scaled) products accumulate into it.  Stage chain: b_2 arrives as b_2 k_2;
+        // mlp_head (no residual, per-token k_2): b_2 at its true scale
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const float4 b2 = *reinterpret_cast<const float4*>(&vec[4][16 * t + 4 * g]);
-            xacc[t][0] = b2.x * k_2; xacc[t][1] = b2.y * k_2; xacc[t][2] = b2.z * k_2; xacc[t][3] = b2.w * k_2;
+            if constexpr (RESID) {
+                xacc[t][0] = fmaf(xacc[t][0], k_2, b2.x); xacc[t][1] = fmaf(xacc[t][1], k_2, b2.y);
+                xacc[t][2] = fmaf(xacc[t][2], k_2, b2.z); xacc[t][3] = fmaf(xacc[t][3], k_2, b2.w);
+            } else {
+                xacc[t][0] = b2.x * k_2; xacc[t][1] = b2.y * k_2; xacc[t][2] = b2.z * k_2; xacc[t][3] = b2.w * k_2;
+            }
         }
-        ffn_pass(std::integral_constant<bool, true>{});
+
+        // ---- phase 2: per hidden tile hc: h = GELU(W_1[hc] . xn + b_1[hc]);  x'' += W_2[:, hc] . h ----
+        // DYN (mlp_head on a raw row): per-token factors, b_1 (row `b1row` of vec) at its true scale; otherwise it arrives as b_1 / c_1
+        auto ffn_pass = [&](auto dyn_c, const float* b1row) {
+            constexpr bool DYN = decltype(dyn_c)::value;
+#pragma unroll 1
+            for (int hc = 0; hc < NH; ++hc) {
+                step_begin();
+                float4v hacc[2];                                 // starts from b_1 / c_1
+#pragma unroll
+                for (int T = 0; T < 2; ++T) {
+                    const float4 b1 = *reinterpret_cast<const float4*>(&b1row[32 * hc + 16 * T + 4 * g]);
+                    if constexpr (DYN) {
+                        hacc[T][0] = b1.x * b1_pre; hacc[T][1] = b1.y * b1_pre; hacc[T][2] = b1.z * b1_pre; hacc[T][3] = b1.w * b1_pre;
+                    } else {
+                        hacc[T][0] = b1.x; hacc[T][1] = b1.y; hacc[T][2] = b1.z; hacc[T][3] = b1.w;
+                    }
+                }
+                mma_proj16(hacc, slot(cc), ah, al, lane);
+                products_end(false);
+                half8 hh, hl;                                    // hidden channel 32 hc + 16 (j >> 2) + 4 g + (j & 3) = hacc[j >> 2][j & 3]
+#pragma unroll
+                for (int j = 0; j < 8; ++j) split_h(gelu_f(hacc[j >> 2][j & 3] * c_1) * s_g, hh[j], hl[j]);
+                step_end(false);
+                step_begin();
+                mma_slice16(xacc, slot(cc), hh, hl, lane);
+                products_end(false);
+                step_end(false);
+            }
+        };
+        ffn_pass(std::integral_constant<bool, !OUTPROJ && !LN>{}, vec[3]);
         {
             const float k_inv = pow2_inv(k_2);
 #pragma unroll
             for (int t = 0; t < 16; ++t) xacc[t] *= k_inv;
         }
-        if (valid) {
-            float* op = J.out + (size_t)(4 * g) * P + tok;      // (C, P) map
-#pragma unroll
-            for (int t = 0; t < 16; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) op[(size_t)(16 * t + r) * P] = xacc[t][r];
-        }
-    }
 
-    if constexpr (QKV) {
-        if (n_tail > 0) {
-            for (int i = threadIdx.x; i < C; i += X16_THREADS) {
-                vec[1][i] = qp->gamma[ty * C + i];
-                vec[2][i] = qp->beta[ty * C + i];
+        auto store_x = [&]() {
+            if (valid && !(QKV && J.pad)) {
+                if constexpr (OUT_NCHW) {
+                    float* op = J.out + (size_t)(4 * g) * P + tok;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) op[(size_t)(16 * t + r) * P] = xacc[t][r];
+                } else {
+                    float* op = J.out + (size_t)tok * C + 4 * g;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) *reinterpret_cast<float4*>(op + 16 * t) = make_float4(xacc[t][0], xacc[t][1], xacc[t][2], xacc[t][3]);
+                }
             }
-            __syncthreads();
-            ln_to_operands16(xacc, vec[1], vec[2], g, ah, al);
-            store_x();                                   // x'' leaves while the first tiles are computed
-            const float cq0 = Qj->c[0], cq1 = Qj->c[1], cq2 = Qj->c[2], cq3 = Qj->c[3], cq4 = Qj->c[4];
-            for (int c = 0; c < n_tail; ++c) {
-                const int mat = c / NCH, t = c - mat * NCH;
-                const float cm = mat == 0 ? cq0 : mat == 1 ? cq1 : mat == 2 ? cq2 : mat == 3 ? cq3 : cq4;
-                // (the 16 stores of x'' are older than the first request made after them: that wait covers them too)
-                auto flushes = [](int k) { return k >= 0 && (A16 ? (k & 3) == 3 : (k & 1) != 0); };
-                step_begin();
-                float4v acc[2] = {(float4v)(0.f), (float4v)(0.f)};
-                mma_proj16(acc, slot(cc), ah, al, lane);
-                products_end(flushes(c - 1));
-                if constexpr (A16) store_proj16_h(stg, reinterpret_cast<half_t*>(Qj->y[mat]), t, acc, cm, tk, g, lane, tok_w, P);
-                else store_proj16(stg, reinterpret_cast<float*>(Qj->y[mat]), t, acc, cm, tk, g, lane, tok_w, P);
-                step_end(flushes(c));
+        };
+        if constexpr (TAIL == 0) store_x();
+
+        if constexpr (HEAD) {
+            float s_tok;
+            head_token_scales(s_tok);
+            rows_to_operands16(xacc, ah, al, s_tok);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float4 b2 = *reinterpret_cast<const float4*>(&vec[6][16 * t + 4 * g]);
+                xacc[t][0] = b2.x * k_2; xacc[t][1] = b2.y * k_2; xacc[t][2] = b2.z * k_2; xacc[t][3] = b2.w * k_2;
             }
-        } else {
-            store_x();
+            ffn_pass(std::integral_constant<bool, true>{}, vec[5]);
+            {
+                const float k_inv = pow2_inv(k_2);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) xacc[t] *= k_inv;
+            }
+            if (valid) {
+                float* op = J.out + (size_t)(4 * g) * P + tok;      // (C, P) map
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) op[(size_t)(16 * t + r) * P] = xacc[t][r];
+            }
         }
-    }
+
+        if constexpr (QKV) {
+            if (n_tail > 0) {
+                ln_to_operands16(xacc, vec[5], vec[6], g, ah, al);
+                store_x();                                   // x'' leaves while the first tiles are computed
+                const float cq0 = Qj->c[0], cq1 = Qj->c[1], cq2 = Qj->c[2], cq3 = Qj->c[3], cq4 = Qj->c[4];
+                for (int c = 0; c < n_tail; ++c) {
+                    const int mat = c / NCH, t = c - mat * NCH;
+                    const float cm = mat == 0 ? cq0 : mat == 1 ? cq1 : mat == 2 ? cq2 : mat == 3 ? cq3 : cq4;
+                    // (the 16 stores of x'' are older than the first request made after them: that wait covers them too)
+                    auto flushes = [](int k) { return k >= 0 && (A16 ? (k & 3) == 3 : (k & 1) != 0); };
+                    step_begin();
+                    if constexpr (OUTPROJ && !A16) {
+                        // the next tile's attention rows into the residual registers (idle since store_x): requested at the head
+                        // of a step, i.e. right behind the counted wait of the step before, and landed a step later
+                        if (c == 1 && has_next) {
+                            const int ntok = min(next_tile * X16_TOKENS + wave * 16 + tk, P - 1);
+                            const float* op = reinterpret_cast<const float*>(J.o) + (size_t)ntok * C + 4 * g;
+#pragma unroll
+                            for (int t2 = 0; t2 < 16; ++t2) {
+                                const float4 f = *reinterpret_cast<const float4*>(op + 16 * t2);
+                                xacc[t2][0] = f.x; xacc[t2][1] = f.y; xacc[t2][2] = f.z; xacc[t2][3] = f.w;
+                            }
+                            have_o = true;
+                            extra = 16;
+                        }
+                    }
+                    float4v acc[2] = {(float4v)(0.f), (float4v)(0.f)};
+                    mma_proj16(acc, slot(cc), ah, al, lane);
+                    products_end(flushes(c - 1));
+                    if constexpr (A16) store_proj16_h(stg, reinterpret_cast<half_t*>(Qj->y[mat]), t, acc, cm, tk, g, lane, tok_w, P);
+                    else store_proj16(stg, reinterpret_cast<float*>(Qj->y[mat]), t, acc, cm, tk, g, lane, tok_w, P);
+                    step_end(flushes(c));
+                }
+            } else {
+                store_x();
+            }
+        }
+        gs3 = (gs3 + n_total) % X16_RING;
+    } while (live_mask);
     if (X16_DEPHASE && !grp_b) wg_barrier();             // group A's share of group B's extra first barrier
 }
 
@@ -1739,13 +1806,32 @@ static int launch_out_ffn_c(const FfnParams& p, int n_jobs, int variant, hipStre
     return HMVIT_OK;
 }
 
+// Workgroups per job of the x16 tails.  The kernels can walk several tiles per workgroup (tail16_body), but the shipped grid is
+// ONE TILE PER WORKGROUP: measured at cfg2 on one box (tools/probe/run_libs.sh, four tails of a forward): 5.55 ms with 1100
+// workgroups per job, 5.70 with 204 (5.4 tiles each), 5.96 with 102, 6.05-6.10 with 51 (one workgroup per CU, 22 tiles each) -
+// with and without the row loads of a tile boundary kept in flight.  What the walk saves (inputs and first chunks arriving with
+// nothing to overlap them, once per tile) is less than what a static partition loses to the spread of the CUs' speeds: the
+// hardware dispatcher hands the next tile to whichever CU is free.  -DHMVIT_X16_GX=n / HMVIT_X16_GRID (probe builds) set the
+// walk's width for measurements.
+static int x16_grid_x(int P, int n_jobs) {
+    const int n_tiles = cdiv(P, X16_TOKENS);
+    int gx = n_tiles;
+#ifdef HMVIT_X16_GX
+    gx = HMVIT_X16_GX;
+#endif
+    if (const char* e = HMVIT_ENV("HMVIT_X16_GRID")) gx = atoi(e);
+    if (gx < 1) gx = 1;
+    gx = gx > cdiv(n_tiles, X16_MAX_TILES) ? gx : cdiv(n_tiles, X16_MAX_TILES);
+    return gx < n_tiles ? gx : n_tiles;
+}
+
 int launch_out_ffn_qkv(const FfnParams& p, const QkvParams& q, int n_jobs, int C, int split, hipStream_t st) {
     if (n_jobs == 0) return HMVIT_OK;
     HMVIT_CHECK_ARG(C == 256, "out_ffn_qkv: C=%d unsupported (256)", C);
     dim3 grid(cdiv(p.P, CHAIN_TOKENS), n_jobs), block(CHAIN_THREADS);
     // FfnJob::x_nchw (all jobs of a launch alike): the residual is read from (C, P) maps
     if (split) {
-        const dim3 grid16(cdiv(p.P, X16_TOKENS), n_jobs), block16(X16_THREADS);
+        const dim3 grid16(x16_grid_x(p.P, n_jobs), n_jobs), block16(X16_THREADS);
         if (split == 2) {
             if (p.job[0].x_nchw) hipLaunchKernelGGL((k_out_ffn_qkv16<true, true>), grid16, block16, 0, st, p, q);
             else hipLaunchKernelGGL((k_out_ffn_qkv16<false, true>), grid16, block16, 0, st, p, q);
@@ -1765,8 +1851,8 @@ int launch_out_ffn_head(const FfnParams& p, int n_jobs, int C, int split, hipStr
     if (n_jobs == 0) return HMVIT_OK;
     HMVIT_CHECK_ARG(C == 256 && p.w_head && p.hb_1 && p.hb_2, "out_ffn_head: C=%d (256) / head weights missing", C);
     dim3 grid(cdiv(p.P, CHAIN_TOKENS), n_jobs), block(CHAIN_THREADS);
-    if (split == 2) hipLaunchKernelGGL(k_out_ffn_head16<true>, dim3(cdiv(p.P, X16_TOKENS), n_jobs), dim3(X16_THREADS), 0, st, p);
-    else if (split) hipLaunchKernelGGL(k_out_ffn_head16<false>, dim3(cdiv(p.P, X16_TOKENS), n_jobs), dim3(X16_THREADS), 0, st, p);
+    if (split == 2) hipLaunchKernelGGL(k_out_ffn_head16<true>, dim3(x16_grid_x(p.P, n_jobs), n_jobs), dim3(X16_THREADS), 0, st, p);
+    else if (split) hipLaunchKernelGGL(k_out_ffn_head16<false>, dim3(x16_grid_x(p.P, n_jobs), n_jobs), dim3(X16_THREADS), 0, st, p);
     else hipLaunchKernelGGL((k_out_ffn_head<256, false>), grid, block, 0, st, p);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
@@ -1776,7 +1862,7 @@ int launch_out_ffn(const FfnParams& p, int n_jobs, int C, int variant, int split
     if (n_jobs == 0) return HMVIT_OK;
     HMVIT_CHECK_ARG(split != 2 || C == 256, "mixed precision planes need C = 256 (got %d)", C);
     if (split && C == 256) {
-        const dim3 grid(cdiv(p.P, X16_TOKENS), n_jobs), block(X16_THREADS);
+        const dim3 grid(x16_grid_x(p.P, n_jobs), n_jobs), block(X16_THREADS);
         switch (variant) {
             case FFN_FULL:
                 if (split == 2) hipLaunchKernelGGL((k_out_ffn16<true, true, true, false, true>), grid, block, 0, st, p);
