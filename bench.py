@@ -31,6 +31,11 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                 every parity case, but input-dependent -- a side figure),
   strict_f32    scenes/s of the exact-f32 MFMA mode,
   train_step    milliseconds of one training step of the fusion (forward with dropout + backward + AdamW) on the same scene,
+  encoders      the two BEV encoders north_star names beside the fusion, at the shipped size (5 agents; 20 k pillars on a
+                512 x 512 grid -> PointPillar -> (5, 256, 128, 128); 4 cameras of 512 x 512 per agent -> ResNet-34 + CVT lift ->
+                the same): ms per 5-agent call, algorithmic TFLOP/s of their convolutions against the f16 MFMA peak,
+  model_e2e     pillars + images -> psm / rm of the whole hetero model (agent types 10110) at the shipped 128 x 128 BEV size,
+  other_configs fusion scenes/s of the remaining BASELINE configs (cfg1 / cfg3 / cfg4) and the shipped 128 x 128 size,
   dense_masked_tiles  scenes/s with skip_masked off: `value` skips (ego, source, window) key tiles in which every key
                 is masked (outside the source's field of view) and windows of non-ego agents whose results cannot
                 reach ego 0's output row; this is the same forward without those two shortcuts.
@@ -158,6 +163,85 @@ def cpu_baseline(cfgd, num_iters, seed):
             "thread_sweep_s": {str(k): round(v, 3) for k, v in sweep.items()},
             "reference_itself": "the reference's own HeteroFusion.forward measured in the build container on 8 cores: "
                                 "122.8 s/scene = 0.0081 scenes/s at cfg2 (BASELINE.md section 2)"}
+
+
+def _time_ms(fn, n, warmup):
+    import torch
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def other_configs(args, dev, precision, hmvit_amd, S):
+    """Fusion scenes/s of the BASELINE configs that are not the headline (and the shipped 128 x 128 size), same precision mode."""
+    import torch
+    out = {}
+    for name, cc in CONFIGS.items():
+        if name == args.config or (precision == "mixed" and cc["C"] != 256):
+            continue
+        cfg = S.make_config(cc["C"], cc["window"], cc["L"], voxel=cc["voxel"], downsample=cc["downsample"], num_iters=args.num_iters)
+        net = S.seeded_fusion(cfg, precision=precision, seed=0).to(dev).eval()
+        scene = [t.to(dev) for t in S.synthetic_scene(cc["L"], cc["C"], cc["H"], cc["W"], cc["modes"], seed=1)]
+        with torch.no_grad():
+            ms = _time_ms(lambda: net(*scene), 10, 2)
+        out[name] = {"value": 1e3 / ms, "unit": "scenes/s", "ms_per_step": ms,
+                     "workload": f"{cc['L']} agents modes {''.join(map(str, cc['modes']))}, {cc['H']}x{cc['W']}, C={cc['C']}, window {cc['window']}"}
+        del net, scene
+        torch.cuda.empty_cache()
+    return out
+
+
+def encoder_lines(dev, precision, hmvit_amd, S):
+    """north_star's BEV encoders and the whole hetero model at the shipped size.  Random-init weights
+    (the modules' own default initialisation), synthetic pillars / images; times from HIP events around `n` calls."""
+    import torch
+    from hmvit_amd import replay as R
+    from hmvit_amd.camera import CvtCameraEncoder
+    L, nx, ny, image = 5, 512, 512, 512
+    mcfg = R.lidar_model_config(nx, ny, max_cav=L)
+    torch.manual_seed(0)
+    vf, vc, vn = S.synthetic_pillars(L, 20000, nx, ny, mcfg["lidar"], seed=2)
+    lidar_batch = {"processed_lidar": {"voxel_features": vf.to(dev), "voxel_coords": vc.to(dev), "voxel_num_points": vn.to(dev)},
+                   "record_len": torch.tensor([L])}
+    ccfg = S.camera_config(image=image, num_layers=34, bev_h=256, bev_w=256)
+    cams = {k: v.to(dev) for k, v in S.synthetic_cameras(L, image, seed=8).items()}
+    enc = {}
+    with torch.no_grad():
+        pp = hmvit_amd.PointPillar(mcfg["lidar"], precision=precision).to(dev).eval()
+        pp.set_return_features()
+        ms = _time_ms(lambda: pp(lidar_batch), 10, 4)
+        tf = 0.1436 * L                                   # SURVEY 8a row a16: 143.6 GFLOP of convolutions per agent (20 k pillars)
+        enc["pointpillar"] = {"ms": ms, "algorithmic_TFLOP": tf, "achieved_TFLOPs": tf / (ms * 1e-3), "peak_TFLOPs": PEAK[precision],
+                              "frac": tf / (ms * 1e-3) / PEAK[precision], "traffic": None,
+                              "workload": "5 agents x 20 k pillars, 512x512 grid, layers [3, 5, 8] -> (5, 256, 128, 128)"}
+        del pp
+        cam = CvtCameraEncoder(ccfg, precision=precision).to(dev).eval()
+        ms = _time_ms(lambda: cam(cams), 5, 2)
+        tf = S.resnet_trunk_flops(34, image) * 4 * L / 1e12
+        enc["cvt"] = {"ms": ms, "algorithmic_TFLOP": tf, "achieved_TFLOPs": tf / (ms * 1e-3), "peak_TFLOPs": PEAK[precision],
+                      "frac": tf / (ms * 1e-3) / PEAK[precision], "traffic": None,
+                      "workload": "5 agents x 4 cameras of 512x512, ResNet-34 trunk (the priced flops) + cross-view lift (32x32 queries, "
+                                  "16384 + 1024 keys) + decoder -> (5, 256, 128, 128)"}
+        # whole hetero model: BASELINE configs[2]'s agent types, every agent carries both sensors' inputs and `mode` picks one
+        _, pw, _, _, _ = S.synthetic_scene(L, 1, 1, 1, [1] * L, seed=0)
+        batch = dict(lidar_batch)
+        batch.update({"mode": torch.tensor([[1.0, 0.0, 1.0, 1.0, 0.0]], dtype=torch.float64), "pairwise_t_matrix": pw.to(dev)})
+        batch.update(cams)
+        net = hmvit_amd.BevformerPointPillarHetero(mcfg, camera_encoder=cam, precision=precision).to(dev).eval()
+        ms = _time_ms(lambda: net(batch), 5, 2)
+        e2e = {"ms_per_scene": ms, "value": 1e3 / ms, "unit": "scenes/s", "precision": precision,
+               "workload": "5 agents 10110 (2 camera + 3 LiDAR): pillars + images -> PointPillar / ResNet-34 + CVT -> HeteroFusion "
+                           "(128x128, C=256, window 8, 2 iters) -> HeteroDecoder -> psm / rm; random-init weights"}
+        del net, cam
+    torch.cuda.empty_cache()
+    return enc, e2e
 
 
 def train_bench(args, c, dev, rank, world, scene, make, barrier, D):
@@ -429,11 +513,23 @@ def main(argv=None):
                 "frac": achieved / peak, "traffic": traffic, "avg_launch_ms": avg_s * 1e3,
                 "algorithmic_per_launch": per_launch}
         if dom == "attention":
-            # the same kernel against the HBM roof: compulsory bytes = Q in + every K'/V' map once + O out
+            # the same kernel against the HBM roof: compulsory bytes = Q in + every K'/V' map once + O out, for the (ego, window)
+            # items each launch actually RAN (hmvit_fusion_profile_items: the reachability pruning drops a quarter of the third
+            # stage's items and four fifths of the last one's) - mean over the launches
             L_, C_, P_ = c["L"], c["C"], c["H"] * c["W"]
             n_st = 2 * args.num_iters
-            comp = ((n_st - 1) * (L_ * P_ * C_ * es * 2 + L_ * 2 * P_ * C_ * es) +
-                    (P_ * C_ * es * 2 + L_ * 2 * P_ * C_ * es)) / n_st
+            items = getattr(net, "last_attention_items", None) or []
+            n_win = P_ // (c["window"] ** 2)
+            if len(items) == n_st:
+                q_rows = [live / n_win * P_ for live, _ in items]            # query rows (= output rows) of each launch
+            else:
+                q_rows = [L_ * P_] * (n_st - 1) + [P_]
+            comp = sum(r * C_ * es * 2 + L_ * 2 * P_ * C_ * es for r in q_rows) / n_st
+            if kind == "mfma":
+                per_launch = sum(2 * 2 * r * (L_ * c["window"] ** 2) * C_ for r in q_rows) / n_st
+                achieved = per_launch / avg_s / 1e12
+                roof.update({"achieved": achieved, "frac": achieved / peak, "algorithmic_per_launch": per_launch})
+            roof["items_run_per_launch"] = [int(live) for live, _ in items] or None
             hbm = {"algorithmic_bytes_per_launch": comp, "achieved_GBps": comp / avg_s / 1e9,
                    "peak_GBps": PEAK_HBM, "frac": comp / avg_s / 1e9 / PEAK_HBM}
             if prec == "split":
@@ -514,6 +610,9 @@ def main(argv=None):
                                     "peak_memory_GiB": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
             del tnet, opt, target
             torch.cuda.empty_cache()
+        if side:
+            result["other_configs"] = other_configs(args, dev, precision, hmvit_amd, S)
+            result["encoders"], result["model_e2e"] = encoder_lines(dev, precision if precision != "mixed" else "split", hmvit_amd, S)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(c, args.num_iters, seed=1)
     if rank == 0:

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMVIT_LIB", os.path.join(_HERE, "libhmvit.so"))   # HMVIT_LIB: ablation builds of tools/probe
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 PREC_F32, PREC_F16, PREC_SPLIT, PREC_MIXED = 0, 1, 2, 3
 PART_WINDOW, PART_GRID = 0, 1
 NUM_TYPES = 2
@@ -84,6 +84,7 @@ _SIGNATURES = {
     "hmvit_fusion_workspace_bytes": (C.c_size_t, [C.POINTER(FusionDesc)]),
     "hmvit_fusion_forward": (C.c_int, [C.POINTER(FusionDesc), C.c_void_p]),
     "hmvit_fusion_profile": (C.c_int, [C.POINTER(FusionDesc), C.c_void_p, c_f32p, c_i32p]),
+    "hmvit_fusion_profile_items": (C.c_int, [c_i32p, c_i32p, C.c_int]),
     "hmvit_fusion_train_saved_bytes": (C.c_size_t, [C.POINTER(FusionTrainDesc)]),
     "hmvit_fusion_backward_workspace_bytes": (C.c_size_t, [C.POINTER(FusionTrainDesc)]),
     "hmvit_fusion_train_forward": (C.c_int, [C.POINTER(FusionTrainDesc), C.c_void_p]),

@@ -2650,6 +2650,21 @@ int launch_attn_schedule(const AttnParams& p, int* ws, hipStream_t st) {
     return HMVIT_OK;
 }
 
+// number of items the schedule keeps (bit 31 clear): the profile's count of the attention items actually run (bench.py's
+// roofline numerator)
+__global__ __launch_bounds__(256) void k_count_live(const unsigned* __restrict__ vis_mask, int n, int* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n && !(vis_mask[i] >> 31);
+    const unsigned long long b = __ballot(live);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, __popcll(b));
+}
+int launch_count_live(const unsigned* vis_mask, int n, int* out, hipStream_t st) {
+    if (n <= 0) return HMVIT_OK;
+    hipLaunchKernelGGL(k_count_live, dim3(cdiv(n, 256)), dim3(256), 0, st, vis_mask, n, out);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
 int launch_tile_vis(const AttnParams& p, unsigned* vis_mask, const unsigned char* need, hipStream_t st) {
     HMVIT_CHECK_ARG(p.n_src <= 8 && p.window == 8, "tile_vis: n_src=%d (<= 8), window=%d (8)", p.n_src, p.window);
     const int n_pos = p.B * p.n_ego * (p.H / 8) * (p.W / 8);

@@ -126,22 +126,36 @@ struct PhaseTimer {
     hipStream_t st;
     std::vector<hipEvent_t> ev;
     std::vector<int> phase;
-    int mark(int ph) {
+    std::vector<int> launched;          // 0: the interval closed by this mark held no launch of its phase (counted as time only)
+    int* d_items = nullptr;             // device counters: live attention items per stage (launch_count_live)
+    int n_stages = 0;
+    int total_items[16];
+    int mark(int ph, bool did_launch = true) {
         hipEvent_t e;
         HMVIT_CHECK_HIP(hipEventCreate(&e));
         HMVIT_CHECK_HIP(hipEventRecord(e, st));
         ev.push_back(e);
         phase.push_back(ph);
+        launched.push_back(did_launch ? 1 : 0);
         return HMVIT_OK;
     }
     ~PhaseTimer() {
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        if (d_items) (void)hipFree(d_items);
     }
 };
 #define HMVIT_MARK(ph)                                   \
     do {                                                 \
         if (timer) {                                     \
             int _rc = timer->mark(ph);                   \
+            if (_rc != HMVIT_OK) return _rc;             \
+        }                                                \
+    } while (0)
+
+#define HMVIT_MARK_IF(ph, did)                           \
+    do {                                                 \
+        if (timer) {                                     \
+            int _rc = timer->mark(ph, did);              \
             if (_rc != HMVIT_OK) return _rc;             \
         }                                                \
     } while (0)
@@ -586,8 +600,8 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                     for (int l = 0; l < pl.max_cav; ++l) HMVIT_TRY(qb_.add(qkv_job(wt, si, b * L + l, l, first)));
                 HMVIT_TRY(qb_.flush());
             }
+            HMVIT_MARK_IF(HMVIT_PHASE_QKV, !qkv_done);     // a stage whose projections rode on the previous tail launches nothing here
             qkv_done = false;
-            HMVIT_MARK(HMVIT_PHASE_QKV);
 
             // 3. fused warp + partition + attention
             unsigned char* need = nullptr;
@@ -622,6 +636,13 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                         ap.n_sched = B * n_ego * (d->H / 8) * (d->W / 8);
                         ap.sched_sub = sched_sub;
                     }
+                }
+                if (timer && timer->d_items && timer->n_stages < 16) {      // profile: (ego, window) items this launch runs
+                    const int n_items = B * n_ego * (d->H / d->window) * (d->W / d->window);
+                    timer->total_items[timer->n_stages] = n_items;
+                    if (ap.vis_mask && ap.prune) HMVIT_TRY(launch_count_live(ap.vis_mask, n_items, timer->d_items + timer->n_stages, st));
+                    else HMVIT_CHECK_HIP(hipMemcpyAsync(timer->d_items + timer->n_stages, &timer->total_items[timer->n_stages], sizeof(int), hipMemcpyHostToDevice, st));
+                    ++timer->n_stages;
                 }
                 HMVIT_TRY(launch_attention(ap, split == 1 ? HMVIT_PREC_SPLIT : HMVIT_PREC_F16, st));
             }
@@ -773,19 +794,34 @@ int hmvit_fusion_forward(const HmvitFusionDesc* desc, void* stream) {
     return fusion_forward(desc, reinterpret_cast<hipStream_t>(stream), nullptr);
 }
 
+// (ego, window) attention items per stage of the last hmvit_fusion_profile of this thread: run / in the stage
+static thread_local int g_prof_items[2][16];
+static thread_local int g_prof_stages = 0;
+int hmvit_fusion_profile_items(int32_t* live, int32_t* total, int capacity) {
+    HMVIT_CHECK_ARG(live && total && capacity > 0, "fusion_profile_items: bad argument");
+    const int n = g_prof_stages < capacity ? g_prof_stages : capacity;
+    for (int i = 0; i < n; ++i) { live[i] = g_prof_items[0][i]; total[i] = g_prof_items[1][i]; }
+    return n;
+}
+
 int hmvit_fusion_profile(const HmvitFusionDesc* desc, void* stream, float* phase_ms, int32_t* phase_launches) {
     HMVIT_CHECK_ARG(phase_ms && phase_launches, "fusion_profile: null output");
     PhaseTimer timer;
     timer.st = reinterpret_cast<hipStream_t>(stream);
+    HMVIT_CHECK_HIP(hipMalloc(&timer.d_items, 16 * sizeof(int)));
+    HMVIT_CHECK_HIP(hipMemsetAsync(timer.d_items, 0, 16 * sizeof(int), timer.st));
     int rc = fusion_forward(desc, timer.st, &timer);
     if (rc != HMVIT_OK) return rc;
     HMVIT_CHECK_HIP(hipStreamSynchronize(timer.st));
+    g_prof_stages = timer.n_stages;
+    if (timer.n_stages > 0) HMVIT_CHECK_HIP(hipMemcpy(g_prof_items[0], timer.d_items, timer.n_stages * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < timer.n_stages; ++i) g_prof_items[1][i] = timer.total_items[i];
     for (int i = 0; i < HMVIT_NUM_PHASES; ++i) { phase_ms[i] = 0.f; phase_launches[i] = 0; }
     for (size_t i = 1; i < timer.ev.size(); ++i) {
         float ms = 0.f;
         HMVIT_CHECK_HIP(hipEventElapsedTime(&ms, timer.ev[i - 1], timer.ev[i]));
         phase_ms[timer.phase[i]] += ms;
-        phase_launches[timer.phase[i]] += 1;
+        phase_launches[timer.phase[i]] += timer.launched[i];
     }
     return HMVIT_OK;
 }

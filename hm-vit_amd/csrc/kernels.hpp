@@ -226,6 +226,7 @@ struct AttnParams {
 };
 int launch_attention(const AttnParams& p, int precision, hipStream_t st);
 int launch_tile_vis(const AttnParams& p, unsigned* vis_mask, const unsigned char* need, hipStream_t st);
+int launch_count_live(const unsigned* vis_mask, int n, int* out, hipStream_t st);   // += items with bit 31 clear
 // world-ordered work list of a local-partition stage with p.n_ego egos (p.ainv, B, L, H, W are read); ws: attn_schedule_bytes
 size_t attn_schedule_bytes(int B, int n_ego, int H, int W);
 int launch_attn_schedule(const AttnParams& p, int* ws, hipStream_t st);

@@ -291,6 +291,10 @@ class _FusionBase(nn.Module):
             _lib.check(_lib.lib.hmvit_fusion_profile(ctypes.byref(d), ctypes.c_void_p(stream), ms, cnt),
                        "hmvit_fusion_profile")
         del keep
+        live, total = (ctypes.c_int32 * 16)(), (ctypes.c_int32 * 16)()
+        n_st = _lib.lib.hmvit_fusion_profile_items(live, total, 16)
+        # (ego, window) attention items per stage, (run, in the stage): what the reachability pruning left of each launch
+        self.last_attention_items = [(int(live[i]), int(total[i])) for i in range(max(0, n_st))]
         return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(_lib.PHASES)}
 
 

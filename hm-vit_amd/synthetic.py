@@ -100,3 +100,45 @@ def synthetic_cameras(n_agents: int, image: int, seed: int = 0) -> dict:
             T[:3, 3] = torch.tensor([1.5 * cs, 1.5 * sn, 1.6 + 0.02 * a])
             ext[a, c] = T
     return {"camera": cam, "intrinsic": K.repeat(n_agents, 4, 1, 1), "extrinsic": ext, "cav2cam_extrinsic": ext.clone()}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# LiDAR agents (encoder benchmarks): `n_per_agent` unique random cells of an (nx, ny) pillar grid per agent,
+# voxel_features ~ points inside their cell (x, y, z, intensity), 1..32 points per pillar, zero padded
+# ---------------------------------------------------------------------------------------------------------------------
+def synthetic_pillars(n_agents: int, n_per_agent: int, nx: int, ny: int, lidar_args: dict, seed: int = 3):
+    """(voxel_features (Nv, 32, 4) f32, voxel_coords (Nv, 4) int32 [agent, z, y, x], voxel_num_points (Nv,) int32)."""
+    gen = torch.Generator().manual_seed(seed)
+    vx, vy, vz = lidar_args["voxel_size"]
+    x0, y0, z0 = lidar_args["lidar_range"][:3]
+    feats, coords, counts = [], [], []
+    for a in range(n_agents):
+        cells = torch.randperm(nx * ny, generator=gen)[:n_per_agent]
+        cy, cx = cells // nx, cells % nx
+        n_pts = torch.randint(1, 33, (n_per_agent,), generator=gen)
+        u = torch.rand(n_per_agent, 32, 4, generator=gen)
+        pts = torch.stack([x0 + (cx[:, None] + u[..., 0]) * vx, y0 + (cy[:, None] + u[..., 1]) * vy, z0 + u[..., 2] * vz, u[..., 3]], -1)
+        pts = pts * (torch.arange(32)[None, :] < n_pts[:, None])[..., None]
+        feats.append(pts.float())
+        coords.append(torch.stack([torch.full_like(cy, a), torch.zeros_like(cy), cy, cx], 1))
+        counts.append(n_pts)
+    return torch.cat(feats), torch.cat(coords).int(), torch.cat(counts).int()
+
+
+def resnet_trunk_flops(num_layers: int, image: int) -> float:
+    """FLOPs (2 per MAC) of the convolutions of a torchvision-style ResNet-18 / 34 BasicBlock trunk on one image x image input:
+    7 x 7 / 2 stem, 3 x 3 / 2 max-pool, stages of [64, 128, 256, 512] channels (the pricing of bench.py's camera-encoder line)."""
+    blocks = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3]}[num_layers]
+    hw = (image // 2) ** 2
+    flops = 2.0 * 64 * 3 * 49 * hw
+    hw //= 4
+    cin = 64
+    for stage, (n, c) in enumerate(zip(blocks, [64, 128, 256, 512])):
+        for b in range(n):
+            stride = 2 if (stage > 0 and b == 0) else 1
+            hw_out = hw // (stride * stride)
+            flops += 2.0 * c * cin * 9 * hw_out + 2.0 * c * c * 9 * hw_out
+            if stride != 1 or cin != c:
+                flops += 2.0 * c * cin * hw_out
+            cin, hw = c, hw_out
+    return flops

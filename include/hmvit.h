@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HMVIT_ABI_VERSION 9
+#define HMVIT_ABI_VERSION 10
 
 #define HMVIT_OK 0
 #define HMVIT_EINVAL (-22)   /* bad argument / unsupported shape */
@@ -216,6 +216,10 @@ int hmvit_fusion_forward(const HmvitFusionDesc* desc, void* stream);
 #define HMVIT_NUM_PHASES 10
 int hmvit_fusion_profile(const HmvitFusionDesc* desc, void* stream, float* phase_ms,
                          int32_t* phase_launches);
+/* (ego, window) attention items of every stage of this thread's last hmvit_fusion_profile, in launch order: live[i] = items
+ * the launch ran (what the reachability pruning of the last two stages left: DESIGN 5.1), total[i] = egos x windows of the
+ * stage.  Returns the number of stages written (<= capacity).  bench.py prices the attention kernel's roofline on these. */
+int hmvit_fusion_profile_items(int32_t* live, int32_t* total, int capacity);
 
 /* ---- training: forward that keeps its activations + backward ("autograd must flow to x and all used
  * parameters").  The reference trains this path through torch.autograd (opencood/tools/train_camera.py:163-199, Dropout 0.1
