@@ -270,8 +270,18 @@ def train(model, dataset, pre, hypes: dict, saved_path: str | None = None, init_
                 log("At epoch %d, the validation loss is %f" % (epoch, val))
         if saved_path and rank == 0 and epoch % hypes["train_params"]["save_freq"] == 0:
             save_checkpoint(model_without_ddp, saved_path, epoch)
-    return {"epoch_loss": history, "val_loss": val_history, "ms_per_step": 1e3 * t_step / max(1, n_step), "steps": n_step,
-            "world_size": world}
+    res = {"epoch_loss": history, "val_loss": val_history, "ms_per_step": 1e3 * t_step / max(1, n_step), "steps": n_step,
+           "world_size": world}
+    if info["distributed"]:
+        # after the last step every rank must hold the same parameters (DDP averaged every gradient): largest difference between
+        # the ranks' trainable parameters, relative to their largest magnitude - 0 when the all-reduce did its job
+        import torch.distributed as dist
+        flat = torch.cat([p.detach().float().reshape(-1) for p in model_without_ddp.parameters() if p.requires_grad])
+        hi, lo = flat.clone(), flat.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        res["rank_param_spread"] = float((hi - lo).abs().max() / flat.abs().max().clamp_min(1e-30))
+    return res
 
 
 def build(args):

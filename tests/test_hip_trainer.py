@@ -258,6 +258,7 @@ def test_two_rank_ddp_training_on_one_gpu():
     res = json.loads(line)
     assert res["world_size"] == 2 and res["steps"] >= 3
     assert all(l == l for l in res["epoch_loss"]) and res["epoch_loss"][-1] < res["epoch_loss"][0]
+    assert res["rank_param_spread"] <= 1e-6, res["rank_param_spread"]     # DDP left both ranks with the same parameters
 
 
 def test_mixed_camera_lidar_five_agent_train_loop_with_validation():
