@@ -124,6 +124,9 @@ _SIGNATURES = {
     "hmvit_bn_relu_tokens": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     "hmvit_cross_attention": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_void_p]),
     "hmvit_attention_bias": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]),
+    "hmvit_attention_bias_train": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]),
+    "hmvit_attention_bias_backward": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 5 + [C.c_void_p]),
+    "hmvit_maxpool2d_backward": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p]),
     "hmvit_cross_attention_train": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]),
     "hmvit_cross_attention_backward": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 6 + [C.c_void_p]),
     "hmvit_layernorm_backward": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),

@@ -170,6 +170,69 @@ class CrossAttnFn(torch.autograd.Function):
         return dq, dk, dv, None, None
 
 
+class AttnBiasFn(torch.autograd.Function):
+    """q (b, Q, HD), k / v (b, K, HD), bias (heads, Q, K) -> (b, Q, HD): softmax(q k^T / sqrt(32) + bias) v per head, exact f32 -
+    the self-attention that closes FAXModule (fax_modules.py:136-180) on libhmvit (``hmvit_attention_bias_train`` / ``_backward``)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, bias, heads, dim_head):
+        q, k, v, bias = q.contiguous(), k.contiguous(), v.contiguous(), bias.contiguous().float()
+        b, Q, HD = q.shape
+        K = k.shape[1]
+        a = torch.empty(b, Q, HD, device=q.device, dtype=torch.float32)
+        lse = torch.empty(b, heads, Q, device=q.device, dtype=torch.float32)
+        with torch.cuda.device(q.device):
+            _lib.check(_lib.lib.hmvit_attention_bias_train(q.data_ptr(), k.data_ptr(), v.data_ptr(), bias.data_ptr(), a.data_ptr(), lse.data_ptr(),
+                                                           b, Q, K, heads, dim_head, _stream(q.device)), "attention_bias_train")
+        ctx.save_for_backward(q, k, v, bias, a, lse)
+        ctx.dims = (heads, dim_head)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        q, k, v, bias, a, lse = ctx.saved_tensors
+        heads, dim_head = ctx.dims
+        da = da.contiguous()
+        b, Q, HD = q.shape
+        K = k.shape[1]
+        dq, dk, dv, dbias = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), torch.empty_like(bias)
+        with torch.cuda.device(q.device):
+            _lib.check(_lib.lib.hmvit_attention_bias_backward(q.data_ptr(), k.data_ptr(), v.data_ptr(), bias.data_ptr(), a.data_ptr(), lse.data_ptr(),
+                                                              da.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dbias.data_ptr(), b, Q, K,
+                                                              heads, dim_head, _stream(q.device)), "attention_bias_backward")
+        return dq, dk, dv, dbias, None, None
+
+
+class MaxPoolFn(torch.autograd.Function):
+    """nn.MaxPool2d on an f32 NHWC map: ``hmvit_maxpool2d`` forward, ``hmvit_maxpool2d_backward`` (the gradient of a window goes to its
+    first maximum in row-major order) - the ResNet stem's 3 x 3 / 2 pooling under autograd (resnet_ms.py:71)."""
+
+    @staticmethod
+    def forward(ctx, x, ksize, stride, pad):
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        ho, wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
+        y = torch.empty(n, ho, wo, c, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib.hmvit_maxpool2d(x.data_ptr(), y.data_ptr(), n, h, w, c, ksize, stride, pad, _lib.PREC_F32, _stream(x.device)),
+                       "maxpool2d")
+        ctx.save_for_backward(x)
+        ctx.dims = (ksize, stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        ksize, stride, pad = ctx.dims
+        n, h, w, c = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib.hmvit_maxpool2d_backward(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, h, w, c, ksize, stride, pad,
+                                                         _stream(x.device)), "maxpool2d_backward")
+        return dx, None, None, None
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # layers
 # ---------------------------------------------------------------------------------------------------------------------
@@ -224,7 +287,7 @@ def resnet_encoder_forward(enc, input_images):
     Ho, Wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
     x = LinearFn.apply(cols.transpose(1, 2).reshape(-1, cols.shape[1]), conv.weight, conv.bias).reshape(b * l * m, Ho, Wo, -1)
     x = TT.bn_relu_module(x, e.bn1)
-    x = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()   # value routing
+    x = MaxPoolFn.apply(x, 3, 2, 1)                                                      # value routing on libhmvit
     outs = []
     for li in range(4):
         for blk in getattr(e, f"layer{li + 1}"):
@@ -284,10 +347,10 @@ def cross_view_attention_forward(cva, x, bev, feature, I_inv, E_inv):
     query = bev_embed.reshape(b, n, dim, H, W) + x[:, None]
 
     feat = feature.reshape(b * n, C, h, w).permute(0, 2, 3, 1).contiguous()       # NHWC
-    val = conv1x1(TT.bn_relu_module(feat, cva.feature_linear[0]), cva.feature_linear[2])
-    key = img_embed.permute(0, 2, 3, 1)
+    key = img_embed.permute(0, 2, 3, 1)                                # key before value, as cvt_modules.py:133-139 evaluates them
     if cva.feature_proj is not None:
         key = key + conv1x1(TT.bn_relu_module(feat, cva.feature_proj[0]), cva.feature_proj[2])
+    val = conv1x1(TT.bn_relu_module(feat, cva.feature_linear[0]), cva.feature_linear[2])
     q_tok = query.permute(0, 1, 3, 4, 2).reshape(b, n, H * W, dim)
     k_tok = key.reshape(b, n, h * w, dim)
     v_tok = val.reshape(b, n * h * w, dim)

@@ -1130,6 +1130,25 @@ int hmvit_attention_bias(const float* q, const float* k, const float* v, const f
     return launch_cross_attention(q, k, v, out, batch, 1, Q, K, heads, dim_head, bias, reinterpret_cast<hipStream_t>(stream));
 }
 
+int hmvit_attention_bias_train(const float* q, const float* k, const float* v, const float* bias, float* out, float* lse, int batch,
+                               int Q, int K, int heads, int dim_head, void* stream) {
+    HMVIT_CHECK_ARG(q && k && v && bias && out && lse && batch > 0 && Q > 0 && K > 0 && heads > 0, "attention_bias_train: bad argument");
+    return launch_cross_attention(q, k, v, out, batch, 1, Q, K, heads, dim_head, bias, reinterpret_cast<hipStream_t>(stream), lse);
+}
+int hmvit_attention_bias_backward(const float* q, const float* k, const float* v, const float* bias, const float* out, const float* lse,
+                                  const float* d_out, float* dq, float* dk, float* dv, float* d_bias, int batch, int Q, int K, int heads,
+                                  int dim_head, void* stream) {
+    HMVIT_CHECK_ARG(q && k && v && bias && out && lse && d_out && dq && dk && dv && d_bias && batch > 0 && Q > 0 && K > 0 && heads > 0,
+                    "attention_bias_backward: bad argument");
+    return launch_cross_attention_bwd(q, k, v, out, lse, d_out, dq, dk, dv, batch, 1, Q, K, heads, dim_head,
+                                      reinterpret_cast<hipStream_t>(stream), bias, d_bias);
+}
+int hmvit_maxpool2d_backward(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int ksize, int stride, int pad,
+                             void* stream) {
+    HMVIT_CHECK_ARG(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0, "maxpool2d_backward: bad argument");
+    return launch_maxpool_bwd(x, dy, dx, N, H, W, C, ksize, stride, pad, reinterpret_cast<hipStream_t>(stream));
+}
+
 int hmvit_debug_tr16(uint16_t* out, void* stream) {
     HMVIT_CHECK_ARG(out != nullptr, "debug_tr16: null pointer");
     return launch_debug_tr16(out, reinterpret_cast<hipStream_t>(stream));

@@ -246,9 +246,11 @@ __device__ __forceinline__ void xb_load_tile(float* dst, const float* __restrict
 }
 
 // P and dS of the 4 x 4 pairs (queries 4 tq + i, keys 4 tk + j) of a 64 x 64 tile
+// bias_tile: optional, &bias[(head Q + q0) K + k0] with row stride K (the additive logit bias of hmvit_attention_bias)
 __device__ __forceinline__ void xb_tile_probs(const float* Qs, const float* dOs, const float* Ks, const float* Vs, const float* lse_s,
                                               const float* d_s, int tq, int tk, int q_valid, int k_valid, float scale,
-                                              float (&P)[4][4], float (&dS)[4][4]) {
+                                              float (&P)[4][4], float (&dS)[4][4], const float* __restrict__ bias_tile = nullptr,
+                                              int bias_ld = 0) {
     float s[4][4], dp[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -274,7 +276,8 @@ __device__ __forceinline__ void xb_tile_probs(const float* Qs, const float* dOs,
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool ok = (4 * tq + i < q_valid) && (4 * tk + j < k_valid);
-            const float p = ok ? __expf(s[i][j] * scale - lse_s[4 * tq + i]) : 0.f;
+            const float bv = (bias_tile && ok) ? bias_tile[(size_t)(4 * tq + i) * bias_ld + 4 * tk + j] : 0.f;
+            const float p = ok ? __expf(s[i][j] * scale + bv - lse_s[4 * tq + i]) : 0.f;
             P[i][j] = p;
             dS[i][j] = p * (dp[i][j] - d_s[4 * tq + i]) * scale;
         }
@@ -285,7 +288,8 @@ __device__ __forceinline__ void xb_tile_probs(const float* Qs, const float* dOs,
 __global__ __launch_bounds__(256) void k_cross_attention_bwd_dq(const float* __restrict__ q, const float* __restrict__ k,
                                                                 const float* __restrict__ v, const float* __restrict__ out,
                                                                 const float* __restrict__ lse, const float* __restrict__ d_out,
-                                                                float* __restrict__ dq, int n_cam, int Q, int K, int heads, float scale) {
+                                                                float* __restrict__ dq, int n_cam, int Q, int K, int heads, float scale,
+                                                                const float* __restrict__ bias) {
     __shared__ float Qs[XB_T * XB_LS], dOs[XB_T * XB_LS], Ks[XB_T * XB_LS], Vs[XB_T * XB_LS], Ss[XB_T * (XB_T + 1)];
     __shared__ float lse_s[XB_T], d_s[XB_T];
     const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * XB_T, HD = heads * XB_D;
@@ -313,7 +317,8 @@ __global__ __launch_bounds__(256) void k_cross_attention_bwd_dq(const float* __r
             xb_load_tile(Vs, v + ((size_t)b * n_cam + cam) * K * HD, k0, K, HD, head, 1.f);
             __syncthreads();
             float P[4][4], dS[4][4];
-            xb_tile_probs(Qs, dOs, Ks, Vs, lse_s, d_s, tq, tk, q_valid, min(XB_T, K - k0), scale, P, dS);
+            xb_tile_probs(Qs, dOs, Ks, Vs, lse_s, d_s, tq, tk, q_valid, min(XB_T, K - k0), scale, P, dS,
+                          bias ? bias + ((size_t)head * Q + q0) * K + k0 : nullptr, K);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(256) void k_cross_attention_bwd_dkv(const float* __
                                                                  const float* __restrict__ v, const float* __restrict__ out,
                                                                  const float* __restrict__ lse, const float* __restrict__ d_out,
                                                                  float* __restrict__ dk, float* __restrict__ dv, int n_cam, int Q, int K,
-                                                                 int heads, float scale) {
+                                                                 int heads, float scale, const float* __restrict__ bias) {
     __shared__ float Qs[XB_T * XB_LS], dOs[XB_T * XB_LS], Ks[XB_T * XB_LS], Vs[XB_T * XB_LS], Ss[XB_T * (XB_T + 1)], Ps[XB_T * (XB_T + 1)];
     __shared__ float lse_s[XB_T], d_s[XB_T];
     const int b = blockIdx.z, head = blockIdx.y % heads, cam = blockIdx.y / heads, k0 = blockIdx.x * XB_T, HD = heads * XB_D;
@@ -365,7 +370,8 @@ __global__ __launch_bounds__(256) void k_cross_attention_bwd_dkv(const float* __
         }
         __syncthreads();
         float P[4][4], dS[4][4];
-        xb_tile_probs(Qs, dOs, Ks, Vs, lse_s, d_s, tq, tk, q_valid, k_valid, scale, P, dS);
+        xb_tile_probs(Qs, dOs, Ks, Vs, lse_s, d_s, tq, tk, q_valid, k_valid, scale, P, dS,
+                      bias ? bias + ((size_t)head * Q + q0) * K + k0 : nullptr, K);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -392,15 +398,65 @@ __global__ __launch_bounds__(256) void k_cross_attention_bwd_dkv(const float* __
     }
 }
 
+// d_bias[head][q][k] = sum over the batch of dS / scale: one 64 x 64 tile per workgroup, the batch walked inside (no atomics)
+__global__ __launch_bounds__(256) void k_attention_dbias(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                         const float* __restrict__ out, const float* __restrict__ lse,
+                                                         const float* __restrict__ d_out, const float* __restrict__ bias,
+                                                         float* __restrict__ d_bias, int batch, int Q, int K, int heads, float scale) {
+    __shared__ float Qs[XB_T * XB_LS], dOs[XB_T * XB_LS], Ks[XB_T * XB_LS], Vs[XB_T * XB_LS], Os[XB_T * XB_LS];
+    __shared__ float lse_s[XB_T], d_s[XB_T];
+    const int head = blockIdx.y, q0 = blockIdx.x * XB_T, k0 = blockIdx.z * XB_T, HD = heads * XB_D;
+    const int tid = threadIdx.x, tq = tid >> 4, tk = tid & 15;
+    const int q_valid = min(XB_T, Q - q0), k_valid = min(XB_T, K - k0);
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    const float inv_scale = 1.f / scale;
+    for (int b = 0; b < batch; ++b) {
+        __syncthreads();
+        xb_load_tile(Qs, q + (size_t)b * Q * HD, q0, Q, HD, head, 1.f);
+        xb_load_tile(dOs, d_out + (size_t)b * Q * HD, q0, Q, HD, head, 1.f);
+        xb_load_tile(Os, out + (size_t)b * Q * HD, q0, Q, HD, head, 1.f);
+        xb_load_tile(Ks, k + (size_t)b * K * HD, k0, K, HD, head, 1.f);
+        xb_load_tile(Vs, v + (size_t)b * K * HD, k0, K, HD, head, 1.f);
+        __syncthreads();
+        if (tid < XB_T) {
+            float d = 0.f;
+            for (int c = 0; c < XB_D; ++c) d = fmaf(dOs[tid * XB_LS + c], Os[tid * XB_LS + c], d);
+            d_s[tid] = d;
+            lse_s[tid] = tid < q_valid ? lse[((size_t)b * heads + head) * Q + q0 + tid] : 0.f;
+        }
+        __syncthreads();
+        float P[4][4], dS[4][4];
+        xb_tile_probs(Qs, dOs, Ks, Vs, lse_s, d_s, tq, tk, q_valid, k_valid, scale, P, dS, bias + ((size_t)head * Q + q0) * K + k0, K);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] += dS[i][j] * inv_scale;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * tq + i < q_valid && 4 * tk + j < k_valid) d_bias[((size_t)head * Q + q0 + 4 * tq + i) * K + k0 + 4 * tk + j] = acc[i][j];
+}
+
 int launch_cross_attention_bwd(const float* q, const float* k, const float* v, const float* out, const float* lse, const float* d_out,
-                               float* dq, float* dk, float* dv, int b, int n_cam, int Q, int K, int heads, int dim_head, hipStream_t st) {
+                               float* dq, float* dk, float* dv, int b, int n_cam, int Q, int K, int heads, int dim_head, hipStream_t st,
+                               const float* bias, float* d_bias) {
     HMVIT_CHECK_ARG(dim_head == 32, "cross_attention_bwd: dim_head=%d (32)", dim_head);
+    HMVIT_CHECK_ARG(!bias || n_cam == 1, "cross_attention_bwd: a logit bias needs n_cam = 1 (got %d)", n_cam);
     if (b <= 0 || Q <= 0 || K <= 0) return HMVIT_OK;
     const float scale = 1.f / sqrtf((float)dim_head);
     hipLaunchKernelGGL(k_cross_attention_bwd_dq, dim3(cdiv(Q, 64), heads, b), dim3(256), 0, st, q, k, v, out, lse, d_out, dq, n_cam, Q, K,
-                       heads, scale);
+                       heads, scale, bias);
     hipLaunchKernelGGL(k_cross_attention_bwd_dkv, dim3(cdiv(K, 64), heads * n_cam, b), dim3(256), 0, st, q, k, v, out, lse, d_out, dk, dv,
-                       n_cam, Q, K, heads, scale);
+                       n_cam, Q, K, heads, scale, bias);
+    if (bias && d_bias)
+        hipLaunchKernelGGL(k_attention_dbias, dim3(cdiv(Q, 64), heads, cdiv(K, 64)), dim3(256), 0, st, q, k, v, out, lse, d_out, bias, d_bias,
+                           b, Q, K, heads, scale);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }

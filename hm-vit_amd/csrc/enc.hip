@@ -795,6 +795,47 @@ int launch_maxpool(const void* x, void* y, int N, int H, int W, int C, int ksize
     return HMVIT_OK;
 }
 
+// Adjoint of nn.MaxPool2d on f32 NHWC maps, as a GATHER (deterministic, no atomics): input pixel (iy, ix) collects dy of every
+// window it lies in AND whose maximum it is - the first maximum in the window's row-major scan, the element torch's backward routes to.
+__global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int N,
+                                                     int H, int W, int C, int Ho, int Wo, int ks, int stride, int pad) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * H * W * C) return;
+    const int c = (int)(idx % C);
+    size_t r = idx / C;
+    const int ix = (int)(r % W); r /= W;
+    const int iy = (int)(r % H);
+    const int n = (int)(r / H);
+    const float* xn = x + (size_t)n * H * W * C + c;
+    const float mine = xn[((size_t)iy * W + ix) * C];
+    float acc = 0.f;
+    // output rows whose window covers iy: oy * stride - pad <= iy < oy * stride - pad + ks
+    const int oy_hi = min((iy + pad) / stride, Ho - 1), ox_hi = min((ix + pad) / stride, Wo - 1);
+    for (int oy = oy_hi; oy >= 0 && oy * stride - pad + ks > iy; --oy)
+        for (int ox = ox_hi; ox >= 0 && ox * stride - pad + ks > ix; --ox) {
+            bool is_arg = true;
+            for (int ky = 0; ky < ks && is_arg; ++ky)
+                for (int kx = 0; kx < ks; ++kx) {
+                    const int yy = oy * stride + ky - pad, xx = ox * stride + kx - pad;
+                    if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                    const float v = xn[((size_t)yy * W + xx) * C];
+                    const bool before = yy < iy || (yy == iy && xx < ix);
+                    if (v > mine || (before && v == mine)) { is_arg = false; break; }
+                }
+            if (is_arg) acc += dy[(((size_t)n * Ho + oy) * Wo + ox) * C + c];
+        }
+    dx[idx] = acc;
+}
+int launch_maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int ksize, int stride, int pad, hipStream_t st) {
+    HMVIT_CHECK_ARG(ksize > 0 && stride > 0, "maxpool_bwd: bad kernel / stride");
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const size_t n = (size_t)N * H * W * C;
+    if (n == 0) return HMVIT_OK;
+    hipLaunchKernelGGL(k_maxpool_bwd, dim3((unsigned)cdiv((long long)n, 256)), dim3(256), 0, st, x, dy, dx, N, H, W, C, Ho, Wo, ksize, stride, pad);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
 // max |a| as an f32 bit pattern (non-negative floats order like unsigned integers), atomicMax into slot[which(blockIdx.y)]:
 // the range information of the split-mode convolutions when their caller did not provide it
 __global__ __launch_bounds__(256) void k_absmax2(const float* __restrict__ x, size_t nx, const float* __restrict__ w, size_t nw,

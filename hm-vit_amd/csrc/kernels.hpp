@@ -182,6 +182,7 @@ int launch_conv(const ConvParams& p, int precision, hipStream_t st);
 int launch_absmax(const float* x, size_t n, unsigned* slot, hipStream_t st);
 // max pooling on NHWC maps (the 3x3 / stride 2 / pad 1 stage of a ResNet stem)
 int launch_maxpool(const void* x, void* y, int N, int H, int W, int C, int ksize, int stride, int pad, int precision, hipStream_t st);
+int launch_maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int ksize, int stride, int pad, hipStream_t st);
 
 // ---- split.hip (architect_mode == 'parallel') ----
 struct SplitSlots {
@@ -370,7 +371,8 @@ int launch_cross_attention(const float* q, const float* k, const float* v, float
                            int dim_head, const float* bias, hipStream_t st, float* lse = nullptr);
 // backward of the joint-softmax cross attention: dq (b, n_cam, Q, HD), dk (b, n_cam, K, HD), dv (b, n_cam K, HD)
 int launch_cross_attention_bwd(const float* q, const float* k, const float* v, const float* out, const float* lse, const float* d_out,
-                               float* dq, float* dk, float* dv, int b, int n_cam, int Q, int K, int heads, int dim_head, hipStream_t st);
+                               float* dq, float* dk, float* dv, int b, int n_cam, int Q, int K, int heads, int dim_head, hipStream_t st,
+                               const float* bias = nullptr, float* d_bias = nullptr);   // bias (heads, Q, K), n_cam = 1: d_bias written
 int launch_cross_attention_f16(const half_t* q, const half_t* k, const half_t* v, float* out, int b, int n_cam, int Q, int K,
                                int heads, int dim_head, hipStream_t st);
 

@@ -8,9 +8,9 @@ camera-geometry embeddings over 2-4 channels and residual adds are torch views a
   * ``CrossViewSwapAttention`` (fax_modules.py:325-445): local-to-local and local-to-global ``CrossWinAttention`` (:205-252) with
     one "agent" per window for ``hmvit_cross_attention_train``, each followed by its pre-norm MLP, then ``postnorm``.
   * ``FAXModule`` level loop (:499-525): Bottlenecks, the down-sampling block (conv3x3 - PixelUnshuffle - conv3x3 - BN - ReLU -
-    conv1x1 - BN, :478-492), and the closing self-attention with a relative-position bias (``Attention``, :136-180).  That
-    last block is 64-625 tokens per agent: its two small products are plain library GEMMs (torch.matmul) between HIP Linears,
-    so that the bias table receives its gradient by ordinary autograd.
+    conv1x1 - BN, :478-492), and the closing self-attention with a relative-position bias (``Attention``, :136-180) on
+    ``hmvit_attention_bias_train`` / ``_backward`` (round 4; rounds 2-3 ran its two products as library GEMMs): the kernel
+    returns the gradient of the gathered (heads, N, N) bias, the table receives it through the index gather's autograd.
 Checked against the oracle restatement under float64 autograd (tests/test_hip_camera_train.py)."""
 from __future__ import annotations
 
@@ -87,10 +87,10 @@ def cross_view_swap_attention_forward(m, index, x, bev, feature, I_inv, E_inv):
     else:
         query = x[:, None]                                           # a single camera of queries (:393)
     feat = feature.reshape(b * n, feat_dim, h, w).permute(0, 2, 3, 1).contiguous().float()       # NHWC
-    val = CT.conv1x1(TT.bn_relu_module(feat, m.feature_linear[0]), m.feature_linear[2])
-    key = img_embed.permute(0, 2, 3, 1)
+    key = img_embed.permute(0, 2, 3, 1)                              # key before value, as fax_modules.py evaluates them
     if m.feature_proj is not None:
         key = key + CT.conv1x1(TT.bn_relu_module(feat, m.feature_proj[0]), m.feature_proj[2])
+    val = CT.conv1x1(TT.bn_relu_module(feat, m.feature_linear[0]), m.feature_linear[2])
     key, val = key.reshape(b, n, h, w, dim), val.reshape(b, n, h, w, dim)
     w1, w2 = m.feat_win_size
     if h % w1 or w % w2:                                             # pad_divisble (:317-323)
@@ -116,10 +116,11 @@ def self_attention_forward(att, x):
         raise ValueError(f"Attention: map {h}x{w} does not match window_size {att.window_size}")
     tok = x.permute(0, 2, 3, 1).reshape(b * N, dim)
     qkv = CT.LinearFn.apply(tok, att.to_qkv.weight, None).reshape(b, N, 3, m, dh)
-    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))                  # b m N dh
+    if dh != 32:
+        raise ValueError(f"Attention: dim_head {dh} (the HIP attention kernels are built for 32)")
+    q, k, v = (qkv[:, :, i].reshape(b, N, m * dh) for i in range(3))               # token-major, head h in channels 32 h .. 32 h + 31
     bias = att.rel_pos_bias.weight[att.rel_pos_indices].permute(2, 0, 1)            # (m, N, N), gradient by indexing
-    sim = torch.matmul(q * dh ** -0.5, k.transpose(-1, -2)) + bias[None]
-    out = torch.matmul(sim.softmax(-1), v).permute(0, 2, 1, 3).reshape(b * N, dim)
+    out = CT.AttnBiasFn.apply(q, k, v, bias, m, dh).reshape(b * N, dim)             # softmax(q k^T / sqrt(dh) + bias) v on libhmvit
     z = CT.LinearFn.apply(out, att.to_out[0].weight, None)
     z = att.to_out[1](z)                                                             # nn.Dropout (active in train())
     return z.reshape(b, h, w, dim).permute(0, 3, 1, 2)

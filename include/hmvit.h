@@ -508,6 +508,18 @@ int hmvit_gelu_backward(const float* pre, const float* dy, float* dx, size_t n, 
  * (fax_modules.py:96-180, relative-position bias over the whole BEV map). */
 int hmvit_attention_bias(const float* q, const float* k, const float* v, const float* bias, float* out, int batch, int Q, int K,
                          int heads, int dim_head, void* stream);
+/* The same under autograd (training of the FAX camera lift, fax_modules.py:136-180): _train also returns lse (batch, heads, Q), the
+ * log-sum-exp of every query row; _backward rebuilds the probabilities from it and writes dq / dk / dv (shapes of q / k / v) and
+ * d_bias (heads, Q, K) = the logit gradient summed over the batch (every element written, no atomics). */
+int hmvit_attention_bias_train(const float* q, const float* k, const float* v, const float* bias, float* out, float* lse, int batch,
+                               int Q, int K, int heads, int dim_head, void* stream);
+int hmvit_attention_bias_backward(const float* q, const float* k, const float* v, const float* bias, const float* out, const float* lse,
+                                  const float* d_out, float* dq, float* dk, float* dv, float* d_bias, int batch, int Q, int K, int heads,
+                                  int dim_head, void* stream);
+/* Adjoint of hmvit_maxpool2d on f32 NHWC maps (the ResNet stem's pooling under autograd, resnet_ms.py:71): dx (N, H, W, C) written;
+ * the gradient of a window goes to its first maximum in row-major order, as torch's does. */
+int hmvit_maxpool2d_backward(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int ksize, int stride, int pad,
+                             void* stream);
 
 /* debug: lane mapping of ds_read_b64_tr_b16 (used once to pin the V-operand layout) */
 int hmvit_debug_tr16(uint16_t* out, void* stream);

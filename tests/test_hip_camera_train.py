@@ -330,3 +330,141 @@ def test_fax_training_layers_match_float64():
             e = float((p.grad.cpu().double() - r.grad).abs().max() / max(float(r.grad.abs().max()), 1e-4 * gmax))
             assert e < 1e-3, (index, name, e)
         assert n > 30
+
+
+def test_attention_with_bias_operator_matches_float64_autograd():
+    """hmvit_attention_bias_train / _backward (the FAX self-attention's products) against torch float64: output,
+    dq / dk / dv and the (heads, Q, K) bias gradient summed over the batch; Q = K = 100 (not a multiple of the 64-row tiles)."""
+    from hmvit_amd import camera_train as CT
+    g = torch.Generator().manual_seed(3)
+    b, N, m, dh = 3, 100, 4, 32
+    q, k, v = (torch.randn(b, N, m * dh, generator=g) for _ in range(3))
+    bias = torch.randn(m, N, N, generator=g)
+    da = torch.randn(b, N, m * dh, generator=g)
+    ref_in = [t.double().requires_grad_(True) for t in (q, k, v, bias)]
+    qh, kh, vh = (t.reshape(b, N, m, dh).permute(0, 2, 1, 3) for t in ref_in[:3])
+    sim = qh @ kh.transpose(-1, -2) * dh ** -0.5 + ref_in[3][None]
+    ref = (sim.softmax(-1) @ vh).permute(0, 2, 1, 3).reshape(b, N, m * dh)
+    (ref * da.double()).sum().backward()
+    ins = [t.cuda().requires_grad_(True) for t in (q, k, v, bias)]
+    out = CT.AttnBiasFn.apply(*ins, m, dh)
+    (out * da.cuda()).sum().backward()
+    assert rel_max_err(out.detach().cpu(), ref.detach()) < 2e-6
+    for name, a, r in zip("q k v bias".split(), ins, ref_in):
+        assert rel_max_err(a.grad.cpu(), r.grad) < 5e-6, name
+
+
+def test_maxpool_operator_matches_torch_including_ties():
+    """hmvit_maxpool2d + hmvit_maxpool2d_backward (3 x 3 / stride 2 / pad 1, NHWC f32) against F.max_pool2d in float64 - on a map with
+    many exact ties (post-ReLU zeros), where the gradient must go to the first maximum of the window in row-major order."""
+    import torch.nn.functional as F
+    from hmvit_amd import camera_train as CT
+    g = torch.Generator().manual_seed(5)
+    x = torch.relu(torch.randn(2, 17, 22, 16, generator=g))            # NHWC, odd sizes, ~half zeros
+    x[0, 4:9, 3:8] = 1.25                                              # a plateau: every window inside it is all ties
+    dy = torch.randn(2, 9, 11, 16, generator=g)
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    (yr * dy.double().permute(0, 3, 1, 2)).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    y = CT.MaxPoolFn.apply(xg, 3, 2, 1)
+    (y * dy.cuda()).sum().backward()
+    assert torch.equal(y.detach().cpu().double(), yr.detach().permute(0, 2, 3, 1))
+    assert float((xg.grad.cpu().double() - xr.grad.permute(0, 2, 3, 1)).abs().max()) < 1e-6
+
+
+def _replayed_mask_check(monkeypatch, net, batch, oracle_forward, csd, tag, bound=1e-4):
+    """HIP training forward + backward with every ReLU mask recorded, the float64 restatement with those masks replayed, every
+    parameter gradient compared (relative L2 per tensor)."""
+    import torch.nn.functional as F
+    from hmvit_amd import tail_train as TT
+    tape = []
+    real_bn_relu, real_relu, real_frelu = TT.bn_relu_module, torch.relu, F.relu
+
+    def rec_bn_relu(x, bn, relu=True):
+        y = real_bn_relu(x, bn, relu)
+        if relu:
+            tape.append((y.detach() > 0).permute(0, 3, 1, 2).cpu())      # NHWC -> the oracle's NCHW
+        return y
+
+    def rec_relu(x):
+        y = real_relu(x)
+        tape.append((y.detach() > 0).permute(0, 3, 1, 2).cpu())
+        return y
+
+    monkeypatch.setattr(TT, "bn_relu_module", rec_bn_relu)
+    monkeypatch.setattr(torch, "relu", rec_relu)
+    out = net({k: v.cuda() for k, v in batch.items()})
+    monkeypatch.setattr(TT, "bn_relu_module", real_bn_relu)
+    monkeypatch.setattr(torch, "relu", real_relu)
+    go = torch.randn(out.shape, generator=torch.Generator().manual_seed(43))
+    (out * go.cuda()).sum().backward()
+    assert len(tape) > 30
+    cursor = [0]
+
+    def replay(x, inplace=False):
+        m = tape[cursor[0]]
+        cursor[0] += 1
+        assert tuple(m.shape) == tuple(x.shape), (cursor[0], m.shape, x.shape)
+        return x * m.to(x.dtype)
+
+    ref_sd = _leaf(_f64(csd))
+    monkeypatch.setattr(F, "relu", replay)
+    with CO.batch_statistics():
+        ref = oracle_forward({k: v.double() for k, v in batch.items()}, ref_sd)
+    monkeypatch.setattr(F, "relu", real_frelu)
+    assert cursor[0] == len(tape), (cursor[0], len(tape))
+    assert rel_max_err(out.detach().cpu(), ref.detach()) < 1e-4
+    (ref * go.double()).sum().backward()
+    nmax = max(float(v.grad.norm()) for v in ref_sd.values() if getattr(v, "grad", None) is not None)
+    err = {}
+    for name, p in net.named_parameters():
+        r = ref_sd[name]
+        if getattr(r, "grad", None) is None:
+            continue
+        assert p.grad is not None, name
+        err[name] = float((p.grad.cpu().double() - r.grad).norm() / r.grad.norm().clamp_min(1e-2 * nmax))
+    top = sorted(err.items(), key=lambda kv: -kv[1])[:5]
+    print(f"\n{tag} with replayed ReLU masks: {len(err)} parameter gradients vs float64 autograd, worst", [(k, f"{v:.1e}") for k, v in top])
+    assert len(err) > 150
+    assert top[0][1] < bound, top
+
+
+def test_cvt_branch_every_parameter_gradient_with_the_relu_masks_replayed(monkeypatch):
+    """the float64 comparison of the whole branch above can only be statistical, because ReLU masks behind
+    8-image BatchNorms flip at round-off and one flip moves half of all tensors by a per cent - so a wiring error between two layers
+    that stays under 10 % on one tensor could hide in its bounds.  Here the flips are taken out of the comparison: the HIP run records
+    the mask of every ReLU it applies (the fused BatchNorm + ReLU outputs and the residual ReLUs, in call order), and the float64
+    restatement replays them (`x * mask` instead of `relu(x)`), so both sides differentiate the SAME piecewise-linear function.  Every
+    parameter gradient is then held to 1e-4 (relative L2 per tensor, measured 9e-6; tensors whose gradient is zero in exact arithmetic
+    - a convolution bias in front of a batch-statistics BatchNorm - against 1e-2 of the largest norm)."""
+    from hmvit_amd.camera import CvtCameraEncoder
+    ccfg = CAM.make_config(image=64, num_layers=18)
+    ccfg["cvm"]["bev_embedding"].update(bev_height=32, bev_width=32)
+    csd = CAM.random_state_dict(ccfg, seed=41)
+    net = CvtCameraEncoder(ccfg, precision="f32")
+    net.load_state_dict(csd, strict=False)
+    net = net.cuda().train()
+    batch = CAM.synthetic_batch(2, ccfg, seed=42)
+    _replayed_mask_check(monkeypatch, net, batch, lambda b, sd: CAM.camera_encoder(b, sd, ccfg), csd, "CVT camera branch")
+
+
+def test_fax_branch_every_parameter_gradient_with_the_relu_masks_replayed(monkeypatch):
+    """The same for the FAX camera branch (hm-vit_amd/fax_train.py against oracle/fax_oracle.py), self-attention dropout off."""
+    import hmvit_amd
+    from oracle import fax_oracle as FO
+    cfg = FO.make_camera_config(image=64)
+    cfg["fax"]["self_attn"]["dropout"] = 0.0
+    torch.manual_seed(19)
+    net = hmvit_amd.FaxCameraEncoder(cfg, precision="f32")
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.6, 1.4); m.weight.normal_(1, 0.1); m.bias.normal_(0, 0.1)
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.normal_(1, 0.1); m.bias.normal_(0, 0.1)
+    net.set_return_features()
+    csd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.cuda().train()
+    batch = CAM.synthetic_batch(2, CAM.make_config(image=64), seed=20)
+    _replayed_mask_check(monkeypatch, net, batch, lambda b, sd: FO.fax_camera_encoder(b, sd, cfg), csd, "FAX camera branch")
