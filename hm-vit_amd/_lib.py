@@ -181,14 +181,15 @@ def i32_array(values):
 _RANGE_BLOCKS = {}
 
 
-def grad_pow2(dy):
-    """(dy 2^k, 2^-k): the incoming gradient with its largest magnitude brought to [2^9, 2^10) by a power of two, and the device
+def grad_pow2(dy, target_exp: float = 9.0):
+    """(dy 2^k, 2^-k): the incoming gradient with its largest magnitude brought to [2^target_exp, 2^(target_exp + 1)) - [2^9, 2^10) by
+    default - by a power of two, and the device
     scalar that undoes it.  Every backward function whose products run on split-f16 operands (x = hi + lo) calls this first and
     multiplies its results by the second value: a backward pass is linear in dy, the scaling is exact, and gradients of a real
     loss (1e-4 ... 1e-7 after the focal loss's normalisation) keep their low halves above f16's 2^-24 floor.  No synchronisation."""
     dy = dy.detach().to(torch.float32)
     amax = dy.abs().max()
-    k = torch.where(torch.isfinite(amax) & (amax > 0), 9.0 - torch.floor(torch.log2(amax.clamp_min(1e-38))), torch.zeros_like(amax))
+    k = torch.where(torch.isfinite(amax) & (amax > 0), target_exp - torch.floor(torch.log2(amax.clamp_min(1e-38))), torch.zeros_like(amax))
     k = k.clamp(-100.0, 100.0)
     return (dy * torch.exp2(k)).contiguous(), torch.exp2(-k)
 

@@ -95,6 +95,10 @@ def _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, 
     return t, keep
 
 
+# starting levels of the backward pass: max |d_out| is brought to [2^l, 2^(l + 1)); the next one is tried when a pass overflows
+BACKWARD_LEVELS = (9.0, 3.0, -3.0, -9.0, -15.0)
+
+
 class FusionTrainFunction(torch.autograd.Function):
     """y = HeteroFusion(x) with gradients for x and for the folded weights.  Inputs after ``ctx_args`` are tensors only.
     ``host`` = (mode, record_len, mask) host lists, optionally followed by ``only_stage`` (1 = the window stage, 2 = the grid stage of
@@ -134,25 +138,37 @@ class FusionTrainFunction(torch.autograd.Function):
         # reach this point at 1e-4 ... 1e-7 (focal loss normalised by the positives), where the lo half falls under f16's
         # 2^-24 floor.  The backward pass is LINEAR in d_out, so it runs on d_out 2^k (max |.| brought to [2^9, 2^10)) and every
         # result is multiplied by 2^-k: exact, and independent of the scale of the loss.  No host synchronisation.
-        d_out, unscale = _lib.grad_pow2(d_out)
+        # What a single power of two cannot absorb is GROWTH inside the pass: behind FFN / mlp_head weights 30-100 x their usual size
+        # the gradients gain a factor 1e3-1e6 on their way down and leave f16's range (hi > 65504: Inf) in the weight-gradient and
+        # attention-backward products, which take their operands at their own scale (the per-token scaled x16 Linears
+        # do not care).  Such a pass is detected by its non-finite results (one reduction + one host read per backward) and
+        # repeated from a lower starting level, six binades at a time down to 2^-15 - still inside the range where the hi halves are
+        # normal numbers.  The saved activations are only read by the pass, so it can be repeated.
+        d_raw = d_out
         t, keep = _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, None, saved, None, only_stage)
         need = _lib.lib.hmvit_fusion_backward_workspace_bytes(ctypes.byref(t))
         if need == 0:
             _lib.check(-22, "hmvit_fusion_backward_workspace_bytes")
         ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-        grads = [torch.zeros_like(f) for f in folded]
-        d_x = torch.empty_like(x)
         n = len(STAGE_KEYS)
-        sg = (_lib.StageGrads * 2)()
-        for s in range(2):
-            for i, k in enumerate(STAGE_KEYS):
-                setattr(sg[s], k, grads[s * n + i].data_ptr())
-        hg = grads[2 * n:]
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        with torch.cuda.device(x.device):
-            _lib.check(_lib.lib.hmvit_fusion_backward(ctypes.byref(t), d_out.data_ptr(), d_x.data_ptr(), sg, hg[0].data_ptr(),
-                                                      hg[1].data_ptr(), hg[2].data_ptr(), hg[3].data_ptr(), ws.data_ptr(),
-                                                      ws.numel(), ctypes.c_void_p(stream)), "hmvit_fusion_backward")
+        for level in BACKWARD_LEVELS:
+            d_out, unscale = _lib.grad_pow2(d_raw, level)
+            grads = [torch.zeros_like(f) for f in folded]
+            d_x = torch.empty_like(x)
+            sg = (_lib.StageGrads * 2)()
+            for s in range(2):
+                for i, k in enumerate(STAGE_KEYS):
+                    setattr(sg[s], k, grads[s * n + i].data_ptr())
+            hg = grads[2 * n:]
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.lib.hmvit_fusion_backward(ctypes.byref(t), d_out.data_ptr(), d_x.data_ptr(), sg, hg[0].data_ptr(),
+                                                          hg[1].data_ptr(), hg[2].data_ptr(), hg[3].data_ptr(), ws.data_ptr(),
+                                                          ws.numel(), ctypes.c_void_p(stream)), "hmvit_fusion_backward")
+            probe = torch.stack(list(torch._foreach_norm(grads)) + [d_x.abs().max()])
+            if level == BACKWARD_LEVELS[-1] or bool(torch.isfinite(probe).all()) or not bool(torch.isfinite(d_raw).all()):
+                break
+            module.backward_retries = getattr(module, "backward_retries", 0) + 1
         ctx.launch = None
         d_x.mul_(unscale)
         for g in grads:
