@@ -1883,6 +1883,9 @@ __device__ __forceinline__ unsigned pcs2_bits(const AttnParams& p, const PcItem&
 // tables of one item for this loader wave: lane = (slot in the round, key j of the wave)
 __device__ __forceinline__ void pcs2_tables(const AttnParams& p, PcShared2& sm, const PcItem& it, int par, int lw, int lane) {
     using SM = PcShared2;
+#ifdef HMVIT_EXP_PCS_NOTABLES
+    return;
+#endif
     const int H = p.H, W = p.W, L = p.L, X = H / 8, Y = W / 8;
     const int j = lane & 7, n_slots = 2 * p.n_src;
 #pragma unroll
@@ -2120,7 +2123,9 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
             }
         }
     };
+#ifndef HMVIT_EXP_PCS_NOQ
     request_q(it);
+#endif
 
     float4v biasf[7];
     int bias_head = -1;
@@ -2143,6 +2148,7 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
         {   // Q + b_q -> (hi, lo) operand halves; then the next item's block is requested into the same 8 KB.
             // The 8 DMA pieces are older than the output stores of the previous item (8, + 4 log-sum-exp stores in the training
             // forward): "all but the newest n" leaves those stores in flight (loads and stores share the in-order counter)
+#ifndef HMVIT_EXP_PCS_NOQ
             if (gstep == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (p.lse) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -2172,6 +2178,9 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the block is in registers before its LDS rows are requested again
             __builtin_amdgcn_sched_barrier(0);
             if (nvalid) request_q(itn);
+#else
+            for (int qt = 0; qt < 4; ++qt) { m_run[qt] = -INFINITY; l_acc[qt] = (float4v)(0.f); o_acc[qt][0] = (float4v)(0.f); o_acc[qt][1] = (float4v)(0.f); qhh[qt] = ones; qhl[qt] = ones; }
+#endif
         }
         while (todo) {
             const int h = __builtin_ctz(todo);
@@ -2277,7 +2286,11 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
                 using F_ = std::false_type;
                 tile(std::integral_constant<int, 0>{}, F_{}, 0);
             }
+#ifdef HMVIT_EXP_PCS_NOEPI
+            if (false) {
+#else
             if (h == h_last) {
+#endif
                 float* outp = reinterpret_cast<float*>(p.out) + (size_t)(it.b * L + it.ego) * P * C;
 #pragma unroll
                 for (int qt = 0; qt < 4; ++qt) {
