@@ -66,12 +66,12 @@ __global__ __launch_bounds__(512, 2) void k_tail(const char* __restrict__ w, flo
     if (r == 12345.f) out[0] = r;
 }
 template <typename K>
-void run(const char* name, K k, const char* w, float* out, int tok) {
+void run(const char* name, K k, const char* w, float* out, int tok, int grid = 256) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 20;
-    hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, w, out, 2);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), 0, 0, w, out, 2);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, w, out, iters);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), 0, 0, w, out, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double chunks = (double)iters * N_CHUNKS;
@@ -89,5 +89,10 @@ int main() {
     run("stream + readback + 48 MFMA (16 tok/wave), staggered", k_tail<2, 16, true, false>, w, out, 16);
     run("stream + readback + 96 MFMA (32 tok/wave)", k_tail<2, 32, false, false>, w, out, 32);
     run("stream + readback + 96 MFMA (32 tok/wave), staggered", k_tail<2, 32, true, false>, w, out, 32);
+    // is the loop bound by the chip's power budget?  the same workgroups on 1 / 8 / 32 / 128 CUs
+    run("48 MFMA loop on 1 workgroup", k_tail<2, 16, false, false>, w, out, 16, 1);
+    run("48 MFMA loop on 8 workgroups", k_tail<2, 16, false, false>, w, out, 16, 8);
+    run("48 MFMA loop on 32 workgroups", k_tail<2, 16, false, false>, w, out, 16, 32);
+    run("48 MFMA loop on 128 workgroups", k_tail<2, 16, false, false>, w, out, 16, 128);
     return 0;
 }
