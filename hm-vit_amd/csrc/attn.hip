@@ -444,7 +444,19 @@ struct PcItem {
 struct PcCursor {
     int b, ego, trow, tcol;   // position in the (sample, ego, tile) list
     int started;
+    int wpx;                  // workgroups per XCD
 };
+// gridDim.x comes out of the dispatch packet with a VECTOR load: read inside pc_fetch it put an s_waitcnt vmcnt(0) - a drain of the
+// loader's taps in flight - into every item (round-4 ISA reading); read once, here
+__device__ __forceinline__ PcCursor pc_cursor() {
+    PcCursor c = {0, 0, 0, 0, 0, __builtin_amdgcn_readfirstlane((int)(gridDim.x >> 3))};
+    return c;
+}
+constexpr int kPcs2Grid = 256;     // k_attention_pcs2: one workgroup per CU, a compile-time constant for the item walk
+__device__ __forceinline__ PcCursor pcs2_cursor() {
+    PcCursor c = {0, 0, 0, 0, 0, kPcs2Grid >> 3};
+    return c;
+}
 
 // Head group of a workgroup.  Default: the two head groups of a window alternate inside an XCD (an XCD step = wpx / NG windows x NG
 // head groups).  variant bit 0x800 ("head group per XCD"): XCD x works on head group x % NG only, so its workgroups cover twice
@@ -458,7 +470,7 @@ __device__ __forceinline__ int pc_head_group(const AttnParams& p, int NG) {
 // takes segments x, x + 8, ... and its workgroups walk a segment in sched_sub steps of consecutive items, so that what an
 // XCD's workgroups gather at any moment - for ALL egos - lies under the same few hundred pixels of ground.
 __device__ __forceinline__ bool pc_fetch_sched(const AttnParams& p, int X, int Y, int NG, PcCursor& cur, PcItem& it) {
-    const int wpx = gridDim.x >> 3, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int wpx = cur.wpx, x = blockIdx.x & 7, j = blockIdx.x >> 3;
     const bool hx = (p.variant & 0x800) != 0;
     const int tps = hx ? wpx : wpx / NG, t = hx ? j : j / NG, sub = p.sched_sub;
     const int lanes = hx ? 8 / NG : 8, lane0 = hx ? x / NG : x;          // XCDs sharing a head group, position among them
@@ -489,7 +501,7 @@ __device__ __forceinline__ bool pc_fetch_sched(const AttnParams& p, int X, int Y
 
 __device__ __forceinline__ bool pc_fetch(const AttnParams& p, int X, int Y, int NG, bool ego_fastest, PcCursor& cur, PcItem& it) {
     if (p.sched) return pc_fetch_sched(p, X, Y, NG, cur, it);
-    const int wpx = gridDim.x >> 3, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int wpx = cur.wpx, x = blockIdx.x & 7, j = blockIdx.x >> 3;
     const bool hx = (p.variant & 0x800) != 0;          // head group per XCD (pc_head_group)
     const int TH = (hx ? wpx : wpx / NG) / 8;          // tile = TH x 8 windows
     const int ntx = (X + TH - 1) / TH, nty = (Y + 7) / 8;
@@ -844,7 +856,7 @@ __device__ __forceinline__ void pc_loader_loop_general(const AttnParams& p, PcSh
         allv &= vis;
     };
 
-    PcCursor item = {0, 0, 0, 0, 0};
+    PcCursor item = pc_cursor();
     int chunk = 0, g = 0, qi = 0;
     PcItem it;
     if (!pc_fetch(p, X, Y, NG, ego_fastest, item, it)) { pc_wg_barrier(); return; }
@@ -959,7 +971,7 @@ __device__ __forceinline__ void pc_loader_loop_fast(const AttnParams& p, PcShare
         pc_wg_barrier();
     };
 
-    PcCursor item = {0, 0, 0, 0, 0};
+    PcCursor item = pc_cursor();
     int g = 0, qi = 0;
     PcItem it;
     if (!pc_fetch(p, X, Y, NG, ego_fastest, item, it)) { pc_wg_barrier(); return; }
@@ -1062,7 +1074,7 @@ __device__ __forceinline__ void pc_compute_loop(const AttnParams& p, PcShared<HG
     const int X = H / 8, Y = W / 8, NG = C / (HG * 32);
     const int n_src = p.n_src;
     const int lq = lane & 15, g = lane >> 4;
-    PcCursor item = {0, 0, 0, 0, 0};
+    PcCursor item = pc_cursor();
     PcItem it;
     __syncthreads();
     if (!pc_fetch(p, X, Y, NG, (p.variant & 0x200) == 0, item, it)) return;
@@ -1503,7 +1515,7 @@ __device__ __forceinline__ void pcs_loader_loop(const AttnParams& p, PcSharedS& 
         pc_wg_barrier();
     };
 
-    PcCursor item = {0, 0, 0, 0, 0};
+    PcCursor item = pc_cursor();
     int g = 0, qi = 0;
     PcItem it;
     if (!pc_fetch(p, X, Y, NG, ego_fastest, item, it)) { pc_wg_barrier(); return; }
@@ -1610,7 +1622,7 @@ __device__ __forceinline__ void pcs_compute_loop(const AttnParams& p, PcSharedS&
     const int X = H / 8, Y = W / 8, NG = C / SM::CH;
     const int n_src = p.n_src;
     const int lq = lane & 15, g = lane >> 4;
-    PcCursor item = {0, 0, 0, 0, 0};
+    PcCursor item = pc_cursor();
     PcItem it;
     __syncthreads();
     if (!pc_fetch(p, X, Y, NG, (p.variant & 0x200) == 0, item, it)) return;
@@ -1849,6 +1861,7 @@ struct PcShared2 {
     float tmask[2][LWG][NS][16];                   // [0..7]: 0 / -inf per key, [8]: bit 0 some key visible, bit 1 all (int bits)
     float qstage[CWG][8 * 64 * 4];                 // per compute wave: the next item's raw query block, landed by LDS-DMA
     int iconst[kMaxSlots][2];                      // per (sample, ego): PcItemC, filled once per workgroup
+    unsigned items[4];                             // dynamic assignment: item words handed from the loader role to the compute role
 };
 
 // wave-uniform constants of an item: te | ev << 4 | self_vis << 8, and the (te, ts) pair of every chunk's source (4 bits each)
@@ -1878,6 +1891,112 @@ __device__ __forceinline__ PcItemC pcs2_item_consts(const AttnParams& p, const P
 __device__ __forceinline__ unsigned pcs2_bits(const AttnParams& p, const PcItem& it, int X, int Y) {
     const unsigned half_bits = ((1u << (2 * p.n_src)) - 1u) << 8;
     return ((pc_item_vis(p, it, X, Y, true) & half_bits) >> 8) | 3u;
+}
+
+// ---- dynamic item assignment (AttnParams::queue) ----
+// The static walk gives workgroup j of XCD x the j-th window of every tile the XCD takes; items differ in their number of visible
+// half chunks and CUs in their speed, so the workgroups run out of items 7.5 % of the launch apart on average (round-4 stamps,
+// tools/probe/r04_attn_balance.py: grid launch 2538 us, mean workgroup busy 2346 us).  With a queue the workgroups of an (XCD, head
+// group) pull the SAME item sequence in the same order from one counter: whoever is free takes the next window, the windows in
+// flight on an XCD stay neighbours (the L2 argument of the tile order is unchanged).  Compute wave 0 pulls (one scalar atomic per
+// item, two items ahead) and hands the item word to both roles through a 4-entry LDS ring.
+// The decode of a ticket runs once per item on a wave that also does a quarter of the workgroup's MFMA work, so it is kept to a
+// few dozen scalar instructions: shifts for the powers of two, multiply-high by a precomputed reciprocal for the rest (a plain
+// `/` is ~40 dependent VALU instructions on this target; with five of them per ticket the first version cost 2 us per item).
+struct PcsSeq {
+    int tl;                    // log2(windows per XCD step)
+    int lanes, xs;             // the tiles / list segments of a head group are dealt over `lanes` sequences; XCD x holds number x >> xs
+    int seg, n_tiles, TH, ntx, nty;
+    unsigned m_seg, m_ego, m_nty, m_ntx;
+};
+// ceil(2^32 / d): __umulhi(n, m) == n / d for n d < 2^32 (the caller's size guard, hmvit_fusion_forward); d == 1 is handled apart
+__device__ __forceinline__ unsigned pcs2_magic(int d) { return d > 1 ? (unsigned)((0x100000000ull + d - 1) / (unsigned)d) : 0u; }
+__device__ __forceinline__ int pcs2_div(int n, int d, unsigned m) { return d > 1 ? (int)__umulhi((unsigned)n, m) : n; }
+__device__ __forceinline__ PcsSeq pcs2_seq(const AttnParams& p, int X, int Y, int NG, int wpx) {
+    const bool hx = (p.variant & 0x800) != 0;
+    PcsSeq q;
+    const int tps = hx ? wpx : wpx / NG;                 // windows per XCD step: 32 or 16
+    q.tl = 31 - __builtin_clz(tps);
+    q.lanes = hx ? 8 / NG : 8;
+    q.xs = hx ? 31 - __builtin_clz(NG) : 0;
+    q.seg = p.sched_sub * tps;                           // list mode: a segment = sched_sub steps of consecutive list entries
+    q.TH = tps / 8;
+    q.ntx = (X + q.TH - 1) / q.TH;
+    q.nty = (Y + 7) / 8;
+    q.n_tiles = p.B * p.n_ego * q.ntx * q.nty;
+    q.m_seg = pcs2_magic(q.seg); q.m_ego = pcs2_magic(p.n_ego); q.m_nty = pcs2_magic(q.nty); q.m_ntx = pcs2_magic(q.ntx);
+    return q;
+}
+// n-th item of XCD x's sequence -> packed word wy | wx << 10 | ego << 20 | b << 24, 0xffffffff = past the end,
+// 0xfffffffe = a hole (outside the map / past the list / pruned): pull again
+__device__ __forceinline__ unsigned pcs2_seq_item(const AttnParams& p, const PcsSeq& q, int X, int Y, bool ego_fastest, int x, int n) {
+    const int lane0 = x >> q.xs;
+    unsigned w;
+    if (p.sched) {
+        const int ks = pcs2_div(n, q.seg, q.m_seg), r = n - ks * q.seg;
+        const int s0 = (lane0 + q.lanes * ks) * q.seg;
+        if (s0 >= p.n_sched) return 0xffffffffu;
+        const int pos = s0 + r;
+        if (pos >= p.n_sched) return 0xfffffffeu;
+        const int* a = p.sched + __builtin_amdgcn_readfirstlane(pos);
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(a) : "memory");
+    } else {
+        const int k = n >> q.tl, t = n - (k << q.tl);    // step of this sequence, window inside the step
+        const int T = lane0 + q.lanes * k;               // tile ordinal in the (sample, ego, tile) list
+        if (T >= q.n_tiles) return 0xffffffffu;
+        int b, ego, trow, tcol;
+        if (ego_fastest) {
+            const int r1 = pcs2_div(T, p.n_ego, q.m_ego), r2 = pcs2_div(r1, q.nty, q.m_nty);
+            ego = T - r1 * p.n_ego; tcol = r1 - r2 * q.nty;
+            b = pcs2_div(r2, q.ntx, q.m_ntx); trow = r2 - b * q.ntx;
+        } else {
+            const int r1 = pcs2_div(T, q.nty, q.m_nty), r2 = pcs2_div(r1, q.ntx, q.m_ntx);
+            tcol = T - r1 * q.nty; trow = r1 - r2 * q.ntx;
+            b = pcs2_div(r2, p.n_ego, q.m_ego); ego = r2 - b * p.n_ego;
+        }
+        const int wx = trow * q.TH + (t >> 3), wy = tcol * 8 + (t & 7);
+        if (wx >= X || wy >= Y) return 0xfffffffeu;
+        w = (unsigned)wy | ((unsigned)wx << 10) | ((unsigned)ego << 20) | ((unsigned)b << 24);
+    }
+    if (p.prune) {
+        const int wy = w & 1023, wx = (w >> 10) & 1023, ego = (w >> 20) & 15, b = w >> 24;
+        const unsigned* v_ = p.vis_mask + __builtin_amdgcn_readfirstlane(((b * p.n_ego + ego) * X + wx) * Y + wy);
+        unsigned v;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(v_) : "memory");
+        if (v >> 31) return 0xfffffffeu;
+    }
+    return w;
+}
+// Compute wave 0: turn tickets into the next item word of the ring slot (holes are skipped with further pulls).  The pull is a
+// SCALAR atomic (gfx950 executes s_atomic_add: tools/probe/satomic_probe.hip): its result comes back on lgkmcnt.
+// When the XCD's own sequence is used up the workgroup goes on with the sequences of the other XCDs that serve its head group
+// (`hops` = how many it has left behind): the XCDs differ by a few per cent in speed too, and those items are only the last
+// handful of a launch, so that their rows come out of another XCD's L2 hardly matters.
+__device__ __forceinline__ int pcs2_pull(int* ctr) {
+    int v = 1;
+    asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(ctr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void pcs2_publish(const AttnParams& p, const PcsSeq& q, unsigned* ring, int X, int Y, int NG, bool ego_fastest,
+                                             int& hops, int slot, int lane) {
+    const bool hx = (p.variant & 0x800) != 0;
+    const int stride = hx ? NG : 1;                                // XCDs with this workgroup's head group: every stride-th
+    unsigned w = 0xffffffffu;
+    while (hops < q.lanes) {
+        const int x = ((int)(blockIdx.x & 7) + hops * stride) & 7;
+        int* ctr = p.queue + (hx ? x : x * NG + pc_head_group(p, NG));
+        w = pcs2_seq_item(p, q, X, Y, ego_fastest, x, pcs2_pull(ctr));
+        if (w == 0xffffffffu) ++hops;
+        else if (w != 0xfffffffeu) break;
+    }
+    if (lane == 0) ring[slot & 3] = w;
+}
+__device__ __forceinline__ void pcs2_unpack(const AttnParams& p, unsigned w, int NG, PcItem& it) {
+    it.wy = __builtin_amdgcn_readfirstlane((int)(w & 1023));
+    it.wx = __builtin_amdgcn_readfirstlane((int)((w >> 10) & 1023));
+    it.ego = __builtin_amdgcn_readfirstlane((int)((w >> 20) & 15));
+    it.b = __builtin_amdgcn_readfirstlane((int)(w >> 24));
+    it.hg = __builtin_amdgcn_readfirstlane(pc_head_group(p, NG));
 }
 
 // tables of one item for this loader wave: lane = (slot in the round, key j of the wave)
@@ -1947,6 +2066,7 @@ __device__ __forceinline__ PcGath2 pcs2_gather(const AttnParams& p, const PcItem
     return G;
 }
 
+template <bool DYN>
 __device__ __forceinline__ void pcs2_loader_loop(const AttnParams& p, PcShared2& sm, int lw, int lane) {
     using SM = PcShared2;
     constexpr int KS = SM::KS, VS = SM::VS, TPK = SM::TPK, KPW = SM::KPW, NP = SM::NP, KPP = SM::KPP;
@@ -1996,9 +2116,21 @@ __device__ __forceinline__ void pcs2_loader_loop(const AttnParams& p, PcShared2&
         }
     };
 
-    PcCursor cur = {0, 0, 0, 0, 0};
+    PcCursor cur = pcs2_cursor();
     PcItem it, itn;
-    if (!pc_fetch(p, X, Y, NG, ego_fastest, cur, it)) { pc_wg_barrier(); return; }
+    // item source: the static walk (pc_fetch), or the ring of item words that compute wave 0 fills from the (XCD, head group)
+    // counter (pcs2_compute_loop): item i + 1 is read in the step that blends item i's first half chunk
+    constexpr bool dyn = DYN;
+    int n_items = 0;
+    auto fetch = [&](PcItem& out) -> bool {
+        if constexpr (!dyn) return pc_fetch(p, X, Y, NG, ego_fastest, cur, out);
+        const unsigned w = __builtin_amdgcn_readfirstlane((int)sm.items[n_items & 3]);
+        ++n_items;
+        if (w == 0xffffffffu) return false;
+        pcs2_unpack(p, w, NG, out);
+        return true;
+    };
+    if (!fetch(it)) { pc_wg_barrier(); return; }
     unsigned rest = pcs2_bits(p, it, X, Y), restn = 0;
     PcItemC ic = pcs2_item_consts(p, sm, it), icn = ic;
     bool itn_valid = false;
@@ -2026,7 +2158,7 @@ __device__ __forceinline__ void pcs2_loader_loop(const AttnParams& p, PcShared2&
             if (s == 1) {
                 // G is the item's first half chunk: the last reader of the other table set (the blend of the previous item's
                 // last gather) is behind us - fetch the next item and build its tables now
-                itn_valid = pc_fetch(p, X, Y, NG, ego_fastest, cur, itn);
+                itn_valid = fetch(itn);
                 if (itn_valid) {
                     restn = pcs2_bits(p, itn, X, Y);
                     icn = pcs2_item_consts(p, sm, itn);
@@ -2087,7 +2219,8 @@ __device__ __forceinline__ void pcs2_loader_loop(const AttnParams& p, PcShared2&
     pc_wg_barrier();   // the interval in which the compute waves consume the last gather
 }
 
-__device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2& sm, int wave, int lane) {
+template <bool DYN>
+__device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2& sm, int wave, int lane, int hops, const PcsSeq& seq) {
     using SM = PcShared2;
     constexpr int KS = SM::KS, VS = SM::VS, LWG = SM::LWG;
     const float kl = p.k_logit != 0.f ? p.k_logit : 1.f;
@@ -2097,10 +2230,25 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
     const int X = H / 8, Y = W / 8, NG = C / SM::CH;
     const int lq = lane & 15, g = lane >> 4;
     const bool ego_fastest = (p.variant & 0x200) == 0;
-    PcCursor cur = {0, 0, 0, 0, 0};
+    PcCursor cur = pcs2_cursor();
     PcItem it, itn;
+    constexpr bool dyn = DYN;
+    int n_items = 0;
+    // item i: the static walk, or sm.items[i & 3].  Compute wave 0 draws the tickets: items 0 and 1 before the kernel's last
+    // __syncthreads, item i + 2 at the end of its FIRST step of item i - in the time it would otherwise wait at that step's barrier
+    // for the loader role (the role that bounds the kernel; there the pull cost 0.1 ms of the 5.6).  Readers: this role at the
+    // start of item i + 1, the loader in the step that blends the first half chunk of item i + 1; an item has at least two
+    // steps, so both come behind the barrier that follows the write.
+    auto fetch = [&](PcItem& out) -> bool {
+        if constexpr (!dyn) return pc_fetch(p, X, Y, NG, ego_fastest, cur, out);
+        const unsigned w = __builtin_amdgcn_readfirstlane((int)sm.items[n_items & 3]);
+        ++n_items;
+        if (w == 0xffffffffu) return false;
+        pcs2_unpack(p, w, NG, out);
+        return true;
+    };
     pc_wg_barrier();
-    if (!pc_fetch(p, X, Y, NG, ego_fastest, cur, it)) return;
+    if (!fetch(it)) return;
 
     // this wave's query block of an item: 4 tiles of 16 queries x the head's 32 channels, lane (lq, g) takes channels 8 g .. 8 g + 7.
     // Requested one item ahead by LDS-DMA into the wave's own 8 KB (piece i = 2 qt + half: 64 lanes x 16 bytes), so that the
@@ -2135,7 +2283,8 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
     const half8 ones = (half8)(half_t)1.0f;
     int gstep = 0;
     while (true) {
-        const bool nvalid = pc_fetch(p, X, Y, NG, ego_fastest, cur, itn);
+        const bool nvalid = fetch(itn);
+        bool drawn = false;
         const int head = it.hg * SM::HG + hl;
         unsigned todo = pcs2_bits(p, it, X, Y);
         const int h_last = 31 - __builtin_clz(todo);
@@ -2282,7 +2431,6 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
                         if (qt & 1) __builtin_amdgcn_sched_barrier(0);   // two tiles in flight at a time: four overflow the register file
                     }
                 };
-                using T_ = std::true_type;
                 using F_ = std::false_type;
                 tile(std::integral_constant<int, 0>{}, F_{}, 0);
             }
@@ -2304,6 +2452,8 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
                         p.lse[((size_t)(it.b * L + it.ego) * P + row * W + col) * (C / 32) + head] = m_run[qt] * 0.6931471805599453f + logf(l_acc[qt][0]);
                 }
             }
+            if (dyn && hl == 0 && !drawn) pcs2_publish(p, seq, sm.items, X, Y, NG, ego_fastest, hops, n_items, lane);
+            drawn = true;
             pc_wg_barrier();
             ++gstep;
         }
@@ -2312,6 +2462,7 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
     }
 }
 
+template <bool DYN>
 __global__ __launch_bounds__(512) void k_attention_pcs2(AttnParams p) {
     using SM = PcShared2;
     __shared__ __attribute__((aligned(16))) SM sm;
@@ -2332,24 +2483,43 @@ __global__ __launch_bounds__(512) void k_attention_pcs2(AttnParams p) {
             sm.ego_e[threadIdx.x] = p.ego_e[threadIdx.x];
         }
     }
+    int hops = 0;
+    PcsSeq seq = {};
+    if (DYN && wave == 0) {                 // dynamic item assignment: compute wave 0 draws the first two items (pcs2_compute_loop)
+        const int NG = p.C / SM::CH;
+        seq = pcs2_seq(p, p.H / 8, p.W / 8, NG, kPcs2Grid >> 3);
+        for (int i = 0; i < 2; ++i) pcs2_publish(p, seq, sm.items, p.H / 8, p.W / 8, NG, (p.variant & 0x200) == 0, hops, i, threadIdx.x & 63);
+    }
     __syncthreads();
     pcs2_fill_consts(p, sm);
     __syncthreads();
+#ifdef HMVIT_PROBE
+    if (p.trace && threadIdx.x == 0) p.trace[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();       // 100 MHz
+#endif
     if (wave >= SM::CWG) {
         __builtin_amdgcn_s_setprio(3);
-        pcs2_loader_loop(p, sm, wave - SM::CWG, threadIdx.x & 63);
+        pcs2_loader_loop<DYN>(p, sm, wave - SM::CWG, threadIdx.x & 63);
     } else {
-        pcs2_compute_loop(p, sm, wave, threadIdx.x & 63);
+        pcs2_compute_loop<DYN>(p, sm, wave, threadIdx.x & 63, hops, seq);
     }
+#ifdef HMVIT_PROBE
+    // when this workgroup ran out of items (probe builds: the spread of these over the 256 workgroups is what the static item
+    // partition costs, tools/probe/r04_attn_balance.py)
+    if (p.trace && threadIdx.x == 0) p.trace[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
-static int launch_attn_pcs(const AttnParams& p, hipStream_t st) {
+static int launch_attn_pcs(const AttnParams& p_in, hipStream_t st) {
+    AttnParams p = p_in;
+    if (const char* e = HMVIT_ENV("HMVIT_ATTN_TRACE")) p.trace = (unsigned long long*)strtoull(e, nullptr, 0);
     if (HMVIT_ENV("HMVIT_PCS_OLD")) {       // probe builds: the round-2/3 kernel, for same-box A/B runs
         hipLaunchKernelGGL(k_attention_pcs, dim3(256), dim3(512), 0, st, p);
         HMVIT_CHECK_LAUNCH();
         return HMVIT_OK;
     }
-    hipLaunchKernelGGL(k_attention_pcs2, dim3(256), dim3(512), 0, st, p);
+    // items: pulled from per-(XCD, head group) counters when the caller provides them (AttnParams::queue), else the static walk
+    if (p.queue) hipLaunchKernelGGL(k_attention_pcs2<true>, dim3(kPcs2Grid), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL(k_attention_pcs2<false>, dim3(kPcs2Grid), dim3(512), 0, st, p);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }
@@ -2516,6 +2686,7 @@ static int launch_attn_any(const AttnParams& p, hipStream_t st) {
 __global__ __launch_bounds__(256) void k_tile_vis(AttnParams p, unsigned* __restrict__ vis_mask, const unsigned char* __restrict__ need) {
     const int X = p.H / 8, Y = p.W / 8, n_pos = p.B * p.n_ego * X * Y;
     const int pos = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p.queue && blockIdx.x == 0 && threadIdx.x < 16) p.queue[threadIdx.x] = 0;   // the pull counters of the attention launch that follows
     if (pos >= n_pos) return;
     int r = pos;
     const int wy = r % Y; r /= Y;

@@ -628,6 +628,22 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                 if ((split != 1 || pc_split) && d->skip_masked && d->window == 8 && C > 64 && n_src <= 8 && !HMVIT_ENV("HMVIT_ATTN_DEBUG")) {
                     // tiles without a visible key are skipped by the persistent kernel (launch_tile_vis)
                     unsigned* vis = reinterpret_cast<unsigned*>(ws + pl.off_vis);
+                    // dynamic item assignment of the split kernel (16 pull counters in the slack behind the table, zeroed by
+                    // k_tile_vis) - for the dilated-grid stage over all egos only, its longest launch: 2.53 -> 2.39 ms there (the
+                    // static shares finish 8 % of the launch apart, pulled ones 4 %).  The other launches lose 2 - 10 % with it: their
+                    // items are short (2 - 6 steps instead of 10) and in the pruned stage a third of the sequence positions are
+                    // holes, so the pull latency - one scalar atomic per position - shows
+#ifndef HMVIT_EXP_STATIC_ITEMS
+                    // (the ticket decode divides by multiply-high: exact while sequence length x divisor < 2^32, pcs2_magic)
+                    const bool q_fits = (size_t)B * n_ego * (d->H / 8 + 4) * (d->W / 8 + 8) < ((size_t)1 << 19) && d->H / 8 < 4096 && d->W / 8 < 4096;
+#ifdef HMVIT_EXP_DYN_ALL
+                    const bool q_stage = true;
+#else
+                    const bool q_stage = (s == 1 && n_ego > 1 && !HMVIT_ENV("HMVIT_PCS_STATIC")) || HMVIT_ENV("HMVIT_PCS_DYN_ALL");
+#endif
+                    if (pc_split && q_fits && q_stage)
+                        ap.queue = reinterpret_cast<int*>(vis + (size_t)pl.n_slots * pl.P / 64);
+#endif
                     HMVIT_TRY(launch_tile_vis(ap, vis, need, st));
                     ap.vis_mask = vis;
                     ap.prune = need != nullptr;

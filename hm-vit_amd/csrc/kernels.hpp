@@ -217,6 +217,8 @@ struct AttnParams {
     float* lse;               // optional (B, L, P, heads) f32: log-sum-exp of every query row (f32 kernel; kept for the backward pass)
     const int* sched;         // optional world-ordered item list of the persistent kernels (launch_attn_schedule), n_sched items
     int n_sched, sched_sub;   // sched_sub: steps per list segment (pc_fetch_sched)
+    int* queue;               // optional, 16 zeroed ints: per-(XCD, head group) pull counters of k_attention_pcs2's dynamic item
+                              // assignment (the workgroups of an XCD pull the XCD's item sequence instead of walking fixed shares)
     float k_logit;            // f32-plane kernels: logits formed from the planes * k_logit = natural units (HmvitStageScales;
                               // 0 is read as 1: descriptors that never heard of it)
     int dim_head;             // channels per head (0 is read as 32); anything but 32, or a window other than 4 / 8, takes the generic

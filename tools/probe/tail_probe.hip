@@ -9,7 +9,8 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 constexpr int CHUNK_BYTES = 32768, N_CHUNKS = 48;
 
 template <int MODE, int TOK, bool STAGGER, bool NT>
-__global__ __launch_bounds__(512, 2) void k_tail(const char* __restrict__ w, float* out, int iters) {
+__global__ __launch_bounds__(512, 2) void k_tail(const char* __restrict__ w, float* out, int iters, unsigned long long* clk = nullptr) {
+    const unsigned long long cyc0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
     __shared__ __attribute__((aligned(16))) char ring[3 * CHUNK_BYTES];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ring;
@@ -64,16 +65,21 @@ __global__ __launch_bounds__(512, 2) void k_tail(const char* __restrict__ w, flo
     }
     const float r = acc[0][0] + acc[1][1] + acc2[0][2] + acc2[1][3];
     if (r == 12345.f) out[0] = r;
+    if (clk && threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = __builtin_readcyclecounter() - cyc0; clk[1] = __builtin_amdgcn_s_memrealtime() - rt0; }
 }
 template <typename K>
 void run(const char* name, K k, const char* w, float* out, int tok, int grid = 256) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 20;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), 0, 0, w, out, 2);
+    static unsigned long long* clk = nullptr;
+    if (!clk) hipMalloc(&clk, 64);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), 0, 0, w, out, 2, clk);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), 0, 0, w, out, iters);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), 0, 0, w, out, iters, clk);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long hc[2]; hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost);
+    printf("[cycle counter %.0f MHz-equivalent vs 100 MHz real-time counter: %llu / %llu] ", hc[1] ? 100.0 * hc[0] / hc[1] : 0.0, hc[0], hc[1]);
     const double chunks = (double)iters * N_CHUNKS;
     printf("%-58s %.3f ms  %.0f ns/chunk  %.1f GB/s per CU  (%.2f TB/s chip)  tokens/CU/us %.1f\n", name, ms, ms * 1e6 / chunks,
            chunks * CHUNK_BYTES / ms / 1e6, chunks * CHUNK_BYTES * 256 / ms / 1e9, 8.0 * tok * iters / (ms * 1e3));
