@@ -14,7 +14,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMVIT_LIB", os.path.join(_HERE, "libhmvit.so"))   # HMVIT_LIB: ablation builds of tools/probe
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 PREC_F32, PREC_F16, PREC_SPLIT, PREC_MIXED = 0, 1, 2, 3
 PART_WINDOW, PART_GRID = 0, 1
 NUM_TYPES = 2
@@ -134,6 +134,9 @@ _SIGNATURES = {
     "hmvit_gelu_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hmvit_conv_range": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
     "hmvit_absmax": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "hmvit_conv3x3_image_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "hmvit_conv3x3_image": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "hmvit_conv_weight_image": (C.c_int, [C.c_void_p]),
     "hmvit_conv2d_ex": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 12 + [C.c_void_p]),
     "hmvit_conv2d_rowpack": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 10 + [C.c_void_p]),
     "hmvit_maxpool2d": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 8 + [C.c_void_p]),
@@ -253,6 +256,31 @@ def prescale_weights(w):
     e = max(-40, min(40, math.frexp(wmax)[1] - 1))        # floor(log2 wmax), clamped like pow2_scale (csrc/common.hpp)
     s = 2.0 ** (13 - e)
     return w * s, -s
+
+
+def conv3_image(w_rows, cout: int, cin: int, k: int, stride: int, pad: int, prec: int, wmax: float = 0.0):
+    """Ring image of a 3 x 3 / stride 1 / pad 1 convolution's prepared weight matrix `w_rows` (Cout, 9 Cin) for the LDS-DMA
+    convolution kernel (hmvit_conv3x3_image, include/hmvit.h), or None where that kernel does not apply (other geometry, exact-f32
+    mode, split weights that were not pre-scaled).  Built once per weight version by the modules' prepare steps."""
+    if k != 3 or stride != 1 or pad != 1 or prec not in (PREC_SPLIT, PREC_F16) or cout % 8:
+        return None
+    if prec == PREC_SPLIT and not wmax < 0.0:
+        return None
+    nbytes = int(lib.hmvit_conv3x3_image_bytes(cout, cin, prec))
+    if nbytes == 0:
+        return None
+    import torch
+    img = torch.empty(nbytes, dtype=torch.uint8, device=w_rows.device)
+    with torch.cuda.device(w_rows.device):
+        stream = C.c_void_p(torch.cuda.current_stream(w_rows.device).cuda_stream)
+        check(lib.hmvit_conv3x3_image(w_rows.data_ptr(), cout, cin, prec, img.data_ptr(), stream), "hmvit_conv3x3_image")
+    return img
+
+
+def use_conv_image(img):
+    """Hand a conv3_image to the next hmvit_conv2d / _ex call of this thread (no-op for None)."""
+    if img is not None:
+        check(lib.hmvit_conv_weight_image(img.data_ptr()), "hmvit_conv_weight_image")
 
 
 def inherit_range(dst, src):

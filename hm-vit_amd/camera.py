@@ -58,6 +58,7 @@ class _Conv:
         self.b[:co] = b
         self.stride, self.pad = conv.stride[0], conv.padding[0]
         self.prec, self.dt = prec, dt
+        self.img = _lib.conv3_image(self.w, self.cout, self.cin, k, self.stride, self.pad, prec, self.wmax)
 
     def __call__(self, x, relu=True, residual=None, up2=False):
         n, H, W, ci = x.shape
@@ -69,6 +70,7 @@ class _Conv:
         y = torch.empty(n, Ho, Wo, self.cout, device=x.device, dtype=self.dt)
         if self.prec == _lib.PREC_SPLIT:
             _lib.conv_range(x, self.wmax, y, _stream())
+        _lib.use_conv_image(self.img)
         _lib.check(_lib.lib.hmvit_conv2d_ex(x.data_ptr(), self.w.data_ptr(), self.b.data_ptr(),
                                             residual.data_ptr() if residual is not None else None, y.data_ptr(), n, H, W, self.cin,
                                             self.cout, self.k, self.stride, self.pad, 1 if relu else 0, 1 if up2 else 0, 0,

@@ -933,9 +933,22 @@ int hmvit_pfn_scatter(const float* voxels, const int32_t* coords, const int32_t*
 static thread_local const unsigned* g_next_x_absmax = nullptr;
 static thread_local unsigned* g_next_y_absmax = nullptr;
 static thread_local float g_next_w_absmax = 0.f;
+static thread_local const void* g_next_w_image = nullptr;
 static void take_conv_range(ConvParams& p) {
-    p.x_absmax = g_next_x_absmax; p.w_absmax = g_next_w_absmax; p.y_absmax = g_next_y_absmax;
-    g_next_x_absmax = nullptr; g_next_y_absmax = nullptr; g_next_w_absmax = 0.f;
+    p.x_absmax = g_next_x_absmax; p.w_absmax = g_next_w_absmax; p.y_absmax = g_next_y_absmax; p.w_image = g_next_w_image;
+    g_next_x_absmax = nullptr; g_next_y_absmax = nullptr; g_next_w_absmax = 0.f; g_next_w_image = nullptr;
+}
+size_t hmvit_conv3x3_image_bytes(int Cout, int Cin, int precision) {
+    if (Cout <= 0 || Cin <= 0 || (precision != HMVIT_PREC_SPLIT && precision != HMVIT_PREC_F16)) return 0;
+    if (Cin % (precision == HMVIT_PREC_SPLIT ? 32 : 64)) return 0;
+    return conv3_image_size(Cout, Cin, precision);
+}
+int hmvit_conv3x3_image(const void* w, int Cout, int Cin, int precision, void* image, void* stream) {
+    return launch_conv3_pack(w, Cout, Cin, precision, image, reinterpret_cast<hipStream_t>(stream));
+}
+int hmvit_conv_weight_image(const void* image) {
+    g_next_w_image = image;
+    return HMVIT_OK;
 }
 int hmvit_conv_range(const void* x_absmax, float w_absmax, void* y_absmax) {
     g_next_x_absmax = reinterpret_cast<const unsigned*>(x_absmax);

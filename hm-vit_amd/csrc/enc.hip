@@ -93,6 +93,30 @@ int launch_pfn_scatter(const PfnParams& p, int precision, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 // implicit-GEMM convolution
 // ------------------------------------------------------------------------------------------
+// max |y| of a launch into one device slot (f32 bit pattern; non-negative floats order like unsigned integers).  Every wavefront
+// of every workgroup ends here, on ONE address: as unconditional atomics that serialisation was 5 - 50 % of the split
+// convolutions (round-4 ablation on the PointPillar layers: 64 -> 64 channels on 256 x 256 x 5 maps 143 -> 68 us without it).
+// The slot only ever grows, so a wavefront whose maximum does not exceed what an L2-coherent load sees has nothing to add - after
+// the first few hundred wavefronts that is nearly all of them.  (A stale load can only read too small a value, i.e. cost an
+// atomic that was not needed.)
+__device__ __forceinline__ void absmax_raise(unsigned* slot, float m);
+// the same for a 256-thread workgroup at the end of a kernel (every wavefront is past its last LDS read): one check per workgroup.
+// `scratch`: 4 floats of LDS that nobody reads any more
+__device__ __forceinline__ void absmax_raise_wg(unsigned* slot, float m, float* scratch) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) absmax_raise(slot, fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3])));
+}
+__device__ __forceinline__ void absmax_raise(unsigned* slot, float m) {
+#ifndef HMVIT_EXP_NOAMAX
+    if (m > 0.f) {
+        const unsigned bits = __float_as_uint(m);
+        if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+    }
+#endif
+}
 template <typename T>
 struct ConvCfg;
 template <>
@@ -492,9 +516,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
     }
     if constexpr (SPLIT) {
         if (p.y_absmax) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
-            if (lane == 0 && ymax > 0.f) atomicMax(p.y_absmax, __float_as_uint(ymax));
+            absmax_raise_wg(p.y_absmax, ymax, reinterpret_cast<float*>(As[0]));
         }
     }
 }
@@ -745,9 +767,320 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
     }
     if constexpr (SPLIT) {
         if (p.y_absmax) {
+            absmax_raise_wg(p.y_absmax, ymax, reinterpret_cast<float*>(Ps));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_conv3r: k_conv3 with the weight slabs on an LDS-DMA ring.
+// k_conv3 spends a tap like this: ~0.35 us of matrix work per wavefront, then every wavefront converts / stores the next weight
+// slab from registers and meets the others at a barrier - and that slab was requested only ONE tap earlier, so on the deep layers
+// (72 taps per workgroup, one or two workgroups per CU) a tap lasts 1.2 - 1.5 us whatever the precision (round-4 kernel trace:
+// 256 -> 256 channels on 64 x 64 x 5 maps, 110 us split / 44 us f16 for 24 GF).  Here the weights exist once as an IMAGE of what
+// the ring holds (conv3_pack below: per (channel tile, slab) CBN rows x 128 bytes = [32 hi | 32 lo] halves in split mode, 64
+// halves in f16, rows in conv_row_channel order, 16-byte pieces XOR-swizzled by (row >> 1) & 7 so that rows 128 bytes apart
+// read conflict-free).  A slab travels global -> LDS by global_load_lds_dwordx4, 1 KB per instruction and wavefront, no staging
+// registers, no conversion, requested TWO taps ahead into a three-slot ring; a wavefront confirms only its own pieces of the
+// next slab (counted vmcnt) before the tap's single barrier.  The input patch is k_conv3's (registers -> split -> LDS, once per
+// channel slab); its loads are compiler-visible, so hipcc puts a full vmcnt(0) in front of their use: at a channel slab's last
+// tap the slab two ahead is therefore requested AFTER the patch has been stored (it flies one tap instead of two).
+// Same MFMA order as k_conv3 -> bit-identical results (tests/test_hip_encoder.py).
+// ------------------------------------------------------------------------------------------
+template <int CBN, bool SPLIT>
+struct Conv3rCfg {
+    static constexpr int BK = SPLIT ? 32 : 64;
+    static constexpr int SLAB_HALVES = CBN * 64;          // CBN rows x 128 bytes
+    static constexpr int NSLOT = 3;
+    static constexpr int PPW = CBN / 32;                  // 1 KB DMA pieces per wavefront and slab (4 wavefronts)
+};
+__host__ __device__ inline size_t conv3_image_bytes(int Cout, int Cin, bool split) {
+    const int cbn = Cout <= 64 ? 64 : 128, bk = split ? 32 : 64;
+    return (size_t)((Cout + cbn - 1) / cbn) * 9 * (Cin / bk) * cbn * 128;
+}
+// one thread per 16-byte piece of the image
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void k_conv3_pack(const void* __restrict__ w_, half_t* __restrict__ image, int Cout, int Cin) {
+    const int CBN = Cout <= 64 ? 64 : 128, BK = SPLIT ? 32 : 64;
+    const int G = 9 * (Cin / BK), Ktot = 9 * Cin;
+    const size_t n_pieces = (size_t)((Cout + CBN - 1) / CBN) * G * CBN * 8;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_pieces) return;
+    const int slot = idx & 7, row = (int)((idx >> 3) % CBN);
+    const size_t sl = (idx >> 3) / CBN;
+    const int g = (int)(sl % G), tile = (int)(sl / G);
+    const int pc = slot ^ ((row >> 1) & 7);               // the piece that sits in this slot
+    const int nrow = tile * CBN + (row & ~31) + conv_row_channel(row & 31);
+    const int cs = g / 9, tap = g - cs * 9;
+    half8 out = (half8)(half_t)0.f;
+    if (nrow < Cout) {
+        if constexpr (SPLIT) {
+            const float* src = reinterpret_cast<const float*>(w_) + (size_t)nrow * Ktot + tap * Cin + cs * BK + (pc & 3) * 8;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
-            if (lane == 0 && ymax > 0.f) atomicMax(p.y_absmax, __float_as_uint(ymax));
+            for (int e = 0; e < 8; ++e) {
+                const float v = src[e];
+                const half_t h = (half_t)v;
+                out[e] = (pc & 4) ? (half_t)(v - (float)h) : h;
+            }
+        } else {
+            out = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(w_) + (size_t)nrow * Ktot + tap * Cin + cs * BK + pc * 8);
+        }
+    }
+    *reinterpret_cast<half8*>(image + idx * 8) = out;
+}
+size_t conv3_image_size(int Cout, int Cin, int precision) { return conv3_image_bytes(Cout, Cin, precision == HMVIT_PREC_SPLIT); }
+int launch_conv3_pack(const void* w, int Cout, int Cin, int precision, void* image, hipStream_t st) {
+    const bool split = precision == HMVIT_PREC_SPLIT;
+    HMVIT_CHECK_ARG(split || precision == HMVIT_PREC_F16, "conv3 image: split or f16 (precision %d)", precision);
+    HMVIT_CHECK_ARG(w && image && Cout > 0 && Cin > 0 && Cin % (split ? 32 : 64) == 0, "conv3 image: Cout=%d Cin=%d", Cout, Cin);
+    const size_t n_pieces = conv3_image_bytes(Cout, Cin, split) / 16;
+    if (split) hipLaunchKernelGGL(k_conv3_pack<true>, dim3((unsigned)((n_pieces + 255) / 256)), dim3(256), 0, st, w, reinterpret_cast<half_t*>(image), Cout, Cin);
+    else hipLaunchKernelGGL(k_conv3_pack<false>, dim3((unsigned)((n_pieces + 255) / 256)), dim3(256), 0, st, w, reinterpret_cast<half_t*>(image), Cout, Cin);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+template <int CBN, bool SPLIT = false>
+__global__ __launch_bounds__(256, 2) void k_conv3r(ConvParams p) {
+    using T = half_t;
+    using TG = typename std::conditional<SPLIT, float, half_t>::type;
+    using Cfg = Conv3rCfg<CBN, SPLIT>;
+    constexpr int BK = Cfg::BK, PE = 16 / (int)sizeof(TG);
+    constexpr int LS = 72, TH = 8, TW = 16, PW = TW + 2, NPIX = (TH + 2) * PW;
+    constexpr int NJ = CBN / 64, MI = 2, PPW = Cfg::PPW, NSLOT = Cfg::NSLOT, SLAB = Cfg::SLAB_HALVES;
+    constexpr int NPP = (NPIX * 8 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) T Ps[NPIX * LS];
+    __shared__ __attribute__((aligned(1024))) T ring[NSLOT * SLAB];
+
+    const int NCS = p.Cin / BK, G = 9 * NCS;
+    const int tiles_n = (p.Cout + CBN - 1) / CBN, tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    int tm = blockIdx.x / tiles_n;
+    const int tn = blockIdx.x - tm * tiles_n, n0 = tn * CBN;
+    const int tx = tm % tiles_x; tm /= tiles_x;
+    const int ty = tm % tiles_y, n = tm / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, hi = lane >> 5;
+    const TG* x = reinterpret_cast<const TG*>(p.x);
+    const int4v rs_x = conv_rsrc(x, (size_t)p.N * p.H * p.W * p.Cin * sizeof(TG) >> (p.up2 ? 2 : 0));
+
+    unsigned poff[NPP];
+    int plds[NPP];
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) {
+        const int q = tid + 256 * i, pp = stage_row<SPLIT>(q), ch = q & 7;
+        const int pr = pp / PW, pc = pp - pr * PW;
+        const int iy = oy0 + pr - 1, ix = ox0 + pc - 1;
+        const bool ok = pp < NPIX && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const int pixel = p.up2 ? (n * (p.H >> 1) + (iy >> 1)) * (p.W >> 1) + (ix >> 1) : (n * p.H + iy) * p.W + ix;
+        poff[i] = ok ? (unsigned)(pixel * p.Cin + ch * PE) * (unsigned)sizeof(TG) : 0xffffffffu;
+        plds[i] = pp < NPIX ? pp * LS + ch * PE : -1;
+    }
+    int pbase[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int pix = wm * 64 + i * 32 + r;
+        pbase[i] = ((pix >> 4) * PW + (pix & 15)) * LS + hi * 8;
+    }
+    // weight fragments: row wn * (CBN / 2) + j * 32 + r of the slab, piece kk * 2 + hi (+ 4 for the low halves), swizzled
+    int wrow_h[NJ], wkey[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int row = wn * (CBN / 2) + j * 32 + r;
+        wrow_h[j] = row * 64;
+        wkey[j] = (row >> 1) & 7;
+    }
+
+    float16v acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float sx = 1.f, s_inv = 1.f;
+    if constexpr (SPLIT) {
+        if (p.x_absmax) {
+            sx = pow2_scale(__uint_as_float(p.x_absmax[0]));
+            s_inv = pow2_inv(sx) * pow2_inv(-p.w_absmax);      // the image holds weights pre-multiplied by the power of two -w_absmax
+        }
+    }
+    int4v rp[NPP];
+    auto put = [&](T* dst, const int4v& piece, float sc) {
+        if constexpr (SPLIT) {
+            const float4v f = __builtin_bit_cast(float4v, piece) * sc;
+            half4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[e] = (half_t)f[e];
+                l[e] = (half_t)(f[e] - (float)h[e]);
+            }
+            *reinterpret_cast<half4*>(dst) = h;
+            *reinterpret_cast<half4*>(dst + 32) = l;
+        } else {
+            *reinterpret_cast<half8*>(dst) = __builtin_bit_cast(half8, piece);
+        }
+    };
+    auto load_patch = [&](int ci0) {
+#pragma unroll
+        for (int i = 0; i < NPP; ++i)
+            rp[i] = llvm_raw_buffer_load_b128(rs_x, (int)(poff[i] == 0xffffffffu ? poff[i] : poff[i] + (unsigned)ci0 * (unsigned)sizeof(TG)), 0, 0);
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPP; ++i)
+            if (plds[i] >= 0) put(Ps + plds[i], rp[i], sx);
+    };
+    // slab g of this channel tile -> ring slot g % NSLOT: this wavefront's PPW pieces of 1 KB (piece i * 4 + wave)
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ring;
+    const char* img = reinterpret_cast<const char*>(p.w_image) + (size_t)tn * G * (SLAB * 2) + lane * 16;
+    auto request = [&](int g) {
+#ifdef HMVIT_EXP_C3_NODMA
+        return;
+#endif
+        const char* src = img + (size_t)g * (SLAB * 2);
+        const unsigned dst0 = ring_lds + (unsigned)(g % NSLOT) * (SLAB * 2);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const char* a = src + (i * 4 + wave) * 1024;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(dst0 + (i * 4 + wave) * 1024);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(a), "s"(dst) : "memory");
+        }
+    };
+    auto barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef HMVIT_EXP_C3_NOBAR
+        __builtin_amdgcn_s_barrier();
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // "all but the newest n vector-memory operations of this wavefront are complete" (requests and patch loads share the in-order counter)
+    auto confirm = [&](bool requested, bool patch_in_flight) {
+        if (!requested) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (!patch_in_flight) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW + NPP) : "memory");
+    };
+
+    request(0);
+    if (G > 1) request(1);
+    load_patch(0);
+    store_patch();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    barrier();
+    int g = 0;
+    for (int cs = 0; cs < NCS; ++cs) {
+        const bool more_slabs = cs + 1 < NCS;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++g) {
+            const bool defer = tap == 8 && more_slabs;      // the patch is replaced at the end of this tap: request after that
+            const bool req = g + 2 < G && !defer;
+            if (req) request(g + 2);
+            if (tap == 0 && more_slabs) load_patch((cs + 1) * BK);
+            const T* Wc = ring + (g % NSLOT) * SLAB;
+            const int tapoff = ((tap / 3) * PW + (tap % 3)) * LS;
+#ifdef HMVIT_EXP_C3_NOLOOP
+            if (sx == 1.2345f)
+#endif
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                half8 a[MI], b[NJ];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const half8*>(Ps + pbase[i] + tapoff + kk * 16);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const half8*>(Wc + wrow_h[j] + (((kk * 2 + hi) ^ wkey[j]) << 3));
+#ifdef HMVIT_EXP_C3_NOMFMA
+                if (a[0][0] == (half_t)1.2345f)
+#endif
+                if constexpr (SPLIT) {
+                    half8 al[MI], bl[NJ];
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) al[i] = *reinterpret_cast<const half8*>(Ps + pbase[i] + tapoff + kk * 16 + 32);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) bl[j] = *reinterpret_cast<const half8*>(Wc + wrow_h[j] + (((kk * 2 + hi + 4) ^ wkey[j]) << 3));
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], a[i], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], al[i], acc[i][j], 0, 0, 0);
+                        }
+                }
+#ifdef HMVIT_EXP_C3_NOMFMA
+                if (a[0][0] == (half_t)1.2345f)
+#endif
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+            }
+            // this wavefront's pieces of slab g + 1; what it has issued since: the request of this tap, and - in the first two
+            // taps of a channel slab - the six patch loads (they are older than the request of tap 2, so they have three taps)
+#ifndef HMVIT_EXP_C3_NOWAIT
+            if (g + 1 < G) confirm(req, tap < 2 && more_slabs);
+#endif
+            barrier();
+            if (defer) {                                  // every wavefront is done with the patch: replace it, then the deferred request
+                store_patch();
+                if (g + 2 < G) request(g + 2);
+                barrier();
+            }
+        }
+    }
+
+    // ---- epilogue (k_conv's vector path): lane (r, hi) owns pixel wm * 64 + i * 32 + r and channels 16 qq + 8 hi .. + 7 ----
+    float ymax = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int pix = wm * 64 + i * 32 + r;
+        const int oy = oy0 + (pix >> 4), ox = ox0 + (pix & 15);
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        const size_t opix = ((size_t)n * p.Ho + oy) * p.Wo + ox;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int co = n0 + wn * (CBN / 2) + j * 32 + 16 * qq + 8 * hi;
+                if (co >= p.Cout) continue;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = SPLIT ? acc[i][j][8 * qq + e] * s_inv : acc[i][j][8 * qq + e];
+                if (p.bias) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co), b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                }
+                if (p.res) {
+                    const TG* rp8 = reinterpret_cast<const TG*>(p.res) + opix * p.Cout + co;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rp8[e];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if constexpr (SPLIT) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ymax = fmaxf(ymax, fabsf(v[e]));
+                }
+                const size_t o = opix * p.y_ctot + p.y_coff + co;
+                if (p.out_f32 || SPLIT) {
+                    float* yp = reinterpret_cast<float*>(p.y) + o;
+                    *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+                    half8 h;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = (half_t)v[e];
+                    *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.y) + o) = h;
+                }
+            }
+    }
+    if constexpr (SPLIT) {
+        if (p.y_absmax) {
+            absmax_raise_wg(p.y_absmax, ymax, reinterpret_cast<float*>(Ps));
         }
     }
 }
@@ -863,7 +1196,7 @@ __global__ __launch_bounds__(256) void k_absmax2(const float* __restrict__ x, si
     // NaN / Inf inputs: fmaxf drops NaN; an Inf maximum gives the smallest scale and the Inf propagates through the products
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slot + (is_w ? 1 : 0), __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) absmax_raise(slot + (is_w ? 1 : 0), m);
 }
 int launch_absmax(const float* x, size_t n, unsigned* slot, hipStream_t st) {
     if (n == 0) return HMVIT_OK;
@@ -928,6 +1261,16 @@ int launch_conv(const ConvParams& p_in, int precision, hipStream_t st) {
         const int tiles = p.N * cdiv(p.Ho, 8) * cdiv(p.Wo, 16);
         if (tiles * cdiv(p.Cout, narrow ? 64 : 128) >= 256) {       // enough workgroups to cover the CUs
             dim3 grid3(tiles * cdiv(p.Cout, narrow ? 64 : 128));
+            // the weights also exist as a ring image (hmvit_conv3x3_image; split: of the pre-scaled weights): the LDS-DMA kernel
+            if (p.w_image && (!split || p.w_absmax < 0.f) && !HMVIT_ENV("HMVIT_CONV_NO_RING")) {
+                if (split) {
+                    if (narrow) hipLaunchKernelGGL((k_conv3r<64, true>), grid3, dim3(256), 0, st, p);
+                    else hipLaunchKernelGGL((k_conv3r<128, true>), grid3, dim3(256), 0, st, p);
+                } else if (narrow) hipLaunchKernelGGL((k_conv3r<64>), grid3, dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((k_conv3r<128>), grid3, dim3(256), 0, st, p);
+                HMVIT_CHECK_LAUNCH();
+                return HMVIT_OK;
+            }
             if (split) {
                 if (narrow) hipLaunchKernelGGL((k_conv3<64, true>), grid3, dim3(256), 0, st, p);
                 else hipLaunchKernelGGL((k_conv3<128, true>), grid3, dim3(256), 0, st, p);

@@ -102,8 +102,9 @@ class HeteroDecoder(nn.Module):
             wmax = 0.0
             if prec == _lib.PREC_SPLIT:
                 w, wmax = _lib.prescale_weights(w)              # exact power-of-two multiple, undone in the kernel's epilogue
-            return dict(w=w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous(), b=b.contiguous(),
-                        cin=w.shape[1], cout=w.shape[0], k=w.shape[2], pad=c.padding[0], wmax=wmax)
+            rows = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous()
+            return dict(w=rows, b=b.contiguous(), cin=w.shape[1], cout=w.shape[0], k=w.shape[2], pad=c.padding[0], wmax=wmax,
+                        img=_lib.conv3_image(rows, w.shape[0], w.shape[1], w.shape[2], 1, c.padding[0], prec, wmax))
 
         prep = {}
         for t, name in ((0, "camera"), (1, "lidar")):
@@ -185,6 +186,7 @@ class HeteroDecoder(nn.Module):
                     y = torch.empty(n, H, W, layer["cout"], device=dev, dtype=dt)
                     if prec == _lib.PREC_SPLIT:
                         _lib.conv_range(cur, layer["wmax"], y, stream)
+                    _lib.use_conv_image(layer.get("img"))
                     _lib.check(_lib.lib.hmvit_conv2d(cur.data_ptr(), layer["w"].data_ptr(), layer["b"].data_ptr(),
                                                      y.data_ptr(), n, H, W, layer["cin"], layer["cout"], layer["k"], 1,
                                                      layer["pad"], 1, layer["cout"], 0, 0, 0, prec, stream), "conv2d")

@@ -122,8 +122,10 @@ class PointPillar(nn.Module):
             wmax = 0.0
             if prec == _lib.PREC_SPLIT:
                 w, wmax = _lib.prescale_weights(w)              # exact power-of-two multiple, undone in the kernel's epilogue
-            return dict(w=w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous(), b=b.contiguous(),
-                        cin=w.shape[1], cout=w.shape[0], k=w.shape[2], stride=c.stride[0], pad=c.padding[0], wmax=wmax)
+            rows = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous()
+            return dict(w=rows, b=b.contiguous(), cin=w.shape[1], cout=w.shape[0], k=w.shape[2], stride=c.stride[0],
+                        pad=c.padding[0], wmax=wmax,
+                        img=_lib.conv3_image(rows, w.shape[0], w.shape[1], w.shape[2], c.stride[0], c.padding[0], prec, wmax))
 
         def deconv(c, bn):
             w = c.weight.detach().float()                       # (Cin, Cout, s, s)
@@ -163,6 +165,7 @@ class PointPillar(nn.Module):
         Wo = (W + 2 * layer["pad"] - layer["k"]) // layer["stride"] + 1
         if prec == _lib.PREC_SPLIT:
             _lib.conv_range(x, layer["wmax"], out, stream)       # max |x| from x's producer, max |out| for its consumers
+        _lib.use_conv_image(layer.get("img"))
         _lib.check(_lib.lib.hmvit_conv2d(x.data_ptr(), layer["w"].data_ptr(), layer["b"].data_ptr(), out.data_ptr(), N, H,
                                          W, layer["cin"], layer["cout"], layer["k"], layer["stride"], layer["pad"],
                                          int(relu), ctot, coff, 0, int(out_f32), prec, stream), "hmvit_conv2d")

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HMVIT_ABI_VERSION 10
+#define HMVIT_ABI_VERSION 11
 
 #define HMVIT_OK 0
 #define HMVIT_EINVAL (-22)   /* bad argument / unsupported shape */
@@ -397,6 +397,19 @@ int hmvit_conv2d(const void* x, const void* w, const float* bias, void* y, int N
  * hmvit_absmax: atomicMax(max |x|) into a zeroed slot. */
 int hmvit_conv_range(const void* x_absmax, float w_absmax, void* y_absmax);
 int hmvit_absmax(const float* x, size_t n, void* slot, void* stream);
+
+/* The weights of a 3 x 3 / stride 1 / pad 1 convolution as the image its LDS ring holds (HMVIT_PREC_SPLIT: of the PRE-SCALED f32
+ * weights, i.e. the ones passed with w_absmax < 0; HMVIT_PREC_F16: of the f16 weights).  The convolution kernels then copy weight
+ * slabs global -> LDS by DMA, two taps ahead, instead of staging (and, in split mode, splitting) them through registers in every
+ * workgroup: the Conv2d layers of base_bev_backbone.py:6-122, downsample_conv.py:32-51, resnet_ms.py / torchvision BasicBlock.
+ *   hmvit_conv3x3_image_bytes  size of the image (0: shape / precision without one: Cin % 32 (split) or % 64 (f16) != 0);
+ *   hmvit_conv3x3_image        w (Cout, 9 Cin) in hmvit_conv2d's layout -> image (device, that many bytes), once per weight version;
+ *   hmvit_conv_weight_image    hands the image to the NEXT hmvit_conv2d / _ex call of the calling thread (consumed by it, like
+ *                              hmvit_conv_range); `w` is still passed and is what the other kernels of that entry point read.
+ * Results are bit-identical with and without the image. */
+size_t hmvit_conv3x3_image_bytes(int Cout, int Cin, int precision);
+int hmvit_conv3x3_image(const void* w, int Cout, int Cin, int precision, void* image, void* stream);
+int hmvit_conv_weight_image(const void* image);
 
 /* hmvit_conv2d with a residual operand and an up-sampled input (camera branch):
  *   residual (N, Ho, Wo, Cout) in the precision's element type or NULL: y = act(conv(x) + bias + residual), the tail of a

@@ -313,3 +313,63 @@ def test_naive_compressor_matches_golden(precision):
     x = torch.from_numpy(np.random.RandomState(int(g["seed_x"])).standard_normal((3, 256, 10, 12)).astype(np.float32))
     y = net(x.cuda()).cpu()
     assert rel_max_err(y, g["out"]) < TOL[precision]
+
+
+@pytest.mark.parametrize("prec_name", ["split", "f16"])
+@pytest.mark.parametrize("N,cin,cout,H,W,res,up2", [(5, 128, 256, 44, 75, True, False), (8, 64, 64, 64, 66, False, False),
+                                                    (6, 192, 136, 40, 48, False, False), (6, 128, 128, 42, 80, False, True),
+                                                    (5, 256, 256, 64, 64, False, False), (3, 384, 256, 48, 64, False, False)])
+def test_conv3x3_ring_kernel_is_bit_identical_to_the_patch_kernel(prec_name, N, cin, cout, H, W, res, up2):
+    """The LDS-DMA ring kernel (k_conv3r: weight slabs copied global -> LDS from the prepared image, hmvit_conv3x3_image) against
+    the register-staged patch kernel on the same operands: the MFMA order is the same, so every output bit must be; plus the
+    float64 convolution at the precision's bound.  Shapes: ragged tiles, 64- and 128-channel tiles with a ragged last one, one /
+    many channel slabs (the patch replacement path), residual operand, upsampled input, the PointPillar block-3 shape."""
+    from hmvit_amd import _lib
+    prec = _lib.PREC_SPLIT if prec_name == "split" else _lib.PREC_F16
+    dt = torch.float32 if prec_name == "split" else torch.float16
+    torch.manual_seed(N * cin + cout + 7)
+    h, w_ = (H // 2, W // 2) if up2 else (H, W)
+    x = torch.randn(N, cin, h, w_, device="cuda").to(dt)
+    w = (torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5).to(dt)
+    b = torch.randn(cout, device="cuda")
+    r = torch.randn(N, cout, H, W, device="cuda").to(dt) if res else None
+    xin = F.interpolate(x.double(), scale_factor=2, mode="nearest") if up2 else x.double()
+    ref = F.conv2d(xin, w.double(), b.double(), 1, 1)
+    if res:
+        ref = ref + r.double()
+    ref = F.relu(ref)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    rn = r.permute(0, 2, 3, 1).contiguous() if res else None
+    wmax = 0.0
+    wk = w.float()
+    if prec_name == "split":
+        wk, wmax = _lib.prescale_weights(wk)
+    wn = wk.permute(0, 2, 3, 1).reshape(cout, -1).to(dt).contiguous()
+    img = _lib.conv3_image(wn, cout, cin, 3, 1, 1, prec, wmax)
+    assert img is not None and img.numel() == _lib.lib.hmvit_conv3x3_image_bytes(cout, cin, prec)
+
+    def run(ring):
+        y = torch.empty(N, H, W, cout, device="cuda", dtype=dt)
+        if prec_name == "split":
+            _lib.conv_range(xn, wmax, y, _stream())
+        if ring:
+            _lib.use_conv_image(img)
+        _lib.check(_lib.lib.hmvit_conv2d_ex(xn.data_ptr(), wn.data_ptr(), b.data_ptr(), rn.data_ptr() if res else None, y.data_ptr(), N, H, W,
+                                            cin, cout, 3, 1, 1, 1, 1 if up2 else 0, 0, prec, _stream()), "conv2d_ex")
+        return y
+    y_ring, y_patch = run(True), run(False)
+    assert torch.equal(y_ring, y_patch), float((y_ring.double() - y_patch.double()).abs().max())
+    assert rel_max_err(y_ring.permute(0, 3, 1, 2).double(), ref) < (4e-6 if prec_name == "split" else 1.5e-3)
+    # the image is consumed by ONE call: the next call without it must take the patch kernel again (same bits either way)
+    assert torch.equal(run(False), y_patch)
+
+
+def test_conv3x3_image_is_declined_where_the_ring_kernel_does_not_apply():
+    from hmvit_amd import _lib
+    w = torch.randn(64, 9 * 64, device="cuda")
+    assert _lib.conv3_image(w, 64, 64, 3, 2, 1, _lib.PREC_SPLIT, -2.0) is None        # stride 2
+    assert _lib.conv3_image(w, 64, 64, 1, 1, 0, _lib.PREC_SPLIT, -2.0) is None        # 1 x 1
+    assert _lib.conv3_image(w, 64, 64, 3, 1, 1, _lib.PREC_F32, 0.0) is None           # exact-f32 mode
+    assert _lib.conv3_image(w, 64, 64, 3, 1, 1, _lib.PREC_SPLIT, 3.0) is None         # split weights not pre-scaled
+    assert _lib.lib.hmvit_conv3x3_image_bytes(64, 48, _lib.PREC_SPLIT) == 0           # Cin not a multiple of the slab depth
+    assert _lib.lib.hmvit_conv3x3_image_bytes(64, 96, _lib.PREC_F16) == 0
