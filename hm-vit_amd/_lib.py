@@ -226,6 +226,14 @@ def conv_range(x, w_absmax: float, y, stream, share_out: bool = False):
     check(lib.hmvit_conv_range(xs.data_ptr(), float(w_absmax), ys.data_ptr()), "hmvit_conv_range")
 
 
+def announce_output_range(y, stream=None):
+    """Before a producer kernel that reports max |y| itself (hmvit_pfn_scatter): give it a fresh slot, which `y` then carries to
+    its consumers (conv_range finds it with range_of)."""
+    ys = _range_slot(y.device)
+    set_range(y, ys)
+    check(lib.hmvit_conv_range(None, 0.0, ys.data_ptr()), "hmvit_conv_range")
+
+
 def set_range(t, slot):
     """Attach an absmax slot to a tensor, stamped with the tensor's storage address: a bound is only as good as the bytes it was
     measured on.  (The library's own kernels write `t` through raw pointers, which torch's version counter does not see, so the

@@ -912,13 +912,22 @@ int hmvit_window_attention(const void* q, const void* kv, const float* b_q, cons
     return launch_attention(ap, precision, reinterpret_cast<hipStream_t>(stream));
 }
 
+// range information of the NEXT convolution call of this thread (HMVIT_PREC_SPLIT), consumed by that call
+static thread_local const unsigned* g_next_x_absmax = nullptr;
+static thread_local unsigned* g_next_y_absmax = nullptr;
+static thread_local float g_next_w_absmax = 0.f;
+static thread_local const void* g_next_w_image = nullptr;
 int hmvit_pfn_scatter(const float* voxels, const int32_t* coords, const int32_t* num_points, const float* w,
                       const float* shift, void* canvas, float* pillar_out, int n_pillars, int nx, int ny, int n_agents,
                       int32_t* oob_count, const float* voxel_size, const float* lidar_range, int precision, void* stream) {
+    PfnParams p;
+    // a y_absmax slot left by hmvit_conv_range is consumed here too (first: an early return must not leave it to the next call):
+    // max of the scattered values, for the first convolution of the backbone
+    p.canvas_absmax = canvas ? g_next_y_absmax : nullptr;
+    g_next_x_absmax = nullptr; g_next_y_absmax = nullptr; g_next_w_absmax = 0.f; g_next_w_image = nullptr;
     HMVIT_CHECK_ARG(voxels && coords && num_points && w && shift && (canvas || pillar_out) && voxel_size && lidar_range,
                     "pfn_scatter: null pointer");
     HMVIT_CHECK_ARG(n_pillars >= 0 && nx > 0 && ny > 0 && n_agents > 0, "pfn_scatter: bad sizes");
-    PfnParams p;
     p.voxels = voxels; p.coords = coords; p.num_points = num_points; p.w = w; p.shift = shift;
     p.canvas = canvas; p.pillar_out = pillar_out; p.n_pillars = n_pillars; p.nx = nx; p.ny = ny;
     p.n_agents = n_agents; p.oob_count = oob_count;
@@ -929,11 +938,6 @@ int hmvit_pfn_scatter(const float* voxels, const int32_t* coords, const int32_t*
     return launch_pfn_scatter(p, precision, reinterpret_cast<hipStream_t>(stream));
 }
 
-// range information of the NEXT convolution call of this thread (HMVIT_PREC_SPLIT), consumed by that call
-static thread_local const unsigned* g_next_x_absmax = nullptr;
-static thread_local unsigned* g_next_y_absmax = nullptr;
-static thread_local float g_next_w_absmax = 0.f;
-static thread_local const void* g_next_w_image = nullptr;
 static void take_conv_range(ConvParams& p) {
     p.x_absmax = g_next_x_absmax; p.w_absmax = g_next_w_absmax; p.y_absmax = g_next_y_absmax; p.w_image = g_next_w_image;
     g_next_x_absmax = nullptr; g_next_y_absmax = nullptr; g_next_w_absmax = 0.f; g_next_w_image = nullptr;

@@ -19,6 +19,32 @@
 
 namespace hmvit {
 
+// max |y| of a launch into one device slot (f32 bit pattern; non-negative floats order like unsigned integers).  Every wavefront
+// of every workgroup ends here, on ONE address: as unconditional atomics that serialisation was 5 - 50 % of the split
+// convolutions (round-4 ablation on the PointPillar layers: 64 -> 64 channels on 256 x 256 x 5 maps 143 -> 68 us without it).
+// The slot only ever grows, so a workgroup whose maximum does not exceed a value the slot has already held has nothing to add.
+// absmax_peek: thread 0's L2-coherent look at the slot when the workgroup STARTS (nobody waits for it); absmax_raise_wg: the
+// workgroup's maximum against that value at its end, against a second look where it is larger, and an atomic only if it still is.
+// A stale look can only be too small, i.e. cost a load or an atomic that was not needed.
+__device__ __forceinline__ unsigned absmax_peek(const unsigned* slot) {
+    return (slot && threadIdx.x == 0) ? __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+}
+__device__ __forceinline__ void absmax_raise(unsigned* slot, float m, unsigned seen) {
+#ifndef HMVIT_EXP_NOAMAX
+    // larger than the early look: look again (the slot has usually caught up by now) before paying for an atomic
+    if (m > 0.f && __float_as_uint(m) > seen && __float_as_uint(m) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(slot, __float_as_uint(m));
+#endif
+}
+// 256-thread workgroup, every wavefront past its last LDS read; `scratch`: 4 floats of LDS that nobody reads any more
+__device__ __forceinline__ void absmax_raise_wg(unsigned* slot, float m, unsigned seen, float* scratch) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) absmax_raise(slot, fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3])), seen);
+}
+
 // ------------------------------------------------------------------------------------------
 // PFN + scatter
 // ------------------------------------------------------------------------------------------
@@ -27,6 +53,10 @@ __global__ __launch_bounds__(256) void k_pfn_scatter(PfnParams p) {
     __shared__ float feat[4][32][12];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int v = blockIdx.x * 4 + wave;
+    // split-mode consumers want max |canvas| (hmvit_conv_range before this call): one look at the slot per workgroup; the last,
+    // partial workgroup (wavefronts return early: no workgroup barrier there) raises per wavefront
+    const bool full_wg = blockIdx.x * 4 + 4 <= p.n_pillars;
+    const unsigned amax_seen = full_wg ? absmax_peek(p.canvas_absmax) : 0u;
     if (v >= p.n_pillars) return;
     const int npts = p.num_points[v];
     const int4 co = *reinterpret_cast<const int4*>(p.coords + (size_t)v * 4);   // [agent, z, y, x]
@@ -77,6 +107,16 @@ __global__ __launch_bounds__(256) void k_pfn_scatter(PfnParams p) {
         const size_t cell = ((size_t)co.x * p.ny + co.z) * p.nx + co.w + co.y;   // index z + y * nx + x
         reinterpret_cast<TO*>(p.canvas)[cell * 64 + lane] = (TO)best;
     }
+    if (p.canvas_absmax) {
+        float m = inside ? best : 0.f;
+        if (full_wg) {
+            absmax_raise_wg(p.canvas_absmax, m, amax_seen, &feat[0][0][0]);    // (every wavefront is past its reads of feat)
+        } else {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            if (lane == 0) absmax_raise(p.canvas_absmax, m, 0u);
+        }
+    }
 }
 
 int launch_pfn_scatter(const PfnParams& p, int precision, hipStream_t st) {
@@ -93,30 +133,6 @@ int launch_pfn_scatter(const PfnParams& p, int precision, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 // implicit-GEMM convolution
 // ------------------------------------------------------------------------------------------
-// max |y| of a launch into one device slot (f32 bit pattern; non-negative floats order like unsigned integers).  Every wavefront
-// of every workgroup ends here, on ONE address: as unconditional atomics that serialisation was 5 - 50 % of the split
-// convolutions (round-4 ablation on the PointPillar layers: 64 -> 64 channels on 256 x 256 x 5 maps 143 -> 68 us without it).
-// The slot only ever grows, so a wavefront whose maximum does not exceed what an L2-coherent load sees has nothing to add - after
-// the first few hundred wavefronts that is nearly all of them.  (A stale load can only read too small a value, i.e. cost an
-// atomic that was not needed.)
-__device__ __forceinline__ void absmax_raise(unsigned* slot, float m);
-// the same for a 256-thread workgroup at the end of a kernel (every wavefront is past its last LDS read): one check per workgroup.
-// `scratch`: 4 floats of LDS that nobody reads any more
-__device__ __forceinline__ void absmax_raise_wg(unsigned* slot, float m, float* scratch) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) absmax_raise(slot, fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3])));
-}
-__device__ __forceinline__ void absmax_raise(unsigned* slot, float m) {
-#ifndef HMVIT_EXP_NOAMAX
-    if (m > 0.f) {
-        const unsigned bits = __float_as_uint(m);
-        if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
-    }
-#endif
-}
 template <typename T>
 struct ConvCfg;
 template <>
@@ -201,6 +217,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
         }
     }
     const bool w_mul = sw != 1.f;
+    const unsigned amax_seen = SPLIT ? absmax_peek(p.y_absmax) : 0u;
 
     // the rows this thread stages: decode (image, oy, ox) once
     int rn[RPT], roy[RPT], rox[RPT];
@@ -516,7 +533,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
     }
     if constexpr (SPLIT) {
         if (p.y_absmax) {
-            absmax_raise_wg(p.y_absmax, ymax, reinterpret_cast<float*>(As[0]));
+            absmax_raise_wg(p.y_absmax, ymax, amax_seen, reinterpret_cast<float*>(As[0]));
         }
     }
 }
@@ -610,6 +627,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
         }
     }
     const bool w_mul = sw != 1.f;
+    const unsigned amax_seen = SPLIT ? absmax_peek(p.y_absmax) : 0u;
     int4v rp[NPP], rw[RPW];                        // 16-byte pieces: 8 halves, or 4 floats (SPLIT)
     auto put = [&](T* dst, const int4v& piece, float sc) {   // one piece into its LDS row (SPLIT: scaled, as hi / lo halves)
         if constexpr (SPLIT) {
@@ -767,7 +785,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3(ConvParams p) {
     }
     if constexpr (SPLIT) {
         if (p.y_absmax) {
-            absmax_raise_wg(p.y_absmax, ymax, reinterpret_cast<float*>(Ps));
+            absmax_raise_wg(p.y_absmax, ymax, amax_seen, reinterpret_cast<float*>(Ps));
         }
     }
 }
@@ -906,6 +924,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3r(ConvParams p) {
             s_inv = pow2_inv(sx) * pow2_inv(-p.w_absmax);      // the image holds weights pre-multiplied by the power of two -w_absmax
         }
     }
+    const unsigned amax_seen = SPLIT ? absmax_peek(p.y_absmax) : 0u;
     int4v rp[NPP];
     auto put = [&](T* dst, const int4v& piece, float sc) {
         if constexpr (SPLIT) {
@@ -1080,7 +1099,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3r(ConvParams p) {
     }
     if constexpr (SPLIT) {
         if (p.y_absmax) {
-            absmax_raise_wg(p.y_absmax, ymax, reinterpret_cast<float*>(Ps));
+            absmax_raise_wg(p.y_absmax, ymax, amax_seen, reinterpret_cast<float*>(Ps));
         }
     }
 }
@@ -1196,7 +1215,7 @@ __global__ __launch_bounds__(256) void k_absmax2(const float* __restrict__ x, si
     // NaN / Inf inputs: fmaxf drops NaN; an Inf maximum gives the smallest scale and the Inf propagates through the products
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) absmax_raise(slot + (is_w ? 1 : 0), m);
+    if ((threadIdx.x & 63) == 0) absmax_raise(slot + (is_w ? 1 : 0), m, 0u);
 }
 int launch_absmax(const float* x, size_t n, unsigned* slot, hipStream_t st) {
     if (n == 0) return HMVIT_OK;

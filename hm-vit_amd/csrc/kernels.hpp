@@ -151,6 +151,7 @@ struct PfnParams {
     int n_pillars, nx, ny;
     int n_agents;             // canvas planes: pillars whose agent / y / x index is out of range are dropped
     int* oob_count;           // device counter of dropped pillars, may be null
+    unsigned* canvas_absmax;  // optional, device, zeroed by the caller: atomicMax of the values scattered into the canvas (f32 bits)
     float vx, vy, vz, x_off, y_off, z_off;
 };
 int launch_pfn_scatter(const PfnParams& p, int precision, hipStream_t st);

@@ -205,6 +205,8 @@ class PointPillar(nn.Module):
                 self.oob_count = torch.zeros(1, dtype=torch.int32, device=dev)
             vs = (ctypes.c_float * 3)(*[float(v) for v in self.args["voxel_size"]])
             rng = (ctypes.c_float * 6)(*[float(v) for v in self.args["lidar_range"]])
+            if prec == _lib.PREC_SPLIT:
+                _lib.announce_output_range(canvas)               # max |canvas| comes out of the scatter kernel (no extra pass)
             _lib.check(_lib.lib.hmvit_pfn_scatter(vf.data_ptr(), vc.data_ptr(), vn.data_ptr(), prep["pfn_w"].data_ptr(),
                                                   prep["pfn_shift"].data_ptr(), canvas.data_ptr(), None, vf.shape[0], nx,
                                                   ny, n_agents, self.oob_count.data_ptr(), vs, rng, prec, stream),

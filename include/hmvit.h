@@ -369,7 +369,10 @@ int hmvit_window_attention(const void* q, const void* kv, const float* b_q, cons
  *   voxel_size / lidar_range: host arrays of 3 / 6 floats.  The voxel layout is fixed at 32 points x 4 features
  *   (max_points_per_voxel of the shipped yaml).  A pillar whose agent index is not in [0, n_agents), whose y / x lies
  *   outside the grid or whose z is not 0 is dropped (the reference's indexed scatter raises there) and counted in the
- *   device counter oob_count (may be NULL). */
+ *   device counter oob_count (may be NULL).
+ *   A y_absmax slot announced with hmvit_conv_range(NULL, 0, slot) before this call receives atomicMax(|v|) over the values
+ *   scattered into the canvas (and is consumed): the range the first HMVIT_PREC_SPLIT convolution needs, without a pass over
+ *   the canvas. */
 int hmvit_pfn_scatter(const float* voxels, const int32_t* coords, const int32_t* num_points, const float* w,
                       const float* shift, void* canvas, float* pillar_out, int n_pillars, int nx, int ny, int n_agents,
                       int32_t* oob_count, const float* voxel_size, const float* lidar_range, int precision, void* stream);

@@ -81,6 +81,40 @@ def test_pfn_scatter_drops_out_of_range_pillars():
     assert bool(((canvas.abs().sum(-1) > 0).cpu() <= occupied).all())
 
 
+@pytest.mark.parametrize("drop", [0, 3])
+def test_pfn_scatter_reports_the_canvas_range(drop):
+    """hmvit_conv_range(NULL, 0, slot) before the scatter: the slot receives max |canvas| exactly (the value the first split
+    convolution would otherwise measure with a pass over the canvas) - also when the pillar count is not a multiple of the four
+    a workgroup takes (per-wavefront path of the last workgroup), and dropped pillars do not count."""
+    from hmvit_amd import _lib
+    g, args, sd, (vf, vc, vn) = _golden_inputs()
+    nx, ny = [int(v) for v in g["grid"]]
+    n = vf.shape[0] - drop
+    vf, vc, vn = vf[:n].clone(), vc[:n].clone(), vn[:n].clone()
+    torch.manual_seed(3)
+    w, shift = torch.randn(64, 10).cuda(), torch.randn(64).cuda()
+    vf[5] *= 40.0                     # the largest value sits in one pillar ...
+    vf[9] *= 90.0
+    vc[9, 0] = 7                      # ... and an even larger one in a pillar that is dropped (agent index out of range)
+    canvas = torch.zeros(2, ny, nx, 64, device="cuda")
+    vs = (ctypes.c_float * 3)(*args["voxel_size"])
+    rng = (ctypes.c_float * 6)(*args["lidar_range"])
+    vf, vc, vn = vf.cuda(), vc.cuda(), vn.cuda()
+    _lib.announce_output_range(canvas)
+    slot = _lib.range_of(canvas)
+    _lib.check(_lib.lib.hmvit_pfn_scatter(vf.data_ptr(), vc.data_ptr(), vn.data_ptr(), w.data_ptr(), shift.data_ptr(),
+                                          canvas.data_ptr(), None, n, nx, ny, 2, None, vs, rng, _lib.PREC_SPLIT, _stream()), "pfn")
+    torch.cuda.synchronize()
+    got = slot[:1].view(torch.float32)
+    assert float(got) == float(canvas.abs().max()) > 0.0
+    # the slot was consumed: a second call without an announcement leaves it alone
+    slot.zero_()
+    _lib.check(_lib.lib.hmvit_pfn_scatter(vf.data_ptr(), vc.data_ptr(), vn.data_ptr(), w.data_ptr(), shift.data_ptr(),
+                                          canvas.data_ptr(), None, n, nx, ny, 2, None, vs, rng, _lib.PREC_SPLIT, _stream()), "pfn")
+    torch.cuda.synchronize()
+    assert int(slot[0]) == 0
+
+
 def test_pointpillar_rejects_wrong_voxel_layout():
     import hmvit_amd
     args = PO.make_args(64, 48)
