@@ -996,50 +996,51 @@ __global__ __launch_bounds__(256, 2) void k_conv3r(ConvParams p) {
         for (int tap = 0; tap < 9; ++tap, ++g) {
             const bool defer = tap == 8 && more_slabs;      // the patch is replaced at the end of this tap: request after that
             const bool req = g + 2 < G && !defer;
-            if (req) request(g + 2);
             if (tap == 0 && more_slabs) load_patch((cs + 1) * BK);
             const T* Wc = ring + (g % NSLOT) * SLAB;
             const int tapoff = ((tap / 3) * PW + (tap % 3)) * LS;
-#ifdef HMVIT_EXP_C3_NOLOOP
-            if (sx == 1.2345f)
-#endif
+            // every fragment of the tap first (16 ds_read_b128 in split mode), then its 24 matrix instructions: a wavefront that
+            // is alone on its SIMD - the deep layers leave most CUs one workgroup - waits for LDS once per tap instead of per k-step
+            constexpr int NKK = BK / 16;
+            half8 a[NKK][MI], b[NKK][NJ], al[SPLIT ? NKK : 1][MI], bl[SPLIT ? NKK : 1][NJ];
 #pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
-                half8 a[MI], b[NJ];
+            for (int kk = 0; kk < NKK; ++kk) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const half8*>(Ps + pbase[i] + tapoff + kk * 16);
+                for (int i = 0; i < MI; ++i) a[kk][i] = *reinterpret_cast<const half8*>(Ps + pbase[i] + tapoff + kk * 16);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const half8*>(Wc + wrow_h[j] + (((kk * 2 + hi) ^ wkey[j]) << 3));
-#ifdef HMVIT_EXP_C3_NOMFMA
-                if (a[0][0] == (half_t)1.2345f)
-#endif
+                for (int j = 0; j < NJ; ++j) b[kk][j] = *reinterpret_cast<const half8*>(Wc + wrow_h[j] + (((kk * 2 + hi) ^ wkey[j]) << 3));
                 if constexpr (SPLIT) {
-                    half8 al[MI], bl[NJ];
 #pragma unroll
-                    for (int i = 0; i < MI; ++i) al[i] = *reinterpret_cast<const half8*>(Ps + pbase[i] + tapoff + kk * 16 + 32);
+                    for (int i = 0; i < MI; ++i) al[kk][i] = *reinterpret_cast<const half8*>(Ps + pbase[i] + tapoff + kk * 16 + 32);
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) bl[j] = *reinterpret_cast<const half8*>(Wc + wrow_h[j] + (((kk * 2 + hi + 4) ^ wkey[j]) << 3));
+                    for (int j = 0; j < NJ; ++j) bl[kk][j] = *reinterpret_cast<const half8*>(Wc + wrow_h[j] + (((kk * 2 + hi + 4) ^ wkey[j]) << 3));
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                // the request of the slab two taps ahead goes out in the middle of the tap's matrix work, not in front of it: four
+                // DMA instructions per wavefront back to back stall on the address path (7 ns each per CU), and at the head of a
+                // tap nothing of this wavefront is running yet that the stall could hide behind (-3 ... -7 % per layer)
+                if (kk == NKK / 2 && req) request(g + 2);
+                if constexpr (SPLIT) {
 #pragma unroll
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], a[i], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], al[i], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kk][j], a[kk][i], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[kk][j], al[kk][i], acc[i][j], 0, 0, 0);
                         }
                 }
-#ifdef HMVIT_EXP_C3_NOMFMA
-                if (a[0][0] == (half_t)1.2345f)
-#endif
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[kk][j], a[kk][i], acc[i][j], 0, 0, 0);
             }
-            // this wavefront's pieces of slab g + 1; what it has issued since: the request of this tap, and - in the first two
-            // taps of a channel slab - the six patch loads (they are older than the request of tap 2, so they have three taps)
+            // this wavefront's pieces of slab g + 1; what it has issued since: the request of this tap, and - in the first tap of a
+            // channel slab - the six patch loads before it (they are older than the request confirmed at the end of tap 1: two taps)
 #ifndef HMVIT_EXP_C3_NOWAIT
-            if (g + 1 < G) confirm(req, tap < 2 && more_slabs);
+            if (g + 1 < G) confirm(req, tap == 0 && more_slabs);
 #endif
             barrier();
             if (defer) {                                  // every wavefront is done with the patch: replace it, then the deferred request
@@ -1278,10 +1279,13 @@ int launch_conv(const ConvParams& p_in, int precision, hipStream_t st) {
         p.Cin % (split ? 32 : 64) == 0 && p.Cout % 8 == 0 && p.y_coff % 8 == 0 && p.y_ctot % 8 == 0 && p.Ho == p.H && p.Wo == p.W &&
         !p.no_patch && !HMVIT_ENV("HMVIT_CONV_NO_PATCH")) {
         const int tiles = p.N * cdiv(p.Ho, 8) * cdiv(p.Wo, 16);
-        if (tiles * cdiv(p.Cout, narrow ? 64 : 128) >= 256) {       // enough workgroups to cover the CUs
+        const bool ring = p.w_image && (!split || p.w_absmax < 0.f) && !HMVIT_ENV("HMVIT_CONV_NO_RING");
+        // enough workgroups to cover the CUs.  The ring kernel is taken from half a cover on: on the deep ResNet layers
+        // (512 channels, 16 x 16 maps, 160 workgroups of 144 taps) it still beats the generic kernel's 64-pixel tiles 2 : 1
+        if (tiles * cdiv(p.Cout, narrow ? 64 : 128) >= (ring ? 128 : 256)) {
             dim3 grid3(tiles * cdiv(p.Cout, narrow ? 64 : 128));
             // the weights also exist as a ring image (hmvit_conv3x3_image; split: of the pre-scaled weights): the LDS-DMA kernel
-            if (p.w_image && (!split || p.w_absmax < 0.f) && !HMVIT_ENV("HMVIT_CONV_NO_RING")) {
+            if (ring) {
                 if (split) {
                     if (narrow) hipLaunchKernelGGL((k_conv3r<64, true>), grid3, dim3(256), 0, st, p);
                     else hipLaunchKernelGGL((k_conv3r<128, true>), grid3, dim3(256), 0, st, p);

@@ -392,7 +392,13 @@ def test_conv3x3_ring_kernel_is_bit_identical_to_the_patch_kernel(prec_name, N, 
                                             cin, cout, 3, 1, 1, 1, 1 if up2 else 0, 0, prec, _stream()), "conv2d_ex")
         return y
     y_ring, y_patch = run(True), run(False)
-    assert torch.equal(y_ring, y_patch), float((y_ring.double() - y_patch.double()).abs().max())
+    # below 256 workgroups the library keeps the generic kernel for calls WITHOUT an image (the ring kernel is taken from 128
+    # on): other summation order there, so round-off-level agreement instead of equal bits
+    n_wg = N * -(-H // 8) * -(-W // 16) * -(-cout // (64 if cout <= 64 else 128))
+    if n_wg >= 256:
+        assert torch.equal(y_ring, y_patch), float((y_ring.double() - y_patch.double()).abs().max())
+    else:
+        assert n_wg >= 128 and rel_max_err(y_ring.double(), y_patch.double()) < (4e-6 if prec_name == "split" else 1e-3)
     assert rel_max_err(y_ring.permute(0, 3, 1, 2).double(), ref) < (4e-6 if prec_name == "split" else 1.5e-3)
     # the image is consumed by ONE call: the next call without it must take the patch kernel again (same bits either way)
     assert torch.equal(run(False), y_patch)
