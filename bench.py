@@ -209,7 +209,7 @@ def encoder_lines(dev, precision, hmvit_amd, S):
     torch.manual_seed(0)
     vf, vc, vn = S.synthetic_pillars(L, 20000, nx, ny, mcfg["lidar"], seed=2)
     lidar_batch = {"processed_lidar": {"voxel_features": vf.to(dev), "voxel_coords": vc.to(dev), "voxel_num_points": vn.to(dev)},
-                   "record_len": torch.tensor([L])}
+                   "record_len": torch.tensor([L]), "n_agents": L}    # (the assembled model passes the count too: no read-back per call)
     ccfg = S.camera_config(image=image, num_layers=34, bev_h=256, bev_w=256)
     cams = {k: v.to(dev) for k, v in S.synthetic_cameras(L, image, seed=8).items()}
     enc = {}

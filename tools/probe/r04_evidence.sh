@@ -21,6 +21,11 @@ for p in f32 split f16; do timeout 600 python tests/tools/ap_replay.py --precisi
  python tests/tools/encoder_bench.py 2>&1 | grep PointPillar;
  python tests/tools/camera_bench.py f16 split f32 2>&1 | grep Cvt) > profiles/r04_model.txt; echo "model rc=$?"
 bash tools/probe/r04_attn_prof.sh final > profiles/r04_attention_per_stage.txt 2>&1
+(echo "# PointPillar encoder, per-launch kernel durations (tools/probe/r04_conv_layers.sh)"; bash tools/probe/r04_conv_layers.sh 2>&1 | grep -v "^\[") > profiles/r04_conv_layers.txt
+(echo "# CVT camera encoder (split), kernels per forward (tools/probe/r04_cvt_layers.sh)"; bash tools/probe/r04_cvt_layers.sh split 2>&1) > profiles/r04_cvt_layers.txt
+(echo "# finish times of the 256 persistent attention workgroups, dilated-grid launch: pulled (shipped) vs static item assignment (probe build, tools/probe/r04_attn_balance.py)";
+ HMVIT_LIB=$GRAFT_REPO_ROOT/tools/probe/lib_probe.so python tools/probe/r04_attn_balance.py 2>&1 | tail -2;
+ HMVIT_LIB=$GRAFT_REPO_ROOT/tools/probe/lib_probe.so HMVIT_PCS_STATIC=1 python tools/probe/r04_attn_balance.py 2>&1 | tail -2) > profiles/r04_attn_balance.txt
 bash tools/probe/r04_train_pmc.sh > gpurun_out/r04/train_pmc.log 2>&1; cp gpurun_out/r04/train_pmc.txt profiles/r04_train_pmc.txt; cp gpurun_out/r04/train_kernel_stats.csv profiles/r04_train_kernel_stats.csv
 grep -E "^range\[" gpurun_out/r04/gputest.log > profiles/r04_range.txt
 cp profiles/r04_* profiles/pmc_traffic.json gpurun_out/r04/profiles/
