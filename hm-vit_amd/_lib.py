@@ -136,7 +136,9 @@ _SIGNATURES = {
     "hmvit_absmax": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "hmvit_conv3x3_image_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "hmvit_conv3x3_image": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    "hmvit_conv_weight_image": (C.c_int, [C.c_void_p]),
+    "hmvit_conv_gemm_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "hmvit_conv_gemm_image": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "hmvit_conv_weight_image": (C.c_int, [C.c_void_p, C.c_int]),
     "hmvit_conv2d_ex": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 12 + [C.c_void_p]),
     "hmvit_conv2d_rowpack": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 10 + [C.c_void_p]),
     "hmvit_maxpool2d": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 8 + [C.c_void_p]),
@@ -266,29 +268,48 @@ def prescale_weights(w):
     return w * s, -s
 
 
-def conv3_image(w_rows, cout: int, cin: int, k: int, stride: int, pad: int, prec: int, wmax: float = 0.0):
-    """Ring image of a 3 x 3 / stride 1 / pad 1 convolution's prepared weight matrix `w_rows` (Cout, 9 Cin) for the LDS-DMA
-    convolution kernel (hmvit_conv3x3_image, include/hmvit.h), or None where that kernel does not apply (other geometry, exact-f32
-    mode, split weights that were not pre-scaled).  Built once per weight version by the modules' prepare steps."""
-    if k != 3 or stride != 1 or pad != 1 or prec not in (PREC_SPLIT, PREC_F16) or cout % 8:
+def conv_image(w_rows, ncols: int, cin: int, k: int, stride: int, pad: int, prec: int, wmax: float = 0.0, deconv: bool = False):
+    """LDS ring image of a convolution's prepared weight matrix `w_rows` (Ncols, k k Cin) for the LDS-DMA convolution kernels
+    (include/hmvit.h): (tensor, kind) - kind 0 for a 3 x 3 / stride 1 / pad 1 layer (hmvit_conv3x3_image; split and f16), kind 1
+    in the GEMM's column order for every other geometry in split mode (hmvit_conv_gemm_image: strided, 1 x 1, transposed) - or
+    None where neither kernel applies (exact-f32 mode, split weights that were not pre-scaled, a K that is not a multiple of the
+    slab depth).  Built once per weight version by the modules' prepare steps."""
+    import torch
+    if prec not in (PREC_SPLIT, PREC_F16) or (prec == PREC_SPLIT and not wmax < 0.0):
         return None
-    if prec == PREC_SPLIT and not wmax < 0.0:
+    ktot = w_rows.shape[1]
+    if k == 3 and stride == 1 and pad == 1 and not deconv and ncols % 8 == 0:
+        nbytes, kind = int(lib.hmvit_conv3x3_image_bytes(ncols, cin, prec)), 0
+    elif prec == PREC_SPLIT:
+        nbytes, kind = int(lib.hmvit_conv_gemm_image_bytes(ncols, ktot)), 1
+    else:
         return None
-    nbytes = int(lib.hmvit_conv3x3_image_bytes(cout, cin, prec))
     if nbytes == 0:
         return None
-    import torch
     img = torch.empty(nbytes, dtype=torch.uint8, device=w_rows.device)
     with torch.cuda.device(w_rows.device):
         stream = C.c_void_p(torch.cuda.current_stream(w_rows.device).cuda_stream)
-        check(lib.hmvit_conv3x3_image(w_rows.data_ptr(), cout, cin, prec, img.data_ptr(), stream), "hmvit_conv3x3_image")
-    return img
+        if kind == 0:
+            check(lib.hmvit_conv3x3_image(w_rows.data_ptr(), ncols, cin, prec, img.data_ptr(), stream), "hmvit_conv3x3_image")
+        else:
+            check(lib.hmvit_conv_gemm_image(w_rows.data_ptr(), ncols, ktot, img.data_ptr(), stream), "hmvit_conv_gemm_image")
+    return img, kind
 
 
-def use_conv_image(img):
-    """Hand a conv3_image to the next hmvit_conv2d / _ex call of this thread (no-op for None)."""
-    if img is not None:
-        check(lib.hmvit_conv_weight_image(img.data_ptr()), "hmvit_conv_weight_image")
+def conv3_image(w_rows, cout: int, cin: int, k: int, stride: int, pad: int, prec: int, wmax: float = 0.0):
+    """The kind-0 image alone (3 x 3 / stride 1 / pad 1), or None."""
+    r = conv_image(w_rows, cout, cin, k, stride, pad, prec, wmax) if (k == 3 and stride == 1 and pad == 1) else None
+    return r[0] if r is not None and r[1] == 0 else None
+
+
+def use_conv_image(img, kind: int = 0):
+    """Hand a weight image - a conv_image() result, or a bare kind-0 tensor - to the next hmvit_conv2d / _ex call of this thread
+    (no-op for None)."""
+    if img is None:
+        return
+    if isinstance(img, tuple):
+        img, kind = img
+    check(lib.hmvit_conv_weight_image(img.data_ptr(), kind), "hmvit_conv_weight_image")
 
 
 def inherit_range(dst, src):

@@ -58,7 +58,7 @@ class _Conv:
         self.b[:co] = b
         self.stride, self.pad = conv.stride[0], conv.padding[0]
         self.prec, self.dt = prec, dt
-        self.img = _lib.conv3_image(self.w, self.cout, self.cin, k, self.stride, self.pad, prec, self.wmax)
+        self.img = _lib.conv_image(self.w, self.cout, self.cin, k, self.stride, self.pad, prec, self.wmax)
 
     def __call__(self, x, relu=True, residual=None, up2=False):
         n, H, W, ci = x.shape

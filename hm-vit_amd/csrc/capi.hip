@@ -917,6 +917,7 @@ static thread_local const unsigned* g_next_x_absmax = nullptr;
 static thread_local unsigned* g_next_y_absmax = nullptr;
 static thread_local float g_next_w_absmax = 0.f;
 static thread_local const void* g_next_w_image = nullptr;
+static thread_local int g_next_w_image_kind = 0;
 int hmvit_pfn_scatter(const float* voxels, const int32_t* coords, const int32_t* num_points, const float* w,
                       const float* shift, void* canvas, float* pillar_out, int n_pillars, int nx, int ny, int n_agents,
                       int32_t* oob_count, const float* voxel_size, const float* lidar_range, int precision, void* stream) {
@@ -939,7 +940,7 @@ int hmvit_pfn_scatter(const float* voxels, const int32_t* coords, const int32_t*
 }
 
 static void take_conv_range(ConvParams& p) {
-    p.x_absmax = g_next_x_absmax; p.w_absmax = g_next_w_absmax; p.y_absmax = g_next_y_absmax; p.w_image = g_next_w_image;
+    p.x_absmax = g_next_x_absmax; p.w_absmax = g_next_w_absmax; p.y_absmax = g_next_y_absmax; p.w_image = g_next_w_image; p.w_image_kind = g_next_w_image_kind;
     g_next_x_absmax = nullptr; g_next_y_absmax = nullptr; g_next_w_absmax = 0.f; g_next_w_image = nullptr;
 }
 size_t hmvit_conv3x3_image_bytes(int Cout, int Cin, int precision) {
@@ -950,8 +951,17 @@ size_t hmvit_conv3x3_image_bytes(int Cout, int Cin, int precision) {
 int hmvit_conv3x3_image(const void* w, int Cout, int Cin, int precision, void* image, void* stream) {
     return launch_conv3_pack(w, Cout, Cin, precision, image, reinterpret_cast<hipStream_t>(stream));
 }
-int hmvit_conv_weight_image(const void* image) {
+size_t hmvit_conv_gemm_image_bytes(int Ncols, int Ktot) {
+    if (Ncols <= 0 || Ktot <= 0 || Ktot % 32) return 0;
+    return conv_gemm_image_size(Ncols, Ktot);
+}
+int hmvit_conv_gemm_image(const float* w, int Ncols, int Ktot, void* image, void* stream) {
+    return launch_conv_gemm_pack(w, Ncols, Ktot, image, reinterpret_cast<hipStream_t>(stream));
+}
+int hmvit_conv_weight_image(const void* image, int kind) {
+    HMVIT_CHECK_ARG(kind == 0 || kind == 1, "conv_weight_image: kind %d (0: 3 x 3 ring order, 1: GEMM order)", kind);
     g_next_w_image = image;
+    g_next_w_image_kind = kind;
     return HMVIT_OK;
 }
 int hmvit_conv_range(const void* x_absmax, float w_absmax, void* y_absmax) {

@@ -181,9 +181,14 @@ __device__ __forceinline__ int conv_row_channel(int rho) {
 // as (hi + lo) halves - x w = x_hi w_hi + x_lo w_hi + x_hi w_lo, f32 accumulate (the scheme of the fusion's split mode, DESIGN
 // 5.0).  A 32-deep K slab is split on its way into LDS: a staged row holds [32 hi | 32 lo | pad] halves, i.e. the f16
 // kernel's 72-half row, so the LDS footprint and the conflict-free fragment reads are the f16 kernel's.
-template <typename T, int CBN, int CBM, bool SPLIT = false>
+// RING (split only): the weight slabs come out of the GEMM-order image (launch_conv_pack, kind 1) by LDS-DMA - slab g + 1 is
+// requested into the other of two unpadded, swizzled buffers at the start of iteration g; no weight registers, no hi / lo split,
+// no ds_write for them.  Confirmation rides on hipcc's own wait for the input rows: the request is issued BEFORE this iteration's
+// row loads, and the vmcnt(rows of one slab) in front of the row stores at the end of the iteration completes everything older.
+template <typename T, int CBN, int CBM, bool SPLIT = false, bool RING = false>
 __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
     static_assert(!SPLIT || sizeof(T) == 4, "the split instantiation reads f32 operands");
+    static_assert(!RING || SPLIT, "the weight ring is built for the split instantiation");
     using TL = typename std::conditional<SPLIT, half_t, T>::type;        // LDS element
     constexpr int BK = ConvCfg<T>::BK, LS = SPLIT ? 72 : ConvCfg<T>::LS;
     constexpr int MI = CBM / 64;         // 32-pixel MFMA tiles per wave (pixel tile of 128 or, for small maps, 64)
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
     constexpr int RPW = CBN / 32;        // staged W rows per thread
     constexpr int NJ = CBN / 64;         // 32-channel MFMA tiles per wave
     __shared__ __attribute__((aligned(16))) TL As[2][CBM * LS];
-    __shared__ __attribute__((aligned(16))) TL Ws[2][CBN * LS];
+    __shared__ __attribute__((aligned(1024))) TL Ws[2][CBN * (RING ? 64 : LS)];
 
     const int M = p.N * p.Ho * p.Wo;
     const int Ncols = p.deconv_s ? p.deconv_s * p.deconv_s * p.Cout : p.Cout;
@@ -315,9 +320,28 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
                 }
             }
         }
+        if constexpr (!RING) {
 #pragma unroll
-        for (int i = 0; i < RPW; ++i)
-            rw[SET][i] = __builtin_bit_cast(Vec, llvm_raw_buffer_load_b128(rs_w, (int)(wvalid[i] ? wrow[i] + (unsigned)k0 * (unsigned)sizeof(T) : 0xffffffffu), 0, 0));
+            for (int i = 0; i < RPW; ++i)
+                rw[SET][i] = __builtin_bit_cast(Vec, llvm_raw_buffer_load_b128(rs_w, (int)(wvalid[i] ? wrow[i] + (unsigned)k0 * (unsigned)sizeof(T) : 0xffffffffu), 0, 0));
+        }
+    };
+    // RING: slab g of this channel tile -> buffer `buf`; this wavefront's CBN / 32 pieces of 1 KB
+    const unsigned ws_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&Ws[0][0];
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const char* img = RING ? reinterpret_cast<const char*>(p.w_image) + (size_t)tn * (Ktot / BK) * (CBN * 128) + lane * 16 : nullptr;
+    auto request = [&](int g, int buf) {
+        if constexpr (RING) {
+            const char* src = img + (size_t)g * (CBN * 128);
+#pragma unroll
+            for (int i = 0; i < CBN / 32; ++i) {
+                const char* a = src + (i * 4 + wave_u) * 1024;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(ws_lds + (unsigned)buf * (CBN * 128) + (i * 4 + wave_u) * 1024);
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(a), "s"(dst) : "memory");
+            }
+        }
     };
     auto store_slab = [&](int buf, auto set_c) {
         constexpr int SET = decltype(set_c)::value;
@@ -342,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
                 for (int e = 0; e < 4; ++e) da[e] = ra[SET][i][e];
             }
         }
+        if constexpr (!RING)
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const int c = tid + 256 * i, row = stage_row<SPLIT>(c), kc = (c & 7) * VE;
@@ -372,6 +397,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
     // its global loads.)
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
+    request(0, 0);
     load_slab(0, I0{});
     if (BK < Ktot) load_slab(BK, I1{});
     store_slab(0, I0{});
@@ -380,6 +406,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
         constexpr int PAR = decltype(par_c)::value;
         using Same = std::integral_constant<int, PAR>;
         using Other = std::integral_constant<int, 1 - PAR>;
+        if (k0 + BK < Ktot) request(k0 / BK + 1, 1 - PAR);     // (that buffer was last read before the previous barrier)
         if (k0 + 2 * BK < Ktot) load_slab(k0 + 2 * BK, Same{});
         // D[channel][pixel]: the weights are the A operand, so that an accumulator lane owns one output pixel and
         // runs of 4 consecutive channels (vector stores in the epilogue instead of 2-byte ones)
@@ -395,9 +422,15 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvParams p) {
                 }
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const half_t* q = Ws[PAR] + (wn * (CBN / 2) + j * 32 + r) * LS + kk * 16 + hi * 8;
-                    bh[j] = *reinterpret_cast<const half8*>(q);
-                    bl[j] = *reinterpret_cast<const half8*>(q + 32);
+                    if constexpr (RING) {       // unpadded 128-byte rows, 16-byte pieces swizzled by (row >> 1) & 7
+                        const int row = wn * (CBN / 2) + j * 32 + r, key = (row >> 1) & 7;
+                        bh[j] = *reinterpret_cast<const half8*>(Ws[PAR] + row * 64 + (((kk * 2 + hi) ^ key) << 3));
+                        bl[j] = *reinterpret_cast<const half8*>(Ws[PAR] + row * 64 + (((kk * 2 + hi + 4) ^ key) << 3));
+                    } else {
+                        const half_t* q = Ws[PAR] + (wn * (CBN / 2) + j * 32 + r) * LS + kk * 16 + hi * 8;
+                        bh[j] = *reinterpret_cast<const half8*>(q);
+                        bl[j] = *reinterpret_cast<const half8*>(q + 32);
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
@@ -816,11 +849,18 @@ __host__ __device__ inline size_t conv3_image_bytes(int Cout, int Cin, bool spli
     const int cbn = Cout <= 64 ? 64 : 128, bk = split ? 32 : 64;
     return (size_t)((Cout + cbn - 1) / cbn) * 9 * (Cin / bk) * cbn * 128;
 }
+// kind 1: the same slabs in the GEMM's own k order (slab g = columns 32 g .. 32 g + 31 of the (Ncols, Ktot) weight matrix), for the
+// generic implicit-GEMM kernel k_conv<..., SPLIT, RING>: strided / 1 x 1 / transposed convolutions
+__host__ __device__ inline size_t conv_gemm_image_bytes(int Ncols, int Ktot) {
+    const int cbn = Ncols <= 64 ? 64 : 128;
+    return (size_t)((Ncols + cbn - 1) / cbn) * (Ktot / 32) * cbn * 128;
+}
 // one thread per 16-byte piece of the image
+// gemm_ktot > 0: kind 1 (Cout = Ncols rows of gemm_ktot columns, slabs in k order; split only)
 template <bool SPLIT>
-__global__ __launch_bounds__(256) void k_conv3_pack(const void* __restrict__ w_, half_t* __restrict__ image, int Cout, int Cin) {
+__global__ __launch_bounds__(256) void k_conv3_pack(const void* __restrict__ w_, half_t* __restrict__ image, int Cout, int Cin, int gemm_ktot) {
     const int CBN = Cout <= 64 ? 64 : 128, BK = SPLIT ? 32 : 64;
-    const int G = 9 * (Cin / BK), Ktot = 9 * Cin;
+    const int G = gemm_ktot ? gemm_ktot / BK : 9 * (Cin / BK), Ktot = gemm_ktot ? gemm_ktot : 9 * Cin;
     const size_t n_pieces = (size_t)((Cout + CBN - 1) / CBN) * G * CBN * 8;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n_pieces) return;
@@ -833,7 +873,7 @@ __global__ __launch_bounds__(256) void k_conv3_pack(const void* __restrict__ w_,
     half8 out = (half8)(half_t)0.f;
     if (nrow < Cout) {
         if constexpr (SPLIT) {
-            const float* src = reinterpret_cast<const float*>(w_) + (size_t)nrow * Ktot + tap * Cin + cs * BK + (pc & 3) * 8;
+            const float* src = reinterpret_cast<const float*>(w_) + (size_t)nrow * Ktot + (gemm_ktot ? g * BK : tap * Cin + cs * BK) + (pc & 3) * 8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float v = src[e];
@@ -852,8 +892,16 @@ int launch_conv3_pack(const void* w, int Cout, int Cin, int precision, void* ima
     HMVIT_CHECK_ARG(split || precision == HMVIT_PREC_F16, "conv3 image: split or f16 (precision %d)", precision);
     HMVIT_CHECK_ARG(w && image && Cout > 0 && Cin > 0 && Cin % (split ? 32 : 64) == 0, "conv3 image: Cout=%d Cin=%d", Cout, Cin);
     const size_t n_pieces = conv3_image_bytes(Cout, Cin, split) / 16;
-    if (split) hipLaunchKernelGGL(k_conv3_pack<true>, dim3((unsigned)((n_pieces + 255) / 256)), dim3(256), 0, st, w, reinterpret_cast<half_t*>(image), Cout, Cin);
-    else hipLaunchKernelGGL(k_conv3_pack<false>, dim3((unsigned)((n_pieces + 255) / 256)), dim3(256), 0, st, w, reinterpret_cast<half_t*>(image), Cout, Cin);
+    if (split) hipLaunchKernelGGL(k_conv3_pack<true>, dim3((unsigned)((n_pieces + 255) / 256)), dim3(256), 0, st, w, reinterpret_cast<half_t*>(image), Cout, Cin, 0);
+    else hipLaunchKernelGGL(k_conv3_pack<false>, dim3((unsigned)((n_pieces + 255) / 256)), dim3(256), 0, st, w, reinterpret_cast<half_t*>(image), Cout, Cin, 0);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+size_t conv_gemm_image_size(int Ncols, int Ktot) { return conv_gemm_image_bytes(Ncols, Ktot); }
+int launch_conv_gemm_pack(const float* w, int Ncols, int Ktot, void* image, hipStream_t st) {
+    HMVIT_CHECK_ARG(w && image && Ncols > 0 && Ktot > 0 && Ktot % 32 == 0, "conv image (GEMM order): Ncols=%d Ktot=%d", Ncols, Ktot);
+    const size_t n_pieces = conv_gemm_image_bytes(Ncols, Ktot) / 16;
+    hipLaunchKernelGGL(k_conv3_pack<true>, dim3((unsigned)((n_pieces + 255) / 256)), dim3(256), 0, st, w, reinterpret_cast<half_t*>(image), Ncols, 0, Ktot);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }
@@ -1279,7 +1327,7 @@ int launch_conv(const ConvParams& p_in, int precision, hipStream_t st) {
         p.Cin % (split ? 32 : 64) == 0 && p.Cout % 8 == 0 && p.y_coff % 8 == 0 && p.y_ctot % 8 == 0 && p.Ho == p.H && p.Wo == p.W &&
         !p.no_patch && !HMVIT_ENV("HMVIT_CONV_NO_PATCH")) {
         const int tiles = p.N * cdiv(p.Ho, 8) * cdiv(p.Wo, 16);
-        const bool ring = p.w_image && (!split || p.w_absmax < 0.f) && !HMVIT_ENV("HMVIT_CONV_NO_RING");
+        const bool ring = p.w_image && p.w_image_kind == 0 && (!split || p.w_absmax < 0.f) && !HMVIT_ENV("HMVIT_CONV_NO_RING");
         // enough workgroups to cover the CUs.  The ring kernel is taken from half a cover on: on the deep ResNet layers
         // (512 channels, 16 x 16 maps, 160 workgroups of 144 taps) it still beats the generic kernel's 64-pixel tiles 2 : 1
         if (tiles * cdiv(p.Cout, narrow ? 64 : 128) >= (ring ? 128 : 256)) {
@@ -1308,7 +1356,10 @@ int launch_conv(const ConvParams& p_in, int precision, hipStream_t st) {
     dim3 grid(cdiv(M, small ? 64 : 128) * cdiv(Ncols, narrow ? 64 : 128)), block(256);
 #define HMVIT_CONV_CASE(T, N_, M_) hipLaunchKernelGGL((k_conv<T, N_, M_>), grid, block, 0, st, p)
     if (precision == HMVIT_PREC_SPLIT) {
-#define HMVIT_CONV_SPLIT(N_, M_) hipLaunchKernelGGL((k_conv<float, N_, M_, true>), grid, block, 0, st, p)
+        // the weights also exist as the GEMM-order ring image (hmvit_conv_gemm_image, of the pre-scaled weights): weight slabs by LDS-DMA
+        const bool gring = p.w_image && p.w_image_kind == 1 && p.w_absmax < 0.f && !p.rowpack && !HMVIT_ENV("HMVIT_CONV_NO_RING");
+#define HMVIT_CONV_SPLIT(N_, M_) do { if (gring) hipLaunchKernelGGL((k_conv<float, N_, M_, true, true>), grid, block, 0, st, p); \
+                                      else hipLaunchKernelGGL((k_conv<float, N_, M_, true>), grid, block, 0, st, p); } while (0)
         if (narrow) { if (small) HMVIT_CONV_SPLIT(64, 64); else HMVIT_CONV_SPLIT(64, 128); }
         else { if (small) HMVIT_CONV_SPLIT(128, 64); else HMVIT_CONV_SPLIT(128, 128); }
 #undef HMVIT_CONV_SPLIT

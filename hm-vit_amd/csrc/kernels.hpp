@@ -174,7 +174,8 @@ struct ConvParams {
                               // launch_conv runs itself
     float w_absmax;           // > 0: max |w| (host value); < 0: weights pre-multiplied by the power of two -w_absmax; 0: measured
     unsigned* y_absmax;       // optional, device, zeroed by the caller: atomicMax of |y| over everything this launch stores
-    const void* w_image;      // optional: the weights as the ring image of k_conv3r (launch_conv3_pack), 3 x 3 / stride 1 layers
+    const void* w_image;      // optional: the weights as an LDS ring image: kind 0 for k_conv3r (launch_conv3_pack: 3 x 3 / stride 1),
+    int w_image_kind;         // kind 1 in the GEMM's k order for the generic kernel (launch_conv_gemm_pack); a kind the chosen kernel does not read is ignored
     int rowpack;              // 1: few-channel stem.  x is a physically zero-padded (N, H, W, 4) map, output pixel (oy, ox) reads
                               // rows oy*stride .. + KH - 1 and pixels ox*stride .. + 7 of it; w is (Ncols, KH * 32) with
                               // k = ky * 32 + px * 4 + ci; Ho, Wo are given, pad / KW / Cin are not used
@@ -183,6 +184,8 @@ int launch_conv(const ConvParams& p, int precision, hipStream_t st);
 // ring image of a 3 x 3 convolution's weights (w: (Cout, 9 Cin) in the precision's element type; split: pre-scaled f32)
 size_t conv3_image_size(int Cout, int Cin, int precision);
 int launch_conv3_pack(const void* w, int Cout, int Cin, int precision, void* image, hipStream_t st);
+size_t conv_gemm_image_size(int Ncols, int Ktot);
+int launch_conv_gemm_pack(const float* w, int Ncols, int Ktot, void* image, hipStream_t st);
 // atomicMax of max |x| (f32 bit pattern) into slot[0]; the caller zeroes the slot
 int launch_absmax(const float* x, size_t n, unsigned* slot, hipStream_t st);
 // max pooling on NHWC maps (the 3x3 / stride 2 / pad 1 stage of a ResNet stem)

@@ -104,7 +104,7 @@ class HeteroDecoder(nn.Module):
                 w, wmax = _lib.prescale_weights(w)              # exact power-of-two multiple, undone in the kernel's epilogue
             rows = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous()
             return dict(w=rows, b=b.contiguous(), cin=w.shape[1], cout=w.shape[0], k=w.shape[2], pad=c.padding[0], wmax=wmax,
-                        img=_lib.conv3_image(rows, w.shape[0], w.shape[1], w.shape[2], 1, c.padding[0], prec, wmax))
+                        img=_lib.conv_image(rows, w.shape[0], w.shape[1], w.shape[2], 1, c.padding[0], prec, wmax))
 
         prep = {}
         for t, name in ((0, "camera"), (1, "lidar")):

@@ -125,7 +125,7 @@ class PointPillar(nn.Module):
             rows = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous()
             return dict(w=rows, b=b.contiguous(), cin=w.shape[1], cout=w.shape[0], k=w.shape[2], stride=c.stride[0],
                         pad=c.padding[0], wmax=wmax,
-                        img=_lib.conv3_image(rows, w.shape[0], w.shape[1], w.shape[2], c.stride[0], c.padding[0], prec, wmax))
+                        img=_lib.conv_image(rows, w.shape[0], w.shape[1], w.shape[2], c.stride[0], c.padding[0], prec, wmax))
 
         def deconv(c, bn):
             w = c.weight.detach().float()                       # (Cin, Cout, s, s)
@@ -135,8 +135,9 @@ class PointPillar(nn.Module):
             wmax = 0.0
             if prec == _lib.PREC_SPLIT:
                 w, wmax = _lib.prescale_weights(w)
-            return dict(w=w.permute(2, 3, 1, 0).reshape(us * us * w.shape[1], w.shape[0]).to(dt).contiguous(),
-                        b=sh.contiguous(), cin=w.shape[0], cout=w.shape[1], us=us, wmax=wmax)
+            rows = w.permute(2, 3, 1, 0).reshape(us * us * w.shape[1], w.shape[0]).to(dt).contiguous()
+            return dict(w=rows, b=sh.contiguous(), cin=w.shape[0], cout=w.shape[1], us=us, wmax=wmax,
+                        img=_lib.conv_image(rows, rows.shape[0], w.shape[0], 1, 1, 0, prec, wmax, deconv=True))
 
         pfn = self.pillar_vfe.pfn_layers[0]
         s, sh = self._fold_bn(pfn.norm)
@@ -232,6 +233,7 @@ class PointPillar(nn.Module):
                 assert (H * us, W * us) == (Hc, Wc), "up-sampled maps must share one size"
                 if prec == _lib.PREC_SPLIT:
                     _lib.conv_range(x, de["wmax"], cat, stream, share_out=True)
+                _lib.use_conv_image(de.get("img"))
                 _lib.check(_lib.lib.hmvit_conv2d(x.data_ptr(), de["w"].data_ptr(), de["b"].data_ptr(), cat.data_ptr(),
                                                  n_agents, H, W, de["cin"], de["cout"], 1, 1, 0, 1, ctot, coff, us, 0, prec,
                                                  stream), "hmvit_conv2d(deconv)")

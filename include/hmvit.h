@@ -407,12 +407,18 @@ int hmvit_absmax(const float* x, size_t n, void* slot, void* stream);
  * workgroup: the Conv2d layers of base_bev_backbone.py:6-122, downsample_conv.py:32-51, resnet_ms.py / torchvision BasicBlock.
  *   hmvit_conv3x3_image_bytes  size of the image (0: shape / precision without one: Cin % 32 (split) or % 64 (f16) != 0);
  *   hmvit_conv3x3_image        w (Cout, 9 Cin) in hmvit_conv2d's layout -> image (device, that many bytes), once per weight version;
- *   hmvit_conv_weight_image    hands the image to the NEXT hmvit_conv2d / _ex call of the calling thread (consumed by it, like
- *                              hmvit_conv_range); `w` is still passed and is what the other kernels of that entry point read.
- * Results are bit-identical with and without the image. */
+ *   hmvit_conv_gemm_image(_bytes)  the same for every other geometry in HMVIT_PREC_SPLIT (strided, 1 x 1, transposed): w is the
+ *                              (Ncols, Ktot) pre-scaled f32 matrix hmvit_conv2d takes (Ncols = Cout, or stride^2 Cout for a transposed
+ *                              convolution; Ktot = k k Cin, a multiple of 32), the slabs follow its own column order;
+ *   hmvit_conv_weight_image    hands an image to the NEXT hmvit_conv2d / _ex call of the calling thread (consumed by it, like
+ *                              hmvit_conv_range); kind 0: hmvit_conv3x3_image, 1: hmvit_conv_gemm_image.  `w` is still passed and is
+ *                              what the call reads when the kernel it selects does not use that kind of image.
+ * Results are bit-identical with and without an image. */
 size_t hmvit_conv3x3_image_bytes(int Cout, int Cin, int precision);
 int hmvit_conv3x3_image(const void* w, int Cout, int Cin, int precision, void* image, void* stream);
-int hmvit_conv_weight_image(const void* image);
+size_t hmvit_conv_gemm_image_bytes(int Ncols, int Ktot);
+int hmvit_conv_gemm_image(const float* w, int Ncols, int Ktot, void* image, void* stream);
+int hmvit_conv_weight_image(const void* image, int kind);
 
 /* hmvit_conv2d with a residual operand and an up-sampled input (camera branch):
  *   residual (N, Ho, Wo, Cout) in the precision's element type or NULL: y = act(conv(x) + bias + residual), the tail of a

@@ -413,3 +413,51 @@ def test_conv3x3_image_is_declined_where_the_ring_kernel_does_not_apply():
     assert _lib.conv3_image(w, 64, 64, 3, 1, 1, _lib.PREC_SPLIT, 3.0) is None         # split weights not pre-scaled
     assert _lib.lib.hmvit_conv3x3_image_bytes(64, 48, _lib.PREC_SPLIT) == 0           # Cin not a multiple of the slab depth
     assert _lib.lib.hmvit_conv3x3_image_bytes(64, 96, _lib.PREC_F16) == 0
+
+
+@pytest.mark.parametrize("N,cin,cout,k,stride,pad,H,W,deconv", [(5, 384, 256, 3, 2, 1, 64, 64, 0),     # the shrink header's strided layer
+                                                              (4, 64, 64, 3, 2, 1, 50, 38, 0),       # narrow channel tile, ragged pixels
+                                                              (3, 128, 256, 1, 1, 0, 20, 12, 0),     # 1 x 1, small map (64-pixel tiles)
+                                                              (2, 256, 128, 1, 1, 0, 24, 20, 2),     # ConvTranspose2d(kernel = stride = 2)
+                                                              (2, 64, 136, 3, 1, 0, 21, 19, 0)])     # ragged channel tile, pad 0
+def test_conv_gemm_ring_is_bit_identical_to_the_register_staged_kernel(N, cin, cout, k, stride, pad, H, W, deconv):
+    """Generic implicit-GEMM kernel in split mode with its weight slabs on the LDS-DMA ring (hmvit_conv_gemm_image, kind 1) against
+    the same kernel staging the weights through registers: same MFMA order, so equal bits; plus the float64 convolution."""
+    from hmvit_amd import _lib
+    torch.manual_seed(N * cin + cout + k)
+    x = torch.randn(N, cin, H, W, device="cuda")
+    b = torch.randn(cout, device="cuda")
+    if deconv:
+        w = torch.randn(cin, cout, deconv, deconv, device="cuda") / cin ** 0.5
+        ref = F.relu(F.conv_transpose2d(x.double(), w.double(), b.double(), deconv))
+        wk, wmax = _lib.prescale_weights(w)
+        wn = wk.permute(2, 3, 1, 0).reshape(deconv * deconv * cout, cin).contiguous()
+        Ho, Wo = H * deconv, W * deconv
+    else:
+        w = torch.randn(cout, cin, k, k, device="cuda") / (cin * k * k) ** 0.5
+        ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), stride, pad))
+        wk, wmax = _lib.prescale_weights(w)
+        wn = wk.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    img = _lib.conv_image(wn, wn.shape[0], cin, k, stride, pad, _lib.PREC_SPLIT, wmax, deconv=bool(deconv))
+    assert img is not None and img[1] == 1 and img[0].numel() == _lib.lib.hmvit_conv_gemm_image_bytes(wn.shape[0], wn.shape[1])
+
+    def run(ring):
+        y = torch.empty(N, Ho, Wo, cout, device="cuda")
+        _lib.conv_range(xn, wmax, y, _stream())
+        if ring:
+            _lib.use_conv_image(img)
+        _lib.check(_lib.lib.hmvit_conv2d(xn.data_ptr(), wn.data_ptr(), b.data_ptr(), y.data_ptr(), N, H, W, cin, cout, 1 if deconv else k,
+                                         1 if deconv else stride, 0 if deconv else pad, 1, cout, 0, deconv, 0, _lib.PREC_SPLIT, _stream()), "conv")
+        return y
+    y_ring, y_regs = run(True), run(False)
+    assert torch.equal(y_ring, y_regs), float((y_ring - y_regs).abs().max())
+    assert rel_max_err(y_ring.permute(0, 3, 1, 2).double(), ref) < 4e-6
+    # a kind-0 image handed to a call that takes the generic kernel is ignored, not misread
+    y = torch.empty_like(y_ring)
+    _lib.conv_range(xn, wmax, y, _stream())
+    _lib.use_conv_image(img[0], 0)
+    _lib.check(_lib.lib.hmvit_conv2d(xn.data_ptr(), wn.data_ptr(), b.data_ptr(), y.data_ptr(), N, H, W, cin, cout, 1 if deconv else k,
+                                     1 if deconv else stride, 0 if deconv else pad, 1, cout, 0, deconv, 0, _lib.PREC_SPLIT, _stream()), "conv")
+    assert torch.equal(y, y_regs)
