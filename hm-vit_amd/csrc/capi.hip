@@ -1132,6 +1132,10 @@ int hmvit_cross_attention(const void* q, const void* k, const void* v, float* ou
     if (precision == HMVIT_PREC_F16)
         return launch_cross_attention_f16(reinterpret_cast<const half_t*>(q), reinterpret_cast<const half_t*>(k),
                                           reinterpret_cast<const half_t*>(v), out, n_agents, n_cam, Q, K, heads, dim_head, st);
+    // split mode: fp32-class products on the f16 matrix pipes where the tile sizes allow; the exact-f32 MFMA kernel otherwise
+    if (precision == HMVIT_PREC_SPLIT && dim_head == 32 && Q % 64 == 0 && K % 64 == 0)
+        return launch_cross_attention_split(reinterpret_cast<const float*>(q), reinterpret_cast<const float*>(k),
+                                            reinterpret_cast<const float*>(v), out, n_agents, n_cam, Q, K, heads, dim_head, st);
     return launch_cross_attention(reinterpret_cast<const float*>(q), reinterpret_cast<const float*>(k),
                                   reinterpret_cast<const float*>(v), out, n_agents, n_cam, Q, K, heads, dim_head, nullptr, st);
 }

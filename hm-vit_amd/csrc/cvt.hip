@@ -569,6 +569,181 @@ __global__ __launch_bounds__(256) void k_cross_attention_mfma(const half_t* __re
     *reinterpret_cast<float4*>(op + 4) = make_float4(o_acc[1][0] * inv, o_acc[1][1] * inv, o_acc[1][2] * inv, o_acc[1][3] * inv);
 }
 
+// ------------------------------------------------------------------------------------------
+// The same joint-softmax cross attention on f32 operands with split-f16 products (HMVIT_PREC_SPLIT): every product x y as
+// x_hi y_hi + x_lo y_hi + x_hi y_lo on v_mfma_f32_16x16x32_f16, f32 accumulate - fp32-class results at a fifth of the matrix cycles
+// of the exact-f32 kernel above (v_mfma_f32_16x16x4_f32), which the split model used until round 4: 0.87 ms of the 6.3 ms CVT
+// encoder for its largest launch (5 agents x 4 cameras x 4096 keys, 1024 queries: 43 GF at 49 TF/s).
+// Workgroup = 64 queries of one head of one agent, EIGHT wavefronts: wavefront (qg, kh) takes queries 16 qg .. 16 qg + 15 and the
+// 32 keys kh of every 64-key tile (the launch has only Q / 64 x heads x agents = 320 workgroups: two wavefronts per SIMD and
+// half the matrix work per wavefront instead of one workgroup of four on most CUs); the two halves keep their own running
+// maximum / denominator / output and are merged once, through LDS, at the end.  K / V rows travel global (f32) -> registers ->
+// (hi, lo) halves -> LDS, one tile ahead, one barrier per tile; fragments and the V^T transposed reads as in
+// k_cross_attention_mfma.  Q and K multiples of 64, no logit bias, no saved log-sum-exp (those calls keep the f32 kernel).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_cross_attention_split(const float* __restrict__ q, const float* __restrict__ k,
+                                                               const float* __restrict__ v, float* __restrict__ out, int n_cam,
+                                                               int Q, int K, int heads, float qscale) {
+    constexpr int D = 32, KS = D + 8, VS = D + 16;
+    __shared__ __attribute__((aligned(16))) half_t Kh[2][64 * KS], Kl[2][64 * KS];
+    __shared__ __attribute__((aligned(16))) half_t Vh[2][64 * VS], Vl[2][64 * VS];
+    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 64;
+    const int HD = heads * D;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, lq = lane & 15, g = lane >> 4;
+    const int qg = wave & 3, kh = wave >> 2;
+    // staging role of this thread: key row and 4-channel piece of a 64 x 32 tile
+    const int srow = threadIdx.x >> 3, spiece = (threadIdx.x & 7) * 4;
+
+    float m_run = -INFINITY;
+    float4v o_acc[2], l_acc;
+    o_acc[0] = o_acc[1] = l_acc = (float4v)(0.f);
+    const half8 ones = (half8)(half_t)1.0f;
+    const int n_tiles = K / 64, total = n_cam * n_tiles;
+
+    auto load_tile = [&](int it, float4& rk, float4& rv) {
+        const int cam = it / n_tiles, kt = it - cam * n_tiles;
+        const size_t key = (size_t)(b * n_cam + cam) * K + (size_t)kt * 64 + srow;
+        rk = *reinterpret_cast<const float4*>(k + key * HD + head * D + spiece);
+        rv = *reinterpret_cast<const float4*>(v + key * HD + head * D + spiece);      // v is (b, n K, HD): same row index
+    };
+    auto split4 = [&](const float4& x, half_t* hi, half_t* lo) {
+        const float f[4] = {x.x, x.y, x.z, x.w};
+        half4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = (half_t)f[e];
+            l[e] = (half_t)(f[e] - (float)h[e]);
+        }
+        *reinterpret_cast<half4*>(hi) = h;
+        *reinterpret_cast<half4*>(lo) = l;
+    };
+    auto store_tile = [&](int buf, const float4& rk, const float4& rv) {
+        split4(rk, Kh[buf] + srow * KS + spiece, Kl[buf] + srow * KS + spiece);
+        split4(rv, Vh[buf] + srow * VS + spiece, Vl[buf] + srow * VS + spiece);
+    };
+
+    // rows one tile ahead in registers.  (Tried on top of this, measured on the 4 x 4096-key launch: four tiles ahead with the
+    // query operands in LDS and hipcc's waits made countable - vmcnt(5 / 4) instead of vmcnt(0) in front of the row stores -
+    // 350 -> 460 us: the tile time is not the global round trip.)
+    float4 rk, rv;
+    half8 qh, ql;
+    load_tile(0, rk, rv);
+    store_tile(0, rk, rv);
+    __syncthreads();
+    int cam_loaded = -1;
+    for (int it = 0; it < total; ++it) {
+        {
+            const int buf = it & 1, cam = it / n_tiles;
+            if (it + 1 < total) load_tile(it + 1, rk, rv);
+            if (cam != cam_loaded) {      // the query operand of this camera, pre-scaled by log2(e) / sqrt(d), as (hi, lo)
+                const float* qp = q + ((size_t)(b * n_cam + cam) * Q + q0 + qg * 16 + lq) * HD + head * D + g * 8;
+                const float4 a0 = *reinterpret_cast<const float4*>(qp), a1 = *reinterpret_cast<const float4*>(qp + 4);
+                const float f[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = f[e] * qscale;
+                    qh[e] = (half_t)x;
+                    ql[e] = (half_t)(x - (float)qh[e]);
+                }
+                cam_loaded = cam;
+            }
+            // this wavefront's 32 keys of the tile: key sub-tiles 2 kh, 2 kh + 1
+            half8 k_h[2], k_l[2], v_h[2], v_l[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                k_h[kt] = *reinterpret_cast<const half8*>(Kh[buf] + ((2 * kh + kt) * 16 + lq) * KS + g * 8);
+                k_l[kt] = *reinterpret_cast<const half8*>(Kl[buf] + ((2 * kh + kt) * 16 + lq) * KS + g * 8);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) {
+                    const half_t* base = (hl ? Vl[buf] : Vh[buf]) + (kh * 32 + 4 * g + (lq >> 2)) * VS + (lq & 3) * 8 + dt * 4;
+                    const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base));
+                    const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base + 16 * VS));
+                    half8 t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { t[e] = (half_t)lo[e]; t[4 + e] = (half_t)hi[e]; }
+                    if (hl) v_l[dt] = t; else v_h[dt] = t;
+                }
+            float4v s[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                float4v acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_l[kt], qh, (float4v)(0.f), 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_h[kt], ql, acc, 0, 0, 0);
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_h[kt], qh, acc, 0, 0, 0);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+            mx = max_over_lane_groups(mx);
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            half8 ph, pl;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
+                    const half_t eh = (half_t)e;
+                    ph[4 * kt + r] = eh;
+                    pl[4 * kt + r] = (half_t)(e - (float)eh);
+                }
+            m_run = m_new;
+            o_acc[0] *= alpha; o_acc[1] *= alpha; l_acc *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                o_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v_l[dt], ph, o_acc[dt], 0, 0, 0);
+                o_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v_h[dt], pl, o_acc[dt], 0, 0, 0);
+                o_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v_h[dt], ph, o_acc[dt], 0, 0, 0);
+            }
+            l_acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pl, l_acc, 0, 0, 0);
+            l_acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, ph, l_acc, 0, 0, 0);
+            if (it + 1 < total) store_tile(buf ^ 1, rk, rv);    // that buffer was last read before the previous barrier
+            __syncthreads();
+        }
+    }
+    // merge the two key halves of a query group (same lane, wavefronts qg and qg + 4): LDS is free after the last barrier
+    __shared__ float merge[4][10][64];
+    if (kh == 1) {
+        merge[qg][0][lane] = m_run;
+        merge[qg][1][lane] = l_acc[0];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) merge[qg][2 + 4 * dt + r][lane] = o_acc[dt][r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+        const float m2 = merge[qg][0][lane], l2 = merge[qg][1][lane];
+        const float m = fmaxf(m_run, m2);
+        const float a1 = __builtin_amdgcn_exp2f(m_run - m), a2 = __builtin_amdgcn_exp2f(m2 - m);
+        const float inv = 1.f / (l_acc[0] * a1 + l2 * a2);
+        float o[8];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[4 * dt + r] = (o_acc[dt][r] * a1 + merge[qg][2 + 4 * dt + r][lane] * a2) * inv;
+        // lane (query lq, g) holds channels 8 g + 4 dt + r (row order of the V^T tiles)
+        float* op = out + ((size_t)b * Q + q0 + qg * 16 + lq) * HD + head * D + 8 * g;
+        *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+int launch_cross_attention_split(const float* q, const float* k, const float* v, float* out, int b, int n_cam, int Q, int K,
+                                 int heads, int dim_head, hipStream_t st) {
+    HMVIT_CHECK_ARG(dim_head == 32 && Q % 64 == 0 && K % 64 == 0, "cross_attention (split): dim_head=%d (32), Q=%d, K=%d (multiples of 64)",
+                    dim_head, Q, K);
+    if (b <= 0 || Q <= 0) return HMVIT_OK;
+    const float qscale = 1.44269504088896341f / sqrtf((float)dim_head);
+    hipLaunchKernelGGL(k_cross_attention_split, dim3(Q / 64, heads, b), dim3(512), 0, st, q, k, v, out, n_cam, Q, K, heads, qscale);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
 int launch_cross_attention_f16(const half_t* q, const half_t* k, const half_t* v, float* out, int b, int n_cam, int Q, int K,
                                int heads, int dim_head, hipStream_t st) {
     HMVIT_CHECK_ARG(dim_head == 32 && Q % 64 == 0 && K % 64 == 0, "cross_attention (f16): dim_head=%d (32), Q=%d, K=%d (multiples of 64)",

@@ -385,5 +385,7 @@ int launch_cross_attention_bwd(const float* q, const float* k, const float* v, c
                                const float* bias = nullptr, float* d_bias = nullptr);   // bias (heads, Q, K), n_cam = 1: d_bias written
 int launch_cross_attention_f16(const half_t* q, const half_t* k, const half_t* v, float* out, int b, int n_cam, int Q, int K,
                                int heads, int dim_head, hipStream_t st);
+int launch_cross_attention_split(const float* q, const float* k, const float* v, float* out, int b, int n_cam, int Q, int K,
+                                 int heads, int dim_head, hipStream_t st);
 
 }  // namespace hmvit

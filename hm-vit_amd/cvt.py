@@ -162,8 +162,9 @@ class CrossAttention(nn.Module):
             vp = _linear(_layernorm(v.reshape(-1, dim), self.to_v[0]), self.to_v[1].weight, self.to_v[1].bias)
         a = torch.empty(b * Q, hd, device=q.device, dtype=torch.float32)
         _lib.check(_lib.lib.hmvit_cross_attention(qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), a.data_ptr(), b, n, Q, K,
-                                                  self.heads, self.dim_head, _lib.PREC_F16 if half else _F32, _stream()),
-                   "cross_attention")
+                                                  self.heads, self.dim_head,
+                                                  _lib.PREC_F16 if half else (_lib.PREC_SPLIT if _SPLIT_LINEARS[0] else _F32), _stream()),
+                   "cross_attention")      # split model: the attention core on split-f16 products too (the library keeps the exact-f32 kernel for ragged sizes)
         res = None if skip is None else skip.reshape(-1, dim).contiguous()
         if half and dim % 64 == 0:
             # the rest of the block on f16 operands too (f32 accumulate; LayerNorm and both residual adds stay in f32)

@@ -77,3 +77,34 @@ def test_cross_attention_core_f16_vs_torch(b, n, Q, K, heads):
     assert rel_max_err(out.cpu(), ref) < 3e-3       # P and the scaled q operand are rounded to f16
     assert _lib.lib.hmvit_cross_attention(qc.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr(), b, n, Q - 1, K, heads, 32,
                                           _lib.PREC_F16, st) != 0     # Q not a multiple of 64: refused, no silent fallback
+
+
+@pytest.mark.parametrize("b,n,Q,K,heads,spread", [(1, 1, 64, 64, 1, 1.5), (2, 3, 128, 192, 4, 1.5), (1, 4, 1024, 1024, 4, 3.0),
+                                                 (2, 2, 64, 200, 2, 1.5)])
+def test_cross_attention_core_split_vs_float64(b, n, Q, K, heads, spread):
+    """HMVIT_PREC_SPLIT: the split-f16 matrix-core kernel (f32 operands as hi + lo halves, three products each) against a float64
+    evaluation of the joint softmax over the cameras' keys (cvt_modules.py:148-158), at fp32 round-off class and no worse than the
+    exact-f32 kernel it replaces; logits spread over many units (peaked rows, running-max rescales).  K = 200 is not a multiple
+    of 64: that call keeps the exact-f32 kernel."""
+    import ctypes
+    from hmvit_amd import _lib
+    gen = torch.Generator().manual_seed(b * 1000 + Q + K + 1)
+    hd = heads * 32
+    q = torch.randn(b, n, Q, hd, generator=gen) * spread
+    k = torch.randn(b, n, K, hd, generator=gen) * spread
+    v = torch.randn(b, n * K, hd, generator=gen) * 2.0
+    qd = q.double().reshape(b, n, Q, heads, 32).permute(0, 3, 1, 2, 4)
+    kd = k.double().reshape(b, n, K, heads, 32).permute(0, 3, 1, 2, 4)
+    dot = (32 ** -0.5) * torch.einsum("bmnqd,bmnkd->bmnqk", qd, kd)
+    att = dot.permute(0, 1, 3, 2, 4).reshape(b, heads, Q, n * K).softmax(-1)
+    ref = torch.einsum("bmqk,bkmd->bqmd", att, v.double().reshape(b, n * K, heads, 32)).reshape(b, Q, hd)
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = {}
+    for name, prec in (("split", _lib.PREC_SPLIT), ("f32", _lib.PREC_F32)):
+        out = torch.empty(b, Q, hd, device="cuda")
+        _lib.check(_lib.lib.hmvit_cross_attention(qc.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr(), b, n, Q, K, heads, 32,
+                                                  prec, st), "cross_attention")
+        outs[name] = rel_max_err(out.cpu().double(), ref)
+    print(f"cross attention b={b} n={n} Q={Q} K={K}: split {outs['split']:.2e}, exact-f32 kernel {outs['f32']:.2e}")
+    assert outs["split"] < 5e-6 and outs["split"] < 4 * outs["f32"] + 1e-6
