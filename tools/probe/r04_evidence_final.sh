@@ -3,7 +3,7 @@
 # Every artefact is copied into gpurun_out/r04/profiles/ as soon as it exists (a call that is cut off keeps what it has).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 P=gpurun_out/r04/profiles; mkdir -p $P
-timeout 1500 python -m pytest tests/test_hip_encoder.py tests/test_hip_camera.py tests/test_hip_model.py tests/test_hip_range.py tests/test_hip_post.py tests/test_hip_ap.py tests/test_hip_cvt.py tests/test_hip_fax.py tests/test_hip_trainer.py tests/test_hip_camera_train.py -m gpu -q -s > gpurun_out/r04/gputest_final.log 2>&1; echo "rc=$?" >> gpurun_out/r04/gputest_final.log
+timeout 2400 python -m pytest tests -m gpu -q -s > gpurun_out/r04/gputest_final.log 2>&1; echo "rc=$?" >> gpurun_out/r04/gputest_final.log
 grep -E "FAILED|ERROR|passed|failed|rc=" gpurun_out/r04/gputest_final.log | head -20
 grep -E "^range\[" gpurun_out/r04/gputest_final.log > $P/r04_range.txt
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r04/smoke.log 2>&1; echo "smoke rc=$?"
