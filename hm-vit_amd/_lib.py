@@ -270,15 +270,15 @@ def prescale_weights(w):
 
 def conv_image(w_rows, ncols: int, cin: int, k: int, stride: int, pad: int, prec: int, wmax: float = 0.0, deconv: bool = False):
     """LDS ring image of a convolution's prepared weight matrix `w_rows` (Ncols, k k Cin) for the LDS-DMA convolution kernels
-    (include/hmvit.h): (tensor, kind) - kind 0 for a 3 x 3 / stride 1 / pad 1 layer (hmvit_conv3x3_image; split and f16), kind 1
-    in the GEMM's column order for every other geometry in split mode (hmvit_conv_gemm_image: strided, 1 x 1, transposed) - or
+    (include/hmvit.h): (tensor, kind) - kind 0 for a 3 x 3 / pad 1 layer of stride 1 or 2 (hmvit_conv3x3_image; split and f16), kind 1
+    in the GEMM's column order for every other geometry in split mode (hmvit_conv_gemm_image: other strided layers, 1 x 1, transposed) - or
     None where neither kernel applies (exact-f32 mode, split weights that were not pre-scaled, a K that is not a multiple of the
     slab depth).  Built once per weight version by the modules' prepare steps."""
     import torch
     if prec not in (PREC_SPLIT, PREC_F16) or (prec == PREC_SPLIT and not wmax < 0.0):
         return None
     ktot = w_rows.shape[1]
-    if k == 3 and stride == 1 and pad == 1 and not deconv and ncols % 8 == 0:
+    if k == 3 and stride in (1, 2) and pad == 1 and not deconv and ncols % 8 == 0:      # the ring kernels: stride 1 and stride 2
         nbytes, kind = int(lib.hmvit_conv3x3_image_bytes(ncols, cin, prec)), 0
     elif prec == PREC_SPLIT:
         nbytes, kind = int(lib.hmvit_conv_gemm_image_bytes(ncols, ktot)), 1

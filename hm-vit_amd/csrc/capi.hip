@@ -1008,7 +1008,7 @@ int hmvit_conv2d_ex(const void* x, const void* w, const float* bias, const void*
     p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = p.KW = ksize; p.stride = stride; p.pad = pad;
     p.relu = relu; p.y_ctot = Cout; p.y_coff = 0; p.deconv_s = 0; p.out_f32 = out_f32;
-    p.res = residual; p.up2 = upsample2 & 1; p.no_patch = (upsample2 >> 1) & 1;
+    p.res = residual; p.up2 = upsample2 & 1; p.no_patch = (upsample2 >> 1) & 1; p.force_patch = (upsample2 >> 2) & 1;
     p.Ho = (H + 2 * pad - ksize) / stride + 1;
     p.Wo = (W + 2 * pad - ksize) / stride + 1;
     return launch_conv(p, precision, reinterpret_cast<hipStream_t>(stream));

@@ -906,13 +906,17 @@ int launch_conv_gemm_pack(const float* w, int Ncols, int Ktot, void* image, hipS
     return HMVIT_OK;
 }
 
-template <int CBN, bool SPLIT = false>
-__global__ __launch_bounds__(256, 2) void k_conv3r(ConvParams p) {
+// STRIDE = 2: the 3 x 3 / stride 2 / pad 1 layers (the first layer of every backbone block, the shrink header's 384 -> 256 layer)
+// with the same tile and ring: the patch is the 17 x 33 input pixels under the 8 x 16 outputs (81 KB per channel slab: one
+// workgroup per CU, 18 pieces per thread in flight), output pixel (py, px) and tap (ky, kx) read patch pixel (2 py + ky, 2 px + kx).
+// The generic kernel fetches every input pixel 2.25 times per channel slab through the address path for these layers.
+template <int CBN, bool SPLIT = false, int STRIDE = 1>
+__global__ __launch_bounds__(256, STRIDE == 1 ? 2 : 1) void k_conv3r(ConvParams p) {
     using T = half_t;
     using TG = typename std::conditional<SPLIT, float, half_t>::type;
     using Cfg = Conv3rCfg<CBN, SPLIT>;
     constexpr int BK = Cfg::BK, PE = 16 / (int)sizeof(TG);
-    constexpr int LS = 72, TH = 8, TW = 16, PW = TW + 2, NPIX = (TH + 2) * PW;
+    constexpr int LS = 72, TH = 8, TW = 16, PW = TW * STRIDE + 3 - STRIDE, NPIX = (TH * STRIDE + 3 - STRIDE) * PW;
     constexpr int NJ = CBN / 64, MI = 2, PPW = Cfg::PPW, NSLOT = Cfg::NSLOT, SLAB = Cfg::SLAB_HALVES;
     constexpr int NPP = (NPIX * 8 + 255) / 256;
     __shared__ __attribute__((aligned(16))) T Ps[NPIX * LS];
@@ -936,7 +940,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3r(ConvParams p) {
     for (int i = 0; i < NPP; ++i) {
         const int q = tid + 256 * i, pp = stage_row<SPLIT>(q), ch = q & 7;
         const int pr = pp / PW, pc = pp - pr * PW;
-        const int iy = oy0 + pr - 1, ix = ox0 + pc - 1;
+        const int iy = oy0 * STRIDE + pr - 1, ix = ox0 * STRIDE + pc - 1;
         const bool ok = pp < NPIX && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         const int pixel = p.up2 ? (n * (p.H >> 1) + (iy >> 1)) * (p.W >> 1) + (ix >> 1) : (n * p.H + iy) * p.W + ix;
         poff[i] = ok ? (unsigned)(pixel * p.Cin + ch * PE) * (unsigned)sizeof(TG) : 0xffffffffu;
@@ -946,7 +950,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3r(ConvParams p) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int pix = wm * 64 + i * 32 + r;
-        pbase[i] = ((pix >> 4) * PW + (pix & 15)) * LS + hi * 8;
+        pbase[i] = ((pix >> 4) * STRIDE * PW + (pix & 15) * STRIDE) * LS + hi * 8;
     }
     // weight fragments: row wn * (CBN / 2) + j * 32 + r of the slab, piece kk * 2 + hi (+ 4 for the low halves), swizzled
     int wrow_h[NJ], wkey[NJ];
@@ -1321,8 +1325,27 @@ int launch_conv(const ConvParams& p_in, int precision, hipStream_t st) {
         HMVIT_CHECK_ARG(xb < 0xfffffff0ull && wb < 0xfffffff0ull, "conv: input (%zu bytes) or weights (%zu bytes) exceed the 4 GB a launch can address",
                         xb, wb);
     }
-    // 3 x 3 / stride 1 / pad 1 in f16: the patch-in-LDS kernel (one fetch per input pixel and channel slab instead of nine)
     const bool split = precision == HMVIT_PREC_SPLIT;
+    // 3 x 3 / stride 2 / pad 1 with a kind-0 weight image: the ring kernel on a 17 x 33 patch
+    if ((!f32_maps || split) && p.KH == 3 && p.KW == 3 && p.stride == 2 && p.pad == 1 && !p.deconv_s && !p.rowpack && !p.up2 &&
+        p.Cin % (split ? 32 : 64) == 0 && p.Cout % 8 == 0 && p.y_coff % 8 == 0 && p.y_ctot % 8 == 0 && !p.no_patch &&
+        p.w_image && p.w_image_kind == 0 && (!split || p.w_absmax < 0.f) && !HMVIT_ENV("HMVIT_CONV_NO_RING")) {
+        const int tiles = p.N * cdiv(p.Ho, 8) * cdiv(p.Wo, 16);
+        // measured on the PointPillar layers (split): 384 -> 256 channels 591 -> 515 us; 64 -> 64, 64 -> 128 and 128 -> 256 channels no
+        // better than the generic kernel with its own weight ring (185 / 72 / 67 -> 191 / 72 / 74 us: with few channel slabs the
+        // 81 KB patch is replaced too often for what it saves) - so deep inputs only (tests: HMVIT_CONV_S2_ALL in probe builds)
+        if (tiles * cdiv(p.Cout, narrow ? 64 : 128) >= 128 && (p.Cin >= 256 || p.force_patch || HMVIT_ENV("HMVIT_CONV_S2_ALL"))) {
+            dim3 grid3(tiles * cdiv(p.Cout, narrow ? 64 : 128));
+            if (split) {
+                if (narrow) hipLaunchKernelGGL((k_conv3r<64, true, 2>), grid3, dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((k_conv3r<128, true, 2>), grid3, dim3(256), 0, st, p);
+            } else if (narrow) hipLaunchKernelGGL((k_conv3r<64, false, 2>), grid3, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((k_conv3r<128, false, 2>), grid3, dim3(256), 0, st, p);
+            HMVIT_CHECK_LAUNCH();
+            return HMVIT_OK;
+        }
+    }
+    // 3 x 3 / stride 1 / pad 1 in f16: the patch-in-LDS kernel (one fetch per input pixel and channel slab instead of nine)
     if ((!f32_maps || split) && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && !p.deconv_s && !p.rowpack &&
         p.Cin % (split ? 32 : 64) == 0 && p.Cout % 8 == 0 && p.y_coff % 8 == 0 && p.y_ctot % 8 == 0 && p.Ho == p.H && p.Wo == p.W &&
         !p.no_patch && !HMVIT_ENV("HMVIT_CONV_NO_PATCH")) {

@@ -167,6 +167,7 @@ struct ConvParams {
     int out_f32;
     const void* res;          // optional residual (N, Ho, Wo, Cout) in the precision's element type, added before the ReLU
     int no_patch;             // 1: never take the patch-in-LDS 3 x 3 kernel (A/B checks of the two kernels against each other)
+    int force_patch;          // 1: take the stride-2 ring kernel wherever it applies, also where the generic kernel is as fast (tests)
     int up2;                  // 1: the input is the nearest-neighbour x2 upsampling of x (N, H/2, W/2, Cin); H, W are the upsampled sizes
     // split mode: both operands are brought to [2^13, 2^14) by a power of two on their way into LDS and the product is scaled back.
     const unsigned* x_absmax; // device, f32 bit pattern of max |x| (an upper bound is as good): written by the producer of x

@@ -146,6 +146,8 @@ class PointPillar(nn.Module):
         for blk, de in zip(self.backbone.blocks, self.backbone.deblocks):
             layers = [conv(blk[1], blk[2])]
             layers[0]["pad"] = 1                                 # ZeroPad2d(1) + padding 0
+            l0 = layers[0]
+            l0["img"] = _lib.conv_image(l0["w"], l0["cout"], l0["cin"], l0["k"], l0["stride"], 1, prec, l0["wmax"])
             k = 4
             while k < len(blk):
                 layers.append(conv(blk[k], blk[k + 1]))

@@ -401,7 +401,7 @@ int hmvit_conv2d(const void* x, const void* w, const float* bias, void* y, int N
 int hmvit_conv_range(const void* x_absmax, float w_absmax, void* y_absmax);
 int hmvit_absmax(const float* x, size_t n, void* slot, void* stream);
 
-/* The weights of a 3 x 3 / stride 1 / pad 1 convolution as the image its LDS ring holds (HMVIT_PREC_SPLIT: of the PRE-SCALED f32
+/* The weights of a 3 x 3 / pad 1 convolution (stride 1 or 2) as the image its LDS ring holds (HMVIT_PREC_SPLIT: of the PRE-SCALED f32
  * weights, i.e. the ones passed with w_absmax < 0; HMVIT_PREC_F16: of the f16 weights).  The convolution kernels then copy weight
  * slabs global -> LDS by DMA, two taps ahead, instead of staging (and, in split mode, splitting) them through registers in every
  * workgroup: the Conv2d layers of base_bev_backbone.py:6-122, downsample_conv.py:32-51, resnet_ms.py / torchvision BasicBlock.
@@ -426,7 +426,8 @@ int hmvit_conv_weight_image(const void* image, int kind);
  *   cvt_modules.py:13,303-305);
  *   upsample2 = 1: x is (N, H/2, W/2, Cin) and stands for its nearest-neighbour x2 upsampling (N, H, W, Cin)
  *   (NaiveDecoder.upsample, naive_decoder.py:56-61), which is never materialised.  Bit 1 of `upsample2` (value 2) selects the
- *   generic implicit-GEMM kernel where the library would take the patch-in-LDS 3 x 3 kernel (for A/B checks). */
+ *   generic implicit-GEMM kernel where the library would take the patch-in-LDS 3 x 3 kernel (for A/B checks); bit 2 (value 4)
+ *   takes the stride-2 ring kernel wherever it applies (by default only for Cin >= 256, where it is the faster one). */
 int hmvit_conv2d_ex(const void* x, const void* w, const float* bias, const void* residual, void* y, int N, int H, int W, int Cin,
                     int Cout, int ksize, int stride, int pad, int relu, int upsample2, int out_f32, int precision, void* stream);
 

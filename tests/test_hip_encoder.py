@@ -415,8 +415,8 @@ def test_conv3x3_image_is_declined_where_the_ring_kernel_does_not_apply():
     assert _lib.lib.hmvit_conv3x3_image_bytes(64, 96, _lib.PREC_F16) == 0
 
 
-@pytest.mark.parametrize("N,cin,cout,k,stride,pad,H,W,deconv", [(5, 384, 256, 3, 2, 1, 64, 64, 0),     # the shrink header's strided layer
-                                                              (4, 64, 64, 3, 2, 1, 50, 38, 0),       # narrow channel tile, ragged pixels
+@pytest.mark.parametrize("N,cin,cout,k,stride,pad,H,W,deconv", [(5, 384, 256, 3, 2, 0, 64, 64, 0),     # strided, no padding
+                                                              (4, 64, 64, 3, 3, 1, 50, 38, 0),       # narrow channel tile, ragged pixels, stride 3
                                                               (3, 128, 256, 1, 1, 0, 20, 12, 0),     # 1 x 1, small map (64-pixel tiles)
                                                               (2, 256, 128, 1, 1, 0, 24, 20, 2),     # ConvTranspose2d(kernel = stride = 2)
                                                               (2, 64, 136, 3, 1, 0, 21, 19, 0)])     # ragged channel tile, pad 0
@@ -461,3 +461,45 @@ def test_conv_gemm_ring_is_bit_identical_to_the_register_staged_kernel(N, cin, c
     _lib.check(_lib.lib.hmvit_conv2d(xn.data_ptr(), wn.data_ptr(), b.data_ptr(), y.data_ptr(), N, H, W, cin, cout, 1 if deconv else k,
                                      1 if deconv else stride, 0 if deconv else pad, 1, cout, 0, deconv, 0, _lib.PREC_SPLIT, _stream()), "conv")
     assert torch.equal(y, y_regs)
+
+
+@pytest.mark.parametrize("prec_name", ["split", "f16"])
+@pytest.mark.parametrize("N,cin,cout,H,W", [(5, 384, 256, 64, 64),      # the shrink header's strided layer (scaled down)
+                                            (4, 64, 64, 50, 38),       # narrow channel tile, odd sizes: ragged output tiles
+                                            (3, 128, 136, 33, 65),     # ragged channel tile, odd input sizes
+                                            (6, 256, 256, 32, 32)])    # first layer of a deep block
+def test_conv3x3_stride2_ring_kernel(prec_name, N, cin, cout, H, W):
+    """The stride-2 form of the ring kernel (17 x 33 input patch under 8 x 16 outputs, weights from the kind-0 image) against
+    float64 and against the generic kernel on the same operands (other summation order: round-off-level agreement)."""
+    from hmvit_amd import _lib
+    prec = _lib.PREC_SPLIT if prec_name == "split" else _lib.PREC_F16
+    dt = torch.float32 if prec_name == "split" else torch.float16
+    torch.manual_seed(N * cin + cout + 11)
+    x = torch.randn(N, cin, H, W, device="cuda").to(dt)
+    w = (torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5).to(dt)
+    b = torch.randn(cout, device="cuda")
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), 2, 1))
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    wmax = 0.0
+    wk = w.float()
+    if prec_name == "split":
+        wk, wmax = _lib.prescale_weights(wk)
+    wn = wk.permute(0, 2, 3, 1).reshape(cout, -1).to(dt).contiguous()
+    img = _lib.conv_image(wn, cout, cin, 3, 2, 1, prec, wmax)
+    assert img is not None and img[1] == 0
+
+    def run(ring):
+        y = torch.empty(N, Ho, Wo, cout, device="cuda", dtype=dt)
+        if prec_name == "split":
+            _lib.conv_range(xn, wmax, y, _stream())
+        if ring:
+            _lib.use_conv_image(img)
+        # upsample2 bit 2: the stride-2 ring kernel also for the shapes where the library prefers the generic one (Cin < 256)
+        _lib.check(_lib.lib.hmvit_conv2d_ex(xn.data_ptr(), wn.data_ptr(), b.data_ptr(), None, y.data_ptr(), N, H, W, cin, cout, 3, 2, 1, 1,
+                                            4 if ring else 0, 0, prec, _stream()), "conv")
+        return y
+    y_ring, y_gen = run(True), run(False)
+    tol = 4e-6 if prec_name == "split" else 1.5e-3
+    assert rel_max_err(y_ring.permute(0, 3, 1, 2).double(), ref) < tol
+    assert rel_max_err(y_ring.double(), y_gen.double()) < tol
