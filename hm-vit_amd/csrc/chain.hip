@@ -887,6 +887,9 @@ constexpr int X16_STG_ROW = 64 + 4;                 // floats per staged token r
 constexpr int X16_STG_WAVE = 16 * X16_STG_ROW;      // floats per wave
 
 __device__ __forceinline__ void stage_chunk16(const half_t* __restrict__ chunk, half_t* lds_buf) {
+#ifdef HMVIT_EXP_X16_NODMA
+    return;
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_buf;
 #pragma unroll
@@ -1077,7 +1080,11 @@ __device__ __forceinline__ void store_proj16(float* stg, float* y, int c, const 
         for (int k = 0; k < 4; ++k) {
             const int token = 4 * k + (lane >> 4), piece = lane & 15;
             const float4 v = *reinterpret_cast<const float4*>(stg + token * X16_STG_ROW + piece * 4);
+#ifndef HMVIT_EXP_X16_NOSTORE
             if (tok_w + token < P) *reinterpret_cast<float4*>(yo + (size_t)token * C + piece * 4) = v;
+#else
+            if (v.x == 1.2345e-30f) *reinterpret_cast<float4*>(yo + (size_t)token * C + piece * 4) = v;
+#endif
         }
     }
 }
@@ -1664,7 +1671,11 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
                 } else {
                     float* op = J.out + (size_t)tok * C + 4 * g;
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) *reinterpret_cast<float4*>(op + 16 * t) = make_float4(xacc[t][0], xacc[t][1], xacc[t][2], xacc[t][3]);
+                    for (int t = 0; t < 16; ++t)
+#ifdef HMVIT_EXP_X16_NOSTORE
+                        if (xacc[t][0] == 1.2345e-30f)
+#endif
+                        *reinterpret_cast<float4*>(op + 16 * t) = make_float4(xacc[t][0], xacc[t][1], xacc[t][2], xacc[t][3]);
                 }
             }
         };
