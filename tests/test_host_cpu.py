@@ -300,3 +300,19 @@ def test_grad_pow2_is_an_exact_rescaling(pkg):
     bad = torch.tensor([1.0, float("inf")])
     s, un = _lib.grad_pow2(bad)
     assert float(un) == 1.0 and torch.equal(s, bad)
+
+
+def test_conv_weight_image_sizes_are_host_arithmetic(pkg):
+    """hmvit_conv3x3_image_bytes / hmvit_conv_gemm_image_bytes need no GPU: channel tiles of 64 (Cout <= 64) or 128 rows x 128 bytes
+    per 32-channel (split) / 64-channel (f16) slab, nine slabs per channel slab for the 3 x 3 image; 0 where no image exists."""
+    from hmvit_amd import _lib
+    L = _lib.lib
+    assert L.hmvit_conv3x3_image_bytes(256, 256, _lib.PREC_SPLIT) == 2 * 9 * 8 * 128 * 128      # = Cout * 9 Cin * 4 bytes
+    assert L.hmvit_conv3x3_image_bytes(256, 256, _lib.PREC_F16) == 2 * 9 * 4 * 128 * 128        # = Cout * 9 Cin * 2 bytes
+    assert L.hmvit_conv3x3_image_bytes(64, 64, _lib.PREC_SPLIT) == 1 * 9 * 2 * 64 * 128
+    assert L.hmvit_conv3x3_image_bytes(136, 128, _lib.PREC_SPLIT) == 2 * 9 * 4 * 128 * 128      # ragged channel tile: padded rows
+    assert L.hmvit_conv3x3_image_bytes(64, 48, _lib.PREC_SPLIT) == 0 and L.hmvit_conv3x3_image_bytes(64, 96, _lib.PREC_F16) == 0
+    assert L.hmvit_conv3x3_image_bytes(64, 64, _lib.PREC_F32) == 0 and L.hmvit_conv3x3_image_bytes(0, 64, _lib.PREC_SPLIT) == 0
+    assert L.hmvit_conv_gemm_image_bytes(512, 256) == 4 * 8 * 128 * 128                         # ConvTranspose2d(256 -> 128, stride 2)
+    assert L.hmvit_conv_gemm_image_bytes(64, 9 * 64) == 1 * 18 * 64 * 128
+    assert L.hmvit_conv_gemm_image_bytes(64, 100) == 0 and L.hmvit_conv_gemm_image_bytes(0, 64) == 0
