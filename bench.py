@@ -600,7 +600,7 @@ def main(argv=None):
             train_once()
             sync()
             t0 = time.perf_counter()
-            k = 3
+            k = 5
             for _ in range(k):
                 train_once()
             sync()
