@@ -19,6 +19,7 @@ from torch import nn
 
 from . import _lib
 from .camera import Bottleneck, ResnetEncoder, _Conv, _Prepared, _to_nchw, _to_nhwc, _PREC
+from . import cvt as _cvt
 from .cvt import _layernorm, _linear, _linear_f16, _stream, generate_grid
 from .decoder import NaiveDecoder
 
@@ -137,8 +138,9 @@ class CrossViewSwapAttention(nn.Module):
         vw = _win_tokens(vp, w1, w2, grid).contiguous()
         a = torch.empty(b * X * Y * Q, hd, device=q_tok.device, dtype=torch.float32)
         _lib.check(_lib.lib.hmvit_cross_attention(qw.data_ptr(), kw.data_ptr(), vw.data_ptr(), a.data_ptr(), b * X * Y, 1, Q, K,
-                                                  att.heads, att.dim_head, _lib.PREC_F16 if half else _lib.PREC_F32, _stream()),
-                   "cross_attention")
+                                                  att.heads, att.dim_head,
+                                                  _lib.PREC_F16 if half else (_lib.PREC_SPLIT if _cvt._SPLIT_LINEARS[0] else _lib.PREC_F32), _stream()),
+                   "cross_attention")      # split model: split-f16 products where the window sizes allow (cvt.CrossAttention does the same)
         z = _linear_f16(a, att.proj.weight, att.proj.bias, out_f32=True) if half else _linear(a, att.proj.weight, att.proj.bias)
         z = z.reshape(b, X, Y, nq, W1, W2, dim).mean(3)                  # reduce the query cameras (fax_modules.py:246)
         z = z.permute(0, 1, 3, 2, 4, 5).reshape(b, H, W, dim)            # reverse the window partition
