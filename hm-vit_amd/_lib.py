@@ -97,6 +97,8 @@ _SIGNATURES = {
     "hmvit_bn_train_stats_centered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "hmvit_bn_train_apply": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hmvit_bn_train_backward": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "hmvit_pack_small": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "hmvit_nchw_to_tokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hmvit_tokens_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hmvit_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, c_i32p, C.c_void_p, C.c_void_p, C.c_int,

@@ -842,6 +842,20 @@ int hmvit_fusion_profile(const HmvitFusionDesc* desc, void* stream, float* phase
     return HMVIT_OK;
 }
 
+int hmvit_pack_small(const void* mode, int mode_dtype, int n_mode, const void* record_len, int rl_dtype, int n_rl, const void* mask,
+                     int mask_dtype, int n_mask, const void* pairwise, int pw_dtype, int B, int L, int64_t* out, void* stream) {
+    HMVIT_CHECK_ARG(mode && record_len && mask && out && n_mode >= 0 && n_rl >= 0 && n_mask >= 0, "pack_small: bad argument");
+    for (int dt : {mode_dtype, rl_dtype, mask_dtype}) HMVIT_CHECK_ARG(dt >= 0 && dt <= 5, "pack_small: dtype code %d (0..5)", dt);
+    HMVIT_CHECK_ARG(!pairwise || ((pw_dtype == 0 || pw_dtype == 1) && B > 0 && L > 0), "pack_small: pairwise dtype %d / B=%d L=%d", pw_dtype, B, L);
+    SmallPack a;
+    a.src[0] = mode; a.src[1] = record_len; a.src[2] = mask;
+    a.dtype[0] = mode_dtype; a.dtype[1] = rl_dtype; a.dtype[2] = mask_dtype;
+    a.n[0] = n_mode; a.n[1] = n_rl; a.n[2] = n_mask;
+    a.pairwise = pairwise; a.pw_dtype = pw_dtype; a.B = B; a.L = L;
+    a.out = reinterpret_cast<long long*>(out);
+    return launch_pack_small(a, reinterpret_cast<hipStream_t>(stream));
+}
+
 int hmvit_nchw_to_tokens(const float* x, float* y, int n_agents, int C, int P, void* stream) {
     HMVIT_CHECK_ARG(x && y && n_agents > 0 && C > 0 && P > 0, "nchw_to_tokens: bad argument");
     return launch_transpose(x, y, n_agents, C, P, reinterpret_cast<hipStream_t>(stream));

@@ -181,6 +181,15 @@ struct ConvParams {
                               // rows oy*stride .. + KH - 1 and pixels ox*stride .. + 7 of it; w is (Ncols, KH * 32) with
                               // k = ky * 32 + px * 4 + ci; Ho, Wo are given, pad / KW / Cin are not used
 };
+// tok.hip: mode / record_len / mask (any of six dtypes) + the identity check of pairwise[b, l, l] -> int64 words (k_pack_small)
+struct SmallPack {
+    const void* src[3];
+    int dtype[3], n[3];
+    const void* pairwise;     // (B, L, L, 4, 4) f32 (pw_dtype 0) or f64 (1), or null: no flag word
+    int pw_dtype, B, L;
+    long long* out;           // n[0] + n[1] + n[2] (+ 1) words
+};
+int launch_pack_small(const SmallPack& a, hipStream_t st);
 int launch_conv(const ConvParams& p, int precision, hipStream_t st);
 // ring image of a 3 x 3 convolution's weights (w: (Cout, 9 Cin) in the precision's element type; split: pre-scaled f32)
 size_t conv3_image_size(int Cout, int Cin, int precision);

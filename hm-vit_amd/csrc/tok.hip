@@ -175,4 +175,49 @@ int launch_warp(const float* src, const float* ainv, float* dst, float* roi, int
     return HMVIT_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Small integer inputs of a forward (mode, record_len, mask: a few dozen values in whatever dtype the caller holds them) and the
+// "every self transform is the identity" flag -> one int64 buffer, so that the host reads them back with ONE copy after ONE launch
+// (the Python side used ~10 aten micro-launches for the same: casts, cat, arange / index / eye / eq / all).
+// dtype codes: 0 f32, 1 f64, 2 i32, 3 i64, 4 u8 / bool, 5 f16.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long small_value(const void* p, int dtype, int i) {
+    switch (dtype) {
+        case 0: return (long long)reinterpret_cast<const float*>(p)[i];
+        case 1: return (long long)reinterpret_cast<const double*>(p)[i];
+        case 2: return (long long)reinterpret_cast<const int*>(p)[i];
+        case 3: return reinterpret_cast<const long long*>(p)[i];
+        case 4: return (long long)reinterpret_cast<const unsigned char*>(p)[i];
+        default: return (long long)(float)reinterpret_cast<const half_t*>(p)[i];
+    }
+}
+__global__ __launch_bounds__(256) void k_pack_small(SmallPack a) {
+    __shared__ int not_identity;
+    if (threadIdx.x == 0) not_identity = 0;
+    __syncthreads();
+    const int n_int = a.n[0] + a.n[1] + a.n[2];
+    for (int i = threadIdx.x; i < n_int; i += 256) {
+        const int which = i < a.n[0] ? 0 : (i < a.n[0] + a.n[1] ? 1 : 2);
+        const int j = i - (which > 0 ? a.n[0] : 0) - (which > 1 ? a.n[1] : 0);
+        a.out[i] = small_value(a.src[which], a.dtype[which], j);
+    }
+    if (a.pairwise) {
+        // pairwise (B, L, L, 4, 4) in f32 or f64: entry (b, l, l) against the 4 x 4 identity, exactly (as torch's == does)
+        const int n = a.B * a.L * 16;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int e = i & 15, bl = i >> 4, b = bl / a.L, l = bl - b * a.L;
+            const size_t off = ((size_t)(b * a.L + l) * a.L + l) * 16 + e;
+            const double v = a.pw_dtype == 1 ? reinterpret_cast<const double*>(a.pairwise)[off] : (double)reinterpret_cast<const float*>(a.pairwise)[off];
+            if (v != (((e >> 2) == (e & 3)) ? 1.0 : 0.0)) atomicOr(&not_identity, 1);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) a.out[n_int] = not_identity ? 0 : 1;
+    }
+}
+int launch_pack_small(const SmallPack& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_small, dim3(1), dim3(256), 0, st, a);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
 }  // namespace hmvit

@@ -124,6 +124,9 @@ class _FusionBase(nn.Module):
         cached across calls: a data loader hands over a fresh tensor per frame and the caching allocator reuses addresses,
         so identity is not content."""
         ts = [t if torch.is_tensor(t) else torch.as_tensor(t) for t in (mode, record_len, mask)]
+        packed = _FusionBase._pack_small_on_device(ts, pairwise)
+        if packed is not None:
+            return packed
         extra = []
         if pairwise is not None:
             # "every self transform is the identity" (always so for the reference's datasets) rides on the same read-back:
@@ -139,6 +142,35 @@ class _FusionBase(nn.Module):
         n0, n1, n2 = ts[0].numel(), ts[1].numel(), ts[2].numel()
         out = ([int(v) for v in flat[:n0]], [int(v) for v in flat[n0:n0 + n1]], [int(v) for v in flat[n0 + n1:n0 + n1 + n2]])
         return out + (bool(flat[-1]),) if pairwise is not None else out
+
+    _SMALL_DTYPES = {torch.float32: 0, torch.float64: 1, torch.int32: 2, torch.int64: 3, torch.uint8: 4, torch.bool: 4, torch.float16: 5}
+
+    @staticmethod
+    def _pack_small_on_device(ts, pairwise):
+        """The read-back of _host_small as ONE launch and ONE copy (hmvit_pack_small) when mode / record_len / mask all sit on the
+        same GPU in dtypes the kernel reads (and pairwise, if the identity flag is wanted, on that GPU in f32 / f64); None
+        otherwise: the caller falls back to the aten formulation."""
+        dev = ts[0].device
+        if dev.type != "cuda" or any(t.device != dev or t.dtype not in _FusionBase._SMALL_DTYPES for t in ts):
+            return None
+        if pairwise is not None and (pairwise.device != dev or pairwise.dtype not in (torch.float32, torch.float64) or pairwise.dim() != 5):
+            return None
+        ts = [t.contiguous() for t in ts]
+        n = [t.numel() for t in ts]
+        codes = [_FusionBase._SMALL_DTYPES[t.dtype] for t in ts]
+        words = sum(n) + (1 if pairwise is not None else 0)
+        out = torch.empty(words, dtype=torch.int64, device=dev)
+        pw = pairwise.contiguous() if pairwise is not None else None
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(_lib.lib.hmvit_pack_small(ts[0].data_ptr(), codes[0], n[0], ts[1].data_ptr(), codes[1], n[1], ts[2].data_ptr(), codes[2],
+                                                 n[2], pw.data_ptr() if pw is not None else None,
+                                                 1 if (pw is not None and pw.dtype == torch.float64) else 0,
+                                                 pw.shape[0] if pw is not None else 0, pw.shape[1] if pw is not None else 0,
+                                                 out.data_ptr(), stream), "hmvit_pack_small")
+        flat = out.cpu().tolist()
+        res = ([int(v) for v in flat[:n[0]]], [int(v) for v in flat[n[0]:n[0] + n[1]]], [int(v) for v in flat[n[0] + n[1]:n[0] + n[1] + n[2]]])
+        return res + (bool(flat[-1]),) if pairwise is not None else res
 
     def _weights(self, device, prec: int):
         params = list(self.parameters()) + list(self.buffers())

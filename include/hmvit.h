@@ -307,6 +307,13 @@ int hmvit_bn_train_backward(const float* x, const float* y, const float* dy, con
 
 /* ---- single operators (used by the parity tests; same kernels as the fused forward) ---- */
 
+/* The small integer inputs of HeteroFusion.forward - mode (B, L), record_len (B), mask (B, L), in whatever dtype the caller holds
+ * them on the device (codes: 0 f32, 1 f64, 2 i32, 3 i64, 4 u8 / bool, 5 f16) - as int64 words out[0 .. n_mode + n_rl + n_mask), so
+ * that the host reads them with one copy (the launch plan needs them: hetero_fusion.py:127-131 reads them back element by element).
+ * pairwise (B, L, L, 4, 4) f32 (pw_dtype 0) / f64 (1) or NULL: one more word, 1 when every pairwise[b, l, l] equals the identity. */
+int hmvit_pack_small(const void* mode, int mode_dtype, int n_mode, const void* record_len, int rl_dtype, int n_rl, const void* mask,
+                     int mask_dtype, int n_mask, const void* pairwise, int pw_dtype, int B, int L, int64_t* out, void* stream);
+
 /* (n_agents, C, P) f32 -> (n_agents, P, C) f32 and back: the layout change between the
  * reference's NCHW maps and the token-major residual stream used internally. */
 int hmvit_nchw_to_tokens(const float* x, float* y, int n_agents, int C, int P, void* stream);

@@ -233,3 +233,39 @@ def test_linear16_matches_float64(lib, M, n_mat, bias, res, a_scale, w_scale):
         lib.check(lib.lib.hmvit_linear16(a.data_ptr(), w.data_ptr(), b.data_ptr() if bias else None, y2.data_ptr(), y2.data_ptr(),
                                          M, n_mat, ws.data_ptr(), _stream()), "linear16")
         assert torch.equal(y2, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtypes", [(torch.float64, torch.int64, torch.float32), (torch.int32, torch.int32, torch.bool),
+                                    (torch.float16, torch.int64, torch.uint8), (torch.float32, torch.float32, torch.float64)])
+@pytest.mark.parametrize("pw_dtype", [None, torch.float32, torch.float64])
+def test_small_inputs_read_back_in_one_launch(dtypes, pw_dtype):
+    """hmvit_pack_small (one launch, one copy) returns what the aten formulation of HeteroFusion._host_small returns: mode / record_len /
+    mask in every dtype a caller may hold them in, and the "all self transforms are the identity" flag - exact comparison, one
+    perturbed diagonal block turns it off."""
+    import hmvit_amd
+    from hmvit_amd.fusion import _FusionBase
+    B, L = 3, 5
+    g = torch.Generator().manual_seed(7)
+    mode = torch.randint(0, 2, (B, L), generator=g)
+    rl = torch.randint(1, L + 1, (B,), generator=g)
+    mask = torch.randint(0, 2, (B, L), generator=g)
+    host = [mode.to(dtypes[0]), rl.to(dtypes[1]), mask.to(dtypes[2])]
+    dev = [t.cuda() for t in host]
+    for perturb in (False, True):
+        pw = None
+        if pw_dtype is not None:
+            pw = torch.eye(4, dtype=pw_dtype).repeat(B, L, L, 1, 1)
+            pw[:, 0, 1, 0, 3] = 2.5                        # off-diagonal pairs may be anything
+            if perturb:
+                pw[2, 3, 3, 1, 3] += 1e-6 if pw_dtype == torch.float32 else 1e-13
+        want = _FusionBase._host_small(*host, pw)                                   # CPU tensors: the aten formulation
+        got = _FusionBase._pack_small_on_device(dev, pw.cuda() if pw is not None else None)
+        assert got is not None and got == want
+        assert _FusionBase._host_small(*dev, pw.cuda() if pw is not None else None) == want
+        if pw is not None:
+            assert want[3] == (not perturb)
+    # mixed placement / an unsupported dtype: no device path, the aten formulation takes over
+    assert _FusionBase._pack_small_on_device([dev[0], host[1], dev[2]], None) is None
+    assert _FusionBase._pack_small_on_device([dev[0].to(torch.int16), dev[1], dev[2]], None) is None
+    assert _FusionBase._host_small(dev[0].to(torch.int16), dev[1], dev[2]) == _FusionBase._host_small(*host)
