@@ -247,6 +247,14 @@ def encoder_lines(dev, precision, hmvit_amd, S):
                            "(128x128, C=256, window 8, 2 iters) -> HeteroDecoder -> psm / rm; random-init weights"}
         del net, cam
     torch.cuda.empty_cache()
+    # HBM bytes per forward from the PMC passes of the same sources (tools/probe/r04_encoder_traffic.sh), null when the sources changed
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if precision == "split" and os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("kernel_source_hash") == kernel_source_hash():
+            for k, v in tj.get("encoders_split", {}).items():
+                if k in enc:
+                    enc[k]["traffic"] = v
     return enc, e2e
 
 
