@@ -144,6 +144,24 @@ class CrossAttention(nn.Module):
         self.mlp = nn.Sequential(nn.Linear(dim, 2 * dim), nn.GELU(), nn.Linear(2 * dim, dim))
         self.postnorm = norm(dim)
 
+    def _split_core_in_range(self) -> bool:
+        """The split-product attention core takes q / k / v as (hi, lo) f16 halves at their own scale (no range normalisation in
+        that kernel): it is used only while a bound on |q|, |k|, |v| - LayerNorm output (<= sqrt(dim) max|gamma| + max|beta| per
+        element) through the projection (largest row L1 norm, + bias) - stays far inside f16's range; beyond it (weights hundreds
+        of times their usual size) the exact-f32 kernel runs, as it did before round 4.  Cached per weight version."""
+        params = [p_ for seq in (self.to_q, self.to_k, self.to_v) for p_ in seq.parameters()]
+        key = tuple((p_.data_ptr(), p_._version) for p_ in params)
+        if getattr(self, "_range_key", None) != key:
+            worst = 0.0
+            for seq in (self.to_q, self.to_k, self.to_v):
+                ln, lin = seq[0], seq[1]
+                dim = lin.weight.shape[1]
+                x_max = float(dim) ** 0.5 * float(ln.weight.detach().abs().max()) + float(ln.bias.detach().abs().max())
+                y_max = float(lin.weight.detach().abs().sum(1).max()) * x_max + (float(lin.bias.detach().abs().max()) if lin.bias is not None else 0.0)
+                worst = max(worst, y_max)
+            self._range_ok, self._range_key = bool(worst < 3.0e4), key      # f16 max 65504; non-finite weights fail the test too
+        return self._range_ok
+
     def forward(self, q, k, v, skip=None):
         b, n, Q, dim = q.shape
         K = k.shape[2]
@@ -163,7 +181,7 @@ class CrossAttention(nn.Module):
         a = torch.empty(b * Q, hd, device=q.device, dtype=torch.float32)
         _lib.check(_lib.lib.hmvit_cross_attention(qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), a.data_ptr(), b, n, Q, K,
                                                   self.heads, self.dim_head,
-                                                  _lib.PREC_F16 if half else (_lib.PREC_SPLIT if _SPLIT_LINEARS[0] else _F32), _stream()),
+                                                  _lib.PREC_F16 if half else (_lib.PREC_SPLIT if (_SPLIT_LINEARS[0] and self._split_core_in_range()) else _F32), _stream()),
                    "cross_attention")      # split model: the attention core on split-f16 products too (the library keeps the exact-f32 kernel for ragged sizes)
         res = None if skip is None else skip.reshape(-1, dim).contiguous()
         if half and dim % 64 == 0:

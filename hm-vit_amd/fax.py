@@ -139,7 +139,7 @@ class CrossViewSwapAttention(nn.Module):
         a = torch.empty(b * X * Y * Q, hd, device=q_tok.device, dtype=torch.float32)
         _lib.check(_lib.lib.hmvit_cross_attention(qw.data_ptr(), kw.data_ptr(), vw.data_ptr(), a.data_ptr(), b * X * Y, 1, Q, K,
                                                   att.heads, att.dim_head,
-                                                  _lib.PREC_F16 if half else (_lib.PREC_SPLIT if _cvt._SPLIT_LINEARS[0] else _lib.PREC_F32), _stream()),
+                                                  _lib.PREC_F16 if half else (_lib.PREC_SPLIT if (_cvt._SPLIT_LINEARS[0] and _cvt.CrossAttention._split_core_in_range(att)) else _lib.PREC_F32), _stream()),
                    "cross_attention")      # split model: split-f16 products where the window sizes allow (cvt.CrossAttention does the same)
         z = _linear_f16(a, att.proj.weight, att.proj.bias, out_f32=True) if half else _linear(a, att.proj.weight, att.proj.bias)
         z = z.reshape(b, X, Y, nq, W1, W2, dim).mean(3)                  # reduce the query cameras (fax_modules.py:246)

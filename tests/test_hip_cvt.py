@@ -108,3 +108,35 @@ def test_cross_attention_core_split_vs_float64(b, n, Q, K, heads, spread):
         outs[name] = rel_max_err(out.cpu().double(), ref)
     print(f"cross attention b={b} n={n} Q={Q} K={K}: split {outs['split']:.2e}, exact-f32 kernel {outs['f32']:.2e}")
     assert outs["split"] < 5e-6 and outs["split"] < 4 * outs["f32"] + 1e-6
+
+
+def test_split_attention_core_is_declined_when_the_projections_could_leave_f16_range():
+    """The split-product core has no range normalisation: with key weights 1000 x their usual size the module must fall back to
+    the exact-f32 kernel (and still match float64), as the f32 kernel did for such weights before."""
+    from hmvit_amd.cvt import CrossAttention, split_linears
+    torch.manual_seed(0)
+    m = CrossAttention(128, 4, 32, True).cuda().eval()
+    assert m._split_core_in_range()
+    with torch.no_grad():
+        m.to_k[1].weight.mul_(1000.0)
+        m.to_q[1].weight.mul_(1e-3)
+    assert not m._split_core_in_range()
+    q, k, v = torch.randn(1, 2, 64, 128).cuda(), torch.randn(1, 2, 128, 128).cuda(), torch.randn(1, 2 * 128, 128).cuda()
+    with torch.no_grad(), split_linears(True):
+        y = m(q, k, v)
+    assert bool(torch.isfinite(y).all())
+    md = CrossAttention(128, 4, 32, True).double()
+    md.load_state_dict({k_: v_.double().cpu() for k_, v_ in m.state_dict().items()})
+    with torch.no_grad():                      # float64 restatement of cvt_modules.py:95-173 with torch ops
+        qd, kd, vd = q.double().cpu(), k.double().cpu(), v.double().cpu()
+        qp, kp, vp = md.to_q(qd), md.to_k(kd), md.to_v(vd)
+        b, n, Q, _ = qp.shape
+        K = kp.shape[2]
+        qh = qp.reshape(b, n, Q, 4, 32).permute(0, 3, 1, 2, 4)
+        kh = kp.reshape(b, n, K, 4, 32).permute(0, 3, 1, 2, 4)
+        dot = 32 ** -0.5 * torch.einsum("bmnqd,bmnkd->bmnqk", qh, kh)
+        att = dot.permute(0, 1, 3, 2, 4).reshape(b, 4, Q, n * K).softmax(-1)
+        a = torch.einsum("bmqk,bkmd->bqmd", att, vp.reshape(b, n * K, 4, 32)).reshape(b, Q, 128)
+        z = md.prenorm(md.proj(a))
+        z = md.postnorm(z + md.mlp(z))
+    assert rel_max_err(y.cpu().double().reshape(b, Q, 128), z) < 1e-4
