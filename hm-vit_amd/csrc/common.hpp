@@ -34,6 +34,19 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #define HMVIT_ENV(name) ((const char*)nullptr)
 #endif
 
+// Timing-only ablation switches (results wrong by construction) and debug fingerprints must never reach a shipped library:
+// they compile only together with -DHMVIT_PROBE or -DHMVIT_ALLOW_EXP (tools/probe/build_var.sh adds the latter: probe stamps off).  tests/test_host_cpu.py checks the Makefile's
+// default flags carry none of them.
+#if !defined(HMVIT_PROBE) && !defined(HMVIT_ALLOW_EXP) && (                                                                                          \
+    defined(HMVIT_EXP_C3_NOBAR) || defined(HMVIT_EXP_C3_NODMA) || defined(HMVIT_EXP_C3_NOWAIT) || defined(HMVIT_EXP_DYN_ALL) || \
+    defined(HMVIT_EXP_NOAMAX) || defined(HMVIT_EXP_NOBAR) || defined(HMVIT_EXP_NOMMA) || defined(HMVIT_EXP_NOSTORE) ||       \
+    defined(HMVIT_EXP_NOWAIT) || defined(HMVIT_EXP_PCS_NOEPI) || defined(HMVIT_EXP_PCS_NOLOAD) ||                           \
+    defined(HMVIT_EXP_PCS_NOLOADER) || defined(HMVIT_EXP_PCS_NOMATH) || defined(HMVIT_EXP_PCS_NOQ) ||                       \
+    defined(HMVIT_EXP_PCS_NOSTORE) || defined(HMVIT_EXP_PCS_NOTABLES) || defined(HMVIT_EXP_STATIC_ITEMS) ||                 \
+    defined(HMVIT_EXP_X16_NODMA) || defined(HMVIT_EXP_X16_NOSTORE) || defined(HMVIT_DBG_SUMS))
+#error "HMVIT_EXP_* / HMVIT_DBG_* are timing / debug experiments: build them with -DHMVIT_ALLOW_EXP (tools/probe/build_var.sh), never into the shipped library"
+#endif
+
 // ---- thread-local error string (hmvit_last_error) ----
 void set_error(const char* fmt, ...);
 #define HMVIT_CHECK_ARG(cond, ...)            \

@@ -51,6 +51,7 @@ __device__ __forceinline__ void absmax_raise_wg(unsigned* slot, float m, unsigne
 template <typename TO>
 __global__ __launch_bounds__(256) void k_pfn_scatter(PfnParams p) {
     __shared__ float feat[4][32][12];
+    __shared__ float amax_scratch[4];      // its own words: a wavefront may still be reading feat[0] when another one reports
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int v = blockIdx.x * 4 + wave;
     // split-mode consumers want max |canvas| (hmvit_conv_range before this call): one look at the slot per workgroup; the last,
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void k_pfn_scatter(PfnParams p) {
     if (p.canvas_absmax) {
         float m = inside ? best : 0.f;
         if (full_wg) {
-            absmax_raise_wg(p.canvas_absmax, m, amax_seen, &feat[0][0][0]);    // (every wavefront is past its reads of feat)
+            absmax_raise_wg(p.canvas_absmax, m, amax_seen, amax_scratch);
         } else {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));

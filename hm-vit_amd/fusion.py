@@ -7,11 +7,12 @@ Mirror of the reference's fuse-module surface:
   ``opencood/models/bevformer_point_pillar_hetero.py:22-49`` so a reference checkpoint loads with
   ``load_state_dict`` and the model file can do ``self.fusion_net = HeteroFusion(cfg)`` unchanged.
 * ``HeteroFusionBlock(config)`` -- ``opencood/models/sub_modules/hetero_fusion.py:279-474``
-  (sequential mode).
+  (sequential and parallel modes).
 
 The parameter containers below only hold parameters under the reference's names; the arithmetic
-is one call into ``hmvit_fusion_forward`` (include/hmvit.h).  Inference only in this round: the
-output does not carry autograd history.  No CPU path: CPU tensors raise.
+is one call into ``hmvit_fusion_forward`` (include/hmvit.h) in eval mode, and
+``hmvit_amd.train.FusionTrainFunction`` (``hmvit_fusion_train_forward`` / ``hmvit_fusion_backward``)
+whenever the module trains or ``x`` requires a gradient.  No CPU path: CPU tensors raise.
 """
 from __future__ import annotations
 

@@ -113,7 +113,8 @@ class PointPillar(nn.Module):
             return self._prep
         dt = torch.float16 if prec == _lib.PREC_F16 else torch.float32
 
-        def conv(c, bn=None):
+        def conv(c, bn=None, pad=None):
+            pad = c.padding[0] if pad is None else pad          # (a block's first convolution: ZeroPad2d(1) + padding 0)
             w = c.weight.detach().float()                       # (Cout, Cin, k, k)
             b = c.bias.detach().float() if c.bias is not None else torch.zeros(w.shape[0], device=w.device)
             if bn is not None:
@@ -124,8 +125,8 @@ class PointPillar(nn.Module):
                 w, wmax = _lib.prescale_weights(w)              # exact power-of-two multiple, undone in the kernel's epilogue
             rows = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous()
             return dict(w=rows, b=b.contiguous(), cin=w.shape[1], cout=w.shape[0], k=w.shape[2], stride=c.stride[0],
-                        pad=c.padding[0], wmax=wmax,
-                        img=_lib.conv_image(rows, w.shape[0], w.shape[1], w.shape[2], c.stride[0], c.padding[0], prec, wmax))
+                        pad=pad, wmax=wmax,
+                        img=_lib.conv_image(rows, w.shape[0], w.shape[1], w.shape[2], c.stride[0], pad, prec, wmax))
 
         def deconv(c, bn):
             w = c.weight.detach().float()                       # (Cin, Cout, s, s)
@@ -144,10 +145,7 @@ class PointPillar(nn.Module):
         prep = {"pfn_w": (pfn.linear.weight.detach().float() * s[:, None]).contiguous(), "pfn_shift": sh.contiguous(),
                 "blocks": [], "deblocks": [], "shrink": []}
         for blk, de in zip(self.backbone.blocks, self.backbone.deblocks):
-            layers = [conv(blk[1], blk[2])]
-            layers[0]["pad"] = 1                                 # ZeroPad2d(1) + padding 0
-            l0 = layers[0]
-            l0["img"] = _lib.conv_image(l0["w"], l0["cout"], l0["cin"], l0["k"], l0["stride"], 1, prec, l0["wmax"])
+            layers = [conv(blk[1], blk[2], pad=1)]               # ZeroPad2d(1) + padding 0: one weight image, built for pad 1
             k = 4
             while k < len(blk):
                 layers.append(conv(blk[k], blk[k + 1]))

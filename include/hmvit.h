@@ -512,7 +512,12 @@ int hmvit_bn_relu_tokens(const float* x, const float* scale, const float* shift,
 /* CrossAttention core (cvt_modules.py:148-158): q (n_agents, n_cam, Q, heads * 32), k (n_agents, n_cam, K, heads * 32),
  * v (n_agents, n_cam * K, heads * 32) in the precision's element type -> out (n_agents, Q, heads * 32) f32; logits
  * q_cam . k_cam / sqrt(32), one softmax over the keys of all cameras.  HMVIT_PREC_F16 runs on the matrix cores and needs
- * Q and K to be multiples of 64. */
+ * Q and K to be multiples of 64.
+ * PRECONDITION of HMVIT_PREC_SPLIT (ABI >= 11): the f32 operands are taken at their own scale and split into f16 (hi, lo)
+ * halves, so |q| / sqrt(dim_head), |k| and |v| must stay below 65504 (f16's largest finite value; comfortably below for
+ * full accuracy of the low halves: 1e-3 < typical magnitude < 1e4).  The library cannot see the operands' range without a
+ * pass over them: callers that cannot bound it (hm-vit_amd/cvt.py bounds it from the LayerNorm output and the projection's
+ * largest row L1 norm) must pass HMVIT_PREC_F32, which is exact at any scale. */
 int hmvit_cross_attention(const void* q, const void* k, const void* v, float* out, int n_agents, int n_cam, int Q, int K,
                           int heads, int dim_head, int precision, void* stream);
 

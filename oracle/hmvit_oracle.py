@@ -67,7 +67,7 @@ def hetero_feed_forward(x: Tensor, mode: Tensor, sd: Dict[str, Tensor], prefix: 
         if mask_out is not None:
             h = h * mask_out[sel]
         if out is None:
-            out = torch.zeros(x.shape[:-1] + (h.shape[-1],), dtype=x.dtype)
+            out = torch.zeros(x.shape[:-1] + (h.shape[-1],), dtype=x.dtype, device=x.device)
         out[sel] = h
     return out
 
@@ -100,6 +100,7 @@ def warp_affine(src: Tensor, A: Tensor, mode: str = "bilinear") -> Tensor:
     (torch_transformation_utils.py:317-355): lift A to 3x3, conjugate with the
     pixel->[-1, 1] normalisation, invert in fp32, ``affine_grid`` + ``grid_sample``."""
     N, C, H, W = src.shape
+    A = A.cpu()                      # the sampling geometry is ALWAYS the CPU's fp32 arithmetic (see `hetero_fusion(device=)`)
     M = torch.zeros(N, 3, 3, dtype=A.dtype)
     M[:, :2] = A
     M[:, 2, 2] = 1.0
@@ -111,7 +112,7 @@ def warp_affine(src: Tensor, A: Tensor, mode: str = "bilinear") -> Tensor:
     grid = F.affine_grid(src_norm_from_dst_norm[:, :2], [N, C, H, W], align_corners=True)
     # (the sampling positions are always the reference's fp32 ones; a float64 `src` - the "truth" runs of the precision
     # stress tests - only changes the arithmetic of the blend)
-    return F.grid_sample(src, grid.to(src.dtype), mode=mode, padding_mode="zeros", align_corners=True)
+    return F.grid_sample(src, grid.to(device=src.device, dtype=src.dtype), mode=mode, padding_mode="zeros", align_corners=True)
 
 
 def warp_agents(x: Tensor, t_to_target: Tensor, discrete_ratio: float,
@@ -119,7 +120,7 @@ def warp_agents(x: Tensor, t_to_target: Tensor, discrete_ratio: float,
     """SpatialTransformation.forward (spatial_transformation.py:16-44): warp every agent map
     x[b, l] (B, L, C, H, W) with its transform t_to_target[b, l] (B, L, 4, 4)."""
     B, L, C, H, W = x.shape
-    A = pixel_affine(t_to_target, discrete_ratio, downsample_rate, H, W).reshape(-1, 2, 3)
+    A = pixel_affine(t_to_target.cpu(), discrete_ratio, downsample_rate, H, W).reshape(-1, 2, 3)
     return warp_affine(x.reshape(-1, C, H, W), A).reshape(B, L, C, H, W)
 
 
@@ -129,10 +130,10 @@ def roi_and_cav_mask(H: int, W: int, cav_mask: Tensor, t_to_target: Tensor,
     an all-ones map (which target pixels see source agent l) times agent validity.
     Returns (B, H, W, 1, L) float."""
     B, L = t_to_target.shape[:2]
-    A = pixel_affine(t_to_target, discrete_ratio, downsample_rate, H, W).reshape(-1, 2, 3)
+    A = pixel_affine(t_to_target.cpu(), discrete_ratio, downsample_rate, H, W).reshape(-1, 2, 3)
     ones = torch.ones(B * L, 1, H, W, dtype=A.dtype)
-    roi = warp_affine(ones, A, mode="nearest").reshape(B, L, 1, H, W)
-    com = roi * cav_mask.reshape(B, L, 1, 1, 1)
+    roi = warp_affine(ones, A, mode="nearest").reshape(B, L, 1, H, W)          # nearest-mode visibility: CPU, whatever the device
+    com = roi * cav_mask.cpu().reshape(B, L, 1, 1, 1)
     return com.permute(0, 3, 4, 2, 1)
 
 
@@ -162,6 +163,7 @@ def hetero_attention(xw: Tensor, mode: Tensor, mask: Tensor, sd: Dict[str, Tenso
     ->   (B, 1, X, Y, w, w, C)   ego update (before the residual)
     """
     B, L, X, Y, w1, w2, C = xw.shape
+    mode = mode.to(xw.device)
     M = C // dim_head
     n = w1 * w2
     scale = dim_head ** -0.5
@@ -197,11 +199,11 @@ def hetero_attention(xw: Tensor, mode: Tensor, mask: Tensor, sd: Dict[str, Tenso
 
     # relative position bias, identical for every source agent (:227-233)
     table = sd[f"{prefix}.relative_position_bias_table.weight"]    # ((2w-1)^2, M)
-    bias = table[relative_position_index(window)].permute(2, 0, 1)  # (M, n, n)
+    bias = table[relative_position_index(window).to(table.device)].permute(2, 0, 1)  # (M, n, n)
     sim = sim + bias[None, None, None, :, :, None, :]
 
     # key mask after the bias, -inf fill, softmax over all L*n keys (:243-251)
-    key_mask = mask.reshape(B, X, Y, n, L).permute(0, 1, 2, 4, 3)   # (B,X,Y,L,n)
+    key_mask = mask.to(sim.device).reshape(B, X, Y, n, L).permute(0, 1, 2, 4, 3)   # (B,X,Y,L,n)
     sim = sim.masked_fill(key_mask[:, :, :, None, None] == 0, -float("inf"))
     sim_flat = sim.reshape(B, X, Y, M, n, L * n)
     attn = torch.softmax(sim_flat, dim=-1).reshape(B, X, Y, M, n, L, n)
@@ -326,7 +328,7 @@ def hetero_fusion_block(x: Tensor, pairwise_t: Tensor, mode: Tensor, record_len:
 
 def hetero_fusion(x: Tensor, pairwise_t: Tensor, mode: Tensor, record_len: Tensor,
                   mask: Tensor, sd: Dict[str, Tensor], cfg: dict, drop_masks=None,
-                  dtype: torch.dtype = torch.float32) -> Tensor:
+                  dtype: torch.dtype = torch.float32, device=None) -> Tensor:
     """HeteroFusion.forward (bevformer_point_pillar_hetero.py:39-49).  Plain torch, so torch.autograd differentiates it:
     the gradient checker of the HIP backward pass.  drop_masks: None (eval) or, per iteration, [window, grid] triples of
     Dropout masks replaying a training-mode run (fusion_stage).
@@ -334,11 +336,20 @@ def hetero_fusion(x: Tensor, pairwise_t: Tensor, mode: Tensor, record_len: Tenso
     x (B, L, C, H, W) f32; pairwise_t (B, L, L, 4, 4), [b, i, j] maps agent i -> agent j;
     mode (B, L) int 1 = lidar / 0 = camera (padding 0); record_len (B,); mask (B, L) 1/0.
     Returns (B, C, H, W).  dtype=torch.float64 evaluates the same network on the same fp32 sampling geometry in double
-    precision: the yardstick that tells fp32 round-off of the reference apart from error of the implementation under test."""
-    sd = {k: v.to(dtype) if v.is_floating_point() else v for k, v in sd.items()}
-    mode = mode.to(torch.int64)
-    pairwise_t = pairwise_t.to(torch.float32)
-    x = x.to(dtype)
+    precision: the yardstick that tells fp32 round-off of the reference apart from error of the implementation under test.
+    device: where the token arithmetic (LayerNorm, Linears, einsums, softmax, the bilinear blend) runs; default = x's device
+    (the CPU in every pinned comparison).  The GPU tests pass "cuda" for the float64 yardstick at the sizes where the CPU
+    needs minutes: the sampling positions (fp32 `affine_grid`) and the nearest-mode visibility masks are ALWAYS computed on
+    the CPU and copied over, so only the double-precision arithmetic moves
+    (tests/test_hip_range.py::test_float64_yardstick_is_the_same_on_both_devices holds the two to 1e-12)."""
+    device = x.device if device is None else torch.device(device)
+    sd = {k: (v.to(dtype) if v.is_floating_point() else v).to(device) for k, v in sd.items()}
+    mode = mode.to(torch.int64).to(device)
+    pairwise_t = pairwise_t.to(torch.float32).cpu()
+    mask, record_len = mask.cpu(), record_len.cpu()
+    x = x.to(device=device, dtype=dtype)
+    if drop_masks is not None:
+        drop_masks = [[[m.to(device=device, dtype=dtype) for m in stage] for stage in it] for it in drop_masks]
     for it in range(cfg["num_iters"]):
         x = hetero_fusion_block(x, pairwise_t, mode, record_len, mask, sd,
                                 "hetero_fusion_block", cfg["hetero_fusion_block"],

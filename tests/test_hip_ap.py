@@ -11,10 +11,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+_module = []
+
+
 def _replay():
+    """tests/tools/ap_replay.py, loaded once: its cache of the CPU oracle's heads per scene is shared by the precisions below."""
+    if _module:
+        return _module[0]
     spec = importlib.util.spec_from_file_location("ap_replay", os.path.join(ROOT, "tests", "tools", "ap_replay.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
+    _module.append(m)
     return m
 
 

@@ -21,14 +21,17 @@ def _net(cfg, sd):
     return net.cuda()
 
 
-def _oracle_grads(cfg, sd, scene, gy, drop_masks=None, dtype=torch.float32):
-    """Output, d/dx and d/dparam of <oracle(x), gy> by torch.autograd on the CPU (dtype=torch.float64: the yardstick run)."""
+def _oracle_grads(cfg, sd, scene, gy, drop_masks=None, dtype=torch.float32, device=None):
+    """Output, d/dx and d/dparam of <oracle(x), gy> by torch.autograd through the oracle (dtype=torch.float64: the yardstick
+    run).  device="cuda": the oracle's token arithmetic runs through torch on the GPU (its sampling geometry and visibility
+    masks stay on the CPU, oracle/hmvit_oracle.py `hetero_fusion(device=)`) - used for the float64 yardstick at sizes where
+    the CPU takes minutes; the leaves, and therefore the returned gradients, live on the CPU either way."""
     x, pw, mode, rl, mask = scene
     sd = {k: (v.to(dtype).clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
     x = x.to(dtype).clone().requires_grad_(True)
-    y = O.hetero_fusion(x, pw, mode, rl, mask, sd, cfg, drop_masks=drop_masks, dtype=dtype)
-    (y * gy.to(dtype)).sum().backward()
-    return y.detach(), x.grad, {k: v.grad for k, v in sd.items() if v.is_floating_point()}
+    y = O.hetero_fusion(x, pw, mode, rl, mask, sd, cfg, drop_masks=drop_masks, dtype=dtype, device=device)
+    (y * gy.to(device=y.device, dtype=dtype)).sum().backward()
+    return y.detach().cpu(), x.grad, {k: v.grad for k, v in sd.items() if v.is_floating_point()}
 
 
 def _check_grads(net, ref_grads, x_grad, ref_x_grad, used_only=True, tol=None):
@@ -207,7 +210,8 @@ def test_ddp_wraps_the_module_over_rccl():
 def test_backward_matches_oracle_autograd_five_agents_64x176():
     """BASELINE configs[4]'s fusion at a size where every scheduling path of the training kernels is live:
     5 agents 10110 (camera and LiDAR types, camera-type collaborators), C = 256, window 8, 64 x 176 px = 176 windows per agent,
-    against torch.autograd through the oracle on the CPU (about a minute, ~15 GB)."""
+    against torch.autograd through the oracle in float64 (token arithmetic on the GPU through torch, geometry on the CPU: on the
+    CPU alone this took 130 s of the suite's budget)."""
     C, w, L, H, W = 256, 8, 5, 64, 176
     cfg = O.make_config(C, w, L, voxel=0.4, downsample=2)
     sd = O.random_state_dict(cfg, seed=45)
@@ -215,8 +219,8 @@ def test_backward_matches_oracle_autograd_five_agents_64x176():
     gy = torch.randn(1, C, H, W, generator=torch.Generator().manual_seed(47))
     # The yardstick is the oracle's autograd in FLOAT64; the same in float32 tells how far fp32 arithmetic itself is from it at
     # this size (sums over 56 k tokens): a parameter gradient is held to max(1e-3, 3 x that distance).
-    y_ref, gx_ref, gp_ref = _oracle_grads(cfg, sd, scene, gy, dtype=torch.float64)
-    _, gx32, gp32 = _oracle_grads(cfg, sd, scene, gy)
+    y_ref, gx_ref, gp_ref = _oracle_grads(cfg, sd, scene, gy, dtype=torch.float64, device="cuda")
+    _, gx32, gp32 = _oracle_grads(cfg, sd, scene, gy, device="cuda")
     gmax = max(float(g.abs().max()) for g in gp_ref.values() if g is not None)
     noise = {k: float((gp32[k].double() - g).abs().max()) / max(float(g.abs().max()), 1e-4 * gmax)
              for k, g in gp_ref.items() if g is not None and float(g.abs().max()) > 0}
@@ -402,8 +406,8 @@ def test_backward_under_input_and_weight_scaling(case, xscale, wscale, C, w):
     scene = list(O.synthetic_scene(L, C, H, W, [0, 1, 0], n_valid=3, seed=6, tx_step=3.0, ty_step=-2.0))
     scene[0] = scene[0] * xscale
     gy = torch.randn(1, C, H, W, generator=torch.Generator().manual_seed(7))
-    y_ref, gx_ref, gp_ref = _oracle_grads(cfg, sd, scene, gy, dtype=torch.float64)
-    y32, gx32, gp32 = _oracle_grads(cfg, sd, scene, gy)
+    y_ref, gx_ref, gp_ref = _oracle_grads(cfg, sd, scene, gy, dtype=torch.float64, device="cuda")
+    y32, gx32, gp32 = _oracle_grads(cfg, sd, scene, gy)        # the reference arithmetic's own noise: fp32 on the CPU
     gmax = max(float(g.abs().max()) for g in gp_ref.values() if g is not None)
     noise = {k: float((gp32[k].double() - g).abs().max()) / max(float(g.abs().max()), 1e-4 * gmax)
              for k, g in gp_ref.items() if g is not None and float(g.abs().max()) > 0}

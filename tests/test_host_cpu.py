@@ -316,3 +316,25 @@ def test_conv_weight_image_sizes_are_host_arithmetic(pkg):
     assert L.hmvit_conv_gemm_image_bytes(512, 256) == 4 * 8 * 128 * 128                         # ConvTranspose2d(256 -> 128, stride 2)
     assert L.hmvit_conv_gemm_image_bytes(64, 9 * 64) == 1 * 18 * 64 * 128
     assert L.hmvit_conv_gemm_image_bytes(64, 100) == 0 and L.hmvit_conv_gemm_image_bytes(0, 64) == 0
+
+
+def test_shipped_build_carries_no_experiment_switches():
+    """the timing-only `HMVIT_EXP_*` / `HMVIT_DBG_*` switches produce wrong results by construction.  The
+    Makefile's default flags name none of them, `common.hpp` refuses them outside probe builds, and no object file is tracked."""
+    import re
+    import subprocess
+    csrc = os.path.join(ROOT, "hm-vit_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    assert "HMVIT_EXP" not in mk and "HMVIT_DBG" not in mk and "HMVIT_ALLOW_EXP" not in mk
+    hpp = open(os.path.join(csrc, "common.hpp")).read()
+    assert "#error" in hpp and "HMVIT_ALLOW_EXP" in hpp
+    # every experiment macro the sources test is named by the guard
+    used = set()
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".hpp")):
+            used |= set(re.findall(r"HMVIT_(?:EXP|DBG)_[A-Z0-9_]+", open(os.path.join(csrc, f)).read()))
+    guard = hpp[hpp.index("!defined(HMVIT_ALLOW_EXP)"):hpp.index("#error")]
+    assert used and all(m in guard for m in used), sorted(m for m in used if m not in guard)
+    if os.path.isdir(os.path.join(ROOT, ".git")):
+        tracked = subprocess.run(["git", "-C", ROOT, "ls-files"], capture_output=True, text=True).stdout.split("\n")
+        assert not [t for t in tracked if re.search(r"\.(o|so|a|hsaco)($|\.)", t)]

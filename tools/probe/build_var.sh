@@ -14,6 +14,6 @@ if [ $# -gt 0 ]; then
   for f in "$@"; do touch $D/hm-vit_amd/csrc/$f; done
   touch $D/hm-vit_amd/csrc/*.o; for f in "$@"; do rm -f $D/hm-vit_amd/csrc/${f%.hip}.o; done
 fi
-make -C $D/hm-vit_amd/csrc -j4 CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-variable -Wno-unused-but-set-variable $FLAGS" > /dev/null
+make -C $D/hm-vit_amd/csrc -j4 CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-variable -Wno-unused-but-set-variable -DHMVIT_ALLOW_EXP $FLAGS" > /dev/null
 cp $D/hm-vit_amd/libhmvit.so tools/probe/lib_$NAME.so
 echo "tools/probe/lib_$NAME.so <- current sources + $FLAGS"
