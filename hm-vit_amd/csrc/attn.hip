@@ -1392,12 +1392,7 @@ __device__ __forceinline__ void pcs_taps(const AttnParams& p, PcSharedS& sm, con
 // 4 f32 values -> hi / lo halves, stored to two LDS rows
 __device__ __forceinline__ void store_split4(half_t* dh, half_t* dl, const float (&v)[4]) {
     half4 h, l;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const half_t hh = (half_t)v[e];
-        h[e] = hh;
-        l[e] = (half_t)(v[e] - (float)hh);
-    }
+    split_pk4(v[0], v[1], v[2], v[3], h, l);          // 6 instructions for the four values (common.hpp)
     *reinterpret_cast<half4*>(dh) = h;
     *reinterpret_cast<half4*>(dl) = l;
 }
@@ -2096,24 +2091,27 @@ __device__ __forceinline__ void pcs2_loader_loop(const AttnParams& p, PcShared2&
 #endif
         }
     };
+    // four taps x four channels as packed f32 multiply-adds (v_pk_fma_f32: two channels per instruction, the tap weight
+    // broadcast by op_sel) - written on 2-vectors: the packed-split asm below hides the pairs from hipcc's own vectoriser
     auto blend4 = [&](const uint4v (&t)[4], const float4 w, const float4 b, bool ident, float (&o)[4]) {
-        const float bb[4] = {b.x, b.y, b.z, b.w};
+        const float4v t0 = __builtin_bit_cast(float4v, t[0]), t1 = __builtin_bit_cast(float4v, t[1]);
+        const float4v t2 = __builtin_bit_cast(float4v, t[2]), t3 = __builtin_bit_cast(float4v, t[3]);
+        const float2v b01 = {b.x, b.y}, b23 = {b.z, b.w};
+        float2v a01, a23;
         if (ident) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned t0 = t[0][e];
-                o[e] = __builtin_bit_cast(float, t0) + bb[e];
-            }
-            return;
+            a01 = t0.xy + b01;
+            a23 = t0.zw + b23;
+        } else {
+            a01 = __builtin_elementwise_fma((float2v)(w.x), t0.xy, b01);
+            a23 = __builtin_elementwise_fma((float2v)(w.x), t0.zw, b23);
+            a01 = __builtin_elementwise_fma((float2v)(w.y), t1.xy, a01);
+            a23 = __builtin_elementwise_fma((float2v)(w.y), t1.zw, a23);
+            a01 = __builtin_elementwise_fma((float2v)(w.z), t2.xy, a01);
+            a23 = __builtin_elementwise_fma((float2v)(w.z), t2.zw, a23);
+            a01 = __builtin_elementwise_fma((float2v)(w.w), t3.xy, a01);
+            a23 = __builtin_elementwise_fma((float2v)(w.w), t3.zw, a23);
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const unsigned t0 = t[0][e], t1 = t[1][e], t2 = t[2][e], t3 = t[3][e];
-            float acc = fmaf(w.x, __builtin_bit_cast(float, t0), bb[e]);
-            acc = fmaf(w.y, __builtin_bit_cast(float, t1), acc);
-            acc = fmaf(w.z, __builtin_bit_cast(float, t2), acc);
-            o[e] = fmaf(w.w, __builtin_bit_cast(float, t3), acc);
-        }
+        o[0] = a01.x; o[1] = a01.y; o[2] = a23.x; o[3] = a23.y;
     };
 
     PcCursor cur = pcs2_cursor();
@@ -2310,13 +2308,12 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const float4 q4 = *reinterpret_cast<const float4*>(&sm.qstage[hl][((2 * qt + hf) * 64 + lane) * 4]);
-                    const float qq[4] = {q4.x, q4.y, q4.z, q4.w};
+                    half4 h4, l4;
+                    split_pk4(q4.x + bb[4 * hf], q4.y + bb[4 * hf + 1], q4.z + bb[4 * hf + 2], q4.w + bb[4 * hf + 3], h4, l4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float v = qq[e] + bb[4 * hf + e];
-                        const half_t hh = (half_t)v;
-                        qhh[qt][4 * hf + e] = hh;
-                        qhl[qt][4 * hf + e] = (half_t)(v - (float)hh);
+                        qhh[qt][4 * hf + e] = h4[e];
+                        qhl[qt][4 * hf + e] = l4[e];
                     }
                 }
                 m_run[qt] = -INFINITY;
@@ -2407,15 +2404,14 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
                         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
                         const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_safe);
                         half8 ph, pl;
+                        {
+                            float e8[8];
 #pragma unroll
-                        for (int kt = 0; kt < 2; ++kt)
+                            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], LOG2E, -m_safe));
-                                const half_t eh = (half_t)e;
-                                ph[4 * kt + r] = eh;
-                                pl[4 * kt + r] = (half_t)(e - (float)eh);
-                            }
+                                for (int r = 0; r < 4; ++r) e8[4 * kt + r] = __builtin_amdgcn_exp2f(fmaf(s[kt][r], LOG2E, -m_safe));
+                            split_pk8(e8, ph, pl);
+                        }
                         m_run[qt] = m_new;
                         o_acc[qt][0] *= alpha;
                         o_acc[qt][1] *= alpha;

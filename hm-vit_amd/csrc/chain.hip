@@ -993,9 +993,12 @@ __device__ __forceinline__ void mma_slice16(float4v (&xacc)[16], const half_t* b
 // f32 rows in accumulator layout -> operand halves: slot j of k-step s <- x[2 s + (j >> 2)][j & 3]
 __device__ __forceinline__ void rows_to_operands16(const float4v (&x)[16], half8 (&ah)[8], half8 (&al)[8], float sc) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
+    for (int s = 0; s < 8; ++s) {
+        float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) split_h(x[2 * s + (j >> 2)][j & 3] * sc, ah[s][j], al[s][j]);
+        for (int j = 0; j < 8; ++j) v[j] = x[2 * s + (j >> 2)][j & 3] * sc;
+        split_pk8(v, ah[s], al[s]);
+    }
 }
 // max |x| over the token's 256 channels (the 4 lanes of the token each hold 64)
 __device__ __forceinline__ float row_absmax16(const float4v (&x)[16]) {
@@ -1026,16 +1029,18 @@ __device__ __forceinline__ void ln_to_operands16(const float4v (&x)[16], const f
     const float shift = -mean * rstd;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
+        float v[8];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int t = 2 * s + jj, c = 16 * t + 4 * g;
             const float4 ga = *reinterpret_cast<const float4*>(lg + c);
             const float4 be = *reinterpret_cast<const float4*>(lb + c);
-            split_h(fmaf(x[t][0], rstd, shift) * ga.x + be.x, ah[s][4 * jj + 0], al[s][4 * jj + 0]);
-            split_h(fmaf(x[t][1], rstd, shift) * ga.y + be.y, ah[s][4 * jj + 1], al[s][4 * jj + 1]);
-            split_h(fmaf(x[t][2], rstd, shift) * ga.z + be.z, ah[s][4 * jj + 2], al[s][4 * jj + 2]);
-            split_h(fmaf(x[t][3], rstd, shift) * ga.w + be.w, ah[s][4 * jj + 3], al[s][4 * jj + 3]);
+            v[4 * jj + 0] = fmaf(x[t][0], rstd, shift) * ga.x + be.x;
+            v[4 * jj + 1] = fmaf(x[t][1], rstd, shift) * ga.y + be.y;
+            v[4 * jj + 2] = fmaf(x[t][2], rstd, shift) * ga.z + be.z;
+            v[4 * jj + 3] = fmaf(x[t][3], rstd, shift) * ga.w + be.w;
         }
+        split_pk8(v, ah[s], al[s]);
     }
 }
 
@@ -1644,8 +1649,12 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
                 mma_proj16(hacc, slot(cc), ah, al, lane);
                 products_end(false);
                 half8 hh, hl;                                    // hidden channel 32 hc + 16 (j >> 2) + 4 g + (j & 3) = hacc[j >> 2][j & 3]
+                {
+                    float gv[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) split_h(gelu_f(hacc[j >> 2][j & 3] * c_1) * s_g, hh[j], hl[j]);
+                    for (int j = 0; j < 8; ++j) gv[j] = gelu_f(hacc[j >> 2][j & 3] * c_1) * s_g;
+                    split_pk8(gv, hh, hl);
+                }
                 step_end(false);
                 step_begin();
                 mma_slice16(xacc, slot(cc), hh, hl, lane);

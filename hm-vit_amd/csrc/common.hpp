@@ -13,6 +13,7 @@ typedef _Float16 half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -24,6 +25,32 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
         (H) = _h;                            \
         (L) = (half_t)(_x - (float)_h);      \
     } while (0)
+
+// The same split for a PAIR of values, in three instructions instead of ten: one packed conversion for the two hi halves, then
+// v_fma_mixlo / v_fma_mixhi_f16 form x * 1.0 - hi (an exact f32 fma: hi is x rounded to 11 bits) and round it to f16 straight into
+// the low / high half of the destination.  Bit-identical to split_h (tools/probe/split2_probe.hip: 16.7 M random bit patterns,
+// denormals, overflow to inf / -inf included; NaN payloads aside).  hi, lo: packed f16 pairs (element 0 in the low half).
+__device__ __forceinline__ void split_pk2(float a, float b, unsigned& hi, unsigned& lo) {
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(a), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(b), "v"(hi));
+}
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+typedef unsigned uint4v_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_pk4(float a, float b, float c, float d, half4& h, half4& l) {
+    unsigned h0, l0, h1, l1;
+    split_pk2(a, b, h0, l0);
+    split_pk2(c, d, h1, l1);
+    h = __builtin_bit_cast(half4, uint2v{h0, h1});
+    l = __builtin_bit_cast(half4, uint2v{l0, l1});
+}
+__device__ __forceinline__ void split_pk8(const float (&v)[8], half8& h, half8& l) {
+    unsigned hh[4], ll[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_pk2(v[2 * i], v[2 * i + 1], hh[i], ll[i]);
+    h = __builtin_bit_cast(half8, uint4v_{hh[0], hh[1], hh[2], hh[3]});
+    l = __builtin_bit_cast(half8, uint4v_{ll[0], ll[1], ll[2], ll[3]});
+}
 
 // Tuning / ablation switches read from the environment exist only in probe builds (`make PROBE=1` -> -DHMVIT_PROBE, used by
 // tools/probe and tests/tools): the shipped library never calls getenv and never takes a pointer out of the environment.
