@@ -597,8 +597,15 @@ __device__ __forceinline__ int pc_src(int c, int ego) { return c == 0 ? ego : (c
         if (p.trace && blockIdx.x == 0 && (cond) && (iter) < 64)                                \
             p.trace[(iter) * 8 + (slot)] = __builtin_readcyclecounter();                        \
     } while (0)
+// k_attention_pcs2: workgroup 0, compute wave 0 (region 0) and loader wave 0 (region 1), 16 slots per step (tests/tools/pcs2_trace.py)
+#define PC2_TRACE(region, cond, iter, slot)                                                              \
+    do {                                                                                                 \
+        if (p.trace && blockIdx.x == 0 && (cond) && (iter) < 64)                                         \
+            p.trace[4096 + (region) * 1024 + (iter) * 16 + (slot)] = __builtin_readcyclecounter();       \
+    } while (0)
 #else
 #define PC_TRACE(cond, iter, slot) do {} while (0)
+#define PC2_TRACE(region, cond, iter, slot) do {} while (0)
 #endif
 
 // 16 bytes of a projected map through a STRUCTURED buffer descriptor (record = the C channels of
@@ -1271,47 +1278,13 @@ static int launch_attn_pc(const AttnParams& p, hipStream_t st, int wg_per_cu) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Split-precision persistent kernel (HMVIT_PREC_SPLIT): k_attention_pcs.
-//
-// Same producer / consumer structure, schedule and tap tables as k_attention_pc<4, 1, 1>, for f32 planes and fp32-class
-// products on the f16 matrix pipe: every MFMA operand is a (hi, lo) pair of f16 halves (x = hi + lo, |lo| <= 2^-11 |hi|) and
-// every product is three MFMAs (lo x hi, hi x lo, hi x hi; f32 accumulate).  What changes against the f16 kernel:
-//   * Q / K' / V' are f32 in memory: a loader lane owns 4 channels (one 16-byte tap load), a key row takes 32 lanes;
-//   * the bilinear blend is f32 FMAs on the loaded words, the sum is split into hi / lo and stored to two LDS tiles;
-//   * a gather is a HALF chunk of 32 keys (same 32 tap loads per lane in flight, same LDS bytes per buffer), the
-//     compute wave's online softmax advances by 32 keys; the query tile (64 rows) is fetched with the first half chunk;
-//   * the visibility word carries a bit per half chunk (k_tile_vis), walked by both roles alike;
-//   * logits are in natural units (the folded weights are shared with the exact-f32 kernel): exp(x) = exp2(x log2 e);
-//   * O is stored as f32.
+// Split-precision persistent kernel (HMVIT_PREC_SPLIT).  The round-2/3 form (k_attention_pcs: Q through the loader and LDS, tap
+// tables per step) was superseded by k_attention_pcs2 below and is no longer in the source (git history: round 4).  f32 planes,
+// fp32-class products on the f16 matrix pipe: every MFMA operand is a (hi, lo) pair of f16 halves (x = hi + lo, |lo| <= 2^-11 |hi|)
+// and every product is three MFMAs (lo x hi, hi x lo, hi x hi; f32 accumulate); a gather is a HALF chunk of 32 keys, the visibility
+// word carries a bit per half chunk (k_tile_vis); logits in natural units (exp(x) = exp2(x log2 e)); O is stored as f32.
 // Requires identity self transforms (pairwise_t[b, i, i] = I, HmvitFusionDesc::self_identity).
 // ------------------------------------------------------------------------------------------
-struct PcSharedS {
-    static constexpr int HG = 4, CH = 128, KEYS = 32;
-    static constexpr int QS = CH + 8, KS = CH + 8, VS = CH + 16;   // halves per LDS row
-    static constexpr int TPK = CH / 4;             // loader lanes per key row (4 f32 channels each)
-    static constexpr int KPW = 64 / TPK;           // keys per loader wave and pass (2)
-    static constexpr int LWG = 4, CWG = 4;
-    static constexpr int KPP = LWG * KPW;          // keys per pass (8)
-    static constexpr int NP = KEYS / KPP;          // passes per half chunk (4)
-    static constexpr int NK = NP * KPW;            // keys owned by one loader wave (8)
-    static constexpr int TGH = 4;                  // half chunks whose taps sit in the tables (= 2 sources)
-    static constexpr int MAX_PAIRS = 128;
-    half_t Qh[2][64 * QS], Ql[2][64 * QS];
-    half_t Kh[2][KEYS * KS], Kl[2][KEYS * KS];
-    half_t Vh[2][KEYS * VS], Vl[2][KEYS * VS];
-    float maskadd[2][KEYS];
-    int vis[2][LWG];
-    float ainv[MAX_PAIRS * 8];
-    float bkv[HMVIT_NUM_TYPES * HMVIT_NUM_TYPES][2][CH];
-    float bq[HMVIT_NUM_TYPES][CH];
-    int mode[kMaxSlots], cav[kMaxSlots], ego_e[kMaxSlots];
-    // two sets of tap tables (group parity): a gather is blended - weights and visibility re-read from here - while the
-    // first gather of the NEXT group is already being issued from freshly written tables
-    int tidx[LWG][2 * TGH][NK][4];
-    float tw[LWG][2 * TGH][NK][4];
-    int tvis[LWG][2 * TGH][NK];
-};
-
 __device__ __forceinline__ uint4v tok_load4f(int4v rs, int token, int off_bytes, int soff) {
     return llvm_struct_buffer_load_b128(rs, token, off_bytes, soff, 0);
 }
@@ -1321,73 +1294,6 @@ __device__ __forceinline__ unsigned tok_load1(int4v rs, int token, int off_bytes
     return llvm_struct_buffer_load_b32(rs, token, off_bytes, soff, 0);
 }
 
-struct PcGatherS {
-    PcItem it;
-    int4v rs_kv, rs_q;
-    int half, slot, kvbuf, qbuf, te, tsel;
-    bool valid, self_vis;
-};
-
-__device__ __forceinline__ PcGatherS pcs_describe(const AttnParams& p, const PcSharedS& sm, const PcItem& it, int chunk, int half,
-                                                  int slot, int g, int qi, bool valid) {
-    const int L = p.L, P = p.H * p.W, C = p.C;
-    PcGatherS G;
-    G.it = it; G.half = half; G.slot = slot; G.kvbuf = g & 1; G.qbuf = qi; G.valid = valid;
-    const int src = pc_src(chunk, it.ego);
-    const int te = __builtin_amdgcn_readfirstlane(sm.mode[it.b * L + it.ego]);
-    const int ts = __builtin_amdgcn_readfirstlane(sm.mode[it.b * L + src]);
-    const int ev = __builtin_amdgcn_readfirstlane(sm.ego_e[it.b * L + it.ego]);
-    G.te = te; G.tsel = te * HMVIT_NUM_TYPES + ts;
-    const float* kpl = reinterpret_cast<const float*>(p.kv) + ((size_t)((it.b * L + src) * p.E + ev) * 2) * P * C + it.hg * PcSharedS::CH;
-    const float* qpl = reinterpret_cast<const float*>(p.q) + (size_t)(it.b * L + it.ego) * P * C + it.hg * PcSharedS::CH;
-    G.rs_kv = token_rsrc(kpl, C * 4, P);
-    G.rs_q = token_rsrc(qpl, C * 4, P);
-    G.self_vis = __builtin_amdgcn_readfirstlane(sm.cav[it.b * L + it.ego]) != 0;
-    return G;
-}
-
-// taps of this loader wave's keys for the TGH half chunks starting at half chunk hc0 of the item's general chunks
-// (half chunk h = 2 (chunk - 1) + half)
-__device__ __forceinline__ void pcs_taps(const AttnParams& p, PcSharedS& sm, const PcItem& it, int hc0, int lw, int lane) {
-    using SM = PcSharedS;
-    constexpr int KPW = SM::KPW, NK = SM::NK, KPP = SM::KPP, TGH = SM::TGH;
-    const int H = p.H, W = p.W, L = p.L, X = H / 8, Y = W / 8;
-    const int e = lane, cc = e / NK, j = e % NK;
-    const int hc = hc0 + cc, chunk = 1 + (hc >> 1), half = hc & 1;
-    const int c = ((hc0 / TGH) & 1) * TGH + cc;            // table slot: group parity, position in the group
-    if (e < TGH * NK && chunk < p.n_src) {
-        const int src = pc_src(chunk, it.ego);
-        const float* a = sm.ainv + ((it.b * L + src) * L + it.ego) * 8;
-        const int n = half * 32 + (j / KPW) * KPP + KPW * lw + (j % KPW);
-        int row, col;
-        token_pixel(p.partition, 8, X, Y, it.wx, it.wy, n, row, col);
-        const bool cav = sm.cav[it.b * L + src] != 0;
-        int ix[4];
-        float w[4];
-        bool vis;
-        if (a[6] != 0.f) {   // identity map: the key's own pixel
-            ix[0] = row * W + col; ix[1] = ix[2] = ix[3] = -1;
-            w[0] = 1.f; w[1] = w[2] = w[3] = 0.f;
-            vis = cav;
-        } else {
-            const Taps t = make_taps(a, col, row, H, W);
-            vis = cav && t.roi != 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                ix[k] = (t.w[k] != 0.f) ? t.idx[k] : -1;
-                w[k] = t.w[k];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (!vis) ix[k] = -1;
-        *reinterpret_cast<int4*>(sm.tidx[lw][c][j]) = make_int4(ix[0], ix[1], ix[2], ix[3]);
-        *reinterpret_cast<float4*>(sm.tw[lw][c][j]) = make_float4(w[0], w[1], w[2], w[3]);
-        sm.tvis[lw][c][j] = vis ? 1 : 0;
-    }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read ordering
-}
 
 // 4 f32 values -> hi / lo halves, stored to two LDS rows
 __device__ __forceinline__ void store_split4(half_t* dh, half_t* dl, const float (&v)[4]) {
@@ -1397,414 +1303,6 @@ __device__ __forceinline__ void store_split4(half_t* dh, half_t* dl, const float
     *reinterpret_cast<half4*>(dl) = l;
 }
 
-__device__ __forceinline__ void pcs_loader_loop(const AttnParams& p, PcSharedS& sm, int lw, int ltid) {
-    using SM = PcSharedS;
-    constexpr int QS = SM::QS, KS = SM::KS, VS = SM::VS, TPK = SM::TPK, KPW = SM::KPW, NP = SM::NP, KPP = SM::KPP, TGH = SM::TGH;
-    const int X = p.H / 8, Y = p.W / 8, NG = p.C / SM::CH;
-    const int n_src = p.n_src;
-    const int plane_bytes = p.H * p.W * p.C * 4;
-    const int lane = ltid & 63;
-    const int cl = (ltid % TPK) * 4, cl_bytes = cl * 4;
-    const int kin = ltid / TPK;                  // key row of this lane inside a KPP-key pass
-    const int kj = kin % KPW;
-    const bool ego_fastest = (p.variant & 0x200) == 0;
-
-    // the only state carried from the issue of a gather to its blend: the 32 tap loads per lane.  Tap weights, visibility
-    // and biases are re-read from LDS when the taps are blended (the register file is the scarce resource of this role)
-    uint4v R[NP][2][4];
-    bool any = false, allv = true;
-
-    auto issueG = [&](int pass, const PcGatherS& G) {
-#ifdef HMVIT_EXP_PCS_NOLOADER
-        return;
-#endif
-        const int j = pass * KPW + kj;
-        const int4 ix = *reinterpret_cast<const int4*>(sm.tidx[lw][G.slot][j]);
-        const int ixa[4] = {ix.x, ix.y, ix.z, ix.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-#ifdef HMVIT_EXP_PCS_NOLOAD
-            R[pass][0][k] = tok_load4f(G.rs_kv, -1 - (ixa[k] & 1), cl_bytes, 0);
-            R[pass][1][k] = tok_load4f(G.rs_kv, -1 - (ixa[k] & 1), cl_bytes, plane_bytes);
-#else
-            R[pass][0][k] = tok_load4f(G.rs_kv, G.valid ? ixa[k] : -1, cl_bytes, 0);
-            R[pass][1][k] = tok_load4f(G.rs_kv, G.valid ? ixa[k] : -1, cl_bytes, plane_bytes);
-#endif
-        }
-    };
-    // identity half chunk: the ego's own rows; the first half also brings the whole 64-row query tile
-    auto issueI = [&](int pass, const PcGatherS& G) {
-#ifdef HMVIT_EXP_PCS_NOLOADER
-        return;
-#endif
-        int row, col;
-        token_pixel(p.partition, 8, X, Y, G.it.wx, G.it.wy, G.half * 32 + pass * KPP + kin, row, col);
-        const int tok = row * p.W + col;
-        const int tk = (G.valid && G.self_vis) ? tok : -1;
-        R[pass][0][0] = tok_load4f(G.rs_kv, tk, cl_bytes, 0);
-        R[pass][1][0] = tok_load4f(G.rs_kv, tk, cl_bytes, plane_bytes);
-        if (G.half == 0) {
-            token_pixel(p.partition, 8, X, Y, G.it.wx, G.it.wy, 32 + pass * KPP + kin, row, col);
-            R[pass][0][1] = tok_load4f(G.rs_q, G.valid ? tok : -1, cl_bytes, 0);
-            R[pass][0][2] = tok_load4f(G.rs_q, G.valid ? row * p.W + col : -1, cl_bytes, 0);
-        }
-    };
-    auto load_bias = [&](const PcGatherS& G) {};
-    auto blend4 = [&](const uint4v (&t)[4], const float4 w, const float4 b, float (&o)[4]) {
-        const float bb[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const unsigned t0 = t[0][e], t1 = t[1][e], t2 = t[2][e], t3 = t[3][e];
-            float acc = fmaf(w.x, __builtin_bit_cast(float, t0), bb[e]);
-            acc = fmaf(w.y, __builtin_bit_cast(float, t1), acc);
-            acc = fmaf(w.z, __builtin_bit_cast(float, t2), acc);
-            o[e] = fmaf(w.w, __builtin_bit_cast(float, t3), acc);
-        }
-    };
-    auto add4 = [&](const uint4v t, const float4 b, float (&o)[4]) {
-        const unsigned t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
-        o[0] = __builtin_bit_cast(float, t0) + b.x; o[1] = __builtin_bit_cast(float, t1) + b.y;
-        o[2] = __builtin_bit_cast(float, t2) + b.z; o[3] = __builtin_bit_cast(float, t3) + b.w;
-    };
-    auto blendG = [&](int pass, const PcGatherS& G) {
-        const int kk = pass * KPP + kin;
-        const int j = pass * KPW + kj;
-#ifdef HMVIT_EXP_PCS_NOLOADER
-        { const bool v_ = sm.tvis[lw][G.slot][j] != 0; any |= v_; allv &= v_; return; }
-#endif
-        const float4 wt = *reinterpret_cast<const float4*>(sm.tw[lw][G.slot][j]);
-        float k4[4];
-        blend4(R[pass][0], wt, *reinterpret_cast<const float4*>(&sm.bkv[G.tsel][0][cl]), k4);
-        store_split4(sm.Kh[G.kvbuf] + kk * KS + cl, sm.Kl[G.kvbuf] + kk * KS + cl, k4);
-        blend4(R[pass][1], wt, *reinterpret_cast<const float4*>(&sm.bkv[G.tsel][1][cl]), k4);
-        store_split4(sm.Vh[G.kvbuf] + kk * VS + cl, sm.Vl[G.kvbuf] + kk * VS + cl, k4);
-        const bool vis = sm.tvis[lw][G.slot][j] != 0;
-        if ((ltid % TPK) == 0) sm.maskadd[G.kvbuf][kk] = vis ? 0.f : -INFINITY;
-        any |= vis;
-        allv &= vis;
-    };
-    auto blendI = [&](int pass, const PcGatherS& G) {
-        const int kk = pass * KPP + kin;
-#ifdef HMVIT_EXP_PCS_NOLOADER
-        return;
-#endif
-        float k4[4];
-        add4(R[pass][0][0], *reinterpret_cast<const float4*>(&sm.bkv[G.tsel][0][cl]), k4);
-        store_split4(sm.Kh[G.kvbuf] + kk * KS + cl, sm.Kl[G.kvbuf] + kk * KS + cl, k4);
-        add4(R[pass][1][0], *reinterpret_cast<const float4*>(&sm.bkv[G.tsel][1][cl]), k4);
-        store_split4(sm.Vh[G.kvbuf] + kk * VS + cl, sm.Vl[G.kvbuf] + kk * VS + cl, k4);
-        if (G.half == 0) {
-            const float4 bq = *reinterpret_cast<const float4*>(&sm.bq[G.te][cl]);
-            float q4[4];
-            add4(R[pass][0][1], bq, q4);
-            store_split4(sm.Qh[G.qbuf] + kk * QS + cl, sm.Ql[G.qbuf] + kk * QS + cl, q4);
-            add4(R[pass][0][2], bq, q4);
-            store_split4(sm.Qh[G.qbuf] + (32 + kk) * QS + cl, sm.Ql[G.qbuf] + (32 + kk) * QS + cl, q4);
-        }
-        if ((ltid % TPK) == 0) sm.maskadd[G.kvbuf][kk] = G.self_vis ? 0.f : -INFINITY;
-    };
-    auto publish = [&](const PcGatherS& G, bool some, bool every) {
-        __builtin_amdgcn_sched_barrier(0);
-        const bool wave_any = __any(some), wave_all = __all(every);
-        if (lane == 0) sm.vis[G.kvbuf][lw] = (wave_any ? 1 : 0) | (wave_all ? 2 : 0);
-        pc_wg_barrier();
-    };
-
-    PcCursor item = pc_cursor();
-    int g = 0, qi = 0;
-    PcItem it;
-    if (!pc_fetch(p, X, Y, NG, ego_fastest, item, it)) { pc_wg_barrier(); return; }
-    unsigned vis = pc_item_vis(p, it, X, Y, true);
-    PcGatherS G = pcs_describe(p, sm, it, 0, 0, 0, 0, 0, true);
-#pragma unroll
-    for (int pass = 0; pass < NP; ++pass) issueI(pass, G);
-
-    // Per item: identity halves I0, I1, then the visible general half chunks, then on to the next item; every body is
-    // "blend the gather whose loads are in the registers, pass by pass, while the next gather's loads are issued".
-    const unsigned half_bits = ((1u << (2 * n_src)) - 1u) << 8;
-#pragma unroll 1
-    while (true) {
-        // I0 -> I1
-        PcGatherS N = pcs_describe(p, sm, it, 0, 1, 0, g + 1, qi, true);
-        load_bias(G);
-#pragma unroll
-        for (int pass = 0; pass < NP; ++pass) {
-            __builtin_amdgcn_sched_barrier(0);
-            blendI(pass, G);
-            __builtin_amdgcn_sched_barrier(0);
-            issueI(pass, N);
-        }
-        publish(G, G.self_vis, G.self_vis);
-        G = N; ++g;
-        // visible general half chunks: bit 8 + h' of the word, h' = 2 chunk + half (chunk >= 1)
-        unsigned rest = (vis & half_bits) >> 10;            // bit h = half chunk h = 2 (chunk - 1) + half
-        bool blend_is_identity = true;
-        int tap_group = -1;
-#pragma unroll 1
-        while (rest) {
-            const int h = __builtin_ctz(rest);
-            rest &= rest - 1;
-            if (h / TGH != tap_group) {
-                tap_group = h / TGH;
-                pcs_taps(p, sm, it, tap_group * TGH, lw, lane);
-            }
-            N = pcs_describe(p, sm, it, 1 + (h >> 1), h & 1, (tap_group & 1) * TGH + h % TGH, g + 1, qi, true);
-            load_bias(G);
-            if (blend_is_identity) {
-#pragma unroll
-                for (int pass = 0; pass < NP; ++pass) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    blendI(pass, G);
-                    __builtin_amdgcn_sched_barrier(0);
-                    issueG(pass, N);
-                }
-                publish(G, G.self_vis, G.self_vis);
-                blend_is_identity = false;
-            } else {
-                any = false; allv = true;
-#pragma unroll
-                for (int pass = 0; pass < NP; ++pass) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    blendG(pass, G);
-                    __builtin_amdgcn_sched_barrier(0);
-                    issueG(pass, N);
-                }
-                publish(G, any, allv);
-            }
-            G = N; ++g;
-        }
-        // last gather of the item while the first identity half of the next item is requested
-        const bool nvalid = pc_fetch(p, X, Y, NG, ego_fastest, item, it);
-        if (nvalid) vis = pc_item_vis(p, it, X, Y, true);
-        qi ^= 1;
-        N = pcs_describe(p, sm, it, 0, 0, 0, g + 1, qi, nvalid);
-        load_bias(G);
-        if (blend_is_identity) {
-#pragma unroll
-            for (int pass = 0; pass < NP; ++pass) {
-                __builtin_amdgcn_sched_barrier(0);
-                blendI(pass, G);
-                __builtin_amdgcn_sched_barrier(0);
-                issueI(pass, N);
-            }
-            publish(G, G.self_vis, G.self_vis);
-        } else {
-            any = false; allv = true;
-#pragma unroll
-            for (int pass = 0; pass < NP; ++pass) {
-                __builtin_amdgcn_sched_barrier(0);
-                blendG(pass, G);
-                __builtin_amdgcn_sched_barrier(0);
-                issueI(pass, N);
-            }
-            publish(G, any, allv);
-        }
-        if (!nvalid) break;
-        G = N; ++g;
-    }
-    pc_wg_barrier();   // the interval in which the compute waves consume the last gather
-}
-
-__device__ __forceinline__ void pcs_compute_loop(const AttnParams& p, PcSharedS& sm, int wave, int lane) {
-    using SM = PcSharedS;
-    constexpr int QS = SM::QS, KS = SM::KS, VS = SM::VS, LWG = SM::LWG;
-    // the planes (and the bias fragments) carry the logits at a power of two (HmvitStageScales::k_logit brings them back to
-    // natural units): it rides on the log2(e) factor of the exp2 argument, the running maximum stays in plane units
-    const float kl = p.k_logit != 0.f ? p.k_logit : 1.f;
-    const float LOG2E = 1.4426950408889634f * kl;
-    const int hl = wave;
-    const int C = p.C, H = p.H, W = p.W, L = p.L, P = H * W;
-    const int X = H / 8, Y = W / 8, NG = C / SM::CH;
-    const int n_src = p.n_src;
-    const int lq = lane & 15, g = lane >> 4;
-    PcCursor item = pc_cursor();
-    PcItem it;
-    __syncthreads();
-    if (!pc_fetch(p, X, Y, NG, (p.variant & 0x200) == 0, item, it)) return;
-
-    float4v biasf[7];
-    int bias_head = -1;
-    half8 qhh[4], qhl[4];
-    float m_run[4];
-    float4v o_acc[4][2], l_acc[4];
-    const half8 ones = (half8)(half_t)1.0f;
-    int gstep = 0, qi = 0;
-    const unsigned half_bits = ((1u << (2 * n_src)) - 1u) << 8;
-    while (true) {
-        const int head = it.hg * SM::HG + hl;
-        // half chunks to walk: both identity halves, then the visible general ones (the loader walks the same list)
-        unsigned todo = ((pc_item_vis(p, it, X, Y, true) & half_bits) >> 8) | 3u;
-        const int h_last = 31 - __builtin_clz(todo);
-        if (head != bias_head) {
-#pragma unroll
-            for (int v = 0; v < 7; ++v)
-                biasf[v] = *reinterpret_cast<const float4v*>(p.bias_frag + ((size_t)(head * 7 + v) * 64 + lane) * 4);
-            bias_head = head;
-        }
-        bool first = true;
-        while (todo) {
-            const int h = __builtin_ctz(todo);
-            todo &= todo - 1;
-            const int buf = gstep & 1;
-            if (first) {
-                first = false;
-#pragma unroll
-                for (int qt = 0; qt < 4; ++qt) {
-                    qhh[qt] = *reinterpret_cast<const half8*>(sm.Qh[qi] + (qt * 16 + lq) * QS + hl * 32 + g * 8);
-                    qhl[qt] = *reinterpret_cast<const half8*>(sm.Ql[qi] + (qt * 16 + lq) * QS + hl * 32 + g * 8);
-                    m_run[qt] = -INFINITY;
-                    l_acc[qt] = (float4v)(0.f);
-                    o_acc[qt][0] = (float4v)(0.f);
-                    o_acc[qt][1] = (float4v)(0.f);
-                }
-            }
-            int vis_or = 0, vis_and = 3;
-#pragma unroll
-            for (int w = 0; w < LWG; ++w) {
-                vis_or |= sm.vis[buf][w];
-                vis_and &= sm.vis[buf][w];
-            }
-            const bool any_visible = (vis_or & 1) != 0;
-            const bool all_visible = (vis_and & 2) != 0;
-#ifdef HMVIT_EXP_PCS_NOMATH
-            if (false) {
-#else
-            if (any_visible || !p.skip_masked) {
-#endif
-                float4v madd[2];
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) madd[kt] = (float4v)(0.f);
-                if (!all_visible) {
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt) madd[kt] = *reinterpret_cast<const float4v*>(sm.maskadd[buf] + kt * 16 + 4 * g);
-                }
-                half8 khh[2], khl[2], vhh[2], vhl[2];
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    khh[kt] = *reinterpret_cast<const half8*>(sm.Kh[buf] + (kt * 16 + lq) * KS + hl * 32 + g * 8);
-                    khl[kt] = *reinterpret_cast<const half8*>(sm.Kl[buf] + (kt * 16 + lq) * KS + hl * 32 + g * 8);
-                }
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    // V^T tile dt takes the head's channels 8 q4 + 4 dt + r (q4 = lq & 3) as its rows 4 q4 + r, so that an
-                    // accumulator lane ends up with 8 consecutive channels over the two tiles (as in k_attention_pc)
-                    const int off = (4 * g + (lq >> 2)) * VS + hl * 32 + (lq & 3) * 8 + dt * 4;
-#pragma unroll
-                    for (int hlx = 0; hlx < 2; ++hlx) {
-                        const half_t* base = (hlx ? sm.Vl[buf] : sm.Vh[buf]) + off;
-                        const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base));
-                        const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base + 16 * VS));
-                        half8 v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = (half_t)lo[e];
-                            v[4 + e] = (half_t)hi[e];
-                        }
-                        if (hlx) vhl[dt] = v; else vhh[dt] = v;
-                    }
-                }
-                const int hk = h & 1;                        // which half of the 64 key positions: bias tiles 2 hk + kt
-#pragma unroll
-                for (int qt = 0; qt < 4; ++qt) {
-                    float4v s[2];
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt) {
-                        // bias fragment of (query tile qt, key tile 2 hk + kt): index qt - kt - 2 hk + 3, selected without
-                        // dynamic register indexing
-                        const float4v b0 = biasf[qt - kt + 3], b1 = biasf[qt - kt + 1 >= 0 ? qt - kt + 1 : 0];
-                        float4v acc = hk ? b1 : b0;
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(khl[kt], qhh[qt], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(khh[kt], qhl[qt], acc, 0, 0, 0);
-                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(khh[kt], qhh[qt], acc, 0, 0, 0);
-                    }
-                    if (!all_visible) {
-#pragma unroll
-                        for (int kt = 0; kt < 2; ++kt) s[kt] += madd[kt];
-                    }
-                    float mx = -INFINITY;
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
-                    mx = max_over_lane_groups(mx);
-                    const float m_new = max_raw(m_run[qt], mx);
-                    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-                    const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_safe) * LOG2E);
-                    half8 ph, pl;
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float e = __builtin_amdgcn_exp2f((s[kt][r] - m_safe) * LOG2E);
-                            const half_t eh = (half_t)e;
-                            ph[4 * kt + r] = eh;
-                            pl[4 * kt + r] = (half_t)(e - (float)eh);
-                        }
-                    m_run[qt] = m_new;
-                    o_acc[qt][0] *= alpha;
-                    o_acc[qt][1] *= alpha;
-                    l_acc[qt] *= alpha;
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        o_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhl[dt], ph, o_acc[qt][dt], 0, 0, 0);
-                        o_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhh[dt], pl, o_acc[qt][dt], 0, 0, 0);
-                        o_acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhh[dt], ph, o_acc[qt][dt], 0, 0, 0);
-                    }
-                    l_acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pl, l_acc[qt], 0, 0, 0);
-                    l_acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, ph, l_acc[qt], 0, 0, 0);
-                }
-            }
-            if (h == h_last) {
-                float* outp = reinterpret_cast<float*>(p.out) + (size_t)(it.b * L + it.ego) * P * C;
-#pragma unroll
-                for (int qt = 0; qt < 4; ++qt) {
-                    int row, col;
-                    token_pixel(p.partition, 8, X, Y, it.wx, it.wy, qt * 16 + lq, row, col);
-                    const float inv = 1.f / l_acc[qt][0];
-                    float* o = outp + (size_t)(row * W + col) * C + head * 32 + 8 * g;
-                    *reinterpret_cast<float4*>(o) = make_float4(o_acc[qt][0][0] * inv, o_acc[qt][0][1] * inv, o_acc[qt][0][2] * inv, o_acc[qt][0][3] * inv);
-                    *reinterpret_cast<float4*>(o + 4) = make_float4(o_acc[qt][1][0] * inv, o_acc[qt][1][1] * inv, o_acc[qt][1][2] * inv, o_acc[qt][1][3] * inv);
-                    // row log-sum-exp for the backward pass (training forward, same layout as k_attention's)
-                    if (p.lse && g == 0)
-                        p.lse[((size_t)(it.b * L + it.ego) * P + row * W + col) * (C / 32) + head] = m_run[qt] * kl + logf(l_acc[qt][0]);
-                }
-            }
-            __syncthreads();
-            ++gstep;
-        }
-        if (!pc_fetch(p, X, Y, NG, (p.variant & 0x200) == 0, item, it)) break;
-        qi ^= 1;
-    }
-}
-
-__global__ __launch_bounds__(512) void k_attention_pcs(AttnParams p) {
-    using SM = PcSharedS;
-    __shared__ __attribute__((aligned(16))) SM sm;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int hg = pc_head_group(p, p.C / SM::CH);
-    {
-        const int n_rec = p.B * p.L * p.L * 8;
-        for (int i = threadIdx.x; i < n_rec; i += blockDim.x) sm.ainv[i] = p.ainv[i];
-        for (int i = threadIdx.x; i < HMVIT_NUM_TYPES * HMVIT_NUM_TYPES * 2 * SM::CH; i += blockDim.x) {
-            const int e = i / (2 * SM::CH), pl = (i / SM::CH) & 1, c = i % SM::CH;
-            sm.bkv[e][pl][c] = p.b_kv[(size_t)e * 2 * p.C + pl * p.C + hg * SM::CH + c];
-        }
-        for (int i = threadIdx.x; i < HMVIT_NUM_TYPES * SM::CH; i += blockDim.x)
-            sm.bq[i / SM::CH][i % SM::CH] = p.b_q[(i / SM::CH) * p.C + hg * SM::CH + (i % SM::CH)];
-        if (threadIdx.x < kMaxSlots) {
-            sm.mode[threadIdx.x] = p.mode[threadIdx.x];
-            sm.cav[threadIdx.x] = p.cav[threadIdx.x];
-            sm.ego_e[threadIdx.x] = p.ego_e[threadIdx.x];
-        }
-    }
-    __syncthreads();
-    if (wave >= SM::CWG) {
-        __builtin_amdgcn_s_setprio(3);
-        pcs_loader_loop(p, sm, wave - SM::CWG, threadIdx.x - SM::CWG * 64);
-    } else {
-        pcs_compute_loop(p, sm, wave, threadIdx.x & 63);
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // k_attention_pcs2 (round 4): the same persistent producer / consumer kernel with the LOADER role rebuilt around what the
@@ -2061,6 +1559,29 @@ __device__ __forceinline__ PcGath2 pcs2_gather(const AttnParams& p, const PcItem
     return G;
 }
 
+// The 64 x 32 f32 query block of head `head` (absolute) of item t -> 8 KB of LDS at `qlds` by LDS-DMA: piece i = 2 qt + half,
+// 64 lanes x 16 bytes; lane (lq, g) of piece (qt, half) takes channels 16 half + 4 g .. + 3 of query qt 16 + lq, so that one
+// request reads 64 contiguous bytes per token (as 16-byte pieces 32 bytes apart the 8 requests of an item took 3-6 k cycles to
+// issue, round-5 trace).  No registers while it is in flight.
+__device__ __forceinline__ void pcs2_request_q(const AttnParams& p, const PcItem& t, int head, unsigned qlds, int lane, int X, int Y) {
+    const int lq = lane & 15, g = lane >> 4, L = p.L, W = p.W, C = p.C, P = p.H * p.W;
+    const float* qpl = reinterpret_cast<const float*>(p.q) + (size_t)(t.b * L + t.ego) * P * C + head * 32 + g * 4;
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        int row, col;
+        token_pixel(p.partition, 8, X, Y, t.wx, t.wy, qt * 16 + lq, row, col);
+        const float* a = qpl + (size_t)(row * W + col) * C;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const float* src = a + 16 * hf;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(qlds + (2 * qt + hf) * 1024);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        }
+    }
+}
+
 template <bool DYN>
 __device__ __forceinline__ void pcs2_loader_loop(const AttnParams& p, PcShared2& sm, int lw, int lane) {
     using SM = PcShared2;
@@ -2133,6 +1654,15 @@ __device__ __forceinline__ void pcs2_loader_loop(const AttnParams& p, PcShared2&
     PcItemC ic = pcs2_item_consts(p, sm, it), icn = ic;
     bool itn_valid = false;
     int par = 0, g = 0;
+    // The query block of the NEXT item is requested by this role (loader wave lw for compute wave lw's head), two steps after the
+    // blend of an item's first gather: the compute wave has its own block in registers by then (it converts it in the step after
+    // that blend), and the earliest reader of the new block comes behind this step's closing barrier (an item has at least two
+    // steps), which a counted wait in front of the barrier covers.  Issued by the compute waves themselves (round 4) the 8 requests
+    // of an item took 4-6 k cycles - at priority 0, behind the loaders' tap requests in the vector-memory queue, on the one role
+    // whose lateness stalls the whole workgroup at the item boundary (tests/tools/pcs2_trace.py, round 5).
+    PcItem qit = it;
+    int q_delay = 0;
+    const unsigned qlds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)sm.qstage[lw];
     pcs2_tables(p, sm, it, par, lw, lane);
     PcGath2 G = pcs2_gather(p, it, ic, par, __builtin_ctz(rest), g);
     rest &= rest - 1;
@@ -2142,6 +1672,14 @@ __device__ __forceinline__ void pcs2_loader_loop(const AttnParams& p, PcShared2&
 
 #pragma unroll 1
     while (true) {
+        // ---- the next item's query block (before this step's own fetch can replace qit) ----
+        bool q_fired = false;
+#ifndef HMVIT_EXP_PCS_NOQ
+        if (q_delay > 0 && --q_delay == 0) {
+            pcs2_request_q(p, qit, qit.hg * SM::HG + lw, qlds, lane, X, Y);
+            q_fired = true;
+        }
+#endif
         // ---- the gather after G ----
         bool nvalid = true;
         if (rest == 0) {
@@ -2161,6 +1699,8 @@ __device__ __forceinline__ void pcs2_loader_loop(const AttnParams& p, PcShared2&
                     restn = pcs2_bits(p, itn, X, Y);
                     icn = pcs2_item_consts(p, sm, itn);
                     pcs2_tables(p, sm, itn, par ^ 1, lw, lane);
+                    qit = itn;
+                    q_delay = 2;          // this step blends the item's first gather: fire at the top of the step after the next
                 }
             }
         } else {
@@ -2173,6 +1713,7 @@ __device__ __forceinline__ void pcs2_loader_loop(const AttnParams& p, PcShared2&
         N.rs.z = __builtin_amdgcn_readfirstlane(N.rs.z); N.rs.w = __builtin_amdgcn_readfirstlane(N.rs.w);
         N.par = __builtin_amdgcn_readfirstlane(N.par); N.slot = __builtin_amdgcn_readfirstlane(N.slot);
         N.buf = __builtin_amdgcn_readfirstlane(N.buf); N.tsel = __builtin_amdgcn_readfirstlane(N.tsel);
+        PC2_TRACE(1, lw == 0 && lane == 0, g, 0);
         float4 wt[NP];
         int4 ixn[NP];
 #pragma unroll
@@ -2202,7 +1743,9 @@ __device__ __forceinline__ void pcs2_loader_loop(const AttnParams& p, PcShared2&
             if (k4[0] == 1.2345f) store_split4(sm.Vh[G.buf] + kk * VS + cl, sm.Vl[G.buf] + kk * VS + cl, k4);
 #endif
             __builtin_amdgcn_sched_barrier(0);
+            PC2_TRACE(1, lw == 0 && lane == 0, g, 1 + 2 * pass);
             request(pass, N, ixn[pass]);
+            PC2_TRACE(1, lw == 0 && lane == 0, g, 2 + 2 * pass);
 #endif
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -2210,7 +1753,11 @@ __device__ __forceinline__ void pcs2_loader_loop(const AttnParams& p, PcShared2&
             float* dst = lane < 8 ? &sm.maskadd[G.buf][mrow] : reinterpret_cast<float*>(&sm.vis[G.buf][lw]);
             *dst = mk;
         }
+        PC2_TRACE(1, lw == 0 && lane == 0, g, 9);
+        // the query block requested at the top of this step is older than the step's 32 tap requests
+        if (q_fired) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         pc_wg_barrier();
+        PC2_TRACE(1, lw == 0 && lane == 0, g, 10);
         if (!nvalid) break;
         G = N; ++g;
     }
@@ -2248,29 +1795,12 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
     pc_wg_barrier();
     if (!fetch(it)) return;
 
-    // this wave's query block of an item: 4 tiles of 16 queries x the head's 32 channels, lane (lq, g) takes channels 8 g .. 8 g + 7.
-    // Requested one item ahead by LDS-DMA into the wave's own 8 KB (piece i = 2 qt + half: 64 lanes x 16 bytes), so that the
-    // block costs the compute role no registers while it waits
+    // this wave's query block of an item: 4 tiles of 16 queries x the head's 32 channels, lane (lq, g) takes channels 8 g .. 8 g + 7,
+    // in the wave's own 8 KB of LDS (piece i = 2 qt + half: 64 lanes x 16 bytes).  The first item's block is requested here; every
+    // later one by loader wave `hl` while this wave works on the item before (pcs2_loader_loop)
     const unsigned qlds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)sm.qstage[hl];
-    auto request_q = [&](const PcItem& t) {
-        const float* qpl = reinterpret_cast<const float*>(p.q) + (size_t)(t.b * L + t.ego) * P * C + (t.hg * SM::HG + hl) * 32 + g * 8;
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {
-            int row, col;
-            token_pixel(p.partition, 8, X, Y, t.wx, t.wy, qt * 16 + lq, row, col);
-            const float* a = qpl + (size_t)(row * W + col) * C;
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const float* src = a + 4 * hf;
-                const unsigned dst = __builtin_amdgcn_readfirstlane(qlds + (2 * qt + hf) * 1024);
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-            }
-        }
-    };
 #ifndef HMVIT_EXP_PCS_NOQ
-    request_q(it);
+    pcs2_request_q(p, it, it.hg * SM::HG + hl, qlds, lane, X, Y);
 #endif
 
     float4v biasf[7];
@@ -2281,10 +1811,12 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
     const half8 ones = (half8)(half_t)1.0f;
     int gstep = 0;
     while (true) {
+        PC2_TRACE(0, hl == 0 && lane == 0, gstep, 5);
         const bool nvalid = fetch(itn);
         bool drawn = false;
         const int head = it.hg * SM::HG + hl;
         unsigned todo = pcs2_bits(p, it, X, Y);
+        PC2_TRACE(0, hl == 0 && lane == 0, gstep, 6);
         const int h_last = 31 - __builtin_clz(todo);
         if (head != bias_head) {
 #pragma unroll
@@ -2292,13 +1824,10 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
                 biasf[v] = *reinterpret_cast<const float4v*>(p.bias_frag + ((size_t)(head * 7 + v) * 64 + lane) * 4);
             bias_head = head;
         }
-        {   // Q + b_q -> (hi, lo) operand halves; then the next item's block is requested into the same 8 KB.
-            // The 8 DMA pieces are older than the output stores of the previous item (8, + 4 log-sum-exp stores in the training
-            // forward): "all but the newest n" leaves those stores in flight (loads and stores share the in-order counter)
+        {   // Q + b_q -> (hi, lo) operand halves
 #ifndef HMVIT_EXP_PCS_NOQ
-            if (gstep == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (p.lse) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (gstep == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (later blocks: landed before the loader's barrier)
+            PC2_TRACE(0, hl == 0 && lane == 0, gstep, 7);
             const int te = sm.mode[it.b * L + it.ego];
             const float4 b0 = *reinterpret_cast<const float4*>(&sm.bq[te][hl * 32 + g * 8]);
             const float4 b1 = *reinterpret_cast<const float4*>(&sm.bq[te][hl * 32 + g * 8 + 4]);
@@ -2307,7 +1836,8 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
             for (int qt = 0; qt < 4; ++qt) {
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    const float4 q4 = *reinterpret_cast<const float4*>(&sm.qstage[hl][((2 * qt + hf) * 64 + lane) * 4]);
+                    // this lane's channel quad 2 g + hf sits in piece (qt, g >> 1) at lane slot (2 (g & 1) + hf, lq)
+                    const float4 q4 = *reinterpret_cast<const float4*>(&sm.qstage[hl][((2 * qt + (g >> 1)) * 64 + (2 * (g & 1) + hf) * 16 + lq) * 4]);
                     half4 h4, l4;
                     split_pk4(q4.x + bb[4 * hf], q4.y + bb[4 * hf + 1], q4.z + bb[4 * hf + 2], q4.w + bb[4 * hf + 3], h4, l4);
 #pragma unroll
@@ -2323,7 +1853,7 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the block is in registers before its LDS rows are requested again
             __builtin_amdgcn_sched_barrier(0);
-            if (nvalid) request_q(itn);
+            PC2_TRACE(0, hl == 0 && lane == 0, gstep, 8);
 #else
             for (int qt = 0; qt < 4; ++qt) { m_run[qt] = -INFINITY; l_acc[qt] = (float4v)(0.f); o_acc[qt][0] = (float4v)(0.f); o_acc[qt][1] = (float4v)(0.f); qhh[qt] = ones; qhl[qt] = ones; }
 #endif
@@ -2332,6 +1862,7 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
             const int h = __builtin_ctz(todo);
             todo &= todo - 1;
             const int buf = gstep & 1;
+            PC2_TRACE(0, hl == 0 && lane == 0, gstep, 0);
             int vis_or = 0, vis_and = 3;
 #pragma unroll
             for (int w = 0; w < LWG; ++w) {
@@ -2425,6 +1956,7 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
                         l_acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pl, l_acc[qt], 0, 0, 0);
                         l_acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, ph, l_acc[qt], 0, 0, 0);
                         if (qt & 1) __builtin_amdgcn_sched_barrier(0);   // two tiles in flight at a time: four overflow the register file
+                        if (qt & 1) PC2_TRACE(0, hl == 0 && lane == 0, gstep, 1 + (qt >> 1));
                     }
                 };
                 using F_ = std::false_type;
@@ -2435,22 +1967,40 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
 #else
             if (h == h_last) {
 #endif
+                PC2_TRACE(0, hl == 0 && lane == 0, gstep, 10);
+                // the loader role runs at priority 3 and owns the issue slots and the vector-memory queue most of the time: at
+                // priority 0 the 8 output stores of an item took 4-11 k cycles (tests/tools/pcs2_trace.py, round 5)
+                __builtin_amdgcn_s_setprio(3);
                 float* outp = reinterpret_cast<float*>(p.out) + (size_t)(it.b * L + it.ego) * P * C;
 #pragma unroll
                 for (int qt = 0; qt < 4; ++qt) {
                     int row, col;
                     token_pixel(p.partition, 8, X, Y, it.wx, it.wy, qt * 16 + lq, row, col);
                     const float inv = 1.f / l_acc[qt][0];
-                    float* o = outp + (size_t)(row * W + col) * C + head * 32 + 8 * g;
-                    *reinterpret_cast<float4*>(o) = make_float4(o_acc[qt][0][0] * inv, o_acc[qt][0][1] * inv, o_acc[qt][0][2] * inv, o_acc[qt][0][3] * inv);
-                    *reinterpret_cast<float4*>(o + 4) = make_float4(o_acc[qt][1][0] * inv, o_acc[qt][1][1] * inv, o_acc[qt][1][2] * inv, o_acc[qt][1][3] * inv);
+                    // lane (lq, g) holds channel quads 2 g and 2 g + 1 of its token; stored like that, one store instruction writes
+                    // 16-byte pieces 32 bytes apart (64 of them) and the item's 32 stores held the vector-memory path for 4-10 k
+                    // cycles (round-5 trace).  Two row swaps per register (lanes l, l ^ 16, l ^ 32, l ^ 48 belong to one token) give
+                    // lane g quads g and 4 + g: each store writes 64 contiguous bytes per token.
+                    float a[4] = {o_acc[qt][0][0] * inv, o_acc[qt][0][1] * inv, o_acc[qt][0][2] * inv, o_acc[qt][0][3] * inv};
+                    float b[4] = {o_acc[qt][1][0] * inv, o_acc[qt][1][1] * inv, o_acc[qt][1][2] * inv, o_acc[qt][1][3] * inv};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        swap16_rows(a[e], b[e]);      // a: quads (0, 1, 4, 5) by row, b: (2, 3, 6, 7)
+                        swap32_rows(a[e], b[e]);      // a: (0, 1, 2, 3),          b: (4, 5, 6, 7)
+                    }
+                    float* o = outp + (size_t)(row * W + col) * C + head * 32 + 4 * g;
+                    *reinterpret_cast<float4*>(o) = make_float4(a[0], a[1], a[2], a[3]);
+                    *reinterpret_cast<float4*>(o + 16) = make_float4(b[0], b[1], b[2], b[3]);
                     if (p.lse && g == 0)
                         p.lse[((size_t)(it.b * L + it.ego) * P + row * W + col) * (C / 32) + head] = m_run[qt] * 0.6931471805599453f + logf(l_acc[qt][0]);
                 }
+                __builtin_amdgcn_s_setprio(0);
             }
             if (dyn && hl == 0 && !drawn) pcs2_publish(p, seq, sm.items, X, Y, NG, ego_fastest, hops, n_items, lane);
             drawn = true;
+            PC2_TRACE(0, hl == 0 && lane == 0, gstep, 3);
             pc_wg_barrier();
+            PC2_TRACE(0, hl == 0 && lane == 0, gstep, 4);
             ++gstep;
         }
         if (!nvalid) break;
@@ -2508,11 +2058,6 @@ __global__ __launch_bounds__(512) void k_attention_pcs2(AttnParams p) {
 static int launch_attn_pcs(const AttnParams& p_in, hipStream_t st) {
     AttnParams p = p_in;
     if (const char* e = HMVIT_ENV("HMVIT_ATTN_TRACE")) p.trace = (unsigned long long*)strtoull(e, nullptr, 0);
-    if (HMVIT_ENV("HMVIT_PCS_OLD")) {       // probe builds: the round-2/3 kernel, for same-box A/B runs
-        hipLaunchKernelGGL(k_attention_pcs, dim3(256), dim3(512), 0, st, p);
-        HMVIT_CHECK_LAUNCH();
-        return HMVIT_OK;
-    }
     // items: pulled from per-(XCD, head group) counters when the caller provides them (AttnParams::queue), else the static walk
     if (p.queue) hipLaunchKernelGGL(k_attention_pcs2<true>, dim3(kPcs2Grid), dim3(512), 0, st, p);
     else hipLaunchKernelGGL(k_attention_pcs2<false>, dim3(kPcs2Grid), dim3(512), 0, st, p);
@@ -2871,7 +2416,7 @@ int launch_attention(const AttnParams& p, int precision, hipStream_t st) {
     HMVIT_CHECK_ARG(p.C == 64 || p.C == 128 || p.C == 256, "attention: C=%d unsupported (64, 128, 256)", p.C);
     const bool w8 = p.window == 8;
     if (precision == HMVIT_PREC_SPLIT && w8 && p.C >= 128 && p.self_identity && p.n_src <= 8 &&
-        p.B * p.L * p.L <= PcSharedS::MAX_PAIRS) {
+        p.B * p.L * p.L <= PcShared2::MAX_PAIRS) {
         AttnParams q = p;
         if (p.partition == HMVIT_PART_GRID) q.variant ^= 0x200;   // item order as for k_attention_pc
         // head group per XCD: bit 0 grid stages, bit 1 local stages.  Measured at cfg2 (tools/probe/r03_attn_ab.sh): local stages
@@ -2879,7 +2424,7 @@ int launch_attention(const AttnParams& p, int precision, hipStream_t st) {
         // (2620 -> 2780 us: their time is not set by bytes), so only the local stages take it
         int hgx = 2;
         if (const char* e = HMVIT_ENV("HMVIT_ATTN_HGX")) hgx = atoi(e);
-        if ((8 % (p.C / PcSharedS::CH)) == 0 && ((p.partition == HMVIT_PART_GRID) ? (hgx & 1) : (hgx & 2))) q.variant |= 0x800;
+        if ((8 % (p.C / PcShared2::CH)) == 0 && ((p.partition == HMVIT_PART_GRID) ? (hgx & 1) : (hgx & 2))) q.variant |= 0x800;
         return launch_attn_pcs(q, st);
     }
     if (precision == HMVIT_PREC_F32 || precision == HMVIT_PREC_SPLIT) {   // f32 planes, exact-f32 MFMA

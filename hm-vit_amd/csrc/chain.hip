@@ -96,6 +96,21 @@ __device__ __forceinline__ half8 lds_frag(const half_t* buf, int frag, int lane)
 // -log2 Phi(-t) on [0, 6] (Phi(-6) = 1e-9; t is clamped there).  |error| <= 6.4e-7 over the reals (f32 round-off class;
 // the result is rounded to f16 next): seven multiply-adds and one v_exp_f32, no division, no select -- this sits between
 // the two FFN matrix products of every hidden slice and was a third of the chain tail's VALU work in its erf form.
+// two values at a time: the degree-7 polynomial as packed multiply-adds
+__device__ __forceinline__ float2v gelu_f2(float2v x) {
+    const float2v ax = {fabsf(x.x), fabsf(x.y)};
+    const float2v t = {fminf(ax.x, 6.f), fminf(ax.y, 6.f)};
+    float2v q = __builtin_elementwise_fma((float2v)(1.889626219e-06f), t, (float2v)(-6.268139987e-05f));
+    q = __builtin_elementwise_fma(q, t, (float2v)(9.388679173e-04f));
+    q = __builtin_elementwise_fma(q, t, (float2v)(-8.539461531e-03f));
+    q = __builtin_elementwise_fma(q, t, (float2v)(5.402068794e-02f));
+    q = __builtin_elementwise_fma(q, t, (float2v)(4.584097862e-01f));
+    q = __builtin_elementwise_fma(q, t, (float2v)(1.151269197e+00f));
+    q = __builtin_elementwise_fma(q, t, (float2v)(9.999943376e-01f));
+    const float2v e = {__builtin_amdgcn_exp2f(-q.x), __builtin_amdgcn_exp2f(-q.y)};
+    const float2v pos = {fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)};
+    return __builtin_elementwise_fma(-ax, e, pos);
+}
 __device__ __forceinline__ float gelu_f(float x) {
     const float t = fminf(fabsf(x), 6.f);
     float q = fmaf(1.889626219e-06f, t, -6.268139987e-05f);
@@ -1009,41 +1024,41 @@ __device__ __forceinline__ float row_absmax16(const float4v (&x)[16]) {
         for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(x[t][r]));
     return max_over_lane_groups(m);
 }
-// LayerNorm of the token held by 4 lanes, straight into operand halves (gamma / beta from LDS)
+// LayerNorm of the token held by 4 lanes, straight into operand halves (gamma / beta from LDS).  Written on 2-vectors: every
+// step is a packed f32 instruction (v_pk_add / v_pk_fma_f32, two channels each) - the wave runs this while its SIMD partner
+// owns the matrix pipe, and a lone wave is bound by instruction issue, not by the VALU's width
 __device__ __forceinline__ void ln_to_operands16(const float4v (&x)[16], const float* __restrict__ lg, const float* __restrict__ lb, int g,
                                                  half8 (&ah)[8], half8 (&al)[8]) {
     constexpr int C = 256;
-    float sm = 0.f;
+    float2v s2 = {0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 16; ++t) sm += (x[t][0] + x[t][1]) + (x[t][2] + x[t][3]);
-    const float mean = quad_sum(sm) * (1.f / C);
-    float q = 0.f;
+    for (int t = 0; t < 16; ++t) s2 += x[t].xy + x[t].zw;
+    const float mean = quad_sum(s2.x + s2.y) * (1.f / C);
+    const float2v m2 = {mean, mean};
+    float2v q2 = {0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 16; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float d = x[t][r] - mean;
-            q = fmaf(d, d, q);
-        }
-    const float rstd = rsqrtf(quad_sum(q) * (1.f / C) + 1e-5f);
-    const float shift = -mean * rstd;
+    for (int t = 0; t < 16; ++t) {
+        const float2v d0 = x[t].xy - m2, d1 = x[t].zw - m2;
+        q2 = __builtin_elementwise_fma(d0, d0, q2);
+        q2 = __builtin_elementwise_fma(d1, d1, q2);
+    }
+    const float rstd = rsqrtf(quad_sum(q2.x + q2.y) * (1.f / C) + 1e-5f);
+    const float2v r2 = {rstd, rstd}, sh2 = {-mean * rstd, -mean * rstd};
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         float v[8];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int t = 2 * s + jj, c = 16 * t + 4 * g;
-            const float4 ga = *reinterpret_cast<const float4*>(lg + c);
-            const float4 be = *reinterpret_cast<const float4*>(lb + c);
-            v[4 * jj + 0] = fmaf(x[t][0], rstd, shift) * ga.x + be.x;
-            v[4 * jj + 1] = fmaf(x[t][1], rstd, shift) * ga.y + be.y;
-            v[4 * jj + 2] = fmaf(x[t][2], rstd, shift) * ga.z + be.z;
-            v[4 * jj + 3] = fmaf(x[t][3], rstd, shift) * ga.w + be.w;
+            const float4v ga = *reinterpret_cast<const float4v*>(lg + c);
+            const float4v be = *reinterpret_cast<const float4v*>(lb + c);
+            const float2v n0 = __builtin_elementwise_fma(__builtin_elementwise_fma(x[t].xy, r2, sh2), ga.xy, be.xy);
+            const float2v n1 = __builtin_elementwise_fma(__builtin_elementwise_fma(x[t].zw, r2, sh2), ga.zw, be.zw);
+            v[4 * jj + 0] = n0.x; v[4 * jj + 1] = n0.y; v[4 * jj + 2] = n1.x; v[4 * jj + 3] = n1.y;
         }
         split_pk8(v, ah[s], al[s]);
     }
 }
-
 // LayerNorm of the token held by 4 lanes, in place (f32 rows; k_linear16 scales and splits them afterwards)
 __device__ __forceinline__ void ln_rows16(float4v (&x)[16], const float* __restrict__ lg, const float* __restrict__ lb, int g) {
     constexpr int C = 256;
@@ -1602,15 +1617,16 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
                 step_begin();
                 float4v acc[2];                                          // starts from b_o / c_o (pre-divided on the host)
 #pragma unroll
-                for (int T = 0; T < 2; ++T) {
-                    const float4 bo = *reinterpret_cast<const float4*>(&vec[0][32 * c + 16 * T + 4 * g]);
-                    acc[T][0] = bo.x; acc[T][1] = bo.y; acc[T][2] = bo.z; acc[T][3] = bo.w;
-                }
+                for (int T = 0; T < 2; ++T) acc[T] = *reinterpret_cast<const float4v*>(&vec[0][32 * c + 16 * T + 4 * g]);
                 mma_proj16<!A16>(acc, slot(cc), ah, al, lane);          // f16 attention output: exact operand, no lo half
                 products_end(false);
+                // (the row tiles of chunk c are a run-time index into xacc: 64 selects per step.  Unrolling the loop removes them
+                // and costs 20 spilled registers - measured slower)
+                acc[0] *= c_o;
+                acc[1] *= c_o;
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
-                    if (t == c) { xacc[2 * t] = acc[0] * c_o + xacc[2 * t]; xacc[2 * t + 1] = acc[1] * c_o + xacc[2 * t + 1]; }
+                    if (t == c) { xacc[2 * t] += acc[0]; xacc[2 * t + 1] += acc[1]; }
                 step_end(false);
             }
         }
@@ -1651,8 +1667,13 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
                 half8 hh, hl;                                    // hidden channel 32 hc + 16 (j >> 2) + 4 g + (j & 3) = hacc[j >> 2][j & 3]
                 {
                     float gv[8];
+                    const float2v c1v = {c_1, c_1}, sgv = {s_g, s_g};
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) gv[j] = gelu_f(hacc[j >> 2][j & 3] * c_1) * s_g;
+                    for (int j = 0; j < 8; j += 2) {
+                        const float2v hv = {hacc[j >> 2][j & 3], hacc[j >> 2][(j & 3) + 1]};
+                        const float2v gl = gelu_f2(hv * c1v) * sgv;
+                        gv[j] = gl.x; gv[j + 1] = gl.y;
+                    }
                     split_pk8(gv, hh, hl);
                 }
                 step_end(false);

@@ -162,6 +162,19 @@ __device__ __forceinline__ void xor16_pair(float x, float& lo, float& hi) {
     lo = __builtin_bit_cast(float, r0);
     hi = __builtin_bit_cast(float, r1);
 }
+// two-register forms (rows of 16 lanes: r0 .. r3): swap16: a.r1 <-> b.r0 and a.r3 <-> b.r2; swap32: a.r2, a.r3 <-> b.r0, b.r1
+__device__ __forceinline__ void swap16_rows(float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ void swap32_rows(float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
+}
 __device__ __forceinline__ float max_raw(float a, float b) {   // v_max_f32 without the canonicalising max(x, x) pair
     float m;
     asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
