@@ -1724,8 +1724,7 @@ __device__ __forceinline__ void pcs2_loader_loop(const AttnParams& p, PcShared2&
         const float4 bK = *reinterpret_cast<const float4*>(&sm.bkv[G.tsel][0][cl]);
         const float4 bV = *reinterpret_cast<const float4*>(&sm.bkv[G.tsel][1][cl]);
         const float mk = sm.tmask[G.par][lw][G.slot][lane & 15];
-#pragma unroll
-        for (int pass = 0; pass < NP; ++pass) {
+        auto blend_pass = [&](int pass) {
             __builtin_amdgcn_sched_barrier(0);
             const int kk = pass * KPP + kin;
 #ifndef HMVIT_EXP_PCS_NOLOADER
@@ -1743,10 +1742,24 @@ __device__ __forceinline__ void pcs2_loader_loop(const AttnParams& p, PcShared2&
             if (k4[0] == 1.2345f) store_split4(sm.Vh[G.buf] + kk * VS + cl, sm.Vl[G.buf] + kk * VS + cl, k4);
 #endif
             __builtin_amdgcn_sched_barrier(0);
+#endif
+        };
+        auto request_pass = [&](int pass) {
+#ifndef HMVIT_EXP_PCS_NOLOADER
             PC2_TRACE(1, lw == 0 && lane == 0, g, 1 + 2 * pass);
             request(pass, N, ixn[pass]);
             PC2_TRACE(1, lw == 0 && lane == 0, g, 2 + 2 * pass);
+            __builtin_amdgcn_sched_barrier(0);
 #endif
+        };
+        // (measured and dropped, round 5: loader waves 2, 3 requesting one pass later than waves 0, 1 so that one pair's tap
+        // requests meet the other pair's blend - the two orders in one loop make hipcc drain vmcnt at the join: 3.6 x slower)
+        {
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                blend_pass(pass);
+                request_pass(pass);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (lane < 9) {
@@ -1955,7 +1968,9 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
                         }
                         l_acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pl, l_acc[qt], 0, 0, 0);
                         l_acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, ph, l_acc[qt], 0, 0, 0);
+#ifndef HMVIT_EXP_PCS_Q4
                         if (qt & 1) __builtin_amdgcn_sched_barrier(0);   // two tiles in flight at a time: four overflow the register file
+#endif
                         if (qt & 1) PC2_TRACE(0, hl == 0 && lane == 0, gstep, 1 + (qt >> 1));
                     }
                 };
@@ -2043,7 +2058,11 @@ __global__ __launch_bounds__(512) void k_attention_pcs2(AttnParams p) {
     if (p.trace && threadIdx.x == 0) p.trace[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();       // 100 MHz
 #endif
     if (wave >= SM::CWG) {
+#ifdef HMVIT_EXP_PCS_LPRIO
+        __builtin_amdgcn_s_setprio(HMVIT_EXP_PCS_LPRIO);
+#else
         __builtin_amdgcn_s_setprio(3);
+#endif
         pcs2_loader_loop<DYN>(p, sm, wave - SM::CWG, threadIdx.x & 63);
     } else {
         pcs2_compute_loop<DYN>(p, sm, wave, threadIdx.x & 63, hops, seq);

@@ -70,7 +70,7 @@ __device__ __forceinline__ void split_pk8(const float (&v)[8], half8& h, half8& 
     defined(HMVIT_EXP_NOWAIT) || defined(HMVIT_EXP_PCS_NOEPI) || defined(HMVIT_EXP_PCS_NOLOAD) ||                           \
     defined(HMVIT_EXP_PCS_NOLOADER) || defined(HMVIT_EXP_PCS_NOMATH) || defined(HMVIT_EXP_PCS_NOQ) ||                       \
     defined(HMVIT_EXP_PCS_NOSTORE) || defined(HMVIT_EXP_PCS_NOTABLES) || defined(HMVIT_EXP_STATIC_ITEMS) ||                 \
-    defined(HMVIT_EXP_X16_NODMA) || defined(HMVIT_EXP_X16_NOSTORE) || defined(HMVIT_DBG_SUMS))
+    defined(HMVIT_EXP_X16_NODMA) || defined(HMVIT_EXP_PCS_Q4) || defined(HMVIT_EXP_PCS_LPRIO) || defined(HMVIT_EXP_X16_NOSTORE) || defined(HMVIT_DBG_SUMS))
 #error "HMVIT_EXP_* / HMVIT_DBG_* are timing / debug experiments: build them with -DHMVIT_ALLOW_EXP (tools/probe/build_var.sh), never into the shipped library"
 #endif
 
