@@ -469,7 +469,7 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
 
 // ---- backward workspace layout (floats) ----
 struct BwdPlan {
-    size_t o_G, o_T1, o_T2, o_T3, o_T4, o_dkg, o_dkv, o_wt, o_img, o_winv, total;
+    size_t o_G, o_T1, o_T2, o_T3, o_T4, o_dkg, o_dkv, o_wt, o_img, o_winv, o_vbound, total;
     // transposed weights inside o_wt, per stage s: q (T,C,C), kv (T,T,2,C,C), o (T,C,C), w1t (T,C,mlp), w2t (T,mlp,C); head: w1t, w2t
     size_t wt_stage, wt_q, wt_kv, wt_o, wt_1, wt_2, wt_h1, wt_h2;
 };
@@ -495,6 +495,7 @@ static void make_bwd_plan(const TrainPlan& pl, BwdPlan& bp) {
     // x16 images of the transposed weights (k_linear16), one float of storage per (hi, lo) pair, + one inverse scale per matrix
     bp.o_img = carve(pl.lin16 ? 2 * w + 2 * T * C * C : 0);
     bp.o_winv = carve(pl.lin16 ? (2 * w + 2 * T * C * C) / 65536 : 0);
+    bp.o_vbound = carve(64);            // one a-priori |V'| bound per stage (launch_v_bound)
     bp.total = off;
 }
 
@@ -681,6 +682,10 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
             ab.bias_frag_neg = reinterpret_cast<const float*>(t->bias_frag_neg[s]);
             ab.d_out = T3; ab.dq = T4; ab.dkg = dkg; ab.d_bias_frag = gr.bias_frag;
             ab.probe = 0;
+            // the range of the kernel's derived operands follows from the stage's weights (train.hip k_attention_bwd)
+            ab.v_bound = Wk + bp.o_vbound + sidx;
+            HMVIT_TRY(launch_v_bound(reinterpret_cast<const float*>(wt.w_kv), wt.b_kv, wt.ln_gamma, wt.ln_beta, T * T, T, C,
+                                     Wk + bp.o_vbound + sidx, st));
             // (k_attention_bwd writes every key row of every (ego, source < max_cav) pair, zeros where nothing is visible)
             DBG_SUM("G", G, pl.A);
             DBG_SUM("dO", T3, pl.A);

@@ -26,14 +26,20 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
         (L) = (half_t)(_x - (float)_h);      \
     } while (0)
 
-// The same split for a PAIR of values, in three instructions instead of ten: one packed conversion for the two hi halves, then
-// v_fma_mixlo / v_fma_mixhi_f16 form x * 1.0 - hi (an exact f32 fma: hi is x rounded to 11 bits) and round it to f16 straight into
-// the low / high half of the destination.  Bit-identical to split_h (tools/probe/split2_probe.hip: 16.7 M random bit patterns,
-// denormals, overflow to inf / -inf included; NaN payloads aside).  hi, lo: packed f16 pairs (element 0 in the low half).
+// The same split for a PAIR of values on packed instructions (v_cvt_pk_f16_f32, one v_pk_add_f32 for the two residuals): five
+// instructions per pair.  hi, lo: packed f16 pairs (element 0 in the low half).
+// Round 5 first wrote this as three instructions of inline asm (v_cvt_pk_f16_f32 + v_fma_mixlo_f16 + v_fma_mixhi_f16 forming
+// x * 1.0 - hi straight into the halves of the destination; bit-identical to split_h in isolation, tools/probe/split2_probe.hip)
+// and measured NO gain in the tails / 1 % in the attention - and k_attention_bwd, where the split is followed at once by the
+// matrix instruction that reads it, produced wrong gradients with it in one schedule and right ones in another (the same source
+// with a device-side comparison added passed): hipcc pads hazards between an asm block and an MFMA by its generic rule, not by
+// what the block's partial-register writes need.  Plain C++ leaves the hazard bookkeeping to the compiler.
 __device__ __forceinline__ void split_pk2(float a, float b, unsigned& hi, unsigned& lo) {
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
-    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(a), "v"(hi));
-    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(b), "v"(hi));
+    const float2v x = {a, b};
+    const half2v h = __builtin_convertvector(x, half2v);
+    const half2v l = __builtin_convertvector(x - __builtin_convertvector(h, float2v), half2v);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
 }
 typedef unsigned uint2v __attribute__((ext_vector_type(2)));
 typedef unsigned uint4v_ __attribute__((ext_vector_type(4)));

@@ -181,22 +181,29 @@ __device__ __forceinline__ void fetch_slab(float4 (&f)[8], const float* __restri
         if (row0 + row < rows_valid) f[i] = *reinterpret_cast<const float4*>(g + (size_t)(row0 + row) * ld + k0 + kc);
     }
 }
-__device__ __forceinline__ void put_slab(half_t* __restrict__ lds_hi, half_t* __restrict__ lds_lo, const float4 (&f)[8]) {
+__device__ __forceinline__ void put_slab(half_t* __restrict__ lds_hi, half_t* __restrict__ lds_lo, const float4 (&f)[8], float sc) {
     constexpr int LS = GemmCfg<half_t>::LDS_STRIDE;
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int c = tid + 256 * i, row = c >> 4, kc = (c & 15) * 4;
-        const float v[4] = {f[i].x, f[i].y, f[i].z, f[i].w};
         half4 h, l;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            h[e] = (half_t)v[e];
-            l[e] = (half_t)(v[e] - (float)h[e]);
-        }
+        split_pk4(f[i].x * sc, f[i].y * sc, f[i].z * sc, f[i].w * sc, h, l);
         *reinterpret_cast<half4*>(lds_hi + row * LS + kc) = h;
         *reinterpret_cast<half4*>(lds_lo + row * LS + kc) = l;
     }
+}
+// max |.| of the slab a workgroup holds in registers -> every thread (one LDS round trip, two barriers around the partials)
+__device__ __forceinline__ float slab_absmax(const float4 (&f)[8], float* partial) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m = fmaxf(m, fmaxf(fmaxf(fabsf(f[i].x), fabsf(f[i].y)), fmaxf(fabsf(f[i].z), fabsf(f[i].w))));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(partial[0], partial[1]), fmaxf(partial[2], partial[3]));
+    return m;
 }
 
 template <bool GELU>
@@ -227,9 +234,31 @@ __global__ __launch_bounds__(256) void k_gemm_split(GemmJobs jobs) {
     float4 fa[8], fw[8];
     fetch_slab(fa, Ag, m0, M, K, 0);
     fetch_slab(fw, Wg, n0, N, K, 0);
+    // Range (round 5): every K slab is split at its own powers of two (operands of the training path are gradients at whatever
+    // magnitude the pass has reached); the accumulator runs at the current pair of scales and is multiplied by the ratio - a
+    // power of two, exact - when a slab needs another pair (csrc/train.hip k_gemm_tn_split does the same along the tokens)
+    __shared__ float pmax[2][4];
+    float sa_run = 1.f, sw_run = 1.f;
+    bool live = false;
     for (int k0 = 0; k0 < K; k0 += BK) {
-        put_slab(Ah, Al, fa);
-        put_slab(Wh, Wl, fw);
+        const float ma = slab_absmax(fa, pmax[0]), mw = slab_absmax(fw, pmax[1]);
+        const float ta = ma * sa_run, tw = mw * sw_run;
+        const bool keep = live && ta < 32768.f && tw < 32768.f && (ta >= 256.f || ma == 0.f) && (tw >= 256.f || mw == 0.f);
+        if (!keep) {
+            const float sa = pow2_scale(ma), sw = pow2_scale(mw);
+            if (live) {
+                const float f = (sa * pow2_inv(sa_run)) * (sw * pow2_inv(sw_run));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[i][j][e] *= f;
+            }
+            sa_run = sa; sw_run = sw; live = true;
+        }
+        put_slab(Ah, Al, fa, sa_run);
+        put_slab(Wh, Wl, fw, sw_run);
         __syncthreads();
         if (k0 + BK < K) {                      // the next slab travels while this one is multiplied
             fetch_slab(fa, Ag, m0, M, K, k0 + BK);
@@ -262,6 +291,7 @@ __global__ __launch_bounds__(256) void k_gemm_split(GemmJobs jobs) {
         __syncthreads();
     }
     const int npp = J.n_per_plane;
+    const float unscale = pow2_inv(sa_run) * pow2_inv(sw_run);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + r;
@@ -275,7 +305,7 @@ __global__ __launch_bounds__(256) void k_gemm_split(GemmJobs jobs) {
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
                 if (m >= M) continue;
-                float v = acc[i][j][e] + bias;
+                float v = fmaf(acc[i][j][e], unscale, bias);
                 if constexpr (GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
                 if (J.residual) v += J.residual[(size_t)m * N + n];
                 reinterpret_cast<float*>(J.y)[ybase + (size_t)m * npp] = v;

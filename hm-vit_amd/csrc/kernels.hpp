@@ -292,9 +292,15 @@ struct AttnBwdParams {
     float* dkg;               // (B, n_ego, n_src, 2, P, C): gradient of the gathered K / V keys of every (ego, source) pair,
                               // indexed by EGO pixel; every key row of every pair is written (zeros where nothing is visible)
     float* d_bias_frag;       // (heads, NB, 64, 4) accumulated into
+    const float* v_bound;     // device scalar: a-priori bound on the 2-norm of a head's slice of a V' / O row (launch_v_bound), or null
     int probe;                // probe builds (HMVIT_BWD_PROBE): 1 = skip the products, 3 = skip the prologue's dot products
 };
 int launch_attention_bwd(const AttnBwdParams& p, hipStream_t st);
+// out[0] = max over the V' matrices (w_kv[(pair, 1)], pair < n_pairs) and heads of ||W_head||_F ||xn||_2 + ||b_head||_2 with
+// ||xn||_2 <= sqrt(C) (max|gamma| + max|beta|): an a-priori bound - weights only - on the 2-norm of a head's 32-channel slice of
+// every V' row and, the attention output being a convex combination of V' rows, of every O row
+int launch_v_bound(const float* w_kv, const float* b_kv, const float* ln_gamma, const float* ln_beta, int n_pairs, int n_types, int C,
+                   float* out, hipStream_t st);
 // adjoint of the bilinear key gather: dkv[(b, src), e, plane, s, :] = sum over egos of variant e and ego pixels u whose taps
 // touch source pixel s of weight(u -> s) dkg[(b, ego, src), plane, u, :]   (gather form, no atomics)
 struct WarpAdjParams {

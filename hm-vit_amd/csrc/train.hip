@@ -176,9 +176,18 @@ __device__ __forceinline__ int ts_addr(int row, int token) {       // half index
     return row * TS_LS + blk * 8 + (token & 7);
 }
 
+// Range (round 5): both operands are gradients / activations at whatever magnitude the pass has reached - behind large FFN weights
+// dY grows by 1e3-1e6 on its way down and left f16's range in this kernel (round 4 detected the Inf / NaN afterwards and re-ran the
+// whole backward from a lower level).  Now every 32-token slab is split at its OWN powers of two: the staging threads reduce
+// max |dY| and max |A| of the slab they hold in registers (during the previous slab's products: no extra barrier), the slab is
+// scaled to [2^13, 2^14) on its way into LDS, and the products accumulate at the running pair of scales; when a slab needs
+// different scales (more than a few binades away - rare: magnitudes drift slowly along the token axis) the accumulator is
+// multiplied by the ratio first (a power of two: exact; a second accumulator would cost the kernel its second wave per SIMD).
+// Exact powers of two throughout; no pre-pass, no host read, any magnitude.
 __global__ __launch_bounds__(256) void k_gemm_tn_split(GemmTnJobs jobs) {
     __shared__ __attribute__((aligned(16))) half_t Dh[128 * TS_LS], Dl[128 * TS_LS], Ah[128 * TS_LS], Al[128 * TS_LS];
     __shared__ float red[16][128];
+    __shared__ float smax[2][4][2];          // [slab parity][wave][dY, A]
     const GemmTnJob& J = jobs.j[blockIdx.z];
     const int tiles_k = (J.K + 127) / 128, tiles_n = (J.N + 127) / 128;
     if ((int)blockIdx.x >= tiles_k * tiles_n) return;
@@ -190,13 +199,13 @@ __global__ __launch_bounds__(256) void k_gemm_tn_split(GemmTnJobs jobs) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wn = wave >> 1, wk = wave & 1, r = lane & 31, hi = lane >> 5;
 
-    float16v acc[2][2];
+    float16v run[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) run[i][j][e] = 0.f;
     const bool do_bias = J.dbias != nullptr && tk == 0;
     float4 bsum[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
 
@@ -217,33 +226,74 @@ __global__ __launch_bounds__(256) void k_gemm_tn_split(GemmTnJobs jobs) {
             }
         }
     };
-    auto put_plane = [&](half_t* ph, half_t* pl, const float4& x0, const float4& x1, int pr, int cg) {
-        const float v0[4] = {x0.x, x0.y, x0.z, x0.w}, v1[4] = {x1.x, x1.y, x1.z, x1.w};
+    // max |.| of the slab in this thread's registers -> the wave's partial in smax[par]
+    auto publish_max = [&](int par) {
+        float md = 0.f, ma = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                md = max_raw(max_raw(md, max_raw(fabsf(fd[i][t].x), fabsf(fd[i][t].y))), max_raw(fabsf(fd[i][t].z), fabsf(fd[i][t].w)));
+                ma = max_raw(max_raw(ma, max_raw(fabsf(fa[i][t].x), fabsf(fa[i][t].y))), max_raw(fabsf(fa[i][t].z), fabsf(fa[i][t].w)));
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            md = fmaxf(md, __shfl_xor(md, o, 64));
+            ma = fmaxf(ma, __shfl_xor(ma, o, 64));
+        }
+        if (lane == 0) { smax[par][wave][0] = md; smax[par][wave][1] = ma; }
+    };
+    auto put_plane = [&](half_t* ph, half_t* pl, const float4& x0, const float4& x1, float sc, int pr, int cg) {
+        const float v0[4] = {x0.x * sc, x0.y * sc, x0.z * sc, x0.w * sc}, v1[4] = {x1.x * sc, x1.y * sc, x1.z * sc, x1.w * sc};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const half_t h0 = (half_t)v0[e], h1 = (half_t)v1[e];
-            half2v hh, ll;
-            hh[0] = h0; hh[1] = h1;
-            ll[0] = (half_t)(v0[e] - (float)h0); ll[1] = (half_t)(v1[e] - (float)h1);
+            unsigned hh, ll;
+            split_pk2(v0[e], v1[e], hh, ll);            // (token 2 pr, token 2 pr + 1) of column 4 cg + e
             const int o = ts_addr(4 * cg + e, 2 * pr);
-            *reinterpret_cast<half2v*>(ph + o) = hh;
-            *reinterpret_cast<half2v*>(pl + o) = ll;
+            *reinterpret_cast<unsigned*>(ph + o) = hh;
+            *reinterpret_cast<unsigned*>(pl + o) = ll;
         }
     };
+    float sd_run = 1.f, sa_run = 1.f;        // the scales `run` is accumulated at
+    bool run_live = false;
+    auto rescale = [&](float f) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) run[i][j][e] *= f;
+    };
     fetch(m_begin);
-    for (int m0 = m_begin; m0 < m_end; m0 += TS_BM) {
+    publish_max(0);
+    __syncthreads();
+    int par = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += TS_BM, par ^= 1) {
+        // the slab's scales (every thread computes the same two numbers from the four partials)
+        float md = 0.f, ma = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { md = fmaxf(md, smax[par][w][0]); ma = fmaxf(ma, smax[par][w][1]); }
+        const float sd_need = pow2_scale(md), sa_need = pow2_scale(ma);
+        // keep the running scales while the slab stays inside [2^8, 2^15) with them (top of the f16 range, low halves normal)
+        const float td = md * sd_run, ta = ma * sa_run;
+        const bool keep = run_live && td < 32768.f && ta < 32768.f && (td >= 256.f || md == 0.f) && (ta >= 256.f || ma == 0.f);
+        if (!keep) {
+            if (run_live) rescale((sd_need * pow2_inv(sd_run)) * (sa_need * pow2_inv(sa_run)));
+            sd_run = sd_need; sa_run = sa_need; run_live = true;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int item = tid + 256 * i, pr = item >> 5, cg = item & 31;
-            put_plane(Dh, Dl, fd[i][0], fd[i][1], pr, cg);
-            put_plane(Ah, Al, fa[i][0], fa[i][1], pr, cg);
+            put_plane(Dh, Dl, fd[i][0], fd[i][1], sd_run, pr, cg);
+            put_plane(Ah, Al, fa[i][0], fa[i][1], sa_run, pr, cg);
             if (do_bias) {
                 bsum[i].x += fd[i][0].x + fd[i][1].x; bsum[i].y += fd[i][0].y + fd[i][1].y;
                 bsum[i].z += fd[i][0].z + fd[i][1].z; bsum[i].w += fd[i][0].w + fd[i][1].w;
             }
         }
         __syncthreads();
-        if (m0 + TS_BM < m_end) fetch(m0 + TS_BM);        // the next slab travels during the products
+        const bool more = m0 + TS_BM < m_end;
+        if (more) fetch(m0 + TS_BM);        // the next slab travels during the products
 #pragma unroll
         for (int kk = 0; kk < TS_BM / 16; ++kk) {
             half8 ah[2], al[2], bh[2], bl[2];
@@ -263,13 +313,15 @@ __global__ __launch_bounds__(256) void k_gemm_tn_split(GemmTnJobs jobs) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    run[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], run[i][j], 0, 0, 0);
+                    run[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], run[i][j], 0, 0, 0);
+                    run[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], run[i][j], 0, 0, 0);
                 }
         }
+        if (more) publish_max(par ^ 1);     // (the other parity's partials were last read before this iteration's first barrier)
         __syncthreads();
     }
+    const float inv_run = pow2_inv(sd_run) * pow2_inv(sa_run);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -279,7 +331,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn_split(GemmTnJobs jobs) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = n0 + wn * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                if (n < J.N) unsafeAtomicAdd(J.dw + (size_t)n * J.K + k, acc[i][j][e]);
+                if (n < J.N) unsafeAtomicAdd(J.dw + (size_t)n * J.K + k, run[i][j][e] * inv_run);
             }
         }
     if (do_bias) {
@@ -585,6 +637,48 @@ int launch_layernorm_bwd(const float* x, const float* dy, const float* gamma, co
 }
 
 // ------------------------------------------------------------------------------------------
+// a-priori bound on |V'| (and |O|) of a stage from its weights: launch_v_bound (kernels.hpp)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_v_bound(const float* __restrict__ w_kv, const float* __restrict__ b_kv, const float* __restrict__ g,
+                                                 const float* __restrict__ be, int n_pairs, int n_types, int C, float* out) {
+    __shared__ float red[2][4];
+    // ||LayerNorm(x)||_2 <= sqrt(C) (max|gamma| + max|beta|): the normalised row has 2-norm sqrt(C) exactly
+    float gm = 0.f, bm = 0.f;
+    for (int i = threadIdx.x; i < n_types * C; i += 256) { gm = fmaxf(gm, fabsf(g[i])); bm = fmaxf(bm, fabsf(be[i])); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { gm = fmaxf(gm, __shfl_xor(gm, o, 64)); bm = fmaxf(bm, __shfl_xor(bm, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = gm; red[1][threadIdx.x >> 6] = bm; }
+    __syncthreads();
+    gm = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    bm = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    const float xn2 = sqrtf((float)C) * (gm + bm);
+    // one (V' matrix, head) block of 32 rows x C per wave at a time: Frobenius norm (>= the spectral norm) and the bias slice's 2-norm
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, heads = C / 32;
+    float best = 0.f;
+    for (int blk = blockIdx.x * 4 + wave; blk < n_pairs * heads; blk += gridDim.x * 4) {
+        const int pair = blk / heads, h = blk - pair * heads;
+        const float* w = w_kv + ((size_t)(pair * 2 + 1) * C + h * 32) * C;
+        float f2 = 0.f;
+        for (int k = lane; k < 32 * C; k += 64) f2 = fmaf(w[k], w[k], f2);
+        const float bv = lane < 32 ? b_kv[(size_t)(pair * 2 + 1) * C + h * 32 + lane] : 0.f;
+        float b2 = bv * bv;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { f2 += __shfl_xor(f2, o, 64); b2 += __shfl_xor(b2, o, 64); }
+        best = fmaxf(best, fmaf(sqrtf(f2), xn2, sqrtf(b2)) * 1.0001f);
+    }
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(best));      // non-negative floats order like their bits
+}
+
+int launch_v_bound(const float* w_kv, const float* b_kv, const float* ln_gamma, const float* ln_beta, int n_pairs, int n_types, int C,
+                   float* out, hipStream_t st) {
+    HMVIT_CHECK_ARG(w_kv && b_kv && ln_gamma && ln_beta && out, "v_bound: null pointer%s", "");
+    HMVIT_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float), st));
+    hipLaunchKernelGGL(k_v_bound, dim3(64), dim3(256), 0, st, w_kv, b_kv, ln_gamma, ln_beta, n_pairs, n_types, C, out);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // attention backward
 // ------------------------------------------------------------------------------------------
 // Same decomposition as k_attention<float>: one workgroup per (sample, ego, window, group of HG heads), one wavefront
@@ -657,6 +751,55 @@ __global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp)
     const float* kvplanes = reinterpret_cast<const float*>(p.kv);
 
     BWD_STAMP(0);
+    // ---- range of the gradient operands (round 5: no detect-and-retry) ----
+    // dO arrives at whatever magnitude the pass has reached.  The workgroup brings ITS 64 x CH tile of dO to rho sigma in [T, 2T) with
+    // powers of two sigma and T - rho = the largest 2-norm of a token's 32 channels of one head - and multiplies its results by
+    // 1 / sigma at the stores (the pass is linear in dO).  T comes from the stage's a-priori bound vb on the 2-norm of a head's slice
+    // of any V' row, hence of any O row (launch_v_bound: weights only): by Cauchy-Schwarz |dP| <= vb rho and |D| <= vb rho, so with
+    // T <= 2^13 / vb every dS = P o (dP - D) - the one DERIVED f16 operand - stays below 2^15 whatever the data.  T is capped at 2^9
+    // (the level the whole pass ran at before) and floored at 2^-10; with the shipped initialisation vb ~ 60 and T = 2^7.
+    float do_scale = 1.f;
+    {
+        float T = 512.f;
+        if (bp.v_bound) {
+            const float vb = fmaxf(*bp.v_bound, 1e-30f);
+            // power of two <= 2^13 / vb: exponent field arithmetic, then the clamps
+            const float lim = __uint_as_float(__float_as_uint(8192.f / vb) & 0x7f800000u);
+            T = fminf(512.f, fmaxf(lim, 0.0009765625f));
+        }
+        __shared__ float domax[THREADS / 64];
+        const int cl = (tid % TPK) * 8;
+        float m = 0.f;
+        for (int n = tid / TPK; n < N; n += KPP) {
+            int row, col;
+            token_pixel(p.partition, WIN, X, Y, wx, wy, n, row, col);
+            const float4* s4 = reinterpret_cast<const float4*>(doplane + (size_t)(row * W + col) * C + ch0 + cl);
+            const float4 a = s4[0], c4 = s4[1];
+            // this thread's 8 channels; the 4 threads of a head (lanes l, l ^ 1, l ^ 2, l ^ 3) complete the head's sum of squares.
+            // Scaled by the thread's own largest element first: squares of 1e-25 or 1e25 must not leave f32's range
+            const float am = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                                   fmaxf(fmaxf(fabsf(c4.x), fabsf(c4.y)), fmaxf(fabsf(c4.z), fabsf(c4.w))));
+            float hm = fmaxf(am, __shfl_xor(am, 1, 64));
+            hm = fmaxf(hm, __shfl_xor(hm, 2, 64));
+            const float sc = pow2_scale(hm);                        // the head slice's largest element -> [2^13, 2^14)
+            float q2 = 0.f;
+            q2 = fmaf(a.x * sc, a.x * sc, q2); q2 = fmaf(a.y * sc, a.y * sc, q2); q2 = fmaf(a.z * sc, a.z * sc, q2); q2 = fmaf(a.w * sc, a.w * sc, q2);
+            q2 = fmaf(c4.x * sc, c4.x * sc, q2); q2 = fmaf(c4.y * sc, c4.y * sc, q2); q2 = fmaf(c4.z * sc, c4.z * sc, q2); q2 = fmaf(c4.w * sc, c4.w * sc, q2);
+            q2 += __shfl_xor(q2, 1, 64);
+            q2 += __shfl_xor(q2, 2, 64);
+            m = fmaxf(m, sqrtf(q2) * pow2_inv(sc) * 1.0001f);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) domax[tid >> 6] = m;
+        __syncthreads();
+        m = domax[0];
+#pragma unroll
+        for (int w = 1; w < THREADS / 64; ++w) m = fmaxf(m, domax[w]);
+        // m = rho; pow2_scale brings it to [2^13, 2^14); T / 2^13 takes it to [T, 2T)
+        do_scale = pow2_scale(m) * (T * (1.f / 8192.f));
+    }
+    const float do_inv = pow2_inv(do_scale);
     // ---- query tile (+ bias), dO tile, D and lse ----
     {
         const float* bq = p.b_q + te * C + ch0;
@@ -666,11 +809,14 @@ __global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp)
             token_pixel(p.partition, WIN, X, Y, wx, wy, n, row, col);
             const size_t o = (size_t)(row * W + col) * C + ch0 + cl;
             half8 qh_, ql_, dh_, dl_;
+            float qv[8], dv8[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                split_h(qplane[o + e] + bq[cl + e], qh_[e], ql_[e]);
-                split_h(doplane[o + e], dh_[e], dl_[e]);
+                qv[e] = qplane[o + e] + bq[cl + e];
+                dv8[e] = doplane[o + e] * do_scale;
             }
+            split_pk8(qv, qh_, ql_);
+            split_pk8(dv8, dh_, dl_);
             *reinterpret_cast<half8*>(Qh + n * QS + cl) = qh_;
             *reinterpret_cast<half8*>(Ql + n * QS + cl) = ql_;
             *reinterpret_cast<half8*>(dOh + n * QS + cl) = dh_;
@@ -687,7 +833,7 @@ __global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp)
 #endif
 #pragma unroll 8
             for (int e = 0; e < 32; ++e) d = fmaf(doplane[o + e], oplane[o + e], d);
-            Dl[n][hh] = d;
+            Dl[n][hh] = d * do_scale;
             // kept times log2(e): the probabilities are rebuilt with v_exp_f32 (a base-2 exponential)
             Lse[n][hh] = p.lse[((size_t)(b * L + ego) * P + row * W + col) * heads + hg * HG + hh] * 1.4426950408889634f;
         }
@@ -774,11 +920,8 @@ __global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp)
                     }
                 }
                 half8 kh_, kl_, vh_, vl_;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    split_h(kvv[0][e], kh_[e], kl_[e]);
-                    split_h(kvv[1][e], vh_[e], vl_[e]);
-                }
+                split_pk8(kvv[0], kh_, kl_);
+                split_pk8(kvv[1], vh_, vl_);
                 *reinterpret_cast<half8*>(Kh + kk * KS + cl) = kh_;
                 *reinterpret_cast<half8*>(Kl + kk * KS + cl) = kl_;
                 *reinterpret_cast<half8*>(Vh + kk * KS + cl) = vh_;
@@ -795,11 +938,7 @@ __global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp)
 #endif
 
         if (any_visible) {
-            auto split4 = [](float a, float b, float c, float d, half4& h, half4& l) {
-                const float v[4] = {a, b, c, d};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) split_h(v[e], h[e], l[e]);
-            };
+            auto split4 = [](float a, float b, float c, float d, half4& h, half4& l) { split_pk4(a, b, c, d, h, l); };
             // rows row0 .. row0 + 3, column col0 + lq of a row-major f16 tile as one operand of v_mfma_f32_16x16x16_f16
             // (ds_read_b64_tr_b16: lane l of a 16-lane group points at row row0 + (l >> 2), columns col0 + 4 (l & 3) .. + 3 and
             // receives column l of the 4 x 16 block; tests/test_hip_ops.py::test_tr16_lane_mapping)
@@ -920,8 +1059,8 @@ __global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp)
                                      (size_t)(row * W + col) * C + head * 32 + lq_o;
 #pragma unroll
                         for (int dt = 0; dt < 2; ++dt) {
-                            dst[dt * 16] = dk_acc[dt][r];
-                            dst[(size_t)P * C + dt * 16] = dv_acc[dt][r];
+                            dst[dt * 16] = dk_acc[dt][r] * do_inv;
+                            dst[(size_t)P * C + dt * 16] = dv_acc[dt][r] * do_inv;
                         }
                     }
                 }
@@ -988,7 +1127,8 @@ __global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp)
         float* o = dqp + (size_t)(row * W + col) * C + head * 32 + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
-            *reinterpret_cast<float4*>(o + dt * 16) = make_float4(dq_acc[qt][dt][0], dq_acc[qt][dt][1], dq_acc[qt][dt][2], dq_acc[qt][dt][3]);
+            *reinterpret_cast<float4*>(o + dt * 16) = make_float4(dq_acc[qt][dt][0] * do_inv, dq_acc[qt][dt][1] * do_inv,
+                                                                   dq_acc[qt][dt][2] * do_inv, dq_acc[qt][dt][3] * do_inv);
     }
     BWD_STAMP(30);
     const int vbase = (WIN == 8) ? (khalf == 0 ? 2 : 0) : 0;
@@ -996,7 +1136,7 @@ __global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp)
     for (int v = 0; v < NBW; ++v)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (dbias[v][r] != 0.f) unsafeAtomicAdd(bp.d_bias_frag + ((size_t)(head * NB + vbase + v) * 64 + lane) * 4 + r, dbias[v][r]);
+            if (dbias[v][r] != 0.f) unsafeAtomicAdd(bp.d_bias_frag + ((size_t)(head * NB + vbase + v) * 64 + lane) * 4 + r, dbias[v][r] * do_inv);
 }
 
 template <int WIN, int HG>

@@ -95,8 +95,8 @@ def _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, 
     return t, keep
 
 
-# starting levels of the backward pass: max |d_out| is brought to [2^l, 2^(l + 1)); the next one is tried when a pass overflows
-BACKWARD_LEVELS = (9.0, 3.0, -3.0, -9.0, -15.0)
+# level of the backward pass: max |d_out| is brought to [2^l, 2^(l + 1)) at the entry (exact; every kernel picks its own operand scales after that)
+BACKWARD_LEVEL = 9.0
 
 
 class FusionTrainFunction(torch.autograd.Function):
@@ -134,17 +134,15 @@ class FusionTrainFunction(torch.autograd.Function):
         module, host, drop_p, seed, x, pw, neg, folded, saved = ctx.launch
         mode_h, rl_h, mask_h, only_stage = host
         d_out = d_out.detach().to(torch.float32).contiguous()
-        # The backward kernels form their products on split-f16 operands (x = hi + lo, two f16 halves): gradients of a real loss
-        # reach this point at 1e-4 ... 1e-7 (focal loss normalised by the positives), where the lo half falls under f16's
-        # 2^-24 floor.  The backward pass is LINEAR in d_out, so it runs on d_out 2^k (max |.| brought to [2^9, 2^10)) and every
-        # result is multiplied by 2^-k: exact, and independent of the scale of the loss.  No host synchronisation.
-        # What a single power of two cannot absorb is GROWTH inside the pass: behind FFN / mlp_head weights 30-100 x their usual size
-        # the gradients gain a factor 1e3-1e6 on their way down and leave f16's range (hi > 65504: Inf) in the weight-gradient and
-        # attention-backward products, which take their operands at their own scale (the per-token scaled x16 Linears
-        # do not care).  Such a pass is detected by its non-finite results (one reduction + one host read per backward) and
-        # repeated from a lower starting level, six binades at a time down to 2^-15 - still inside the range where the hi halves are
-        # normal numbers.  The saved activations are only read by the pass, so it can be repeated.
-        d_raw = d_out
+        # The backward kernels form their products on split-f16 operands (x = hi + lo, two f16 halves), and every one of them
+        # takes its operands at powers of two it picks itself, from the data it is about to multiply: k_linear16 per token row,
+        # k_gemm_tn_split / k_gemm_split per slab (the accumulator follows by exact rescaling), k_attention_bwd per workgroup for dO
+        # with a target derived from an a-priori bound on |V'| (the stage's weights, launch_v_bound) so that the one DERIVED operand,
+        # dS = P o (dP - D), cannot leave f16's range.  The pass is therefore in range a priori for gradients of any magnitude -
+        # including growth by 1e3 ... 1e6 INSIDE the pass behind large FFN weights, which round 4 detected afterwards (non-finite
+        # results, one host read per backward) and repaired by re-running the whole pass from a lower level.  One pass, no host
+        # synchronisation.  d_out is still brought to max |.| in [2^9, 2^10) first (exact; the pass is linear in d_out): it keeps
+        # the f32 intermediates of a 1e-7 loss away from the denormals.
         t, keep = _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, None, saved, None, only_stage)
         need = _lib.lib.hmvit_fusion_backward_workspace_bytes(ctypes.byref(t))
         if need == 0:
@@ -152,23 +150,18 @@ class FusionTrainFunction(torch.autograd.Function):
         ws = torch.empty(need, dtype=torch.uint8, device=x.device)
         n = len(STAGE_KEYS)
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        for level in BACKWARD_LEVELS:
-            d_out, unscale = _lib.grad_pow2(d_raw, level)
-            grads = [torch.zeros_like(f) for f in folded]
-            d_x = torch.empty_like(x)
-            sg = (_lib.StageGrads * 2)()
-            for s in range(2):
-                for i, k in enumerate(STAGE_KEYS):
-                    setattr(sg[s], k, grads[s * n + i].data_ptr())
-            hg = grads[2 * n:]
-            with torch.cuda.device(x.device):
-                _lib.check(_lib.lib.hmvit_fusion_backward(ctypes.byref(t), d_out.data_ptr(), d_x.data_ptr(), sg, hg[0].data_ptr(),
-                                                          hg[1].data_ptr(), hg[2].data_ptr(), hg[3].data_ptr(), ws.data_ptr(),
-                                                          ws.numel(), ctypes.c_void_p(stream)), "hmvit_fusion_backward")
-            probe = torch.stack(list(torch._foreach_norm(grads)) + [d_x.abs().max()])
-            if level == BACKWARD_LEVELS[-1] or bool(torch.isfinite(probe).all()) or not bool(torch.isfinite(d_raw).all()):
-                break
-            module.backward_retries = getattr(module, "backward_retries", 0) + 1
+        d_out, unscale = _lib.grad_pow2(d_out, BACKWARD_LEVEL)
+        grads = [torch.zeros_like(f) for f in folded]
+        d_x = torch.empty_like(x)
+        sg = (_lib.StageGrads * 2)()
+        for s in range(2):
+            for i, k in enumerate(STAGE_KEYS):
+                setattr(sg[s], k, grads[s * n + i].data_ptr())
+        hg = grads[2 * n:]
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib.hmvit_fusion_backward(ctypes.byref(t), d_out.data_ptr(), d_x.data_ptr(), sg, hg[0].data_ptr(),
+                                                      hg[1].data_ptr(), hg[2].data_ptr(), hg[3].data_ptr(), ws.data_ptr(),
+                                                      ws.numel(), ctypes.c_void_p(stream)), "hmvit_fusion_backward")
         ctx.launch = None
         d_x.mul_(unscale)
         for g in grads:

@@ -396,7 +396,9 @@ def test_backward_under_input_and_weight_scaling(case, xscale, wscale, C, w):
     and Linear weights far from unit scale (as tests/test_hip_range.py does for inference): forward and every gradient against the
     oracle's autograd in FLOAT64; a tensor is held to max(1e-3, 4 x the fp32 oracle's own distance from float64).  Both Linear
     paths: C = 64 (the generic split GEMM) and C = 256 (the x16 kernels with per-token scaling).  Weights x 30 make the gradients
-    grow past f16's range inside the pass: FusionTrainFunction.backward notices and repeats it from a lower level."""
+    grow by 1e3 - 1e6 inside the pass: every backward kernel scales its own operands (per token row / per slab / per workgroup with an
+    a-priori bound on |V'|), so the pass is in range a priori - round 4 detected the overflow afterwards and re-ran the pass; that
+    retry loop is gone and the module must not carry a retry counter any more."""
     L, H, W = 3, 16, 24
     cfg = O.make_config(C, w, L, voxel=0.4, downsample=4)
     sd = O.random_state_dict(cfg, seed=5)
@@ -420,8 +422,9 @@ def test_backward_under_input_and_weight_scaling(case, xscale, wscale, C, w):
     (y * gy.cuda()).sum().backward()
     assert torch.isfinite(x.grad).all()
     gx_noise = rel_max_err(gx32, gx_ref)
-    # weights x 30: the pass overflows at its usual level and is repeated 12 binades lower, where the low operand halves are f16
-    # subnormals - measured 1-4 x the fp32 oracle's own distance from float64 (2e-4 ... 7e-4 there): held to 8 x
+    # weights x 30: the logits reach 1e6 and the problem is ill-conditioned for ANY 24-bit arithmetic (the fp32 oracle itself is
+    # 2e-4 ... 7e-4 from float64 there).  A split operand carries 22 bits (hi + lo of 11 each, lo x lo dropped), four times
+    # coarser than fp32's 24: measured 2.5 ... 4.2 x the fp32 oracle's own distance - held to 8 x, as before
     k_noise = 8 if wscale > 1 else 4
     assert rel_max_err(x.grad.cpu(), gx_ref) < max(GRAD_TOL, k_noise * gx_noise), case
     worst = {}
@@ -437,5 +440,4 @@ def test_backward_under_input_and_weight_scaling(case, xscale, wscale, C, w):
           [(k.replace("hetero_fusion_block.", ""), f"{v:.1e}", f"{noise.get(k, 0):.1e}") for k, v in top])
     bad = {k: v for k, v in worst.items() if not v < max(GRAD_TOL, k_noise * noise.get(k, 0.0))}
     assert not bad, bad
-    if wscale > 1:
-        assert getattr(net, "backward_retries", 0) >= 1          # the overflow was met and handled, not avoided
+    assert not hasattr(net, "backward_retries")                  # one pass: nothing was detected-and-repeated
