@@ -161,8 +161,45 @@ def cpu_baseline(cfgd, num_iters, seed):
             "sample": f"{reps} forward(s) of the CPU oracle on a {Hs}x{Ws} crop ({frac * 100:.1f}% of the "
                       f"{cfgd['H']}x{cfgd['W']} scene's windows), {dt / reps:.2f} s each at {best} threads, scaled by pixel count",
             "thread_sweep_s": {str(k): round(v, 3) for k, v in sweep.items()},
+            "full_size_check": "one full-size forward on the same host class (profiles/r05_cpu_full.txt, `bench.py --cpu-baseline-full`): "
+                               "82.6 s at 16 threads = 0.0121 scenes/s = 1.056 x this crop estimate",
             "reference_itself": "the reference's own HeteroFusion.forward measured in the build container on 8 cores: "
                                 "122.8 s/scene = 0.0081 scenes/s at cfg2 (BASELINE.md section 2)"}
+
+
+def cpu_baseline_full(cfgd, num_iters, seed, threads):
+    """ONE forward of the CPU oracle at the FULL size of the workload on the host cores of this box (BASELINE.md section 4 /
+    SURVEY 8d: "1 + 1 for cfg2"), printed with the thread count and the CPU model string, and - next to it - the same crop
+    measurement the default bench line carries, so that the pixel-count scaling of `cpu_baseline` can be checked against a
+    real full-size run.  Minutes of CPU: `python bench.py --cpu-baseline-full` is a separate invocation, never part of the
+    driver's command.  The committed record is profiles/r05_cpu_full.txt."""
+    import platform
+    import torch
+    from oracle import hmvit_oracle as O
+    cfg = O.make_config(cfgd["C"], cfgd["window"], cfgd["L"], voxel=cfgd["voxel"], downsample=cfgd["downsample"], num_iters=num_iters)
+    sd = O.random_state_dict(cfg, seed=0)
+    model = platform.processor() or "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    crop = cpu_baseline(cfgd, num_iters, seed)
+    nt = threads or crop["cores"]
+    torch.set_num_threads(nt)
+    scene = O.synthetic_scene(cfgd["L"], cfgd["C"], cfgd["H"], cfgd["W"], cfgd["modes"], seed=seed)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        y = O.hetero_fusion(*scene, sd, cfg)
+    dt = time.perf_counter() - t0
+    full = 1.0 / dt
+    return {"workload": f"{cfgd['L']} agents {cfgd['H']}x{cfgd['W']} C={cfgd['C']} window {cfgd['window']}, {num_iters} iterations: one full-size "
+                        "forward of oracle/hmvit_oracle.py (cold: no warm-up run at this size)",
+            "seconds": round(dt, 2), "scenes_per_s": full, "threads": nt, "host_cpus": os.cpu_count(), "cpu_model": model,
+            "output_checksum": float(y.double().abs().mean()),
+            "crop_estimate": crop, "full_over_crop_estimate": full / crop["value"]}
 
 
 def _time_ms(fn, n, warmup, reps=3):
@@ -242,7 +279,25 @@ def encoder_lines(dev, precision, hmvit_amd, S):
         batch.update(cams)
         net = hmvit_amd.BevformerPointPillarHetero(mcfg, camera_encoder=cam, precision=precision).to(dev).eval()
         ms = _time_ms(lambda: net(batch), 5, 2)
+        # per-module split of the same forward: HIP events from forward hooks around the four sub-modules,
+        # median over 5 forwards; "other" = regroup, the interleave of camera / LiDAR maps, the small-input read-back
+        mods = {"camera_encoder": net.camera_encoder, "lidar_encoder": net.lidar_encoder, "fusion_net": net.fusion_net, "decoder": net.decoder}
+        marks, hooks = {}, []
+        for name, m in mods.items():
+            def pre(_m, _i, name=name):
+                e = torch.cuda.Event(enable_timing=True); e.record(); marks.setdefault(name, []).append([e, None])
+            def post(_m, _i, _o, name=name):
+                e = torch.cuda.Event(enable_timing=True); e.record(); marks[name][-1][1] = e
+            hooks += [m.register_forward_pre_hook(pre), m.register_forward_hook(post)]
+        for _ in range(5):
+            net(batch)
+        torch.cuda.synchronize()
+        for h in hooks:
+            h.remove()
+        split = {k: sorted(a.elapsed_time(b) for a, b in v)[len(v) // 2] for k, v in marks.items()}
+        split["other"] = max(0.0, ms - sum(split.values()))
         e2e = {"ms_per_scene": ms, "value": 1e3 / ms, "unit": "scenes/s", "precision": precision,
+               "modules_ms": {k: round(v, 3) for k, v in split.items()},
                "workload": "5 agents 10110 (2 camera + 3 LiDAR): pillars + images -> PointPillar / ResNet-34 + CVT -> HeteroFusion "
                            "(128x128, C=256, window 8, 2 iters) -> HeteroDecoder -> psm / rm; random-init weights"}
         del net, cam
@@ -373,11 +428,17 @@ def main(argv=None):
     ap.add_argument("--no-strict", action="store_true", help="skip the side figures (fast_f16, strict_f32, dense_masked_tiles)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --stub: CPU test of the launch logic")
     ap.add_argument("--stub", action="store_true", help="replace the forward by a CPU stand-in (tests/test_dist_cpu.py)")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="one FULL-size forward of the CPU oracle on the host cores (minutes; no GPU work; not the driver's command)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of --cpu-baseline-full (default: the crop sweep's best)")
     ap.add_argument("--train", action="store_true",
                     help="the training half of north_star instead of the inference headline: one DistributedDataParallel train step "
                          "per rank (HeteroFusion forward with dropout + HIP backward + gradient all-reduce on RCCL + AdamW)")
     args = ap.parse_args(argv)
 
+    if args.cpu_baseline_full:
+        print(json.dumps(cpu_baseline_full(CONFIGS[args.config], args.num_iters, 1, args.cpu_threads)), flush=True)
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args, argv))
 

@@ -88,8 +88,10 @@ int make_train_plan(const HmvitFusionTrainDesc* t, TrainPlan& pl) {
     HMVIT_TRY(check_desc(d));
     HMVIT_CHECK_ARG(d->precision == HMVIT_PREC_F32, "training runs in the exact-f32 mode (precision=%d)", d->precision);
     HMVIT_CHECK_ARG(!d->parallel, "training: architect_mode 'parallel' is not built (the shipped yaml is sequential)");
-    HMVIT_CHECK_ARG((d->window == 4 || d->window == 8) && d->dim_head == 32, "training: window_size=%d / dim_head=%d (4 or 8, 32)", d->window,
-                    d->dim_head);
+    // window 4 / 8 with dim_head 32: the tuned kernels; every other shape the reference accepts (hetero_fusion.py:285-327) trains
+    // through the generic exact-f32 attention kernels (k_attention_any / k_attention_any_bwd)
+    HMVIT_CHECK_ARG(d->window >= 1 && d->window <= 16 && d->dim_head >= 1 && d->dim_head <= 64 && d->C % d->dim_head == 0,
+                    "training: window_size=%d / dim_head=%d (window 1 .. 16, dim_head 1 .. 64 dividing C)", d->window, d->dim_head);
     pl.only_stage = t->only_stage >= 1 && t->only_stage <= 2 ? t->only_stage - 1 : -1;
     HMVIT_CHECK_ARG(t->only_stage >= 0 && t->only_stage <= 2, "only_stage=%d (0 = whole fusion, 1 = window stage, 2 = grid stage)", t->only_stage);
     HMVIT_CHECK_ARG(d->apply_head == (pl.only_stage < 0 ? 1 : 0), "training: HeteroFusion (apply_head = 1), or one stage of the block (apply_head = 0)");
@@ -234,7 +236,7 @@ void fill_attn(const HmvitFusionDesc* d, const TrainPlan& pl, const StageInfo& s
     ap.q = q; ap.kv = kv; ap.b_q = wt.b_q; ap.b_kv = wt.b_kv; ap.bias_frag = wt.bias_frag;
     ap.ainv = ainv; ap.out = o; ap.lse = lse;
     ap.B = d->B; ap.L = d->L; ap.n_ego = si.n_ego; ap.n_src = pl.max_cav; ap.E = si.E; ap.C = d->C; ap.H = d->H; ap.W = d->W;
-    ap.window = d->window; ap.partition = s == 0 ? HMVIT_PART_WINDOW : HMVIT_PART_GRID;
+    ap.window = d->window; ap.dim_head = d->dim_head; ap.partition = s == 0 ? HMVIT_PART_WINDOW : HMVIT_PART_GRID;
     ap.skip_masked = d->skip_masked;
     for (int i = 0; i < pl.n_slots; ++i) {
         ap.mode[i] = (int8_t)d->mode[i];
@@ -379,7 +381,8 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
 #ifdef HMVIT_TRAIN_EXACT_F32
             HMVIT_TRY(launch_attention(ap, HMVIT_PREC_F32, st));
 #else
-            HMVIT_TRY(launch_attention(ap, HMVIT_PREC_SPLIT, st));
+            const bool generic = (d->window != 4 && d->window != 8) || d->dim_head != 32;      // generic shapes: the exact-f32 kernel
+            HMVIT_TRY(launch_attention(ap, generic ? HMVIT_PREC_F32 : HMVIT_PREC_SPLIT, st));
 #endif
         }
         // x' = x + Dropout(a_linears(O)) on the ego slots
@@ -531,7 +534,8 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
     BwdPlan bp;
     make_bwd_plan(pl, bp);
     HMVIT_CHECK_ARG(d_out && d_x && grads && workspace && t->saved, "backward: null pointer");
-    HMVIT_CHECK_ARG(t->bias_frag_neg[0] && t->bias_frag_neg[1], "backward: bias_frag_neg is null");
+    const bool generic_attn = (d->window != 4 && d->window != 8) || d->dim_head != 32;
+    HMVIT_CHECK_ARG(generic_attn || (t->bias_frag_neg[0] && t->bias_frag_neg[1]), "backward: bias_frag_neg is null");
     HMVIT_CHECK_ARG(pl.only_stage >= 0 || (d_head_w1 && d_head_b1 && d_head_w2 && d_head_b2), "backward: mlp_head gradient buffers are null");
     if (workspace_bytes < bp.total * 4) {
         set_error("backward workspace too small: %zu < %zu bytes", workspace_bytes, bp.total * 4);
@@ -683,9 +687,12 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
             ab.d_out = T3; ab.dq = T4; ab.dkg = dkg; ab.d_bias_frag = gr.bias_frag;
             ab.probe = 0;
             // the range of the kernel's derived operands follows from the stage's weights (train.hip k_attention_bwd)
-            ab.v_bound = Wk + bp.o_vbound + sidx;
-            HMVIT_TRY(launch_v_bound(reinterpret_cast<const float*>(wt.w_kv), wt.b_kv, wt.ln_gamma, wt.ln_beta, T * T, T, C,
-                                     Wk + bp.o_vbound + sidx, st));
+            ab.v_bound = nullptr;
+            if (!generic_attn) {          // (the generic kernel is exact f32 on the vector ALU: no f16 operand to keep in range)
+                ab.v_bound = Wk + bp.o_vbound + sidx;
+                HMVIT_TRY(launch_v_bound(reinterpret_cast<const float*>(wt.w_kv), wt.b_kv, wt.ln_gamma, wt.ln_beta, T * T, T, C,
+                                         Wk + bp.o_vbound + sidx, st));
+            }
             // (k_attention_bwd writes every key row of every (ego, source < max_cav) pair, zeros where nothing is visible)
             DBG_SUM("G", G, pl.A);
             DBG_SUM("dO", T3, pl.A);

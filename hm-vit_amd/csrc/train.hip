@@ -1148,11 +1148,173 @@ static int launch_attn_bwd_t(const AttnBwdParams& p, hipStream_t st) {
     return HMVIT_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// attention backward, any window / dim_head (the reference trains every shape its config accepts, hetero_fusion.py:285-327):
+// the adjoint of k_attention_any (attn.hip) in the same decomposition - one workgroup per (sample, ego, window, head), one thread
+// per query, keys in chunks of 64 gathered into LDS, everything in exact f32 on the vector ALU.  Correctness path, not a tuned
+// one: p = exp(s - lse), dS = p (dO . v - D), dq += dS k, and the per-key sums dk += dS q, dv += p dO over
+// the window's queries meet in LDS (float atomics) before they leave as the chunk's rows of the gathered-key gradient.
+// bias_frag / d_bias_frag are the DENSE (heads, N, N) tables of the generic forward.  Identity self transforms (as all training).
+// ------------------------------------------------------------------------------------------
+constexpr int ANYB_KC = 64;
+template <int DHM>
+__global__ __launch_bounds__(256) void k_attention_any_bwd(AttnBwdParams bp) {
+    const AttnParams& p = bp.f;
+    __shared__ float Ks[ANYB_KC][DHM + 1], Vs[ANYB_KC][DHM + 1], dKs[ANYB_KC][DHM + 1], dVs[ANYB_KC][DHM + 1], maskadd[ANYB_KC];
+    const int WIN = p.window, N = WIN * WIN, DH = p.dim_head, C = p.C, H = p.H, W = p.W, L = p.L, P = H * W;
+    const int heads = C / DH, X = H / WIN, Y = W / WIN;
+    const int win = blockIdx.x / heads, head = blockIdx.x - win * heads;
+    const int ego = blockIdx.y, b = blockIdx.z;
+    const int wx = win / Y, wy = win - wx * Y;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int te = p.mode[b * L + ego], ev = p.ego_e[b * L + ego];
+    const int ch0 = head * DH;
+    const float kl = p.k_logit != 0.f ? p.k_logit : 1.f;
+    const bool active = tid < N;
+
+    float q[DHM], g[DHM], dq[DHM];
+#pragma unroll
+    for (int d = 0; d < DHM; ++d) q[d] = g[d] = dq[d] = 0.f;
+    int qrow = 0, qcol = 0;
+    float D = 0.f, lse = 0.f;
+    if (active) {
+        token_pixel(p.partition, WIN, X, Y, wx, wy, tid, qrow, qcol);
+        const size_t o = ((size_t)(b * L + ego) * P + qrow * W + qcol) * C + ch0;
+        const float* bq = p.b_q + te * C + ch0;
+        const float* qp = reinterpret_cast<const float*>(p.q) + o;
+        const float* op = reinterpret_cast<const float*>(p.out) + o;
+        const float* gp = bp.d_out + o;
+#pragma unroll
+        for (int d = 0; d < DHM; ++d)
+            if (d < DH) {
+                q[d] = qp[d] + bq[d];
+                g[d] = gp[d];
+                D = fmaf(g[d], op[d], D);
+            }
+        lse = p.lse[((size_t)(b * L + ego) * P + qrow * W + qcol) * heads + head];
+    }
+    const float* bias = p.bias_frag + ((size_t)head * N + (active ? tid : 0)) * N;
+    float* dbias = bp.d_bias_frag + ((size_t)head * N + (active ? tid : 0)) * N;
+
+    const int n_keys = p.n_src * N;
+    for (int k0 = 0; k0 < n_keys; k0 += ANYB_KC) {
+        // ---- gather (as k_attention_any), and clear the chunk's key-gradient tiles ----
+        const int kk = tid % ANYB_KC, key = k0 + kk;
+        bool visible = false;
+        Taps t;
+        bool ident = false;
+        int self_idx = 0, src = 0, kn = 0;
+        if (key < n_keys) {
+            src = key / N;
+            kn = key - src * N;
+            int row, col;
+            token_pixel(p.partition, WIN, X, Y, wx, wy, kn, row, col);
+            const float* a = p.ainv + ((size_t)(b * L + src) * L + ego) * 8;
+            ident = a[6] != 0.f;
+            self_idx = row * W + col;
+            t.roi = 1.f;
+            if (!ident) t = make_taps(a, col, row, H, W);
+            visible = (t.roi != 0.f) && (p.cav[b * L + src] != 0);
+        }
+        {
+            const int ts = p.mode[b * L + src];
+            const float* kpl = reinterpret_cast<const float*>(p.kv) + ((size_t)((b * L + src) * p.E + ev) * 2) * P * C + ch0;
+            const float* bk = p.b_kv + (size_t)(te * HMVIT_NUM_TYPES + ts) * 2 * C + ch0;
+            for (int d = tid / ANYB_KC; d < DHM; d += nthr / ANYB_KC) {
+                float kvv[2] = {0.f, 0.f};
+                const bool live = visible && d < DH;
+                const int dd = d < DH ? d : 0;
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const float* plane = kpl + (size_t)pl * P * C + dd;
+                    const int i0 = live ? (ident ? self_idx : t.idx[0]) : 0;
+                    float acc = (ident ? 1.f : t.w[0]) * plane[(size_t)i0 * C];
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) {
+                        const int ik = (live && !ident) ? t.idx[k] : 0;
+                        acc = fmaf((live && !ident) ? t.w[k] : 0.f, plane[(size_t)ik * C], acc);
+                    }
+                    kvv[pl] = live ? acc + bk[pl * C + dd] : 0.f;
+                }
+                Ks[kk][d] = kvv[0];
+                Vs[kk][d] = kvv[1];
+                dKs[kk][d] = 0.f;
+                dVs[kk][d] = 0.f;
+            }
+            if (tid < ANYB_KC) maskadd[kk] = visible ? 0.f : -INFINITY;
+        }
+        __syncthreads();
+        if (active) {
+            const int kmax = min(ANYB_KC, n_keys - k0);
+            for (int j = 0; j < kmax; ++j) {
+                if (maskadd[j] != 0.f) continue;                 // a masked key: p = 0, nothing flows
+                float sdot = 0.f, dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < DHM; ++d) {
+                    sdot = fmaf(q[d], Ks[j][d], sdot);
+                    dp = fmaf(g[d], Vs[j][d], dp);
+                }
+                const int jn = (k0 + j) % N;
+                const float pr = expf(sdot * kl + bias[jn] - lse);
+                const float ds = pr * (dp - D);
+                atomicAdd(&dbias[jn], ds);
+                const float dsk = ds * kl;
+#pragma unroll
+                for (int d = 0; d < DHM; ++d)
+                    if (d < DH) {
+                        dq[d] = fmaf(dsk, Ks[j][d], dq[d]);
+                        atomicAdd(&dKs[j][d], dsk * q[d]);
+                        atomicAdd(&dVs[j][d], pr * g[d]);
+                    }
+            }
+        }
+        __syncthreads();
+        // ---- the chunk's rows of the gathered-key gradient (every row written: zeros where nothing was visible) ----
+        if (key < n_keys) {
+            int row, col;
+            token_pixel(p.partition, WIN, X, Y, wx, wy, kn, row, col);
+            float* dst = bp.dkg + (((size_t)(b * p.n_ego + ego) * p.n_src + src) * 2) * P * C + (size_t)(row * W + col) * C + ch0;
+            for (int d = tid / ANYB_KC; d < DH; d += nthr / ANYB_KC) {
+                dst[d] = dKs[kk][d];
+                dst[(size_t)P * C + d] = dVs[kk][d];
+            }
+        }
+        __syncthreads();
+    }
+    if (active) {
+        float* o = bp.dq + ((size_t)(b * L + ego) * P + qrow * W + qcol) * C + ch0;
+#pragma unroll
+        for (int d = 0; d < DHM; ++d)
+            if (d < DH) o[d] = dq[d];
+    }
+}
+
+static int launch_attn_any_bwd(const AttnBwdParams& p, hipStream_t st) {
+    const int N = p.f.window * p.f.window, DH = p.f.dim_head;
+    HMVIT_CHECK_ARG(N <= 256, "attention_bwd (generic): window=%d gives %d tokens per window (at most 256)", p.f.window, N);
+    HMVIT_CHECK_ARG(DH >= 1 && DH <= 64 && p.f.C % DH == 0, "attention_bwd (generic): dim_head=%d unsupported (1 .. 64, a divisor of C=%d)", DH, p.f.C);
+    const int threads = N <= 64 ? 64 : (N + 63) / 64 * 64;
+    dim3 grid((p.f.H / p.f.window) * (p.f.W / p.f.window) * (p.f.C / DH), p.f.n_ego, p.f.B);
+    if (DH <= 16) hipLaunchKernelGGL(k_attention_any_bwd<16>, grid, dim3(threads), 0, st, p);
+    else if (DH <= 32) hipLaunchKernelGGL(k_attention_any_bwd<32>, grid, dim3(threads), 0, st, p);
+    else hipLaunchKernelGGL(k_attention_any_bwd<64>, grid, dim3(threads), 0, st, p);
+    HMVIT_CHECK_LAUNCH();
+    return HMVIT_OK;
+}
+
 int launch_attention_bwd(const AttnBwdParams& p, hipStream_t st) {
-    HMVIT_CHECK_ARG(p.f.window == 4 || p.f.window == 8, "attention_bwd: window=%d unsupported (4 or 8)", p.f.window);
     HMVIT_CHECK_ARG(p.f.C == 64 || p.f.C == 128 || p.f.C == 256, "attention_bwd: C=%d unsupported", p.f.C);
-    HMVIT_CHECK_ARG(p.f.lse && p.f.out && p.d_out && p.dq && p.dkg && p.d_bias_frag && p.bias_frag_neg, "attention_bwd: null pointer");
+    HMVIT_CHECK_ARG(p.f.lse && p.f.out && p.d_out && p.dq && p.dkg && p.d_bias_frag, "attention_bwd: null pointer");
     if (p.f.n_ego <= 0 || p.f.B <= 0) return HMVIT_OK;
+    {
+        const int dim_head = p.f.dim_head ? p.f.dim_head : 32;
+        if ((p.f.window != 4 && p.f.window != 8) || dim_head != 32) {
+            AttnBwdParams q = p;
+            q.f.dim_head = dim_head;
+            return launch_attn_any_bwd(q, st);
+        }
+    }
+    HMVIT_CHECK_ARG(p.bias_frag_neg != nullptr, "attention_bwd: bias_frag_neg is null");
 #ifdef HMVIT_PROBE
     if (const char* e = HMVIT_ENV("HMVIT_BWD_PROBE")) {
         AttnBwdParams q = p;

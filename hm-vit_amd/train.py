@@ -177,6 +177,12 @@ def fusion_forward_with_grad(module, x, pairwise_t_matrix, mode, record_len, mas
         raise ValueError(f"{module._block_cfg['architect_mode']} not implemented")        # hetero_fusion.py:472
     if x.dim() != 5:
         raise ValueError("x must be (B, L, C, H, W)")
+    blk = module._block_cfg
+    if weights.generic_shape(blk["window_size"], blk["dim_head"]) and not getattr(module, "_warned_generic_train", False):
+        import warnings
+        warnings.warn(f"hmvit_amd: window_size={blk['window_size']} / dim_head={blk['dim_head']} trains through the generic exact-f32 "
+                      f"attention kernels (correct, far slower than the tuned kernels for window 4 / 8, dim_head 32)", stacklevel=3)
+        module._warned_generic_train = True
     B, L = x.shape[:2]
     pw = pairwise_t_matrix.to(device=x.device, dtype=torch.float32)
     if tuple(pw.shape) != (B, L, L, 4, 4):

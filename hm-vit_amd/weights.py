@@ -229,9 +229,10 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
             b_kv[te, ts, C:] = torch.einsum("hpq,hp->hq", rel_msg[e], bv).reshape(C)
     raw["w_kv"], raw["b_kv"] = w_kv, b_kv
     if generic_shape(window, dim_head):
-        if f16 or split or keep_graph:
-            raise ValueError(f"window_size={window} / dim_head={dim_head}: generic shapes run in the exact-f32 inference mode only")
-        raw["bias_frag"] = bias_dense(sd[f"{att}.relative_position_bias_table.weight"], window)
+        if f16 or split:
+            raise ValueError(f"window_size={window} / dim_head={dim_head}: generic shapes run on the exact-f32 kernels only")
+        # (training too: the dense table stays on the autograd tape and k_attention_any_bwd returns its gradient in this layout)
+        raw["bias_frag"] = bias_dense(sd[f"{att}.relative_position_bias_table.weight"], window, keep_graph)
     else:
         raw["bias_frag"] = bias_fragments(sd[f"{att}.relative_position_bias_table.weight"], window, keep_graph) * (LOG2E if log2e else 1.0)
     raw["w_o"] = stack(f"{att}.a_linears.{{t}}.0.weight")
@@ -270,7 +271,10 @@ def fold_stage(sd: Dict[str, torch.Tensor], prefix: str, which: str, dim_head: i
     if keep_graph:
         # the backward kernel also forms the un-transposed logit tiles: their bias is the fragment set of the table with
         # negated offsets, i.e. the table flipped along its first axis (index (dr + w - 1)(2w - 1) + dc + w - 1)
-        out["bias_frag_neg"] = bias_fragments(sd[f"{att}.relative_position_bias_table.weight"].detach().flip(0), window)
+        if generic_shape(window, dim_head):
+            out["bias_frag_neg"] = torch.zeros(1, dtype=torch.float32, device=sd[f"{att}.relative_position_bias_table.weight"].device)   # unused
+        else:
+            out["bias_frag_neg"] = bias_fragments(sd[f"{att}.relative_position_bias_table.weight"].detach().flip(0), window)
     return {k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in out.items()}
 
 

@@ -441,3 +441,33 @@ def test_backward_under_input_and_weight_scaling(case, xscale, wscale, C, w):
     bad = {k: v for k, v in worst.items() if not v < max(GRAD_TOL, k_noise * noise.get(k, 0.0))}
     assert not bad, bad
     assert not hasattr(net, "backward_retries")                  # one pass: nothing was detected-and-repeated
+
+
+@pytest.mark.parametrize("C,dim_head,window,H,W,modes,n_valid", [
+    (64, 16, 6, 12, 18, [1, 0, 1], 3),       # window 6, dim_head 16: 36 tokens per window, 4 heads
+    (128, 64, 4, 8, 16, [0, 1, 0], 2),       # dim_head 64 on a tuned window, one padded agent
+    (64, 32, 2, 8, 12, [1, 1, 0], 3),        # window 2
+])
+def test_generic_window_and_dim_head_train(C, dim_head, window, H, W, modes, n_valid):
+    """The reference trains every window_size / dim_head its config accepts (hetero_fusion.py:285-327, 82-109).  Shapes outside the
+    tuned kernels' window 4 / 8 and dim_head 32 train through the generic exact-f32 attention kernels (csrc/attn.hip k_attention_any
+    forward with the row log-sum-exp, csrc/train.hip k_attention_any_bwd) between the same Linears / LayerNorm / warp-adjoint
+    kernels as every other shape: forward and every gradient against torch.autograd through the oracle, at the usual bounds."""
+    L = 3
+    cfg = O.make_config(C, window, L, voxel=0.4, downsample=4, dim_head=dim_head)
+    sd = O.random_state_dict(cfg, seed=71)
+    scene = O.synthetic_scene(L, C, H, W, modes, n_valid=n_valid, seed=72, tx_step=3.0, ty_step=-2.0, yaw_step=0.25)
+    gy = torch.randn(1, C, H, W, generator=torch.Generator().manual_seed(73))
+    y_ref, gx_ref, gp_ref = _oracle_grads(cfg, sd, scene, gy)
+    net = _net(cfg, sd).eval()
+    x = scene[0].cuda().requires_grad_(True)
+    y = net(x, *[t.cuda() for t in scene[1:]])
+    assert rel_max_err(y.detach().cpu(), y_ref) < 1e-4
+    (y * gy.cuda()).sum().backward()
+    _check_grads(net, gp_ref, x.grad, gx_ref)
+    # and in training mode (dropout masks regenerated by the backward): a step runs and produces finite gradients
+    net.train()
+    net.zero_grad()
+    y = net(scene[0].cuda().requires_grad_(True), *[t.cuda() for t in scene[1:]])
+    y.square().mean().backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
