@@ -1724,8 +1724,7 @@ __device__ __forceinline__ void pcs2_loader_loop(const AttnParams& p, PcShared2&
         const float4 bK = *reinterpret_cast<const float4*>(&sm.bkv[G.tsel][0][cl]);
         const float4 bV = *reinterpret_cast<const float4*>(&sm.bkv[G.tsel][1][cl]);
         const float mk = sm.tmask[G.par][lw][G.slot][lane & 15];
-        auto blend_pass = [&](int pass) {
-            __builtin_amdgcn_sched_barrier(0);
+        auto blend_body = [&](int pass) {
             const int kk = pass * KPP + kin;
 #ifndef HMVIT_EXP_PCS_NOLOADER
             float k4[4];
@@ -1741,25 +1740,25 @@ __device__ __forceinline__ void pcs2_loader_loop(const AttnParams& p, PcShared2&
 #else
             if (k4[0] == 1.2345f) store_split4(sm.Vh[G.buf] + kk * VS + cl, sm.Vl[G.buf] + kk * VS + cl, k4);
 #endif
-            __builtin_amdgcn_sched_barrier(0);
 #endif
         };
-        auto request_pass = [&](int pass) {
+        auto request_body = [&](int pass) {
 #ifndef HMVIT_EXP_PCS_NOLOADER
-            PC2_TRACE(1, lw == 0 && lane == 0, g, 1 + 2 * pass);
             request(pass, N, ixn[pass]);
+#endif
+        };
+        // Measured and dropped (round 5, same-box A/B): the 8 tap requests of pass p - 1 issued one by one between the vector
+        // instructions of the blend of pass p (scheduling groups of 1 request + 5 VALU) instead of back to back behind their own
+        // blend - 5.32 against 5.35 ms for the four launches: the vector-memory queue is not what a pass waits for.
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
+            __builtin_amdgcn_sched_barrier(0);
+            blend_body(pass);
+            __builtin_amdgcn_sched_barrier(0);
+            PC2_TRACE(1, lw == 0 && lane == 0, g, 1 + 2 * pass);
+            request_body(pass);
             PC2_TRACE(1, lw == 0 && lane == 0, g, 2 + 2 * pass);
             __builtin_amdgcn_sched_barrier(0);
-#endif
-        };
-        // (measured and dropped, round 5: loader waves 2, 3 requesting one pass later than waves 0, 1 so that one pair's tap
-        // requests meet the other pair's blend - the two orders in one loop make hipcc drain vmcnt at the join: 3.6 x slower)
-        {
-#pragma unroll
-            for (int pass = 0; pass < NP; ++pass) {
-                blend_pass(pass);
-                request_pass(pass);
-            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (lane < 9) {
