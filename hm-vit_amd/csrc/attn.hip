@@ -1865,6 +1865,7 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the block is in registers before its LDS rows are requested again
             __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(0);        // (raised for the epilogue of the item before: the whole item boundary runs at the loaders' level)
             PC2_TRACE(0, hl == 0 && lane == 0, gstep, 8);
 #else
             for (int qt = 0; qt < 4; ++qt) { m_run[qt] = -INFINITY; l_acc[qt] = (float4v)(0.f); o_acc[qt][0] = (float4v)(0.f); o_acc[qt][1] = (float4v)(0.f); qhh[qt] = ones; qhl[qt] = ones; }
@@ -2008,7 +2009,7 @@ __device__ __forceinline__ void pcs2_compute_loop(const AttnParams& p, PcShared2
                     if (p.lse && g == 0)
                         p.lse[((size_t)(it.b * L + it.ego) * P + row * W + col) * (C / 32) + head] = m_run[qt] * 0.6931471805599453f + logf(l_acc[qt][0]);
                 }
-                __builtin_amdgcn_s_setprio(0);
+                // (the raised priority is kept across the item boundary: back to 0 behind the next item's query conversion)
             }
             if (dyn && hl == 0 && !drawn) pcs2_publish(p, seq, sm.items, X, Y, NG, ego_fastest, hops, n_items, lane);
             drawn = true;
