@@ -1612,22 +1612,39 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
 
         // ---- phase 1: x' = x + b_o + W_o . O, two 16-channel tiles per chunk ----
         if constexpr (OUTPROJ) {
+            // The two row tiles of chunk c are a run-time index into xacc in a rolled loop: one select per register of xacc and
+            // iteration (64 selects per step, ~1300 of a step's 4500 cycles in the round-5 trace, against 3150 for an FFN step).
+            // Unrolled HMVIT_X16_OUT_UNROLL chunks per iteration the selects are paid once per iteration; fully unrolled (8) the
+            // kernel spills 20 registers (measured slower).
+#ifndef HMVIT_X16_OUT_UNROLL
+#define HMVIT_X16_OUT_UNROLL 2
+#endif
+            constexpr int OU = HMVIT_X16_OUT_UNROLL;
+            static_assert(N_OUT % OU == 0, "out-projection unroll");
 #pragma unroll 1
-            for (int c = 0; c < N_OUT; ++c) {
-                step_begin();
-                float4v acc[2];                                          // starts from b_o / c_o (pre-divided on the host)
+            for (int c0 = 0; c0 < N_OUT; c0 += OU) {
+                float4v upd[OU][2];
 #pragma unroll
-                for (int T = 0; T < 2; ++T) acc[T] = *reinterpret_cast<const float4v*>(&vec[0][32 * c + 16 * T + 4 * g]);
-                mma_proj16<!A16>(acc, slot(cc), ah, al, lane);          // f16 attention output: exact operand, no lo half
-                products_end(false);
-                // (the row tiles of chunk c are a run-time index into xacc: 64 selects per step.  Unrolling the loop removes them
-                // and costs 20 spilled registers - measured slower)
-                acc[0] *= c_o;
-                acc[1] *= c_o;
+                for (int u = 0; u < OU; ++u) {
+                    const int c = c0 + u;
+                    step_begin();
+                    float4v acc[2];                                          // starts from b_o / c_o (pre-divided on the host)
 #pragma unroll
-                for (int t = 0; t < 8; ++t)
-                    if (t == c) { xacc[2 * t] += acc[0]; xacc[2 * t + 1] += acc[1]; }
-                step_end(false);
+                    for (int T = 0; T < 2; ++T) acc[T] = *reinterpret_cast<const float4v*>(&vec[0][32 * c + 16 * T + 4 * g]);
+                    mma_proj16<!A16>(acc, slot(cc), ah, al, lane);          // f16 attention output: exact operand, no lo half
+                    products_end(false);
+                    upd[u][0] = acc[0] * c_o;
+                    upd[u][1] = acc[1] * c_o;
+                    if (u == OU - 1) {
+#pragma unroll
+                        for (int t0 = 0; t0 < 8; t0 += OU)
+                            if (t0 == c0) {
+#pragma unroll
+                                for (int v = 0; v < OU; ++v) { xacc[2 * (t0 + v)] += upd[v][0]; xacc[2 * (t0 + v) + 1] += upd[v][1]; }
+                            }
+                    }
+                    step_end(false);
+                }
             }
         }
         if constexpr (LN) ln_to_operands16(xacc, vec[1], vec[2], g, ah, al);
