@@ -181,6 +181,27 @@ __device__ __forceinline__ void swap32_rows(float& a, float& b) {
     a = __builtin_bit_cast(float, r0);
     b = __builtin_bit_cast(float, r1);
 }
+// max over the 64 lanes of a wavefront, in every lane, of non-negative floats taken as their bit patterns (they order like unsigned
+// integers): four DPP steps inside the rows of 16 lanes, two row swaps across them - no LDS round trips (six ds_bpermute with
+// __shfl_xor), no canonicalising v_max pairs
+__device__ __forceinline__ unsigned wave_umax(unsigned u) {
+    u = max(u, (unsigned)__builtin_amdgcn_update_dpp((int)u, (int)u, 0xB1, 0xF, 0xF, false));      // quad_perm [1, 0, 3, 2]
+    u = max(u, (unsigned)__builtin_amdgcn_update_dpp((int)u, (int)u, 0x4E, 0xF, 0xF, false));      // quad_perm [2, 3, 0, 1]
+    u = max(u, (unsigned)__builtin_amdgcn_update_dpp((int)u, (int)u, 0x141, 0xF, 0xF, false));     // row_half_mirror
+    u = max(u, (unsigned)__builtin_amdgcn_update_dpp((int)u, (int)u, 0x140, 0xF, 0xF, false));     // row_mirror
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        u = max(r0, r1);
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        u = max(r0, r1);
+    }
+    return u;
+}
+__device__ __forceinline__ float wave_absmax(float m) { return __uint_as_float(wave_umax(__float_as_uint(m))); }   // m >= 0
 __device__ __forceinline__ float max_raw(float a, float b) {   // v_max_f32 without the canonicalising max(x, x) pair
     float m;
     asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));

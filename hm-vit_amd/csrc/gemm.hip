@@ -198,8 +198,7 @@ __device__ __forceinline__ float slab_absmax(const float4 (&f)[8], float* partia
     float m = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) m = fmaxf(m, fmaxf(fmaxf(fabsf(f[i].x), fabsf(f[i].y)), fmaxf(fabsf(f[i].z), fabsf(f[i].w))));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    m = wave_absmax(m);
     if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = m;
     __syncthreads();
     m = fmaxf(fmaxf(partial[0], partial[1]), fmaxf(partial[2], partial[3]));

@@ -228,19 +228,16 @@ __global__ __launch_bounds__(256) void k_gemm_tn_split(GemmTnJobs jobs) {
     };
     // max |.| of the slab in this thread's registers -> the wave's partial in smax[par]
     auto publish_max = [&](int par) {
-        float md = 0.f, ma = 0.f;
+        unsigned ud = 0u, ua = 0u;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                md = max_raw(max_raw(md, max_raw(fabsf(fd[i][t].x), fabsf(fd[i][t].y))), max_raw(fabsf(fd[i][t].z), fabsf(fd[i][t].w)));
-                ma = max_raw(max_raw(ma, max_raw(fabsf(fa[i][t].x), fabsf(fa[i][t].y))), max_raw(fabsf(fa[i][t].z), fabsf(fa[i][t].w)));
+                // bit patterns with the sign shifted out order like magnitudes: one shift + half a three-input integer maximum per value
+                ud = max(max(ud, __float_as_uint(fd[i][t].x) << 1), max(__float_as_uint(fd[i][t].y) << 1, max(__float_as_uint(fd[i][t].z) << 1, __float_as_uint(fd[i][t].w) << 1)));
+                ua = max(max(ua, __float_as_uint(fa[i][t].x) << 1), max(__float_as_uint(fa[i][t].y) << 1, max(__float_as_uint(fa[i][t].z) << 1, __float_as_uint(fa[i][t].w) << 1)));
             }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            md = fmaxf(md, __shfl_xor(md, o, 64));
-            ma = fmaxf(ma, __shfl_xor(ma, o, 64));
-        }
+        const float md = __uint_as_float(wave_umax(ud) >> 1), ma = __uint_as_float(wave_umax(ua) >> 1);
         if (lane == 0) { smax[par][wave][0] = md; smax[par][wave][1] = ma; }
     };
     auto put_plane = [&](half_t* ph, half_t* pl, const float4& x0, const float4& x1, float sc, int pr, int cg) {
@@ -269,24 +266,34 @@ __global__ __launch_bounds__(256) void k_gemm_tn_split(GemmTnJobs jobs) {
     __syncthreads();
     int par = 0;
     for (int m0 = m_begin; m0 < m_end; m0 += TS_BM, par ^= 1) {
-        // the slab's scales (every thread computes the same two numbers from the four partials)
+        // Optimistic staging: the slab goes into LDS at the RUNNING scales at once, while the four partial maxima published during
+        // the previous slab's products are read and checked; only when the slab does not fit them (outside [2^8, 2^15): rare) it
+        // is staged again at its own scales and the accumulator follows by the ratio.  (Waiting for the maxima first put an LDS
+        // round trip and the scale arithmetic between the two barriers of every slab.)
+        auto stage = [&]() {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int item = tid + 256 * i, pr = item >> 5, cg = item & 31;
+                put_plane(Dh, Dl, fd[i][0], fd[i][1], sd_run, pr, cg);
+                put_plane(Ah, Al, fa[i][0], fa[i][1], sa_run, pr, cg);
+            }
+        };
         float md = 0.f, ma = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { md = fmaxf(md, smax[par][w][0]); ma = fmaxf(ma, smax[par][w][1]); }
-        const float sd_need = pow2_scale(md), sa_need = pow2_scale(ma);
+        if (run_live) stage();
         // keep the running scales while the slab stays inside [2^8, 2^15) with them (top of the f16 range, low halves normal)
         const float td = md * sd_run, ta = ma * sa_run;
         const bool keep = run_live && td < 32768.f && ta < 32768.f && (td >= 256.f || md == 0.f) && (ta >= 256.f || ma == 0.f);
         if (!keep) {
+            const float sd_need = pow2_scale(md), sa_need = pow2_scale(ma);
             if (run_live) rescale((sd_need * pow2_inv(sd_run)) * (sa_need * pow2_inv(sa_run)));
             sd_run = sd_need; sa_run = sa_need; run_live = true;
+            stage();                                         // (same addresses, same threads: plain overwrite)
         }
+        if (do_bias) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int item = tid + 256 * i, pr = item >> 5, cg = item & 31;
-            put_plane(Dh, Dl, fd[i][0], fd[i][1], sd_run, pr, cg);
-            put_plane(Ah, Al, fa[i][0], fa[i][1], sa_run, pr, cg);
-            if (do_bias) {
+            for (int i = 0; i < 2; ++i) {
                 bsum[i].x += fd[i][0].x + fd[i][1].x; bsum[i].y += fd[i][0].y + fd[i][1].y;
                 bsum[i].z += fd[i][0].z + fd[i][1].z; bsum[i].w += fd[i][0].w + fd[i][1].w;
             }
