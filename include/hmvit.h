@@ -271,7 +271,14 @@ size_t hmvit_fusion_backward_workspace_bytes(const HmvitFusionTrainDesc* desc);
 /* HeteroFusion.forward in training mode: fwd.out (B, C, H, W) */
 int hmvit_fusion_train_forward(const HmvitFusionTrainDesc* desc, void* stream);
 /* d_out (B, C, H, W) -> d_x (B, L, C, H, W) (padded agents: 0), grads[2] (window, grid), mlp_head gradients (T, C, C) / (T, C).
- * `desc` must be the descriptor of the matching hmvit_fusion_train_forward call (same saved area, seed, weights). */
+ * `desc` must be the descriptor of the matching hmvit_fusion_train_forward call (same saved area, seed, weights).
+ * Range (ABI-compatible behaviour change in round 5): d_out may have ANY magnitude.  The products of the pass run on split-f16
+ * operands, and every kernel scales its own operands by exact powers of two taken from the data (per token row, per 32-token
+ * slab, per workgroup against a weights-only bound on |V'|): one pass, no non-finite-detect-and-repeat, nothing read back by the
+ * host.  Preconditions are the forward's: the stage's Q, K', V' themselves must be f16-representable (|.| < 65504).
+ * window_size 4 / 8 with dim_head 32 take the tuned kernels; every other (window <= 16, dim_head <= 64 dividing C) trains through
+ * the generic exact-f32 attention kernels, with bias_frag / grads[.].bias_frag in the dense (heads, N, N) layout and bias_frag_neg
+ * unused (may be NULL). */
 int hmvit_fusion_backward(const HmvitFusionTrainDesc* desc, const float* d_out, float* d_x, const HmvitStageGrads* grads,
                           float* d_head_w1, float* d_head_b1, float* d_head_w2, float* d_head_b2, void* workspace,
                           size_t workspace_bytes, void* stream);
