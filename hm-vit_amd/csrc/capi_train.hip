@@ -472,7 +472,7 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
 
 // ---- backward workspace layout (floats) ----
 struct BwdPlan {
-    size_t o_G, o_T1, o_T2, o_T3, o_T4, o_dkg, o_dkv, o_wt, o_img, o_winv, o_vbound, total;
+    size_t o_G, o_T1, o_T2, o_T3, o_T4, o_h, o_dkg, o_dkv, o_wt, o_img, o_winv, o_vbound, total;
     // transposed weights inside o_wt, per stage s: q (T,C,C), kv (T,T,2,C,C), o (T,C,C), w1t (T,C,mlp), w2t (T,mlp,C); head: w1t, w2t
     size_t wt_stage, wt_q, wt_kv, wt_o, wt_1, wt_2, wt_h1, wt_h2;
 };
@@ -482,8 +482,13 @@ static void make_bwd_plan(const TrainPlan& pl, BwdPlan& bp) {
     const size_t big = pl.A > tok * pl.mlp ? pl.A : tok * pl.mlp;
     size_t off = 0;
     auto carve = [&](size_t n) { size_t o = off; off = (off + n + 63) / 64 * 64; return o; };
-    bp.o_G = carve(pl.A); bp.o_T1 = carve(big); bp.o_T2 = carve(big); bp.o_T3 = carve(big); bp.o_T4 = carve(pl.A);
-    bp.o_dkg = carve((size_t)pl.B * pl.max_cav * pl.max_cav * 2 * pl.P * pl.C);
+    // G, T1, T3, T4: one map per slot.  The two hidden-width buffers of the FFN section (T2 = d(pre), h = the recomputed activations)
+    // are dead before the attention section starts and the gathered-key gradients (dkg: the largest buffer, 7.2 GB at cfg2) are dead
+    // once k_warp_adjoint has run, so the three share one region (round 5: 2.9 GB less at cfg2, nothing else changes)
+    const size_t dkg_n = (size_t)pl.B * pl.max_cav * pl.max_cav * 2 * pl.P * pl.C;
+    bp.o_G = carve(pl.A); bp.o_T1 = carve(pl.A); bp.o_T3 = carve(pl.A); bp.o_T4 = carve(pl.A);
+    bp.o_dkg = carve(dkg_n > 2 * big ? dkg_n : 2 * big);
+    bp.o_T2 = bp.o_dkg; bp.o_h = bp.o_dkg + big;
     bp.o_dkv = carve(tok * pl.E_max * 2 * pl.C);
     const size_t T = HMVIT_NUM_TYPES, C = pl.C, mlp = pl.mlp;
     size_t w = 0;
@@ -615,8 +620,9 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
         const float* R = S + (size_t)sidx * pl.stage_floats;
         const float *x_in = R + pl.o_x, *q = R + pl.o_q, *kv = R + pl.o_kv, *o = R + pl.o_o, *lse = R + pl.o_lse,
                     *x1 = R + pl.o_x1, *pre = R + pl.o_pre;
-        // recomputed into T3 where a weight gradient needs them (T3 is otherwise dO, which does not exist yet / any more)
-        float *xn = T3, *xn2 = T3, *h = T3;
+        // recomputed where a weight gradient needs them: the LayerNorm outputs into T3 (otherwise dO, which does not exist yet / any
+        // more), the FFN activations into h (inside the dkg region)
+        float *xn = T3, *xn2 = T3, *h = Wk + bp.o_h;
         const float* wts = WT + (size_t)s * bp.wt_stage;
         const int n_ego = si.n_ego;
 
