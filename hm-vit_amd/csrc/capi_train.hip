@@ -472,7 +472,7 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
 
 // ---- backward workspace layout (floats) ----
 struct BwdPlan {
-    size_t o_G, o_T1, o_T2, o_T3, o_T4, o_h, o_dkg, o_dkv, o_wt, o_img, o_winv, o_vbound, total;
+    size_t o_G, o_T1, o_T2, o_T3, o_T4, o_h, o_dkg, o_dkv, o_wt, o_img, o_winv, o_vbound, o_dbrep, total;
     // transposed weights inside o_wt, per stage s: q (T,C,C), kv (T,T,2,C,C), o (T,C,C), w1t (T,C,mlp), w2t (T,mlp,C); head: w1t, w2t
     size_t wt_stage, wt_q, wt_kv, wt_o, wt_1, wt_2, wt_h1, wt_h2;
 };
@@ -504,6 +504,7 @@ static void make_bwd_plan(const TrainPlan& pl, BwdPlan& bp) {
     bp.o_img = carve(pl.lin16 ? 2 * w + 2 * T * C * C : 0);
     bp.o_winv = carve(pl.lin16 ? (2 * w + 2 * T * C * C) / 65536 : 0);
     bp.o_vbound = carve(64);            // one a-priori |V'| bound per stage (launch_v_bound)
+    bp.o_dbrep = carve(warp_adjoint_replica_floats(HMVIT_NUM_TYPES, pl.C));   // k_warp_adjoint's partial bias gradients
     bp.total = off;
 }
 
@@ -705,35 +706,16 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
             HMVIT_TRY(launch_attention_bwd(ab, st));
             DBG_SUM("dq", T4, (size_t)n_ego * me);
             DBG_SUM("dkg", dkg, (size_t)B * n_ego * pl.max_cav * 2 * me);
-            // biases are added after the gather: their gradients are column sums over the EGO pixels
-            // (one launch per kMaxColsumJobs maps: 11 maps per ego at five agents)
-            ColsumJobs cs;
-            cs.n = 0;
-            auto colsum = [&](const float* y, float* out) -> int {
-                cs.y[cs.n] = y; cs.out[cs.n] = out;
-                if (++cs.n < kMaxColsumJobs) return HMVIT_OK;
-                const int rc = launch_colsum_jobs(cs, P, C, C, st);
-                cs.n = 0;
-                return rc;
-            };
-            for (int b = 0; b < B; ++b)
-                for (int i = 0; i < n_ego; ++i) {
-                    const int te = d->mode[b * L + i];
-                    HMVIT_TRY(colsum(T4 + (size_t)(b * L + i) * me, gr.b_q + te * C));
-                    for (int j = 0; j < pl.max_cav; ++j) {
-                        const int ts = d->mode[b * L + j];
-                        const float* g2 = dkg + ((size_t)((b * n_ego + i) * pl.max_cav + j) * 2) * me;
-                        float* db = gr.b_kv + (size_t)(te * T + ts) * 2 * C;
-                        HMVIT_TRY(colsum(g2, db));
-                        HMVIT_TRY(colsum(g2 + me, db + C));
-                    }
-                }
-            HMVIT_TRY(launch_colsum_jobs(cs, P, C, C, st));
+            // biases are added after the gather: their gradients are column sums over the EGO pixels.  b_q: with the weight gradient
+            // of W_q below (k_gemm_tn_split sums the rows it loads); b_kv: on the way through k_warp_adjoint, which reads every row of
+            // dkg anyway.  (Round 4 ran k_colsum over all 11 maps per ego: a second pass over the 7.2 GB buffer, 1.2 ms per stage.)
             WarpAdjParams wa;
             memset(&wa, 0, sizeof(wa));
             wa.dkg = dkg; wa.ainv = ainv; wa.dkv = dkv;
             wa.B = B; wa.L = L; wa.n_ego = n_ego; wa.n_src = pl.max_cav; wa.E = si.E; wa.C = C; wa.H = d->H; wa.W = d->W;
             for (int i = 0; i < pl.n_slots; ++i) wa.ego_e[i] = ab.f.ego_e[i];
+            wa.db_kv = gr.b_kv; wa.db_rep = Wk + bp.o_dbrep; wa.T = T;
+            for (int i = 0; i < pl.n_slots; ++i) wa.mode[i] = (int8_t)d->mode[i];
             HMVIT_TRY(launch_warp_adjoint(wa, st));
             DBG_SUM("dkv", dkv, (size_t)pl.n_slots * si.E * 2 * me);
         }
@@ -757,7 +739,7 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
                         if (term == 0) {
                             if (!has_q) continue;
                             HMVIT_TRY(jb.add(T4 + slot * me, wts + bp.wt_q + (size_t)ty * C * C, nullptr, res, y, P, C, C));
-                            HMVIT_TRY(tn.add(T4 + slot * me, xn + slot * me, gr.w_q + (size_t)ty * C * C, nullptr, P, C, C));
+                            HMVIT_TRY(tn.add(T4 + slot * me, xn + slot * me, gr.w_q + (size_t)ty * C * C, gr.b_q + ty * C, P, C, C));
                         } else {
                             const int e = (term - 1) >> 1, pln = (term - 1) & 1;
                             const size_t widx = (size_t)((si.e_type[e] * T + ty) * 2 + pln) * C * C;

@@ -309,17 +309,14 @@ struct WarpAdjParams {
     float* dkv;               // (B, L, E, 2, P, C)
     int B, L, n_ego, n_src, E, C, H, W;
     int8_t ego_e[kMaxSlots];
+    // column sums of dkg on the way (the K' / V' bias gradients); null: not wanted
+    float* db_kv;             // (T, T, 2, C): [type of the ego][type of the source][plane]
+    float* db_rep;            // scratch, warp_adjoint_replica_floats(T, C) floats: the workgroups' partial sums before they are folded
+    int T;
+    int8_t mode[kMaxSlots];   // (B, L) agent types
 };
 int launch_warp_adjoint(const WarpAdjParams& p, hipStream_t st);
-// out[n] += sum_m y[m][n]  (bias gradients), y (M, N) with row stride ld
-constexpr int kMaxColsumJobs = 96;
-struct ColsumJobs {
-    const float* y[kMaxColsumJobs];
-    float* out[kMaxColsumJobs];
-    int n;
-};
-int launch_colsum(const float* y, int M, int N, int ld, float* out, hipStream_t st);
-int launch_colsum_jobs(const ColsumJobs& jobs, int M, int N, int ld, hipStream_t st);
+size_t warp_adjoint_replica_floats(int T, int C);
 // training-mode BatchNorm (+ ReLU) on (M, C) maps: csrc/train.hip k_bn_reduce / k_bn_apply
 struct BnArgs {
     const float* x;        // (M, C) pre-normalisation values

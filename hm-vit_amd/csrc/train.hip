@@ -378,74 +378,14 @@ int launch_gemm_tn(const GemmTnJobs& jobs, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
-// column sums (bias gradients)
-// ------------------------------------------------------------------------------------------
-// y (M, N) row-major with leading dimension ld (N and ld multiples of 4, rows 16-byte aligned): out[c] += sum_m y[m][c].
-// One workgroup = 64 rows x 256 columns: thread (q = tid & 63, rg = tid >> 6) owns columns 4 q .. 4 q + 3 of rows rg, rg + 4, ...
-// (16 independent 16-byte loads in flight), the four row groups meet in LDS, one atomic add per column and workgroup.
-// (The first version walked 1024 rows per workgroup with one 4-byte load in flight per thread: 64 workgroups, 100 us per
-// 16 MB call, 46 % of the backward pass at 176 calls per step.)
-constexpr int COLSUM_ROWS = 64;
-__global__ __launch_bounds__(256) void k_colsum(ColsumJobs jobs, int M, int N, int ld, int rows_per_wg) {
-    __shared__ float4 red[4][64];
-    const float* __restrict__ y = jobs.y[blockIdx.z];
-    float* __restrict__ out = jobs.out[blockIdx.z];
-    const int q = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 256 + 4 * q;
-    const int m_begin = blockIdx.y * rows_per_wg, m_end = min(M, m_begin + rows_per_wg);
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < N) {
-        for (int m0 = m_begin; m0 < m_end; m0 += COLSUM_ROWS) {
-            float4 v[COLSUM_ROWS / 4];
-#pragma unroll
-            for (int k = 0; k < COLSUM_ROWS / 4; ++k) {
-                const int m = m0 + rg + 4 * k;
-                v[k] = m < m_end ? *reinterpret_cast<const float4*>(y + (size_t)m * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int k = 0; k < COLSUM_ROWS / 4; ++k) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
-        }
-    }
-    red[rg][q] = s;
-    __syncthreads();
-    if (rg == 0 && c < N) {
-        const float4 a = red[0][q], b = red[1][q], d = red[2][q], e = red[3][q];
-        unsafeAtomicAdd(out + c + 0, (a.x + b.x) + (d.x + e.x));
-        unsafeAtomicAdd(out + c + 1, (a.y + b.y) + (d.y + e.y));
-        unsafeAtomicAdd(out + c + 2, (a.z + b.z) + (d.z + e.z));
-        unsafeAtomicAdd(out + c + 3, (a.w + b.w) + (d.w + e.w));
-    }
-}
-
-// jobs.n maps of the same (M, N, ld) in one launch (several jobs may add into the same out: atomics).  Rows per workgroup:
-// enough workgroups to fill the chip (~4096), few enough that the atomics on the handful of output vectors do not serialise
-// the launch (64 rows per workgroup at cfg2 = 31 M atomics on 2 K addresses: 5 ms per launch for 7.9 GB).
-int launch_colsum_jobs(const ColsumJobs& jobs, int M, int N, int ld, hipStream_t st) {
-    if (M <= 0 || N <= 0 || jobs.n <= 0) return HMVIT_OK;
-    HMVIT_CHECK_ARG(N % 4 == 0 && ld % 4 == 0, "colsum: N=%d / ld=%d must be multiples of 4", N, ld);
-    for (int i = 0; i < jobs.n; ++i) HMVIT_CHECK_ARG(((size_t)jobs.y[i] & 15) == 0, "colsum: map %d is not 16-byte aligned", i);
-    const int col_tiles = cdiv(N, 256);
-    long long want = (long long)M * jobs.n * col_tiles / 4096;          // rows per workgroup for ~4096 workgroups
-    int rows = (int)((want + COLSUM_ROWS - 1) / COLSUM_ROWS) * COLSUM_ROWS;
-    rows = rows < COLSUM_ROWS ? COLSUM_ROWS : (rows > 4096 ? 4096 : rows);
-    hipLaunchKernelGGL(k_colsum, dim3(col_tiles, cdiv(M, rows), jobs.n), dim3(256), 0, st, jobs, M, N, ld, rows);
-    HMVIT_CHECK_LAUNCH();
-    return HMVIT_OK;
-}
-int launch_colsum(const float* y, int M, int N, int ld, float* out, hipStream_t st) {
-    ColsumJobs j;
-    j.n = 1; j.y[0] = y; j.out[0] = out;
-    return launch_colsum_jobs(j, M, N, ld, st);
-}
-
-// ------------------------------------------------------------------------------------------
 // BatchNorm2d in training mode (batch statistics) fused with ReLU, on NHWC maps viewed as (M = N H W, C): the normalisation of
 // the detection tail's convolution blocks when the model trains (naive_decoder.py:45-54 under nn.Module.train()).
 //   forward   sums[c] += sum_m x, sums[C + c] += sum_m x^2          (k_bn_reduce<0>)
 //             y = relu(gamma (x - mean) rstd + beta)                 (k_bn_apply<0>)
 //   backward  g = dy [y > 0];  sums[c] += sum g, sums[C + c] += sum g xhat          (k_bn_reduce<1>)
 //             dx = gamma rstd (g - sums[c] / M - xhat sums[C + c] / M)              (k_bn_apply<1>)
-// Same blocking as k_colsum (64 rows x 256 channels per pass, rows per workgroup scaled to the launch).
+// Blocking: 64 rows x 256 channels per pass (thread (q = tid & 63, rg = tid >> 6) owns columns 4 q .. 4 q + 3 of rows rg, rg + 4, ...),
+// rows per workgroup scaled to the launch; the four row groups meet in LDS, one atomic add per column and workgroup.
 // ------------------------------------------------------------------------------------------
 
 template <int BWD>
@@ -1340,80 +1280,160 @@ int launch_attention_bwd(const AttnBwdParams& p, hipStream_t st) {
 // map): the candidates are the integer points of that box around round(A s), one per lane; lanes with a non-zero weight
 // are then visited in turn by the whole wave (4 channels per lane and plane).
 constexpr int WADJ_R = 3;   // supported candidate radius: 2 covers every rigid transform (radius < sqrt(2) + 0.5)
+// Round 5: the pass doubles as the COLUMN SUMS of the gathered-key gradients (the K' / V' bias gradients: sum over the ego pixels of
+// every (ego, source) pair).  Those were a pass of their own over the 7.2 GB buffer (k_colsum, 1.2 ms per stage at 6.7 TB/s, as long as
+// this kernel).  Here every ego pixel with a tap in bounds is OWNED by exactly one source pixel - the first of its four taps with a
+// non-zero weight - and the wavefront of that pixel, which reads the row for the adjoint anyway, adds it to its running sum; pixels
+// without such a tap are invisible keys, whose rows are zero.  A workgroup takes WADJ_RUN x 4 pixels (its four wavefronts four ADJACENT
+// pixels at a time: they share most of their candidate rows while those are in L1), then its wavefronts' sums meet in LDS: one atomic add
+// per column, plane and workgroup, into one of WADJ_REP replicas of the gradient vector (k_fold_replicas adds them up afterwards:
+// atomics on one address serialise at ~160 ns each).  Pixels per workgroup, measured at cfg2 (tools/probe/wadj_ab.sh; the kernel alone,
+// no sums, one pixel per wavefront: 1.24 ms): 4 -> 1.63 ms, 8 -> 1.49, 16 -> 1.58, 32 -> 1.64, 128 -> 2.04 - few atomics against
+// the balance of many small workgroups (pixels outside a source's footprint cost nothing, pixels inside ~25 row visits).
+#ifndef HMVIT_WADJ_RUN
+#define HMVIT_WADJ_RUN 2
+#endif
+constexpr int WADJ_RUN = HMVIT_WADJ_RUN, WADJ_REP = 64;
 
 template <int VPL>
 __global__ __launch_bounds__(256) void k_warp_adjoint(WarpAdjParams p) {
     constexpr int C = VPL * 64;
+    __shared__ float red[4][2][C];
     const int P = p.H * p.W;
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (s >= P) return;
-    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slot = blockIdx.y;                 // b * L + src
     const int b = slot / p.L, src = slot - b * p.L;
     if (src >= p.n_src) return;
     const int e = blockIdx.z;
-    const int sy = s / p.W, sx = s - sy * p.W;
-    float acc[2][VPL];
+    float csum[2][VPL];
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) acc[pl][i] = 0.f;
+        for (int i = 0; i < VPL; ++i) csum[pl][i] = 0.f;
+    int te = -1;                                 // type of the egos of variant e (all the same: that is what a variant is)
 
-    for (int ego = 0; ego < p.n_ego; ++ego) {
-        if (p.ego_e[b * p.L + ego] != e) continue;
-        const float* a = p.ainv + ((size_t)(b * p.L + src) * p.L + ego) * 8;
-        const float* g = p.dkg + (((size_t)(b * p.n_ego + ego) * p.n_src + src) * 2) * P * C;
-        if (a[6] != 0.f) {   // identity: key u reads source pixel u
+    // the four wavefronts take four ADJACENT pixels at a time (they share most of their candidate rows while those are in L1: with
+    // one run of 32 pixels per wavefront the launch took 2.0 ms against 1.2) and move along the row together
+    for (int k = 0; k < WADJ_RUN; ++k) {
+        const int s = blockIdx.x * (4 * WADJ_RUN) + 4 * k + wave;
+        if (s >= P) break;
+        const int sy = s / p.W, sx = s - sy * p.W;
+        float acc[2][VPL];
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
+        for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-                for (int i = 0; i < VPL; ++i) acc[pl][i] += g[(size_t)pl * P * C + (size_t)s * C + lane * VPL + i];
-            continue;
+            for (int i = 0; i < VPL; ++i) acc[pl][i] = 0.f;
+
+        for (int ego = 0; ego < p.n_ego; ++ego) {
+            if (p.ego_e[b * p.L + ego] != e) continue;
+            te = p.mode[b * p.L + ego];
+            const float* a = p.ainv + ((size_t)(b * p.L + src) * p.L + ego) * 8;
+            const float* g = p.dkg + (((size_t)(b * p.n_ego + ego) * p.n_src + src) * 2) * P * C;
+            if (a[6] != 0.f) {   // identity: key u reads source pixel u (and is owned by it)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int i = 0; i < VPL; ++i) {
+                        const float v = g[(size_t)pl * P * C + (size_t)s * C + lane * VPL + i];
+                        acc[pl][i] += v;
+                        csum[pl][i] += v;
+                    }
+                continue;
+            }
+            // forward map A = Ainv^-1 (2 x 3)
+            const float det = a[0] * a[4] - a[1] * a[3], id = 1.f / det;
+            const float f00 = a[4] * id, f01 = -a[1] * id, f10 = -a[3] * id, f11 = a[0] * id;
+            const float f02 = -(f00 * a[2] + f01 * a[5]), f12 = -(f10 * a[2] + f11 * a[5]);
+            const float ux = f00 * sx + f01 * sy + f02, uy = f10 * sx + f11 * sy + f12;
+            const int cx = (int)rintf(fminf(fmaxf(ux, -1.0e6f), 1.0e6f)), cy = (int)rintf(fminf(fmaxf(uy, -1.0e6f), 1.0e6f));
+            // lane -> candidate offset in a 7 x 7 box (49 of 64 lanes)
+            const int oy = lane / (2 * WADJ_R + 1) - WADJ_R, ox = lane % (2 * WADJ_R + 1) - WADJ_R;
+            const int u = cx + ox, v = cy + oy;
+            float w = 0.f;
+            bool own = false;
+            if (lane < (2 * WADJ_R + 1) * (2 * WADJ_R + 1) && u >= 0 && u < p.W && v >= 0 && v < p.H) {
+                const Taps t = make_taps(a, u, v, p.H, p.W);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w += (t.idx[k] == s) ? t.w[k] : 0.f;
+                const int first = t.w[0] != 0.f ? 0 : t.w[1] != 0.f ? 1 : t.w[2] != 0.f ? 2 : 3;
+                own = t.w[first] != 0.f && t.idx[first] == s;
+            }
+            unsigned long long live = __ballot(w != 0.f);
+            const unsigned long long owned = __ballot(own);
+            // (Measured and dropped: the rows of up to six live candidates requested together before they are used - 2.0 -> 2.3 ms per
+            // launch: the kernel is bound by the rows it moves through L1 - each row of dkg is read by ~4 source pixels - not by their latency.)
+            while (live) {
+                const int i = __ffsll((long long)live) - 1;
+                live &= live - 1;
+                const float wi = __shfl(w, i, 64);
+                const int ui = __shfl(v * p.W + u, i, 64);
+                const bool mine = (owned >> i) & 1ull;              // wave-uniform
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int c = 0; c < VPL; ++c) {
+                        const float val = g[(size_t)pl * P * C + (size_t)ui * C + lane * VPL + c];
+                        acc[pl][c] = fmaf(wi, val, acc[pl][c]);
+                        if (mine) csum[pl][c] += val;
+                    }
+            }
         }
-        // forward map A = Ainv^-1 (2 x 3)
-        const float det = a[0] * a[4] - a[1] * a[3], id = 1.f / det;
-        const float f00 = a[4] * id, f01 = -a[1] * id, f10 = -a[3] * id, f11 = a[0] * id;
-        const float f02 = -(f00 * a[2] + f01 * a[5]), f12 = -(f10 * a[2] + f11 * a[5]);
-        const float ux = f00 * sx + f01 * sy + f02, uy = f10 * sx + f11 * sy + f12;
-        const int cx = (int)rintf(fminf(fmaxf(ux, -1.0e6f), 1.0e6f)), cy = (int)rintf(fminf(fmaxf(uy, -1.0e6f), 1.0e6f));
-        // lane -> candidate offset in a 7 x 7 box (49 of 64 lanes)
-        const int oy = lane / (2 * WADJ_R + 1) - WADJ_R, ox = lane % (2 * WADJ_R + 1) - WADJ_R;
-        const int u = cx + ox, v = cy + oy;
-        float w = 0.f;
-        if (lane < (2 * WADJ_R + 1) * (2 * WADJ_R + 1) && u >= 0 && u < p.W && v >= 0 && v < p.H) {
-            const Taps t = make_taps(a, u, v, p.H, p.W);
+        float* o = p.dkv + ((size_t)(slot * p.E + e) * 2) * P * C + (size_t)s * C + lane * VPL;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) w += (t.idx[k] == s) ? t.w[k] : 0.f;
-        }
-        unsigned long long live = __ballot(w != 0.f);
-        while (live) {
-            const int i = __ffsll((long long)live) - 1;
-            live &= live - 1;
-            const float wi = __shfl(w, i, 64);
-            const int ui = __shfl(v * p.W + u, i, 64);
+        for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-                for (int c = 0; c < VPL; ++c)
-                    acc[pl][c] = fmaf(wi, g[(size_t)pl * P * C + (size_t)ui * C + lane * VPL + c], acc[pl][c]);
-        }
+            for (int i = 0; i < VPL; ++i) o[(size_t)pl * P * C + i] = acc[pl][i];
     }
-    float* o = p.dkv + ((size_t)(slot * p.E + e) * 2) * P * C + (size_t)s * C + lane * VPL;
+    if (!p.db_kv) return;                        // (uniform)
+    // bias gradients: db_kv[(type of the egos, type of the source)][plane][column] += the workgroup's sum
+    __shared__ int te_sh;
+    if (threadIdx.x == 0) te_sh = -1;
+    __syncthreads();
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) o[(size_t)pl * P * C + i] = acc[pl][i];
+        for (int i = 0; i < VPL; ++i) red[wave][pl][lane * VPL + i] = csum[pl][i];
+    if (te >= 0 && lane == 0) te_sh = te;        // (a wave past the end of the map walked no pixel and knows no type: its sums are 0)
+    __syncthreads();
+    const int te_wg = te_sh;
+    if (te_wg < 0) return;
+    const int ts = p.mode[b * p.L + src];
+    float* db = p.db_kv + ((size_t)(blockIdx.x % WADJ_REP) * p.T * p.T + (te_wg * p.T + ts)) * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int pl = i / C, c = i - pl * C;
+        const float v = (red[0][pl][c] + red[1][pl][c]) + (red[2][pl][c] + red[3][pl][c]);
+        if (v != 0.f) unsafeAtomicAdd(db + i, v);
+    }
 }
+
+// out[i] += sum_r rep[r][i], i < n (n a few thousand)
+__global__ __launch_bounds__(256) void k_fold_replicas(const float* __restrict__ rep, float* __restrict__ out, int n, int R) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += rep[(size_t)r * n + i];
+    out[i] += s;
+}
+size_t warp_adjoint_replica_floats(int T, int C) { return (size_t)WADJ_REP * T * T * 2 * C; }
 
 int launch_warp_adjoint(const WarpAdjParams& p, hipStream_t st) {
     if (p.B <= 0 || p.n_src <= 0 || p.E <= 0) return HMVIT_OK;
-    dim3 grid(cdiv(p.H * p.W, 4), p.B * p.L, p.E);
+    dim3 grid(cdiv(p.H * p.W, 4 * WADJ_RUN), p.B * p.L, p.E);
+    WarpAdjParams q = p;
+    const int n_db = p.T * p.T * 2 * p.C;
+    if (p.db_kv) {
+        HMVIT_CHECK_ARG(p.db_rep != nullptr, "warp_adjoint: bias gradients need the replica buffer%s", "");
+        HMVIT_CHECK_HIP(hipMemsetAsync(p.db_rep, 0, warp_adjoint_replica_floats(p.T, p.C) * 4, st));
+        q.db_kv = p.db_rep;                     // the kernel adds into the replicas
+    }
     switch (p.C) {
-        case 64: hipLaunchKernelGGL((k_warp_adjoint<1>), grid, dim3(256), 0, st, p); break;
-        case 128: hipLaunchKernelGGL((k_warp_adjoint<2>), grid, dim3(256), 0, st, p); break;
-        case 256: hipLaunchKernelGGL((k_warp_adjoint<4>), grid, dim3(256), 0, st, p); break;
+        case 64: hipLaunchKernelGGL((k_warp_adjoint<1>), grid, dim3(256), 0, st, q); break;
+        case 128: hipLaunchKernelGGL((k_warp_adjoint<2>), grid, dim3(256), 0, st, q); break;
+        case 256: hipLaunchKernelGGL((k_warp_adjoint<4>), grid, dim3(256), 0, st, q); break;
         default: set_error("warp_adjoint: C=%d unsupported", p.C); return HMVIT_EINVAL;
     }
+    HMVIT_CHECK_LAUNCH();
+    if (p.db_kv) hipLaunchKernelGGL(k_fold_replicas, dim3(cdiv(n_db, 256)), dim3(256), 0, st, p.db_rep, p.db_kv, n_db, WADJ_REP);
     HMVIT_CHECK_LAUNCH();
     return HMVIT_OK;
 }
