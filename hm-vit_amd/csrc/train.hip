@@ -499,12 +499,19 @@ int launch_bn(const BnArgs& a, int bwd, int apply, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 // LayerNorm backward
 // ------------------------------------------------------------------------------------------
-constexpr int LNB_TOK = 16;   // tokens per wavefront
+constexpr int LNB_TOK = 16, LNB_B = 4;   // tokens per wavefront, tokens in flight
 
-__device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// sum over the 64 lanes of a wavefront, in every lane: four DPP steps inside the rows of 16 lanes, two row swaps across them
+// (as wave_umax, common.hpp; six ds_bpermute round trips with __shfl_xor)
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+    auto dpp = [](float v, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, false));
+    };
+    x += dpp(x, std::integral_constant<int, 0xB1>{});       // quad_perm [1, 0, 3, 2]
+    x += dpp(x, std::integral_constant<int, 0x4E>{});       // quad_perm [2, 3, 0, 1]
+    x += dpp(x, std::integral_constant<int, 0x141>{});      // row_half_mirror
+    x += dpp(x, std::integral_constant<int, 0x140>{});      // row_mirror
+    return xor32_sum(xor16_sum(x));
 }
 
 template <int VPL>
@@ -522,39 +529,63 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
         g[i] = gamma[t * C + lane * VPL + i];
         dg[i] = db[i] = 0.f;
     }
+    // LNB_B tokens at a time: their rows are requested together and their four wave sums run side by side (a token at a time the
+    // wavefront waited for one row, then for 24 dependent ds_bpermute round trips: WAIT_ANY 79 %, 4.4 TB/s in the round-5 counters);
+    // the sums themselves on DPP / permlane swaps (wave_sum_dpp)
     const int tok0 = (blockIdx.x * 4 + wave) * LNB_TOK;
-    for (int tt = 0; tt < LNB_TOK; ++tt) {
-        const int tok = tok0 + tt;
-        if (tok >= P) break;
-        const size_t base = ((size_t)agent * P + tok) * C + lane * VPL;
-        float v[VPL], d[VPL];
+    for (int tt = 0; tt < LNB_TOK; tt += LNB_B) {
+        if (tok0 + tt >= P) break;
+        float v[LNB_B][VPL], d[LNB_B][VPL], r[LNB_B][VPL];
+        size_t base[LNB_B];
+        bool on[LNB_B];
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) { v[i] = x[base + i]; d[i] = dy[base + i]; }
-        float s = 0.f;
+        for (int k = 0; k < LNB_B; ++k) {
+            const int tok = tok0 + tt + k;
+            on[k] = tok < P;                                        // wave-uniform
+            base[k] = ((size_t)agent * P + (on[k] ? tok : P - 1)) * C + lane * VPL;
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) s += v[i];
-        const float mean = wave_sum64(s) * (1.f / C);
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) { v[i] -= mean; q += v[i] * v[i]; }
-        const float rstd = rsqrtf(wave_sum64(q) * (1.f / C) + 1e-5f);
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            v[i] *= rstd;                       // xhat
-            const float gd = g[i] * d[i];
-            s1 += gd;
-            s2 += gd * v[i];
-            dg[i] += d[i] * v[i];
-            db[i] += d[i];
+            for (int i = 0; i < VPL; ++i) { v[k][i] = x[base[k] + i]; d[k][i] = dy[base[k] + i]; r[k][i] = dres ? dres[base[k] + i] : 0.f; }
         }
-        s1 = wave_sum64(s1) * (1.f / C);
-        s2 = wave_sum64(s2) * (1.f / C);
+        float mean[LNB_B], rstd[LNB_B], s1[LNB_B], s2[LNB_B];
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            float o = rstd * (g[i] * d[i] - s1 - v[i] * s2);
-            if (dres) o += dres[base + i];
-            dx[base + i] = o;
+        for (int k = 0; k < LNB_B; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) s += v[k][i];
+            mean[k] = s;
+        }
+#pragma unroll
+        for (int k = 0; k < LNB_B; ++k) mean[k] = wave_sum_dpp(mean[k]) * (1.f / C);
+#pragma unroll
+        for (int k = 0; k < LNB_B; ++k) {
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) { v[k][i] -= mean[k]; q += v[k][i] * v[k][i]; }
+            rstd[k] = q;
+        }
+#pragma unroll
+        for (int k = 0; k < LNB_B; ++k) rstd[k] = rsqrtf(wave_sum_dpp(rstd[k]) * (1.f / C) + 1e-5f);
+#pragma unroll
+        for (int k = 0; k < LNB_B; ++k) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                v[k][i] *= rstd[k];                 // xhat
+                const float gd = g[i] * d[k][i];
+                a1 += gd;
+                a2 += gd * v[k][i];
+                if (on[k]) { dg[i] += d[k][i] * v[k][i]; db[i] += d[k][i]; }
+            }
+            s1[k] = a1; s2[k] = a2;
+        }
+#pragma unroll
+        for (int k = 0; k < LNB_B; ++k) { s1[k] = wave_sum_dpp(s1[k]) * (1.f / C); s2[k] = wave_sum_dpp(s2[k]) * (1.f / C); }
+#pragma unroll
+        for (int k = 0; k < LNB_B; ++k) {
+            if (on[k]) {
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) dx[base[k] + i] = rstd[k] * (g[i] * d[k][i] - s1[k] - v[k][i] * s2[k]) + r[k][i];
+            }
         }
     }
 #pragma unroll
