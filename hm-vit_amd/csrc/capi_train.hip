@@ -175,8 +175,9 @@ struct Jobs {
         return false;
 #endif
     }
+    // drop (x16 path only - ask can_fuse_ln first): y = residual + Dropout(a w^T + bias)
     int add(const float* a, const float* w, const float* bias, const float* residual, float* y, int M, int N, int K,
-            const float* ln_g = nullptr, const float* ln_b = nullptr) {
+            const float* ln_g = nullptr, const float* ln_b = nullptr, const DropCfg* drop = nullptr) {
 #ifndef HMVIT_TRAIN_EXACT_F32
         const half_t* img;
         const float* inv;
@@ -195,10 +196,11 @@ struct Jobs {
             memset(&q, 0, sizeof(q));
             q.a = a; q.wimg[0] = img; q.w_inv[0] = inv; q.bias[0] = bias; q.y[0] = y; q.residual = residual;
             q.M = M; q.n_mat = 1; q.ldy = N; q.ln_gamma = ln_g; q.ln_beta = ln_b;
+            if (drop) q.drop = *drop;
             return HMVIT_OK;
         }
 #endif
-        if (ln_g) { set_error("training: LayerNorm fusion asked of the generic GEMM%s", ""); return HMVIT_EINVAL; }
+        if (ln_g || drop) { set_error("training: LayerNorm / dropout fusion asked of the generic GEMM%s", ""); return HMVIT_EINVAL; }
         GemmJob j;
         j.a = a; j.w = w; j.bias = bias; j.residual = residual; j.y = y;
         j.M = M; j.N = N; j.K = K; j.n_per_plane = N; j.plane_stride = 0;
@@ -385,23 +387,31 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
             HMVIT_TRY(launch_attention(ap, generic ? HMVIT_PREC_F32 : HMVIT_PREC_SPLIT, st));
 #endif
         }
-        // x' = x + Dropout(a_linears(O)) on the ego slots
+        // x' = x + Dropout(a_linears(O)) on the ego slots: in the Linear's epilogue where the x16 kernel runs it (round 5), else a pass of
+        // its own.  Element index of the dropout stream = offset inside the slot's (P, C) map, one seed per slot
         for (int b = 0; b < B; ++b) {
             Jobs jb(st, regp);
+            const bool fused = jb.can_fuse_ln(reinterpret_cast<const float*>(wt.w_o), C, C);
+            const DropCfg dc = drop_cfg(t, sidx, 0);
             for (int i = 0; i < n_ego; ++i) {
                 const int slot = b * L + i, ty = d->mode[slot];
-                HMVIT_TRY(jb.add(o + slot * me, reinterpret_cast<const float*>(wt.w_o) + (size_t)ty * C * C, wt.b_o + ty * C, nullptr,
-                                 tmp + slot * me, P, C, C));
+                DropCfg di = dc;
+                di.seed = dc.seed + 0x51ED270B1ull * (unsigned long long)(slot + 1);
+                if (fused)
+                    HMVIT_TRY(jb.add(o + slot * me, reinterpret_cast<const float*>(wt.w_o) + (size_t)ty * C * C, wt.b_o + ty * C, x_in + slot * me,
+                                     x1 + slot * me, P, C, C, nullptr, nullptr, &di));
+                else
+                    HMVIT_TRY(jb.add(o + slot * me, reinterpret_cast<const float*>(wt.w_o) + (size_t)ty * C * C, wt.b_o + ty * C, nullptr,
+                                     tmp + slot * me, P, C, C));
             }
             HMVIT_TRY(jb.flush());
-            DropCfg dc = drop_cfg(t, sidx, 0);
-            // element index of the dropout stream = offset inside the (n_slots, P, C) activation
-            for (int i = 0; i < n_ego; ++i) {
-                const size_t off = (size_t)(b * L + i) * me;
-                DropCfg di = dc;
-                di.seed = dc.seed + 0x51ED270B1ull * (unsigned long long)(b * L + i + 1);
-                HMVIT_TRY(launch_add_drop(x_in + off, tmp + off, x1 + off, me, di, st));
-            }
+            if (!fused)
+                for (int i = 0; i < n_ego; ++i) {
+                    const size_t off = (size_t)(b * L + i) * me;
+                    DropCfg di = dc;
+                    di.seed = dc.seed + 0x51ED270B1ull * (unsigned long long)(b * L + i + 1);
+                    HMVIT_TRY(launch_add_drop(x_in + off, tmp + off, x1 + off, me, di, st));
+                }
         }
         for (int b = 0; b < B; ++b) {
             Jobs j1(st, regp);
@@ -421,18 +431,26 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
                 HMVIT_TRY(launch_gelu_drop(pre + (size_t)slot * P * mlp, h + (size_t)slot * P * mlp, (size_t)P * mlp, di, st));
             }
             Jobs j2(st, regp);
+            const bool fused2 = j2.can_fuse_ln(reinterpret_cast<const float*>(wt.w_2), C, mlp);
             for (int i = 0; i < n_ego; ++i) {
                 const int slot = b * L + i, ty = d->mode[slot];
-                HMVIT_TRY(j2.add(h + (size_t)slot * P * mlp, reinterpret_cast<const float*>(wt.w_2) + (size_t)ty * C * mlp, wt.b_2 + ty * C,
-                                 nullptr, x_out + slot * me, P, C, mlp));
-            }
-            HMVIT_TRY(j2.flush());
-            for (int i = 0; i < n_ego; ++i) {
-                const int slot = b * L + i;
                 DropCfg di = drop_cfg(t, sidx, 2);
                 di.seed += 0x51ED270B1ull * (unsigned long long)(slot + 1);
-                HMVIT_TRY(launch_add_drop(x1 + slot * me, x_out + slot * me, x_out + slot * me, me, di, st));   // in place
+                if (fused2)       // x'' = x' + Dropout(h W_2^T + b_2) in the Linear's epilogue
+                    HMVIT_TRY(j2.add(h + (size_t)slot * P * mlp, reinterpret_cast<const float*>(wt.w_2) + (size_t)ty * C * mlp, wt.b_2 + ty * C,
+                                     x1 + slot * me, x_out + slot * me, P, C, mlp, nullptr, nullptr, &di));
+                else
+                    HMVIT_TRY(j2.add(h + (size_t)slot * P * mlp, reinterpret_cast<const float*>(wt.w_2) + (size_t)ty * C * mlp, wt.b_2 + ty * C,
+                                     nullptr, x_out + slot * me, P, C, mlp));
             }
+            HMVIT_TRY(j2.flush());
+            if (!fused2)
+                for (int i = 0; i < n_ego; ++i) {
+                    const int slot = b * L + i;
+                    DropCfg di = drop_cfg(t, sidx, 2);
+                    di.seed += 0x51ED270B1ull * (unsigned long long)(slot + 1);
+                    HMVIT_TRY(launch_add_drop(x1 + slot * me, x_out + slot * me, x_out + slot * me, me, di, st));   // in place
+                }
         }
     }
     if (pl.only_stage >= 0) {

@@ -1315,6 +1315,9 @@ __global__ __launch_bounds__(X16_THREADS, 2) void k_linear16(LinJobs jobs) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) x[t] = (float4v)(0.f);
     }
+    const bool drop_on = J.drop.p > 0.f;
+    const float inv_keep = drop_on ? 1.f / (1.f - J.drop.p) : 1.f;
+    const unsigned dkey = drop_key(J.drop);
     auto flushes = [](int k) { return k >= 0 && (k & 1) != 0; };
     for (int mat = 0; mat < J.n_mat; ++mat) {
         const float cm = inv_tok * J.w_inv[mat][0];
@@ -1338,10 +1341,13 @@ __global__ __launch_bounds__(X16_THREADS, 2) void k_linear16(LinJobs jobs) {
             for (int T = 0; T < 2; ++T) {
                 const float4 b4 = *reinterpret_cast<const float4*>(bm + 32 * t + 16 * T);
                 const float4v r4 = res ? x[2 * t + T] : (float4v)(0.f);
-                v[T][0] = fmaf(acc[T][0], cm, b4.x) + r4[0];
-                v[T][1] = fmaf(acc[T][1], cm, b4.y) + r4[1];
-                v[T][2] = fmaf(acc[T][2], cm, b4.z) + r4[2];
-                v[T][3] = fmaf(acc[T][3], cm, b4.w) + r4[3];
+                float4v lin = {fmaf(acc[T][0], cm, b4.x), fmaf(acc[T][1], cm, b4.y), fmaf(acc[T][2], cm, b4.z), fmaf(acc[T][3], cm, b4.w)};
+                if (drop_on) {      // (uniform) the training forward's y = residual + Dropout(a W^T + b): the lane's four columns of its token
+                    const unsigned long long i0 = (unsigned long long)tok * J.ldy + 32 * t + 16 * T + 4 * g;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) lin[e] *= drop_scale(J.drop, dkey, i0 + e, inv_keep);
+                }
+                v[T] = lin + r4;
             }
             store_lin16(stg, J.y[mat], J.ldy, t, v, tk, g, lane, tok_w, M);
             const int ahead = c + 2 + (grp_b ? 1 : 0);

@@ -48,6 +48,28 @@ int launch_gemm(const GemmJobs& jobs, bool a_f32, bool gelu, bool out_f32, int p
 // columns are formed in the same workgroup; the training path's skinny GEMMs).  Weights come as x16 split images built on the device
 // by launch_weight_images16 (per-matrix power-of-two scale, its inverse in w_inv); activations are scaled per token inside.
 constexpr int kMaxLinMats = 3, kMaxLinJobs = 16;
+// counter-based dropout: keep(seed, salt, i) is a pure function, so the backward pass regenerates the forward's mask
+struct DropCfg {
+    unsigned long long seed;
+    unsigned salt;
+    float p;                // drop probability, 0 = identity
+};
+// The mask: 16 uniform bits per element, two elements per 32-bit mix of (seed, salt, index of the PAIR): an odd multiply of the index, the
+// launch's key added, murmur3's finaliser; element 2 k takes the low half, 2 k + 1 the high half (callers walk consecutive elements, the
+// pair's mix is computed once).  p is honoured to 2^-16.  (Rounds 3-4 ran a splitmix64 finaliser per element - three 64-bit multiplies,
+// ~25 instructions with six quarter-rate ones; that was affordable in the element-wise passes, which wait for memory, not in the
+// epilogue of the Linear kernels, where the residual + dropout of the training forward now happens: k_linear16.)
+__device__ __forceinline__ unsigned drop_key(const DropCfg& d) {
+    return (unsigned)d.seed ^ ((unsigned)(d.seed >> 32) * 0x9E3779B1u) ^ (d.salt * 0x85EBCA77u + 0x27D4EB2Fu);
+}
+__device__ __forceinline__ float drop_scale(const DropCfg& d, unsigned key, unsigned long long idx, float inv_keep) {
+    const unsigned long long pair = idx >> 1;
+    unsigned h = (unsigned)pair * 0x9E3779B1u + (unsigned)(pair >> 32) * 0xC2B2AE3Du + key;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    const unsigned u = (idx & 1ull) ? h >> 16 : h & 0xffffu;
+    return u < (unsigned)(d.p * 65536.f + 0.5f) ? 0.f : inv_keep;
+}
+
 struct LinJob {
     const float* a;                      // (M, 256) f32 rows
     const half_t* wimg[kMaxLinMats];     // images of the (256, 256) matrices W: y_m = a W_m^T
@@ -58,6 +80,8 @@ struct LinJob {
     const float* ln_gamma;               // (256) or null: the rows are LayerNorm-ed (eps 1e-5) on their way into the products,
     const float* ln_beta;                //   i.e. y = LN(a) W^T: the normalised rows are never written
     int M, n_mat, ldy;
+    DropCfg drop;                        // p > 0 (with a residual, one matrix): y = residual + Dropout(a W^T + bias), element index
+                                         //   row * ldy + column in the mask's stream (the training forward's two residual adds)
 };
 struct LinJobs {
     LinJob j[kMaxLinJobs];
@@ -274,12 +298,6 @@ int launch_gemm_tn(const GemmTnJobs& jobs, hipStream_t st);
 // dx = dres + LayerNorm-backward(dy; x, gamma[type]); dgamma / dbeta (T, C) accumulated with atomics
 int launch_layernorm_bwd(const float* x, const float* dy, const float* gamma, const AgentTypes& types, int n_agents,
                          const float* dres, float* dx, float* dgamma, float* dbeta, int P, int C, hipStream_t st);
-// counter-based dropout: keep(seed, salt, i) is a pure function, so the backward pass regenerates the forward's mask
-struct DropCfg {
-    unsigned long long seed;
-    unsigned salt;
-    float p;                // drop probability, 0 = identity
-};
 int launch_add_drop(const float* x, const float* a, float* y, size_t n, DropCfg d, hipStream_t st);      // y = x + drop(a); x may be null
 int launch_gelu_drop(const float* pre, float* h, size_t n, DropCfg d, hipStream_t st);                   // h = drop(gelu(pre))
 int launch_gelu_bwd(const float* pre, const float* dh, float* dpre, size_t n, DropCfg d, hipStream_t st); // dpre = drop'(dh) gelu'(pre)

@@ -22,16 +22,6 @@ namespace hmvit {
 // ------------------------------------------------------------------------------------------
 // dropout
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float drop_scale(const DropCfg& d, unsigned long long idx, float inv_keep) {
-    // splitmix64 finaliser over (seed, salt, idx): 24 uniform bits
-    unsigned long long z = d.seed + 0x9E3779B97F4A7C15ull * (idx + ((unsigned long long)d.salt << 40) + 1ull);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    const float u = (float)(unsigned)(z >> 40) * (1.f / 16777216.f);
-    return u < d.p ? 0.f : inv_keep;
-}
-
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad(float x) {
     return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
@@ -42,6 +32,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_elementwise(const float* __restrict__ x, const float* __restrict__ a,
                                                       float* __restrict__ y, size_t n4, DropCfg d) {
     const float inv_keep = d.p > 0.f ? 1.f / (1.f - d.p) : 1.f;
+    const unsigned key = drop_key(d);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 av = make_float4(0.f, 0.f, 0.f, 0.f), xv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (MODE != 3) av = reinterpret_cast<const float4*>(a)[i];
@@ -49,7 +40,7 @@ __global__ __launch_bounds__(256) void k_elementwise(const float* __restrict__ x
         float s[4] = {1.f, 1.f, 1.f, 1.f};
         if (d.p > 0.f) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s[e] = drop_scale(d, 4 * i + e, inv_keep);
+            for (int e = 0; e < 4; ++e) s[e] = drop_scale(d, key, 4 * i + e, inv_keep);
         }
         float4 r;
         if (MODE == 0) {
