@@ -210,6 +210,29 @@ struct Jobs {
     }
 };
 
+// y = sum_i a[i] w[i]^T (+ residual): one x16 job, the sum in registers.  true when every weight has an x16 image (else: nothing queued)
+static bool add_sum16(Jobs& J, const float* const* a, const float* const* w, int n_in, const float* residual, float* y, int M, int* rc) {
+    *rc = HMVIT_OK;
+#ifndef HMVIT_TRAIN_EXACT_F32
+    if (!J.reg || n_in < 1 || n_in > kMaxLinMats) return false;
+    const half_t* img[kMaxLinMats];
+    const float* inv[kMaxLinMats];
+    for (int i = 0; i < n_in; ++i)
+        if (!J.reg->find(w[i], img[i], inv[i])) return false;
+    if (J.lin.n == kMaxLinJobs) { *rc = J.flush(); if (*rc != HMVIT_OK) return true; }
+    LinJob& q = J.lin.j[J.lin.n++];
+    memset(&q, 0, sizeof(q));
+    q.a = a[0]; q.residual = residual; q.y[0] = y; q.M = M; q.n_mat = n_in; q.ldy = 256; q.sum_inputs = 1;
+    for (int i = 0; i < n_in; ++i) {
+        q.wimg[i] = img[i]; q.w_inv[i] = inv[i];
+        if (i > 0) q.a_more[i - 1] = a[i];
+    }
+    return true;
+#else
+    return false;
+#endif
+}
+
 struct TnJobs {
     GemmTnJobs jobs;
     hipStream_t st;
@@ -742,31 +765,83 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
         {
             HMVIT_TRY(ln_slots(x_in, xn, wt.ln_gamma, wt.ln_beta, d, pl, pl.max_cav, st));
             TnJobs tn(st);
-            // pass 0: first term of every slot (no accumulate), later passes accumulate through the residual input
+            // The terms of a slot: [dq W_q] + per variant e (dK'_e W_k,e + dV'_e W_v,e).  Where every weight has an x16 image they are
+            // summed in registers, up to kMaxLinMats inputs per pass (one pass at one ego type: round 4 made three, each reading and
+            // writing the whole of d(xn)); else term by term through the residual input.
             const int n_terms = 1 + 2 * si.E;
+            auto term_of = [&](int slot, int l, int term, const float*& g2, const float*& w, float*& dw) {
+                const int ty = d->mode[slot];
+                if (term == 0) {
+                    if (l >= n_ego) return false;
+                    g2 = T4 + slot * me; w = wts + bp.wt_q + (size_t)ty * C * C; dw = gr.w_q + (size_t)ty * C * C;
+                } else {
+                    const int e = (term - 1) >> 1, pln = (term - 1) & 1;
+                    const size_t widx = (size_t)((si.e_type[e] * T + ty) * 2 + pln) * C * C;
+                    g2 = dkv + ((size_t)(slot * si.E + e) * 2 + pln) * me; w = wts + bp.wt_kv + widx; dw = gr.w_kv + widx;
+                }
+                return true;
+            };
+            // weight gradients against xn (b_q's column sums ride on W_q's)
+            for (int b = 0; b < B; ++b)
+                for (int l = 0; l < pl.max_cav; ++l)
+                    for (int term = 0; term < n_terms; ++term) {
+                        const int slot = b * L + l;
+                        const float *g2, *w;
+                        float* dw;
+                        if (!term_of(slot, l, term, g2, w, dw)) continue;
+                        HMVIT_TRY(tn.add(g2, xn + slot * me, dw, term == 0 ? gr.b_q + d->mode[slot] * C : nullptr, P, C, C));
+                    }
+            bool summed = true;
+            {
+                Jobs probe(st, regp);
+                summed = probe.can_fuse_ln(wts + bp.wt_q, C, C);
+            }
+            if (summed) {
+                // pass k takes terms [k kMaxLinMats, (k + 1) kMaxLinMats) of every slot's list; later passes add to y through the residual
+                int max_terms = 0;
+                for (int pass = 0; pass == 0 || pass * kMaxLinMats < max_terms; ++pass) {
+                    Jobs jb(st, regp);
+                    for (int b = 0; b < B; ++b)
+                        for (int l = 0; l < pl.max_cav; ++l) {
+                            const int slot = b * L + l;
+                            const float* a_in[2 * HMVIT_NUM_TYPES + 1];
+                            const float* w_in[2 * HMVIT_NUM_TYPES + 1];
+                            int n = 0;
+                            for (int term = 0; term < n_terms; ++term) {
+                                float* dw;
+                                if (term_of(slot, l, term, a_in[n], w_in[n], dw)) ++n;
+                            }
+                            if (n > max_terms) max_terms = n;
+                            const int first = pass * kMaxLinMats, cnt = n - first < kMaxLinMats ? n - first : kMaxLinMats;
+                            if (cnt <= 0) continue;
+                            float* y = T1 + slot * me;
+                            int rc;
+                            if (!add_sum16(jb, a_in + first, w_in + first, cnt, pass == 0 ? nullptr : y, y, P, &rc)) {
+                                set_error("training: a weight of the d(xn) sum has no x16 image%s", "");
+                                return HMVIT_EINVAL;
+                            }
+                            HMVIT_TRY(rc);
+                        }
+                    HMVIT_TRY(jb.flush());
+                }
+            } else {
+            // pass 0: first term of every slot (no accumulate), later passes accumulate through the residual input
             for (int term = 0; term < n_terms; ++term) {
                 Jobs jb(st, regp);
                 for (int b = 0; b < B; ++b)
                     for (int l = 0; l < pl.max_cav; ++l) {
-                        const int slot = b * L + l, ty = d->mode[slot];
+                        const int slot = b * L + l;
                         float* y = T1 + slot * me;
                         const bool has_q = l < n_ego;
-                        // the first term actually present for this slot writes, the others accumulate
                         const int first_term = has_q ? 0 : 1;
                         const float* res = term == first_term ? nullptr : y;
-                        if (term == 0) {
-                            if (!has_q) continue;
-                            HMVIT_TRY(jb.add(T4 + slot * me, wts + bp.wt_q + (size_t)ty * C * C, nullptr, res, y, P, C, C));
-                            HMVIT_TRY(tn.add(T4 + slot * me, xn + slot * me, gr.w_q + (size_t)ty * C * C, gr.b_q + ty * C, P, C, C));
-                        } else {
-                            const int e = (term - 1) >> 1, pln = (term - 1) & 1;
-                            const size_t widx = (size_t)((si.e_type[e] * T + ty) * 2 + pln) * C * C;
-                            const float* g2 = dkv + ((size_t)(slot * si.E + e) * 2 + pln) * me;
-                            HMVIT_TRY(jb.add(g2, wts + bp.wt_kv + widx, nullptr, res, y, P, C, C));
-                            HMVIT_TRY(tn.add(g2, xn + slot * me, gr.w_kv + widx, nullptr, P, C, C));
-                        }
+                        const float *g2, *w;
+                        float* dw;
+                        if (!term_of(slot, l, term, g2, w, dw)) continue;
+                        HMVIT_TRY(jb.add(g2, w, nullptr, res, y, P, C, C));
                     }
                 HMVIT_TRY(jb.flush());
+            }
             }
             HMVIT_TRY(tn.flush());
         }

@@ -1318,10 +1318,25 @@ __global__ __launch_bounds__(X16_THREADS, 2) void k_linear16(LinJobs jobs) {
     const bool drop_on = J.drop.p > 0.f;
     const float inv_keep = drop_on ? 1.f / (1.f - J.drop.p) : 1.f;
     const unsigned dkey = drop_key(J.drop);
-    auto flushes = [](int k) { return k >= 0 && (k & 1) != 0; };
+    // sum_inputs: y[0] = sum over the job's inputs; x[] (the residual rows, or zero) is the accumulator and leaves once, at the end
+    const bool sum = J.sum_inputs != 0;
+    auto flushes = [&](int k) { return !sum && k >= 0 && (k & 1) != 0; };
+    float inv_in = inv_tok;
     for (int mat = 0; mat < J.n_mat; ++mat) {
-        const float cm = inv_tok * J.w_inv[mat][0];
-        const float* bm = bs + mat * C + 4 * g;
+        if (sum && mat > 0) {
+            float4v r[16];
+            const float* xp = J.a_more[mat - 1] + (size_t)tok_c * C + 4 * g;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float4 f = *reinterpret_cast<const float4*>(xp + 16 * t);
+                r[t][0] = f.x; r[t][1] = f.y; r[t][2] = f.z; r[t][3] = f.w;
+            }
+            const float s_in = pow2_scale(row_absmax16(r));
+            rows_to_operands16(r, ah, al, s_in);
+            inv_in = pow2_inv(s_in);
+        }
+        const float cm = inv_in * J.w_inv[mat][0];
+        const float* bm = bs + (sum ? 0 : mat) * C + 4 * g;
         const bool res = mat == 0;
 #pragma unroll
         for (int t = 0; t < NCH; ++t) {
@@ -1336,6 +1351,10 @@ __global__ __launch_bounds__(X16_THREADS, 2) void k_linear16(LinJobs jobs) {
                 if (grp_b) ring_wait(flushes(c - 1));
                 wg_barrier();
             }
+            if (sum) {
+                x[2 * t] += acc[0] * cm;
+                x[2 * t + 1] += acc[1] * cm;
+            } else {
             float4v v[2];
 #pragma unroll
             for (int T = 0; T < 2; ++T) {
@@ -1350,6 +1369,7 @@ __global__ __launch_bounds__(X16_THREADS, 2) void k_linear16(LinJobs jobs) {
                 v[T] = lin + r4;
             }
             store_lin16(stg, J.y[mat], J.ldy, t, v, tk, g, lane, tok_w, M);
+            }
             const int ahead = c + 2 + (grp_b ? 1 : 0);
             if (ahead < n_chunks) stage_chunk16(chunk_ptr(ahead), slot(ahead));
             if (!grp_b) ring_wait(flushes(c));
@@ -1357,6 +1377,18 @@ __global__ __launch_bounds__(X16_THREADS, 2) void k_linear16(LinJobs jobs) {
         }
     }
     if (X16_DEPHASE && !grp_b) wg_barrier();
+    if (sum) {
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) {
+            float4v v[2];
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bs + 4 * g + 32 * t + 16 * T);
+                v[T] = x[2 * t + T] + float4v{b4.x, b4.y, b4.z, b4.w};
+            }
+            store_lin16(stg, J.y[0], J.ldy, t, v, tk, g, lane, tok_w, M);
+        }
+    }
 }
 
 // (256, 256) f32 matrices -> x16 split images at a power of two: one workgroup per matrix (absmax, then the fragments;
@@ -1953,9 +1985,12 @@ int launch_linear16(const LinJobs& jobs, hipStream_t st) {
     for (int i = 0; i < jobs.n; ++i) {
         const LinJob& j = jobs.j[i];
         HMVIT_CHECK_ARG(j.a && j.M > 0 && j.n_mat >= 1 && j.n_mat <= kMaxLinMats && j.ldy >= 256 && j.ldy % 4 == 0, "linear16: bad job %d", i);
-        HMVIT_CHECK_ARG(!j.residual || j.n_mat == 1, "linear16: a residual goes with a single matrix (job %d)", i);
+        HMVIT_CHECK_ARG(!j.residual || j.n_mat == 1 || j.sum_inputs, "linear16: a residual goes with a single output (job %d)", i);
+        HMVIT_CHECK_ARG(!j.sum_inputs || (!j.ln_gamma && j.drop.p == 0.f), "linear16: the input sum takes no LayerNorm / dropout (job %d)", i);
         HMVIT_CHECK_ARG((j.ln_gamma == nullptr) == (j.ln_beta == nullptr), "linear16: LayerNorm needs gamma and beta (job %d)", i);
-        for (int m = 0; m < j.n_mat; ++m) HMVIT_CHECK_ARG(j.wimg[m] && j.w_inv[m] && j.y[m], "linear16: null pointer (job %d, matrix %d)", i, m);
+        for (int m = 0; m < j.n_mat; ++m)
+            HMVIT_CHECK_ARG(j.wimg[m] && j.w_inv[m] && (j.sum_inputs ? (m == 0 ? j.y[0] != nullptr : j.a_more[m - 1] != nullptr) : j.y[m] != nullptr),
+                            "linear16: null pointer (job %d, matrix %d)", i, m);
         max_m = j.M > max_m ? j.M : max_m;
     }
     hipLaunchKernelGGL(k_linear16, dim3(cdiv(max_m, X16_TOKENS), jobs.n), dim3(X16_THREADS), 0, st, jobs);

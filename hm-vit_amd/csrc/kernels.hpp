@@ -80,6 +80,9 @@ struct LinJob {
     const float* ln_gamma;               // (256) or null: the rows are LayerNorm-ed (eps 1e-5) on their way into the products,
     const float* ln_beta;                //   i.e. y = LN(a) W^T: the normalised rows are never written
     int M, n_mat, ldy;
+    const float* a_more[kMaxLinMats - 1];// sum_inputs: the rows of inputs 1 .. n_mat - 1 (input 0 = a)
+    int sum_inputs;                      // 1: ONE output, y[0] = sum_m a_m W_m^T + bias[0] (+ residual): the sum stays in registers
+                                         //   (the backward's d(xn) = dq W_q + dK' W_k + dV' W_v was three passes over y)
     DropCfg drop;                        // p > 0 (with a residual, one matrix): y = residual + Dropout(a W^T + bias), element index
                                          //   row * ldy + column in the mask's stream (the training forward's two residual adds)
 };
