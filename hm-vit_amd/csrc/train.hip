@@ -181,10 +181,21 @@ __global__ __launch_bounds__(256) void k_gemm_tn_split(GemmTnJobs jobs) {
     __shared__ float smax[2][4][2];          // [slab parity][wave][dY, A]
     const GemmTnJob& J = jobs.j[blockIdx.z];
     const int tiles_k = (J.K + 127) / 128, tiles_n = (J.N + 127) / 128;
-    if ((int)blockIdx.x >= tiles_k * tiles_n) return;
-    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
+    // XCD-aware order (round 5).  The tiles of a token slice read the same rows of dY and A - each operand column block twice at 2 x 2
+    // tiles - and a workgroup's linear index modulo 8 is its XCD, each with an L2 of its own: with (tile, slice) = (blockIdx.x,
+    // blockIdx.y) the four tiles of a slice sat on four XCDs and every operand came from HBM twice (61 GB fetched per cfg2 step for
+    // 29 GB of operands).  With four tiles, groups of 32 consecutive workgroups now cover 8 slices x 4 tiles so that the tiles of a
+    // slice are consecutive workgroups of ONE XCD (the launch pads the slice count to a multiple of 8).
+    int tile = blockIdx.x, slice = blockIdx.y;
+    if (gridDim.x == 4) {
+        const int lid = blockIdx.x + 4 * blockIdx.y;
+        tile = (lid & 31) >> 3;
+        slice = (lid >> 5) * 8 + (lid & 7);
+    }
+    if (tile >= tiles_k * tiles_n) return;
+    const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
     const int n0 = tn * 128, k0 = tk * 128;
-    const int m_begin = blockIdx.y * TN_ROWS;
+    const int m_begin = slice * TN_ROWS;
     if (m_begin >= J.M) return;
     const int m_end = min(J.M, m_begin + TN_ROWS);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -359,6 +370,7 @@ int launch_gemm_tn(const GemmTnJobs& jobs, hipStream_t st) {
         max_slices = max(max_slices, cdiv(j.M, TN_ROWS));
     }
     if (max_tiles == 0 || max_slices == 0) return HMVIT_OK;
+    if (max_tiles == 4) max_slices = (max_slices + 7) / 8 * 8;      // k_gemm_tn_split's XCD-aware order covers slices in eights
 #ifdef HMVIT_TRAIN_EXACT_F32
     hipLaunchKernelGGL(k_gemm_tn, dim3(max_tiles, max_slices, jobs.n), dim3(256), 0, st, jobs);
 #else
