@@ -337,6 +337,7 @@ def train_bench(args, c, dev, rank, world, scene, make, barrier, D):
     else:
         from hmvit_amd import train as T
         net = make("f32").train()
+        net.train_recompute = args.train_recompute
         opt = T.make_optimizer(net.parameters())
         target = torch.zeros(1, c["C"], c["H"], c["W"], device=dev)
     model = net
@@ -381,7 +382,8 @@ def train_bench(args, c, dev, rank, world, scene, make, barrier, D):
            "value": units / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "stub" if args.stub else "f32 master weights; exact-f32 / split-f16 training kernels", "data": "stub" if args.stub else "synthetic",
-           "config": {"workload": "stub" if args.stub else f"{args.config}: train step of the fusion on one scene per rank, dropout 0.1, AdamW",
+           "config": {"workload": "stub" if args.stub else f"{args.config}: train step of the fusion on one scene per rank, dropout 0.1, AdamW"
+                                   + (f", recompute bits {args.train_recompute}" if args.train_recompute else ""),
                       "parallelism": f"dp{world}: DistributedDataParallel(find_unused_parameters=True), backend {args.backend}"},
            "ms_per_step_no_sync": dt_local / args.steps * 1e3,
            "allreduce_exposed_ms": max(0.0, (dt - dt_local) / args.steps * 1e3),
@@ -431,6 +433,9 @@ def main(argv=None):
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="one FULL-size forward of the CPU oracle on the host cores (minutes; no GPU work; not the driver's command)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of --cpu-baseline-full (default: the crop sweep's best)")
+    ap.add_argument("--train-recompute", type=int, default=0, choices=(0, 1, 3),
+                    help="--train: HmvitFusionTrainDesc::recompute bits (1: the FFN pre-activations, 3: + the queries are recomputed in the "
+                         "backward pass instead of kept: cfg2 peak 32.8 -> 30.1 -> 27.4 GiB for +1.9 / +3.1 ms per step)")
     ap.add_argument("--train", action="store_true",
                     help="the training half of north_star instead of the inference headline: one DistributedDataParallel train step "
                          "per rank (HeteroFusion forward with dropout + HIP backward + gradient all-reduce on RCCL + AdamW)")

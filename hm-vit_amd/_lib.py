@@ -71,7 +71,8 @@ class StageGrads(C.Structure):
 
 class FusionTrainDesc(C.Structure):
     _fields_ = [("fwd", FusionDesc), ("drop_p", C.c_float), ("seed", C.c_uint64), ("saved", C.c_void_p),
-                ("saved_bytes", C.c_size_t), ("bias_frag_neg", C.c_void_p * 2), ("only_stage", C.c_int32)]
+                ("saved_bytes", C.c_size_t), ("bias_frag_neg", C.c_void_p * 2), ("only_stage", C.c_int32),
+                ("recompute", C.c_int32)]
 
 
 class HmvitError(RuntimeError):

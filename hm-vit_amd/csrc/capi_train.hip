@@ -43,6 +43,7 @@ struct TrainPlan {
     // weights (WeightLayout), one float of storage per (hi, lo) pair; o_winv: one inverse scale per matrix
     size_t o_img, o_winv;
     bool lin16;
+    bool save_pre, save_q;   // the FFN pre-activations / the queries are kept (HmvitFusionTrainDesc::recompute bits 0 / 1 clear)
 };
 
 // (C, C) blocks of one set of weights: per stage q (T), kv (T, T, 2), o (T), w_1 (T), w_2 (T); then the head's two (T each)
@@ -109,9 +110,11 @@ int make_train_plan(const HmvitFusionTrainDesc* t, TrainPlan& pl) {
     pl.A = tok * pl.C;
     size_t off = 0;
     auto carve = [&](size_t n) { size_t o = off; off = (off + n + 63) / 64 * 64; return o; };
-    pl.o_x = carve(pl.A); pl.o_q = carve(pl.A);
+    pl.save_pre = (t->recompute & 1) == 0;
+    pl.save_q = (t->recompute & 2) == 0;
+    pl.o_x = carve(pl.A); pl.o_q = pl.save_q ? carve(pl.A) : 0;
     pl.o_kv = carve(tok * pl.E_max * 2 * pl.C); pl.o_o = carve(pl.A); pl.o_lse = carve(tok * pl.heads);
-    pl.o_x1 = carve(pl.A); pl.o_pre = carve(tok * pl.mlp);
+    pl.o_x1 = carve(pl.A); pl.o_pre = pl.save_pre ? carve(tok * pl.mlp) : 0;
     pl.stage_floats = off;
     off = pl.stage_floats * pl.n_stages;
     pl.o_xfin = carve(pl.A);
@@ -315,7 +318,9 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
         set_error("saved area too small: %zu < %zu bytes", t->saved_bytes, pl.total_floats * 4);
         return HMVIT_ENOMEM;
     }
-    const size_t scratch = (size_t)(pl.A > (size_t)pl.n_slots * pl.P * pl.mlp ? pl.A : (size_t)pl.n_slots * pl.P * pl.mlp) * 4;
+    const size_t scratch1 = pl.A > (size_t)pl.n_slots * pl.P * pl.mlp ? pl.A : (size_t)pl.n_slots * pl.P * pl.mlp;     // floats
+    // recompute: the queries (until the attention has run), then the pre-activations, live in the second half
+    const size_t scratch = scratch1 * 4 * (pl.save_pre && pl.save_q ? 1 : 2);
     if (!d->workspace || d->workspace_bytes < scratch) {
         set_error("workspace too small: %zu < %zu bytes", d->workspace_bytes, scratch);
         return HMVIT_ENOMEM;
@@ -368,7 +373,9 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
         float* R = S + (size_t)sidx * pl.stage_floats;
         float* x_in = R + pl.o_x;
         float* x_out = (sidx + 1 < pl.n_stages) ? S + (size_t)(sidx + 1) * pl.stage_floats + pl.o_x : S + pl.o_xfin;
-        float *q = R + pl.o_q, *kv = R + pl.o_kv, *o = R + pl.o_o, *lse = R + pl.o_lse, *x1 = R + pl.o_x1, *pre = R + pl.o_pre;
+        float *kv = R + pl.o_kv, *o = R + pl.o_o, *lse = R + pl.o_lse, *x1 = R + pl.o_x1;
+        float* q = pl.save_q ? R + pl.o_q : tmp + scratch1;
+        float* pre = pl.save_pre ? R + pl.o_pre : tmp + scratch1;
         // transient rows live in the one scratch buffer, each dead before the next is written (stream order): LN(x), the
         // out-projection, LN(x'), the FFN activations
         float *xn = tmp, *xn2 = tmp, *h = tmp;
@@ -513,7 +520,7 @@ static int train_forward(const HmvitFusionTrainDesc* t, hipStream_t st) {
 
 // ---- backward workspace layout (floats) ----
 struct BwdPlan {
-    size_t o_G, o_T1, o_T2, o_T3, o_T4, o_h, o_dkg, o_dkv, o_wt, o_img, o_winv, o_vbound, o_dbrep, total;
+    size_t o_G, o_T1, o_T2, o_T3, o_T4, o_h, o_pre, o_dkg, o_dkv, o_wt, o_img, o_winv, o_vbound, o_dbrep, total;
     // transposed weights inside o_wt, per stage s: q (T,C,C), kv (T,T,2,C,C), o (T,C,C), w1t (T,C,mlp), w2t (T,mlp,C); head: w1t, w2t
     size_t wt_stage, wt_q, wt_kv, wt_o, wt_1, wt_2, wt_h1, wt_h2;
 };
@@ -528,8 +535,9 @@ static void make_bwd_plan(const TrainPlan& pl, BwdPlan& bp) {
     // once k_warp_adjoint has run, so the three share one region (round 5: 2.9 GB less at cfg2, nothing else changes)
     const size_t dkg_n = (size_t)pl.B * pl.max_cav * pl.max_cav * 2 * pl.P * pl.C;
     bp.o_G = carve(pl.A); bp.o_T1 = carve(pl.A); bp.o_T3 = carve(pl.A); bp.o_T4 = carve(pl.A);
-    bp.o_dkg = carve(dkg_n > 2 * big ? dkg_n : 2 * big);
-    bp.o_T2 = bp.o_dkg; bp.o_h = bp.o_dkg + big;
+    const size_t ffn_n = (pl.save_pre ? 2 : 3) * big;       // + the recomputed pre-activations (recompute bit 0)
+    bp.o_dkg = carve(dkg_n > ffn_n ? dkg_n : ffn_n);
+    bp.o_T2 = bp.o_dkg; bp.o_h = bp.o_dkg + big; bp.o_pre = bp.o_dkg + 2 * big;
     bp.o_dkv = carve(tok * pl.E_max * 2 * pl.C);
     const size_t T = HMVIT_NUM_TYPES, C = pl.C, mlp = pl.mlp;
     size_t w = 0;
@@ -618,6 +626,15 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
         const int n_mat = (int)((pl.only_stage < 0 ? bp.wt_h1 + 2 * (size_t)T * C * C : 2 * bp.wt_stage) / 65536);
         HMVIT_TRY(launch_weight_images16(WT, reinterpret_cast<half_t*>(Wk + bp.o_img), Wk + bp.o_winv, n_mat, st));
         reg.add(WT, n_mat, Wk + bp.o_img, Wk + bp.o_winv);
+        if (!pl.save_pre || !pl.save_q) {      // the forward's own images of W_1 / W_q (kept in the saved area): the recomputation runs on them
+            const WeightLayout wl = weight_layout(C, mlp);
+            for (int s = 0; s < 2; ++s) {
+                if (pl.only_stage >= 0 && s != pl.only_stage) continue;
+                const size_t off = (size_t)s * wl.stage + wl.w1, offq = (size_t)s * wl.stage + wl.q;
+                if (!pl.save_pre) reg.add(reinterpret_cast<const float*>(d->stage[s].w_1), T, S + pl.o_img + off, S + pl.o_winv + off / 65536);
+                if (!pl.save_q) reg.add(reinterpret_cast<const float*>(d->stage[s].w_q), T, S + pl.o_img + offq, S + pl.o_winv + offq / 65536);
+            }
+        }
         regp = &reg;
     }
 
@@ -660,14 +677,30 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
         const HmvitStageGrads& gr = grads[s];
         const StageInfo si = stage_info(d, pl, sidx);
         const float* R = S + (size_t)sidx * pl.stage_floats;
-        const float *x_in = R + pl.o_x, *q = R + pl.o_q, *kv = R + pl.o_kv, *o = R + pl.o_o, *lse = R + pl.o_lse,
-                    *x1 = R + pl.o_x1, *pre = R + pl.o_pre;
+        const float *x_in = R + pl.o_x, *q = pl.save_q ? R + pl.o_q : T1, *kv = R + pl.o_kv, *o = R + pl.o_o, *lse = R + pl.o_lse,
+                    *x1 = R + pl.o_x1, *pre = pl.save_pre ? R + pl.o_pre : Wk + bp.o_pre;
         // recomputed where a weight gradient needs them: the LayerNorm outputs into T3 (otherwise dO, which does not exist yet / any
         // more), the FFN activations into h (inside the dkg region)
         float *xn = T3, *xn2 = T3, *h = Wk + bp.o_h;
         const float* wts = WT + (size_t)s * bp.wt_stage;
         const int n_ego = si.n_ego;
 
+        // recompute bit 0: pre = W_1 LN(x') + b_1 once more, by the forward's own call (same kernel, same weight images: bit-identical)
+        if (!pl.save_pre) {
+            float* pre_w = Wk + bp.o_pre;
+            for (int b = 0; b < B; ++b) {
+                Jobs j1(st, regp);
+                const bool fuse = j1.can_fuse_ln(reinterpret_cast<const float*>(wt.w_1), mlp, C);
+                if (!fuse) HMVIT_TRY(ln_slots(x1, xn2, wt.ffn_ln_gamma, wt.ffn_ln_beta, d, pl, n_ego, st, b));
+                for (int i = 0; i < n_ego; ++i) {
+                    const int slot = b * L + i, ty = d->mode[slot];
+                    HMVIT_TRY(j1.add((fuse ? x1 : xn2) + slot * me, reinterpret_cast<const float*>(wt.w_1) + (size_t)ty * mlp * C, wt.b_1 + ty * mlp,
+                                     nullptr, pre_w + (size_t)slot * P * mlp, P, mlp, C, fuse ? wt.ffn_ln_gamma + ty * C : nullptr,
+                                     fuse ? wt.ffn_ln_beta + ty * C : nullptr));
+                }
+                HMVIT_TRY(j1.flush());
+            }
+        }
         // G = dL/dx'' (zero on slots the loss does not reach).  FFN: x'' = x' + drop(W_2 drop(gelu(W_1 LN(x') + b_1)) + b_2)
         for (int b = 0; b < B; ++b) {
             for (int i = 0; i < n_ego; ++i) {
@@ -727,6 +760,20 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
             HMVIT_TRY(tn.flush());
         }
 
+        // recompute bit 1: q = LN(x) W_q once more, by the forward's own call, into T1 (free between the out-projection's gradient and
+        // d(xn)); without the x16 kernel the normalised rows pass through T4 (dq: not written yet)
+        if (!pl.save_q) {
+            Jobs jb(st, regp);
+            const bool fuse = jb.can_fuse_ln(reinterpret_cast<const float*>(wt.w_q), C, C);
+            if (!fuse) HMVIT_TRY(ln_slots(x_in, T4, wt.ln_gamma, wt.ln_beta, d, pl, n_ego, st));
+            for (int b = 0; b < B; ++b)
+                for (int l = 0; l < n_ego; ++l) {
+                    const int slot = b * L + l, ty = d->mode[slot];
+                    HMVIT_TRY(jb.add((fuse ? x_in : T4) + slot * me, reinterpret_cast<const float*>(wt.w_q) + (size_t)ty * C * C, nullptr, nullptr,
+                                     T1 + slot * me, P, C, C, fuse ? wt.ln_gamma + ty * C : nullptr, fuse ? wt.ln_beta + ty * C : nullptr));
+                }
+            HMVIT_TRY(jb.flush());
+        }
         // attention backward: dq (T4), gradients of the gathered keys (dkg), bias fragments
         {
             AttnBwdParams ab;

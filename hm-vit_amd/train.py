@@ -18,6 +18,7 @@ PyTorch), the optimiser is ``torch.optim.AdamW`` as in the reference, the gradie
 from __future__ import annotations
 
 import ctypes
+import os
 import re
 from typing import Dict, List
 
@@ -64,6 +65,19 @@ def folded_for_training(module, block_types=None, head_types=None) -> List[torch
     return out, neg
 
 
+def recompute_bits(module) -> int:
+    """Memory for time in training (HmvitFusionTrainDesc::recompute): ``module.train_recompute`` (or HMVIT_TRAIN_RECOMPUTE in the
+    environment) = 1: the FFN pre-activations are not kept for the backward pass, 3: neither are the queries - the backward recomputes
+    them with the forward's own kernels (the same rows bit for bit).  cfg2 (5 agents, 200x704, C=256): peak 32.8 -> 30.1 -> 27.4 GiB
+    for +1.9 / +3.1 ms per step.  (``train_recompute_ffn = True`` is the same as 1.)"""
+    v = getattr(module, "train_recompute", None)
+    if v is None and getattr(module, "train_recompute_ffn", None):
+        v = 1
+    if v is None:
+        v = int(os.environ.get("HMVIT_TRAIN_RECOMPUTE", "0") or 0)
+    return int(v) & 3
+
+
 def _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, out, saved, workspace, only_stage=0):
     blk = module._block_cfg
     B, L, C, H, W = x.shape
@@ -74,6 +88,7 @@ def _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, 
     d.window, d.mlp_dim, d.num_iters = blk["window_size"], blk["mlp_dim"], module.num_iters
     d.precision, d.apply_head, d.skip_masked = _lib.PREC_F32, (1 if only_stage == 0 else 0), 1
     t.only_stage = only_stage
+    t.recompute = recompute_bits(module)
     d.self_identity = 1            # checked by fusion_forward_with_grad: pairwise_t_matrix[b, i, i] = I
     d.discrete_ratio, d.downsample_rate = float(module.discrete_ratio), float(module.downsample_rate)
     keep = (_lib.i32_array(mode_h), _lib.i32_array(rl_h), _lib.i32_array(mask_h))
@@ -121,7 +136,8 @@ class FusionTrainFunction(torch.autograd.Function):
             _lib.check(-22, "hmvit_fusion_train_saved_bytes")
         saved = torch.empty(need, dtype=torch.uint8, device=x.device)
         blk = module._block_cfg
-        scratch = torch.empty(4 * B * L * H * W * max(C, blk["mlp_dim"]), dtype=torch.uint8, device=x.device)
+        scratch = torch.empty(4 * B * L * H * W * max(C, blk["mlp_dim"]) * (2 if recompute_bits(module) else 1), dtype=torch.uint8,
+                              device=x.device)
         t, keep = _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, out, saved, scratch, only_stage)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         with torch.cuda.device(x.device):

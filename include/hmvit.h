@@ -264,6 +264,13 @@ typedef struct HmvitFusionTrainDesc {
                                         (B, L, C, H, W), every agent runs as an ego, no mlp_head (its gradient pointers may be
                                         NULL).  The branches of architect_mode 'parallel' (hetero_fusion.py:459-470) train
                                         through this form; their SplitAttn merge is host-side autograd (hm-vit_amd/train.py)  */
+    int32_t recompute;               /* memory for time.  Bit 0: the FFN pre-activations W_1 LN(x') + b_1 of every stage are not kept for the
+                                        backward pass; bit 1: neither are the queries LN(x) W_q.  The backward recomputes them with the
+                                        forward's own kernels and weight images (the same rows bit for bit).  Each bit takes B L P C
+                                        (mlp) floats per stage off hmvit_fusion_train_saved_bytes (cfg2: 19.8 -> 17.1 -> 14.5 GiB; peak
+                                        of a step 32.8 -> 30.1 -> 27.4 GiB) and adds one Linear per stage to the backward (cfg2: + 1.9
+                                        / + 1.2 ms per step).  With any bit set fwd.workspace must hold 2 x max(B L P C, B L P mlp)
+                                        floats                                                                             */
 } HmvitFusionTrainDesc;
 
 size_t hmvit_fusion_train_saved_bytes(const HmvitFusionTrainDesc* desc);

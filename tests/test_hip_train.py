@@ -471,3 +471,42 @@ def test_generic_window_and_dim_head_train(C, dim_head, window, H, W, modes, n_v
     y = net(scene[0].cuda().requires_grad_(True), *[t.cuda() for t in scene[1:]])
     y.square().mean().backward()
     assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize("C,w", [(256, 8), (64, 4)])
+def test_recompute_saves_memory_and_changes_nothing(C, w):
+    """HmvitFusionTrainDesc::recompute (module.train_recompute = 3): the FFN pre-activations and the queries are not kept; the backward
+    recomputes them with the forward's own kernels.  Same output, the same gradients (dropout on: the masks are replayed), fewer saved bytes.
+    C = 256: the x16 Linear kernels with their weight images; C = 64: the generic GEMM path."""
+    import ctypes
+    from hmvit_amd import _lib, train as T
+    L, H, W, B = 3, 16, 16, 1
+    cfg = O.make_config(C, w, L, voxel=0.4, downsample=4)
+    sd = O.random_state_dict(cfg, seed=31)
+    scene = [t.cuda() for t in O.synthetic_scene(L, C, H, W, [1, 0, 1], seed=32, B=B, tx_step=3.0, ty_step=-2.0)]
+    gy = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(33)).cuda()
+    outs, peaks = [], []
+    for flag in (False, True):
+        net = _net(cfg, sd).train()
+        net.train_recompute = 3 if flag else 0
+        x = scene[0].clone().requires_grad_(True)
+        torch.manual_seed(77)                      # the same dropout stream in both runs
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        y = net(x, *scene[1:])
+        (y * gy).sum().backward()
+        torch.cuda.synchronize()
+        peaks.append(torch.cuda.max_memory_allocated() - base)
+        outs.append((y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
+    (y0, gx0, gp0), (y1, gx1, gp1) = outs
+    # the recomputed rows are the forward's, bit for bit; the gradients agree to the run-to-run level of their atomic sums
+    assert torch.equal(y0, y1)
+    assert rel_max_err(gx1.cpu(), gx0.cpu()) < 2e-6
+    assert gp0.keys() == gp1.keys()
+    for k in gp0:
+        if float(gp0[k].abs().max()) > 0:
+            assert rel_max_err(gp1[k].cpu(), gp0[k].cpu()) < 2e-5, k
+    # two (n_slots, P, .) planes less per stage in the saved area (the forward scratch grows by one such plane, transiently)
+    mlp, n_stages = cfg["hetero_fusion_block"]["mlp_dim"], 2 * cfg["num_iters"]
+    assert peaks[0] - peaks[1] >= (n_stages - 1) * B * L * H * W * (mlp + C) * 4 * 0.9, peaks
