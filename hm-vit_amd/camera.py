@@ -319,7 +319,7 @@ class CrossViewModule(nn.Module):
         prep = self._prep.get(self, prec, lambda: self._build(prec, dt))
         for cross_view in self.cross_views:
             cross_view.cross_attend.precision = "f32" if self.precision == "split" else self.precision   # split: f32 attention, split-operand convolutions
-        I_inv = batch["intrinsic"].reshape(b * l, n, 3, 3).float().inverse()      # 3x3 inverses: host-side plumbing, as the reference
+        I_inv = torch.linalg.inv_ex(batch["intrinsic"].reshape(b * l, n, 3, 3).float())[0]   # (inv_ex: no host read of the status)      # 3x3 inverses: host-side plumbing, as the reference
         E_inv = batch["extrinsic"].reshape(b * l, n, 4, 4).float()
         x = self.bev_embedding.get_prior().detach().float()[None].repeat(b * l, 1, 1, 1).contiguous()
         for cross_view, feature, layer in zip(self.cross_views, batch["features"], prep):

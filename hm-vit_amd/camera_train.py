@@ -362,7 +362,7 @@ def cross_view_attention_forward(cva, x, bev, feature, I_inv, E_inv):
 def cross_view_module_forward(cvm, batch):
     """``CrossViewModule.forward`` (cvt_modules.py:314-331) in training mode -> (b, l, dim, H, W)."""
     b, l, n = batch["inputs"].shape[:3]
-    I_inv = batch["intrinsic"].reshape(b * l, n, 3, 3).float().inverse()
+    I_inv = torch.linalg.inv_ex(batch["intrinsic"].reshape(b * l, n, 3, 3).float())[0]   # (inv_ex: no host read of the status)
     E_inv = batch["extrinsic"].reshape(b * l, n, 4, 4).float()
     x = cvm.bev_embedding.get_prior()[None].expand(b * l, -1, -1, -1)
     for cross_view, feature, layer in zip(cvm.cross_views, batch["features"], cvm.layers):

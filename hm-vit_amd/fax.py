@@ -298,7 +298,7 @@ class FAXModule(nn.Module):
         prep = self._prep.get(self, prec, lambda: self._build(prec, dt))
         for cv in self.cross_views:
             cv.precision = "f32" if self.precision == "split" else self.precision
-        I_inv = batch["intrinsic"].reshape(b * l, n, 3, 3).float().inverse()      # 3x3 inverses: host-side plumbing, as the reference
+        I_inv = torch.linalg.inv_ex(batch["intrinsic"].reshape(b * l, n, 3, 3).float())[0]   # (inv_ex: no host read of the status)      # 3x3 inverses: host-side plumbing, as the reference
         E_inv = batch["extrinsic"].reshape(b * l, n, 4, 4).float()
         x = self.bev_embedding.get_prior().detach().float()[None].repeat(b * l, 1, 1, 1).contiguous()
         n_levels = len(self.cross_views)

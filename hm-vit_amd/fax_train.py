@@ -139,7 +139,7 @@ def downsample_forward(seq, t):
 def fax_module_forward(fm, batch):
     """``FAXModule.forward`` in training mode -> (b, l, dim[-1], H, W)."""
     b, l, n = batch["camera"].shape[:3]
-    I_inv = batch["intrinsic"].reshape(b * l, n, 3, 3).float().inverse()
+    I_inv = torch.linalg.inv_ex(batch["intrinsic"].reshape(b * l, n, 3, 3).float())[0]   # (inv_ex: no host read of the status)
     E_inv = batch["extrinsic"].reshape(b * l, n, 4, 4).float()
     x = fm.bev_embedding.get_prior()[None].expand(b * l, -1, -1, -1)
     n_levels = len(fm.cross_views)
