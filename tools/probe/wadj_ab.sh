@@ -1,3 +1,6 @@
+# k_warp_adjoint with the fused bias sums: pixels per workgroup (HMVIT_WADJ_RUN x 4) against the launch time, one cfg2 training step each.
+# Build the variants first (in the repo, before gpurun):
+#   for r in 1 2 4 8; do bash tools/probe/build_var.sh wadj_run$r "-DHMVIT_WADJ_RUN=$r" train.hip; done
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r05
 for L in tools/probe/lib_wadj_run1.so tools/probe/lib_wadj_run2.so tools/probe/lib_wadj_run4.so tools/probe/lib_wadj_run8.so; do
