@@ -1987,6 +1987,8 @@ int launch_linear16(const LinJobs& jobs, hipStream_t st) {
         HMVIT_CHECK_ARG(j.a && j.M > 0 && j.n_mat >= 1 && j.n_mat <= kMaxLinMats && j.ldy >= 256 && j.ldy % 4 == 0, "linear16: bad job %d", i);
         HMVIT_CHECK_ARG(!j.residual || j.n_mat == 1 || j.sum_inputs, "linear16: a residual goes with a single output (job %d)", i);
         HMVIT_CHECK_ARG(!j.sum_inputs || (!j.ln_gamma && j.drop.p == 0.f), "linear16: the input sum takes no LayerNorm / dropout (job %d)", i);
+        HMVIT_CHECK_ARG(j.drop.p == 0.f || (j.n_mat == 1 && j.residual && j.drop.p > 0.f && j.drop.p < 1.f),
+                        "linear16: dropout (p=%f) goes with one matrix and a residual (job %d)", (double)j.drop.p, i);
         HMVIT_CHECK_ARG((j.ln_gamma == nullptr) == (j.ln_beta == nullptr), "linear16: LayerNorm needs gamma and beta (job %d)", i);
         for (int m = 0; m < j.n_mat; ++m)
             HMVIT_CHECK_ARG(j.wimg[m] && j.w_inv[m] && (j.sum_inputs ? (m == 0 ? j.y[0] != nullptr : j.a_more[m - 1] != nullptr) : j.y[m] != nullptr),
