@@ -782,6 +782,9 @@ __global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp)
     }
     const float do_inv = pow2_inv(do_scale);
     // ---- query tile (+ bias), dO tile, D and lse ----
+    // D = rowsum over a head's 32 channels of dO o O comes out of the same pass: the thread that stages 8 channels of a token's dO
+    // multiplies them with the 8 channels of O and the four threads of a head add up (round 5; a loop of its own walked 64
+    // scalar loads per (token, head) with half the workgroup idle: 7 % of the kernel's cycles)
     {
         const float* bq = p.b_q + te * C + ch0;
         const int cl = (tid % TPK) * 8;
@@ -791,10 +794,24 @@ __global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp)
             const size_t o = (size_t)(row * W + col) * C + ch0 + cl;
             half8 qh_, ql_, dh_, dl_;
             float qv[8], dv8[8];
+            float d = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 qv[e] = qplane[o + e] + bq[cl + e];
-                dv8[e] = doplane[o + e] * do_scale;
+                const float dov = doplane[o + e];
+                dv8[e] = dov * do_scale;
+#ifdef HMVIT_PROBE
+                if (bp.probe != 3)
+#endif
+                d = fmaf(dov, oplane[o + e], d);
+            }
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            if ((tid & 3) == 0) {
+                const int hh = cl >> 5;
+                Dl[n][hh] = d * do_scale;
+                // kept times log2(e): the probabilities are rebuilt with v_exp_f32 (a base-2 exponential)
+                Lse[n][hh] = p.lse[((size_t)(b * L + ego) * P + row * W + col) * heads + hg * HG + hh] * 1.4426950408889634f;
             }
             split_pk8(qv, qh_, ql_);
             split_pk8(dv8, dh_, dl_);
@@ -802,21 +819,6 @@ __global__ __launch_bounds__(HG * 128, 2) void k_attention_bwd(AttnBwdParams bp)
             *reinterpret_cast<half8*>(Ql + n * QS + cl) = ql_;
             *reinterpret_cast<half8*>(dOh + n * QS + cl) = dh_;
             *reinterpret_cast<half8*>(dOl + n * QS + cl) = dl_;
-        }
-        for (int i = tid; i < N * HG; i += THREADS) {
-            const int n = i / HG, hh = i - n * HG;
-            int row, col;
-            token_pixel(p.partition, WIN, X, Y, wx, wy, n, row, col);
-            const size_t o = (size_t)(row * W + col) * C + ch0 + hh * 32;
-            float d = 0.f;
-#ifdef HMVIT_PROBE
-            if (bp.probe != 3)
-#endif
-#pragma unroll 8
-            for (int e = 0; e < 32; ++e) d = fmaf(doplane[o + e], oplane[o + e], d);
-            Dl[n][hh] = d * do_scale;
-            // kept times log2(e): the probabilities are rebuilt with v_exp_f32 (a base-2 exponential)
-            Lse[n][hh] = p.lse[((size_t)(b * L + ego) * P + row * W + col) * heads + hg * HG + hh] * 1.4426950408889634f;
         }
     }
     // (the bias fragments themselves are re-read from global per tile pair: 14 fragment registers sets spilled the kernel)
