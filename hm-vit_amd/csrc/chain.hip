@@ -1528,9 +1528,13 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
     int extra = 0;                                       // pending for this wave's next counted wait
     auto ring_wait = [&](bool flush_since) {
         if ((cc + 2 < n_total || has_next) && full_wave) {
+            // `extra` is 0, 16 (the 16 loads of a token row) or 64 (the 64 scalar loads of a row of an NCHW map: 4 + 64 is past the
+            // counter's 6 bits, 63 is merely stricter); the counts below are exact for those and nothing else, so any other value
+            // waits for everything (the walk's waits were only right for extra == 16, unchecked)
             if (extra == 0) { if (flush_since) ring_wait_newest8(); else ring_wait_newest4(); }
-            else if (extra <= 16) { if (flush_since) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); }
-            else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+            else if (extra == 16) { if (flush_since) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); }
+            else if (extra == 64) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+            else dma_wait();
         } else dma_wait();
         extra = 0;
     };
