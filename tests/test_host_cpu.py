@@ -337,4 +337,4 @@ def test_shipped_build_carries_no_experiment_switches():
     assert used and all(m in guard for m in used), sorted(m for m in used if m not in guard)
     if os.path.isdir(os.path.join(ROOT, ".git")):
         tracked = subprocess.run(["git", "-C", ROOT, "ls-files"], capture_output=True, text=True).stdout.split("\n")
-        assert not [t for t in tracked if re.search(r"\.(o|so|a|hsaco)($|\.)", t)]
+        assert not [t for t in tracked if re.search(r"\.(o|so|a|hsaco|hipi|bc|s)($|\.)", t)]
