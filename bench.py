@@ -592,6 +592,14 @@ def main(argv=None):
         roof = {"kernel": dom, "bound": kind, "achieved": achieved, "peak": peak, "unit": unit,
                 "frac": achieved / peak, "traffic": traffic, "avg_launch_ms": avg_s * 1e3,
                 "algorithmic_per_launch": per_launch}
+        # where `traffic` comes from: a builder-side PMC pass over the same sources, NOT something this run observed
+        tsrc = {"file": "profiles/pmc_traffic.json", "collected_by": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py` on a "
+                "builder box (tools/probe/r06_evidence.sh, tools/pmc_summary.py); FETCH x2 (gfx950 wide-read correction) + WRITE",
+                "file_kernel_source_hash": None, "this_run_kernel_source_hash": kernel_source_hash(), "match": False}
+        if os.path.exists(tpath):
+            tsrc["file_kernel_source_hash"] = json.load(open(tpath)).get("kernel_source_hash")
+            tsrc["match"] = tsrc["file_kernel_source_hash"] == tsrc["this_run_kernel_source_hash"] and args.config == "cfg2"
+        roof["traffic_source"] = tsrc
         if dom == "attention":
             # the same kernel against the HBM roof: compulsory bytes = Q in + every K'/V' map once + O out, for the (ego, window)
             # items each launch actually RAN (hmvit_fusion_profile_items: the reachability pruning drops a quarter of the third
@@ -622,10 +630,74 @@ def main(argv=None):
                              "algorithmic_per_launch": comp, "mfma_view": mfma})
             else:
                 roof["hbm_view"] = hbm
+                roof["mfma_view"] = {"algorithmic_flops_per_launch": per_launch, "achieved_TFLOPs": achieved, "peak_TFLOPs": peak, "frac": achieved / peak}
+        # ---- every phase against both roofs: algorithmic flops and compulsory bytes of the MEAN launch of the phase,
+        # its measured average launch time, and the PMC traffic of the same kernel where the committed pass matches these sources ----
+        if fused:
+            L_, C_, P_ = c["L"], c["C"], c["H"] * c["W"]
+            n_st = 2 * args.num_iters
+            E_ = len(set(c["modes"]))
+            plane = P_ * C_
+            items = getattr(net, "last_attention_items", None) or []
+            n_win = P_ // (c["window"] ** 2)
+            q_rows = [live / n_win * P_ for live, _ in items] if len(items) == n_st else [L_ * P_] * (n_st - 1) + [P_]
+            by = {}
+            # first stage's LayerNorm + projections: the NCHW input once, Q / K' / V' planes out
+            by["ln_qkv"] = (work["ln_qkv"][1], L_ * plane * 4 + (L_ + 2 * L_ * E_) * plane * es)
+            # attention: Q rows in + every K' / V' map once + O rows out, for the items each launch ran; flops on the same rows
+            by["attention"] = (sum(2 * 2 * r * (L_ * c["window"] ** 2) * C_ for r in q_rows) / n_st,
+                               sum(r * C_ * es * 2 + L_ * 2 * plane * es for r in q_rows) / n_st)
+            # stage tails: O + residual stream in, residual stream out, the next stage's Q / K' / V' out (ego 0's Q only in front of the pruned
+            # last stage); the last launch is tail + mlp_head on ego 0's rows with the NCHW map out
+            tail_bytes = 0.0
+            for st in range(n_st - 1):
+                n_q = 1 if st == n_st - 2 else L_
+                tail_bytes += L_ * plane * (es + 4 + 4) + (n_q + 2 * L_ * E_) * plane * es
+            tail_bytes += plane * (es + 4 + 4)
+            head_flops = work["head"][1]
+            by["stage_tail"] = (work["stage_tail"][1] + head_flops / n_st, tail_bytes / n_st)
+            tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+            t_ok = tj.get("kernel_source_hash") == kernel_source_hash() and args.config == "cfg2"
+            rbp = {}
+            for name, (flops, nbytes) in by.items():
+                if name not in phases:
+                    continue
+                t_s = phases[name]["ms_total"] / phases[name]["launches"] * 1e-3
+                tr = tj.get(prec, {}).get(name) if t_ok else None
+                if name == "stage_tail" and t_ok and tr is not None and tj.get(prec, {}).get("stage_tail_head") is not None:
+                    # the file keeps the three fused tails and the tail + head launch apart: mean over the launches of the phase
+                    tr = (tr * (n_st - 1) + tj[prec]["stage_tail_head"]) / n_st
+                rbp[name] = {"launches": phases[name]["launches"], "avg_launch_ms": t_s * 1e3,
+                             "mfma": {"algorithmic_flops_per_launch": flops, "achieved_TFLOPs": flops / t_s / 1e12, "peak_TFLOPs": PEAK[prec],
+                                      "frac": flops / t_s / 1e12 / PEAK[prec]},
+                             "hbm": {"algorithmic_bytes_per_launch": nbytes, "achieved_GBps": nbytes / t_s / 1e9, "peak_GBps": PEAK_HBM,
+                                     "frac": nbytes / t_s / 1e9 / PEAK_HBM},
+                             "traffic": tr, "traffic_over_algorithmic": (tr / nbytes) if tr else None}
+            roof["by_phase"] = rbp
         return roof, phases
 
     if rank == 0 and not args.stub:
         result["roofline"], result["phases"] = roofline_of(net, precision)
+        result["roofline_by_phase"] = result["roofline"].pop("by_phase", None)
+        # host cost of a forward (Python + ctypes + the launches of ~16 kernels) with the GPU queue kept non-empty: the small inputs and
+        # the pairwise matrices are handed over on the HOST, so that nothing is read back and the forwards queue up behind each other;
+        # what `--gpus 8` (eight such processes on one node) has to stay below is the GPU's ms_per_step
+        if not args.train:
+            with torch.no_grad():
+                hs = [scene[0]] + [t.cpu() for t in scene[1:]]
+                for _ in range(3):
+                    net(*hs)
+                sync()
+                n_h = 24
+                t0 = time.perf_counter()
+                for _ in range(n_h):
+                    net(*hs)
+                t_host = time.perf_counter() - t0
+                sync()
+                t_all = time.perf_counter() - t0
+            result["host_ms_per_forward"] = {"value": t_host / n_h * 1e3, "unit": "ms", "gpu_ms_per_forward_same_loop": t_all / n_h * 1e3,
+                                             "what": f"wall time of {n_h} back-to-back forward calls up to the return of the last call (no "
+                                                     "synchronisation inside; mode / record_len / mask / pairwise on the host), per call"}
         side = not args.no_strict and world == 1
         if side:
             # a path that skips fully masked key tiles reports the dense figure too (same outputs,
@@ -635,6 +707,14 @@ def main(argv=None):
             result["dense_masked_tiles"] = {"value": k / timed(net, k, 1)[0], "unit": "scenes/s",
                                             "note": "every (ego, source, window) tile and every window of every agent computed, masked keys at -inf"}
             net.skip_masked = True
+        if side and precision == "split":
+            # the opt-in local-stage kernel of round 6 (k_attention_patch): same results, fewer vector-memory wave loads
+            net.patch_attention = True
+            pdt, _ = timed(net, args.steps, args.warmup)
+            _, pph = roofline_of(net, precision)
+            result["patch_attention"] = {"value": args.steps / pdt, "unit": "scenes/s", "ms_per_step": pdt / args.steps * 1e3, "phases": pph,
+                                         "note": "HeteroFusion.patch_attention = True: the local stages' attention on k_attention_patch"}
+            net.patch_attention = False
         del net
         torch.cuda.empty_cache()
         if side and precision != "f16":

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMVIT_LIB", os.path.join(_HERE, "libhmvit.so"))   # HMVIT_LIB: ablation builds of tools/probe
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 PREC_F32, PREC_F16, PREC_SPLIT, PREC_MIXED = 0, 1, 2, 3
 PART_WINDOW, PART_GRID = 0, 1
 NUM_TYPES = 2
@@ -60,6 +60,7 @@ class FusionDesc(C.Structure):
         ("split_fc2", C.c_void_p),
         ("head_scales", C.c_void_p),
         ("self_identity", C.c_int32),
+        ("rigid_patch", C.c_int32),
     ]
 
 

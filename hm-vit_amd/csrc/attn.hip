@@ -2084,6 +2084,8 @@ static int launch_attn_pcs(const AttnParams& p_in, hipStream_t st) {
     return HMVIT_OK;
 }
 
+#include "attn_patch.hpp"
+
 template <typename T, int WIN, int HG>
 static int launch_attn_t(const AttnParams& p, hipStream_t st) {
     const int NG = p.C / (HG * 32);
@@ -2437,6 +2439,9 @@ int launch_attention(const AttnParams& p, int precision, hipStream_t st) {
     if (precision == HMVIT_PREC_SPLIT && w8 && p.C >= 128 && p.self_identity && p.n_src <= 8 &&
         p.B * p.L * p.L <= PcShared2::MAX_PAIRS) {
         AttnParams q = p;
+        // local stages over rigid transforms: the de-duplicated patch kernel (attn_patch.hpp)
+        if (p.partition == HMVIT_PART_WINDOW && p.C == 256 && p.rigid_patch && p.n_src <= PatchShared::NCH + 1 && !HMVIT_ENV("HMVIT_NO_PATCH"))
+            return launch_attn_patch(q, st);
         if (p.partition == HMVIT_PART_GRID) q.variant ^= 0x200;   // item order as for k_attention_pc
         // head group per XCD: bit 0 grid stages, bit 1 local stages.  Measured at cfg2 (tools/probe/r03_attn_ab.sh): local stages
         // 1660 -> 1593 us and 4.56 -> 4.13 GB fetched; the grid stages fetch 18 % less (11.3 -> 9.2 GB) but run 6 % SLOWER

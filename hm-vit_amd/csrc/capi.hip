@@ -622,6 +622,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                 // the stage after this one is the pruned last stage (ego 0 only): unreachable windows are dead code
                 need = (it == d->num_iters - 1 && s == 0) ? need_last : nullptr;
                 ap.self_identity = d->self_identity;
+                ap.rigid_patch = d->rigid_patch;
                 // split mode: the persistent split kernel needs the table and identity self transforms; otherwise (and for
                 // window 4 / C = 64) the exact-f32 kernel runs on the f32 planes
                 const bool pc_split = split == 1 && d->self_identity && pl.n_slots * L <= 128;

@@ -76,6 +76,7 @@ __device__ __forceinline__ void split_pk8(const float (&v)[8], half8& h, half8& 
     defined(HMVIT_EXP_NOWAIT) || defined(HMVIT_EXP_PCS_NOEPI) || defined(HMVIT_EXP_PCS_NOLOAD) ||                           \
     defined(HMVIT_EXP_PCS_NOLOADER) || defined(HMVIT_EXP_PCS_NOMATH) || defined(HMVIT_EXP_PCS_NOQ) ||                       \
     defined(HMVIT_EXP_PCS_NOSTORE) || defined(HMVIT_EXP_PCS_NOTABLES) || defined(HMVIT_EXP_STATIC_ITEMS) ||                 \
+    defined(HMVIT_EXP_PATCH_NODMA) || defined(HMVIT_EXP_PATCH_NOBLEND) || defined(HMVIT_EXP_PATCH_NOMATH) || defined(HMVIT_EXP_PATCH_NOTABLES) || \
     defined(HMVIT_EXP_X16_NODMA) || defined(HMVIT_EXP_PCS_Q4) || defined(HMVIT_EXP_PCS_LPRIO) || defined(HMVIT_EXP_X16_NOSTORE) || defined(HMVIT_DBG_SUMS))
 #error "HMVIT_EXP_* / HMVIT_DBG_* are timing / debug experiments: build them with -DHMVIT_ALLOW_EXP (tools/probe/build_var.sh), never into the shipped library"
 #endif
@@ -123,8 +124,16 @@ struct Taps {
     float roi;     // 1 when the nearest source pixel is inside the map
 };
 
-__device__ __forceinline__ Taps make_taps(const float* __restrict__ a, int u, int v, int H, int W) {
-    Taps t;
+// The same sample in pixel coordinates: x0 / y0 = floor of the sampling position (clamped far outside the map so that the integer
+// conversion stays defined), w[k] the weight of tap (x0 + (k & 1), y0 + (k >> 1)), already 0 where that pixel lies outside the
+// map.  make_taps is built on it, so both forms hold bit-identical weights and visibility.
+struct TapsXY {
+    int x0, y0;
+    float w[4];
+    float roi;
+};
+__device__ __forceinline__ TapsXY make_taps_xy(const float* __restrict__ a, int u, int v, int H, int W) {
+    TapsXY t;
     const float fu = (float)u, fv = (float)v;
     const float sx = fmaf(a[0], fu, fmaf(a[1], fv, a[2]));
     const float sy = fmaf(a[3], fu, fmaf(a[4], fv, a[5]));
@@ -137,15 +146,25 @@ __device__ __forceinline__ Taps make_taps(const float* __restrict__ a, int u, in
     const int x1 = x0 + 1, y1 = y0 + 1;
     const bool vx0 = (x0 >= 0) & (x0 < W), vx1 = (x1 >= 0) & (x1 < W);
     const bool vy0 = (y0 >= 0) & (y0 < H), vy1 = (y1 >= 0) & (y1 < H);
-    const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
-    const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
-    t.idx[0] = cy0 * W + cx0; t.w[0] = (vx0 & vy0) ? wx0 * wy0 : 0.f;
-    t.idx[1] = cy0 * W + cx1; t.w[1] = (vx1 & vy0) ? wx1 * wy0 : 0.f;
-    t.idx[2] = cy1 * W + cx0; t.w[2] = (vx0 & vy1) ? wx0 * wy1 : 0.f;
-    t.idx[3] = cy1 * W + cx1; t.w[3] = (vx1 & vy1) ? wx1 * wy1 : 0.f;
+    t.x0 = x0; t.y0 = y0;
+    t.w[0] = (vx0 & vy0) ? wx0 * wy0 : 0.f;
+    t.w[1] = (vx1 & vy0) ? wx1 * wy0 : 0.f;
+    t.w[2] = (vx0 & vy1) ? wx0 * wy1 : 0.f;
+    t.w[3] = (vx1 & vy1) ? wx1 * wy1 : 0.f;
     // nearest (round-half-even, as std::nearbyint in grid_sample)
     const float nx = rintf(sx), ny = rintf(sy);
     t.roi = (nx >= 0.f && nx <= (float)(W - 1) && ny >= 0.f && ny <= (float)(H - 1)) ? 1.f : 0.f;
+    return t;
+}
+__device__ __forceinline__ Taps make_taps(const float* __restrict__ a, int u, int v, int H, int W) {
+    const TapsXY q = make_taps_xy(a, u, v, H, W);
+    Taps t;
+    const int cx0 = min(max(q.x0, 0), W - 1), cx1 = min(max(q.x0 + 1, 0), W - 1);
+    const int cy0 = min(max(q.y0, 0), H - 1), cy1 = min(max(q.y0 + 1, 0), H - 1);
+    t.idx[0] = cy0 * W + cx0; t.idx[1] = cy0 * W + cx1; t.idx[2] = cy1 * W + cx0; t.idx[3] = cy1 * W + cx1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t.w[k] = q.w[k];
+    t.roi = q.roi;
     return t;
 }
 

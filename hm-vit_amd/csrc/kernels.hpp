@@ -259,6 +259,8 @@ struct AttnParams {
     int prune;                       // vis_mask bit 31 marks items no later stage can reach: skipped by the schedule
     int self_identity;               // caller's guarantee that every self transform pairwise_t[b, i, i] is the identity
                                      // (needed by the split-precision persistent kernel, which has no general-self loader)
+    int rigid_patch;                 // caller's guarantee that every pair transform is a rotation to 2 % (HmvitFusionDesc::rigid_patch):
+                                     // the local stages of the split mode may take k_attention_patch
     float* lse;               // optional (B, L, P, heads) f32: log-sum-exp of every query row (f32 kernel; kept for the backward pass)
     const int* sched;         // optional world-ordered item list of the persistent kernels (launch_attn_schedule), n_sched items
     int n_sched, sched_sub;   // sched_sub: steps per list segment (pc_fetch_sched)

@@ -192,8 +192,8 @@ __device__ __forceinline__ long long small_value(const void* p, int dtype, int i
     }
 }
 __global__ __launch_bounds__(256) void k_pack_small(SmallPack a) {
-    __shared__ int not_identity;
-    if (threadIdx.x == 0) not_identity = 0;
+    __shared__ int not_identity, not_rigid;
+    if (threadIdx.x == 0) { not_identity = 0; not_rigid = 0; }
     __syncthreads();
     const int n_int = a.n[0] + a.n[1] + a.n[2];
     for (int i = threadIdx.x; i < n_int; i += 256) {
@@ -210,8 +210,20 @@ __global__ __launch_bounds__(256) void k_pack_small(SmallPack a) {
             const double v = a.pw_dtype == 1 ? reinterpret_cast<const double*>(a.pairwise)[off] : (double)reinterpret_cast<const float*>(a.pairwise)[off];
             if (v != (((e >> 2) == (e & 3)) ? 1.0 : 0.0)) atomicOr(&not_identity, 1);
         }
+        // bit 1: every pair transform is a rotation (+ translation) to 2 %: M^T M = I for its upper-left 2 x 2 block (the sampling map is
+        // built from that block and the x / y translation only, k_pair_affines); NaNs fail the test
+        const int n_pairs = a.B * a.L * a.L;
+        for (int i = threadIdx.x; i < n_pairs; i += 256) {
+            double m[4];
+            for (int e = 0; e < 4; ++e) {
+                const size_t off = (size_t)i * 16 + (e >> 1) * 4 + (e & 1);
+                m[e] = a.pw_dtype == 1 ? reinterpret_cast<const double*>(a.pairwise)[off] : (double)reinterpret_cast<const float*>(a.pairwise)[off];
+            }
+            const double g00 = m[0] * m[0] + m[2] * m[2] - 1.0, g01 = m[0] * m[1] + m[2] * m[3], g11 = m[1] * m[1] + m[3] * m[3] - 1.0;
+            if (!(fabs(g00) <= 0.02 && fabs(g01) <= 0.02 && fabs(g11) <= 0.02)) atomicOr(&not_rigid, 1);
+        }
         __syncthreads();
-        if (threadIdx.x == 0) a.out[n_int] = not_identity ? 0 : 1;
+        if (threadIdx.x == 0) a.out[n_int] = (not_identity ? 0 : 1) | (not_rigid ? 0 : 2);
     }
 }
 int launch_pack_small(const SmallPack& a, hipStream_t st) {

@@ -109,6 +109,10 @@ class _FusionBase(nn.Module):
 
     precision = "split"          # the reference's fp32 arithmetic on the f16 matrix pipes (1e-4); "f16" is the opt-in fast mode
     skip_masked = True
+    # split mode, local stages: k_attention_patch (de-duplicated source patch, csrc/attn_patch.hpp) instead of the gather kernel when
+    # every pair transform is rigid.  Same results to fp32 round-off; 2.6x fewer vector-memory wave loads, ~10 % SLOWER at cfg2
+    # (both kernels issue the same VALU work at two waves per SIMD) - off by default, kept tested
+    patch_attention = False
     _warned_eval_grad = False
 
     def _init_runtime(self):
@@ -134,7 +138,12 @@ class _FusionBase(nn.Module):
             # it selects the split mode's persistent attention kernel
             L = pairwise.shape[1]
             idx = torch.arange(L, device=pairwise.device)
-            extra = [(pairwise[:, idx, idx] == torch.eye(4, device=pairwise.device, dtype=pairwise.dtype)).all().reshape(1)]
+            ident = (pairwise[:, idx, idx] == torch.eye(4, device=pairwise.device, dtype=pairwise.dtype)).all()
+            # bit 1: every pair transform is a rotation to 2 % (HmvitFusionDesc::rigid_patch; the same test as k_pack_small)
+            m = pairwise[..., :2, :2].to(torch.float64)
+            gram = m.transpose(-1, -2) @ m - torch.eye(2, device=pairwise.device, dtype=torch.float64)
+            rigid = (gram.abs() <= 0.02).all()
+            extra = [(ident.to(torch.int64) + 2 * rigid.to(torch.int64)).reshape(1)]
         if any(t.device.type != "cpu" for t in ts + extra):
             dev = next(t.device for t in ts + extra if t.device.type != "cpu")
             flat = torch.cat([t.to(dev).reshape(-1).to(torch.int64) for t in ts + extra]).cpu().tolist()
@@ -142,7 +151,7 @@ class _FusionBase(nn.Module):
             flat = torch.cat([t.reshape(-1).to(torch.int64) for t in ts + extra]).tolist()
         n0, n1, n2 = ts[0].numel(), ts[1].numel(), ts[2].numel()
         out = ([int(v) for v in flat[:n0]], [int(v) for v in flat[n0:n0 + n1]], [int(v) for v in flat[n0 + n1:n0 + n1 + n2]])
-        return out + (bool(flat[-1]),) if pairwise is not None else out
+        return out + (int(flat[-1]),) if pairwise is not None else out
 
     _SMALL_DTYPES = {torch.float32: 0, torch.float64: 1, torch.int32: 2, torch.int64: 3, torch.uint8: 4, torch.bool: 4, torch.float16: 5}
 
@@ -171,7 +180,7 @@ class _FusionBase(nn.Module):
                                                  out.data_ptr(), stream), "hmvit_pack_small")
         flat = out.cpu().tolist()
         res = ([int(v) for v in flat[:n[0]]], [int(v) for v in flat[n[0]:n[0] + n[1]]], [int(v) for v in flat[n[0] + n[1]:n[0] + n[1] + n[2]]])
-        return res + (bool(flat[-1]),) if pairwise is not None else res
+        return res + (int(flat[-1]),) if pairwise is not None else res
 
     def _weights(self, device, prec: int):
         params = list(self.parameters()) + list(self.buffers())
@@ -254,6 +263,9 @@ class _FusionBase(nn.Module):
             precision = "f32"
         prec = _PRECISIONS[precision]
         x = x.detach().to(torch.float32).contiguous()
+        # a pairwise matrix handed over on the host is inspected there (identity / rigidity flags): together with host-side mode /
+        # record_len / mask the forward then needs no device read-back at all and the launches queue up behind each other
+        pw_host = pairwise_t_matrix.detach() if pairwise_t_matrix.device.type == "cpu" else None
         pw = pairwise_t_matrix.detach().to(device=x.device, dtype=torch.float32).contiguous()
         if tuple(pw.shape) != (B, L, L, 4, 4):
             raise ValueError(f"pairwise_t_matrix must be {(B, L, L, 4, 4)}, got {tuple(pw.shape)}")
@@ -287,8 +299,9 @@ class _FusionBase(nn.Module):
             for name, t in w["split"].items():
                 setattr(d, name, t.data_ptr())
         if prec in (_lib.PREC_SPLIT, _lib.PREC_MIXED):
-            mode_h, rl_h, mask_h, self_ident = self._host_small(mode, record_len, mask, pw)
-            d.self_identity = int(self_ident)
+            mode_h, rl_h, mask_h, pw_flags = self._host_small(mode, record_len, mask, pw if pw_host is None else pw_host)
+            d.self_identity = pw_flags & 1
+            d.rigid_patch = ((pw_flags >> 1) & 1) if self.patch_attention else 0
         else:
             mode_h, rl_h, mask_h = self._host_small(mode, record_len, mask)
         if len(mode_h) != B * L or len(mask_h) != B * L or len(rl_h) != B:

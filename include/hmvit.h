@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HMVIT_ABI_VERSION 11
+#define HMVIT_ABI_VERSION 12
 
 #define HMVIT_OK 0
 #define HMVIT_EINVAL (-22)   /* bad argument / unsupported shape */
@@ -188,6 +188,11 @@ typedef struct HmvitFusionDesc {
     int32_t self_identity;        /* 1: the caller guarantees pairwise_t[b, i, i] = I for every agent (what the reference's
                                      datasets produce, mixed/intermediate_fusion_dataset.py:163-202); lets HMVIT_PREC_SPLIT use
                                      its persistent attention kernel.  0: unknown (always correct, slower in split mode) */
+    int32_t rigid_patch;          /* 1: the caller guarantees that the upper-left 2 x 2 block M of every pairwise_t[b, i, j] is a rotation
+                                     to 2 % (|M^T M - I| <= 0.02 elementwise; the reference's poses are rigid: x / y / yaw and small
+                                     roll / pitch).  Then the 32 keys of a half window never touch more than 64 source pixels and the
+                                     local stages of HMVIT_PREC_SPLIT run the de-duplicated patch kernel (k_attention_patch).
+                                     0: unknown (always correct: the gather kernel).  hmvit_pack_small reports both guarantees. */
 } HmvitFusionDesc;
 
 int hmvit_abi_version(void);
@@ -324,7 +329,9 @@ int hmvit_bn_train_backward(const float* x, const float* y, const float* dy, con
 /* The small integer inputs of HeteroFusion.forward - mode (B, L), record_len (B), mask (B, L), in whatever dtype the caller holds
  * them on the device (codes: 0 f32, 1 f64, 2 i32, 3 i64, 4 u8 / bool, 5 f16) - as int64 words out[0 .. n_mode + n_rl + n_mask), so
  * that the host reads them with one copy (the launch plan needs them: hetero_fusion.py:127-131 reads them back element by element).
- * pairwise (B, L, L, 4, 4) f32 (pw_dtype 0) / f64 (1) or NULL: one more word, 1 when every pairwise[b, l, l] equals the identity. */
+ * pairwise (B, L, L, 4, 4) f32 (pw_dtype 0) / f64 (1) or NULL: one more word of flags - bit 0: every pairwise[b, l, l] equals the
+ * identity (HmvitFusionDesc::self_identity); bit 1: the upper-left 2 x 2 block M of EVERY pairwise[b, i, j] satisfies
+ * |M^T M - I| <= 0.02 elementwise (HmvitFusionDesc::rigid_patch). */
 int hmvit_pack_small(const void* mode, int mode_dtype, int n_mode, const void* record_len, int rl_dtype, int n_rl, const void* mask,
                      int mask_dtype, int n_mask, const void* pairwise, int pw_dtype, int B, int L, int64_t* out, void* stream);
 

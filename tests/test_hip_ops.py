@@ -1,6 +1,7 @@
 """GPU parity tests of the single operators exported by libhmvit (include/hmvit.h), each against
 plain torch fp32 on the same seeded inputs.  Tolerances: f32 mode = fp32 round-off, f16 mode =
 the 1e-3 relative budget of north_star split over the operators."""
+import math
 import ctypes
 
 import numpy as np
@@ -264,7 +265,16 @@ def test_small_inputs_read_back_in_one_launch(dtypes, pw_dtype):
         assert got is not None and got == want
         assert _FusionBase._host_small(*dev, pw.cuda() if pw is not None else None) == want
         if pw is not None:
-            assert want[3] == (not perturb)
+            assert want[3] == (2 | (0 if perturb else 1))       # bit 0: identity self transforms, bit 1: rigid pairs (still true here)
+    if pw_dtype is not None:                                # a sheared / scaled pair turns the rigidity bit off, a rotation keeps it
+        pw = torch.eye(4, dtype=pw_dtype).repeat(B, L, L, 1, 1)
+        c, s_ = math.cos(0.7), math.sin(0.7)
+        pw[1, 2, 4, :2, :2] = torch.tensor([[c, -s_], [s_, c]], dtype=pw_dtype)
+        assert _FusionBase._pack_small_on_device(dev, pw.cuda())[3] == 3 == _FusionBase._host_small(*host, pw)[3]
+        pw[1, 2, 4, 0, 0] = c * 1.03
+        assert _FusionBase._pack_small_on_device(dev, pw.cuda())[3] == 1 == _FusionBase._host_small(*host, pw)[3]
+        pw[1, 2, 4, 0, 0] = float("nan")
+        assert _FusionBase._pack_small_on_device(dev, pw.cuda())[3] == 1 == _FusionBase._host_small(*host, pw)[3]
     # mixed placement / an unsupported dtype: no device path, the aten formulation takes over
     assert _FusionBase._pack_small_on_device([dev[0], host[1], dev[2]], None) is None
     assert _FusionBase._pack_small_on_device([dev[0].to(torch.int16), dev[1], dev[2]], None) is None
