@@ -435,7 +435,7 @@ def main(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of --cpu-baseline-full (default: the crop sweep's best)")
     ap.add_argument("--train-recompute", type=int, default=0, choices=(0, 1, 3),
                     help="--train: HmvitFusionTrainDesc::recompute bits (1: the FFN pre-activations, 3: + the queries are recomputed in the "
-                         "backward pass instead of kept: cfg2 peak 32.8 -> 30.1 -> 27.4 GiB for +1.9 / +3.1 ms per step)")
+                         "backward pass instead of kept: cfg2 peak 32.8 -> 30.1 -> 27.4 GiB for +1.6 / +4.0 ms per step, cumulative)")
     ap.add_argument("--train", action="store_true",
                     help="the training half of north_star instead of the inference headline: one DistributedDataParallel train step "
                          "per rank (HeteroFusion forward with dropout + HIP backward + gradient all-reduce on RCCL + AdamW)")

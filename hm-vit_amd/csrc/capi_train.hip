@@ -97,6 +97,8 @@ int make_train_plan(const HmvitFusionTrainDesc* t, TrainPlan& pl) {
     HMVIT_CHECK_ARG(t->only_stage >= 0 && t->only_stage <= 2, "only_stage=%d (0 = whole fusion, 1 = window stage, 2 = grid stage)", t->only_stage);
     HMVIT_CHECK_ARG(d->apply_head == (pl.only_stage < 0 ? 1 : 0), "training: HeteroFusion (apply_head = 1), or one stage of the block (apply_head = 0)");
     HMVIT_CHECK_ARG(t->drop_p >= 0.f && t->drop_p < 1.f, "drop_p=%f out of [0, 1)", t->drop_p);
+    // (the field took what was tail padding before ABI 12: an old caller's uninitialised bytes must not pick a layout)
+    HMVIT_CHECK_ARG((t->recompute & ~3) == 0, "recompute=%d (bits 0 and 1 only)", t->recompute);
     pl.B = d->B; pl.L = d->L; pl.C = d->C; pl.H = d->H; pl.W = d->W; pl.P = d->H * d->W; pl.mlp = d->mlp_dim;
     pl.heads = d->heads; pl.n_slots = d->B * d->L; pl.n_stages = pl.only_stage < 0 ? 2 * d->num_iters : 1;
     HMVIT_CHECK_ARG(pl.n_slots <= kMaxSlots, "B*L=%d exceeds %d agent slots per call", pl.n_slots, kMaxSlots);
@@ -589,6 +591,12 @@ static int train_backward(const HmvitFusionTrainDesc* t, const float* d_out, flo
     BwdPlan bp;
     make_bwd_plan(pl, bp);
     HMVIT_CHECK_ARG(d_out && d_x && grads && workspace && t->saved, "backward: null pointer");
+    // the saved area must be the one a forward with THIS plan wrote (same recompute bits, sizes, stages): its offsets come from the plan
+    if (t->saved_bytes < pl.total_floats * 4) {
+        set_error("backward: saved area too small for this descriptor: %zu < %zu bytes (recompute / sizes differ from the forward's?)",
+                  t->saved_bytes, pl.total_floats * 4);
+        return HMVIT_ENOMEM;
+    }
     const bool generic_attn = (d->window != 4 && d->window != 8) || d->dim_head != 32;
     HMVIT_CHECK_ARG(generic_attn || (t->bias_frag_neg[0] && t->bias_frag_neg[1]), "backward: bias_frag_neg is null");
     HMVIT_CHECK_ARG(pl.only_stage >= 0 || (d_head_w1 && d_head_b1 && d_head_w2 && d_head_b2), "backward: mlp_head gradient buffers are null");

@@ -246,13 +246,15 @@ __global__ __launch_bounds__(256) void k_gemm_split(GemmJobs jobs) {
         if (!keep) {
             const float sa = pow2_scale(ma), sw = pow2_scale(mw);
             if (live) {
-                const float f = (sa * pow2_inv(sa_run)) * (sw * pow2_inv(sw_run));
+                // two factors, applied one after the other: each is a power of two within 2^+-80, their product can leave f32 and an
+                // infinite factor would turn an accumulator that holds 0 into NaN
+                const float f1 = sa * pow2_inv(sa_run), f2 = sw * pow2_inv(sw_run);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[i][j][e] *= f;
+                        for (int e = 0; e < 16; ++e) acc[i][j][e] = (acc[i][j][e] * f1) * f2;
             }
             sa_run = sa; sw_run = sw; live = true;
         }
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(256) void k_gemm_split(GemmJobs jobs) {
         __syncthreads();
     }
     const int npp = J.n_per_plane;
-    const float unscale = pow2_inv(sa_run) * pow2_inv(sw_run);
+    const float unscale_a = pow2_inv(sa_run), unscale_w = pow2_inv(sw_run);     // (applied one after the other, as above)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + r;
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(256) void k_gemm_split(GemmJobs jobs) {
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
                 if (m >= M) continue;
-                float v = fmaf(acc[i][j][e], unscale, bias);
+                float v = fmaf(acc[i][j][e] * unscale_a, unscale_w, bias);
                 if constexpr (GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
                 if (J.residual) v += J.residual[(size_t)m * N + n];
                 reinterpret_cast<float*>(J.y)[ybase + (size_t)m * npp] = v;

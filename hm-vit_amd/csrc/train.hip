@@ -289,7 +289,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn_split(GemmTnJobs jobs) {
         const bool keep = run_live && td < 32768.f && ta < 32768.f && (td >= 256.f || md == 0.f) && (ta >= 256.f || ma == 0.f);
         if (!keep) {
             const float sd_need = pow2_scale(md), sa_need = pow2_scale(ma);
-            if (run_live) rescale((sd_need * pow2_inv(sd_run)) * (sa_need * pow2_inv(sa_run)));
+            // in two steps: each ratio is a power of two within 2^+-80, their product can leave f32 (2^+-160) and an infinite factor would
+            // turn an accumulator that holds 0 into NaN
+            if (run_live) { rescale(sd_need * pow2_inv(sd_run)); rescale(sa_need * pow2_inv(sa_run)); }
             sd_run = sd_need; sa_run = sa_need; run_live = true;
             stage();                                         // (same addresses, same threads: plain overwrite)
         }

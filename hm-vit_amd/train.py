@@ -69,7 +69,10 @@ def recompute_bits(module) -> int:
     """Memory for time in training (HmvitFusionTrainDesc::recompute): ``module.train_recompute`` (or HMVIT_TRAIN_RECOMPUTE in the
     environment) = 1: the FFN pre-activations are not kept for the backward pass, 3: neither are the queries - the backward recomputes
     them with the forward's own kernels (the same rows bit for bit).  cfg2 (5 agents, 200x704, C=256): peak 32.8 -> 30.1 -> 27.4 GiB
-    for +1.9 / +3.1 ms per step.  (``train_recompute_ffn = True`` is the same as 1.)"""
+    for 92.8 -> 94.4 -> 96.8 ms per step, i.e. +1.6 ms with bit 0 and +4.0 ms with both bits, cumulative (HISTORY.md 12.8, measured
+    with tests/tools/train_bench.py on one box).  (``train_recompute_ffn = True`` is the same as 1.)
+    The bits are read ONCE per step, here, by the forward: they are part of what the autograd context pins (the saved area's layout
+    depends on them), so changing the attribute or the environment between a forward and its backward cannot move the offsets."""
     v = getattr(module, "train_recompute", None)
     if v is None and getattr(module, "train_recompute_ffn", None):
         v = 1
@@ -78,7 +81,7 @@ def recompute_bits(module) -> int:
     return int(v) & 3
 
 
-def _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, out, saved, workspace, only_stage=0):
+def _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, out, saved, workspace, only_stage=0, recompute=None):
     blk = module._block_cfg
     B, L, C, H, W = x.shape
     t = _lib.FusionTrainDesc()
@@ -88,7 +91,7 @@ def _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, 
     d.window, d.mlp_dim, d.num_iters = blk["window_size"], blk["mlp_dim"], module.num_iters
     d.precision, d.apply_head, d.skip_masked = _lib.PREC_F32, (1 if only_stage == 0 else 0), 1
     t.only_stage = only_stage
-    t.recompute = recompute_bits(module)
+    t.recompute = recompute_bits(module) if recompute is None else int(recompute)
     d.self_identity = 1            # checked by fusion_forward_with_grad: pairwise_t_matrix[b, i, i] = I
     d.discrete_ratio, d.downsample_rate = float(module.discrete_ratio), float(module.downsample_rate)
     keep = (_lib.i32_array(mode_h), _lib.i32_array(rl_h), _lib.i32_array(mask_h))
@@ -130,25 +133,26 @@ class FusionTrainFunction(torch.autograd.Function):
         neg = [neg0.detach().contiguous(), neg1.detach().contiguous()]
         B, L, C, H, W = x.shape
         out = torch.empty((B, C, H, W) if only_stage == 0 else (B, L, C, H, W), device=x.device, dtype=torch.float32)
-        probe, keep0 = _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, out, None, None, only_stage)
+        rec = recompute_bits(module)       # pinned for this step: the backward's descriptor takes it from ctx, not from the module
+        probe, keep0 = _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, out, None, None, only_stage, rec)
         need = _lib.lib.hmvit_fusion_train_saved_bytes(ctypes.byref(probe))
         if need == 0:
             _lib.check(-22, "hmvit_fusion_train_saved_bytes")
         saved = torch.empty(need, dtype=torch.uint8, device=x.device)
         blk = module._block_cfg
-        scratch = torch.empty(4 * B * L * H * W * max(C, blk["mlp_dim"]) * (2 if recompute_bits(module) else 1), dtype=torch.uint8,
+        scratch = torch.empty(4 * B * L * H * W * max(C, blk["mlp_dim"]) * (2 if rec else 1), dtype=torch.uint8,
                               device=x.device)
-        t, keep = _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, out, saved, scratch, only_stage)
+        t, keep = _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, out, saved, scratch, only_stage, rec)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib.hmvit_fusion_train_forward(ctypes.byref(t), ctypes.c_void_p(stream)), "hmvit_fusion_train_forward")
-        ctx.launch = (module, host + (only_stage,), drop_p, seed, x, pw, neg, folded, saved)
+        ctx.launch = (module, host + (only_stage, rec), drop_p, seed, x, pw, neg, folded, saved)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         module, host, drop_p, seed, x, pw, neg, folded, saved = ctx.launch
-        mode_h, rl_h, mask_h, only_stage = host
+        mode_h, rl_h, mask_h, only_stage, rec = host
         d_out = d_out.detach().to(torch.float32).contiguous()
         # The backward kernels form their products on split-f16 operands (x = hi + lo, two f16 halves), and every one of them
         # takes its operands at powers of two it picks itself, from the data it is about to multiply: k_linear16 per token row,
@@ -159,7 +163,7 @@ class FusionTrainFunction(torch.autograd.Function):
         # results, one host read per backward) and repaired by re-running the whole pass from a lower level.  One pass, no host
         # synchronisation.  d_out is still brought to max |.| in [2^9, 2^10) first (exact; the pass is linear in d_out): it keeps
         # the f32 intermediates of a 1e-7 loss away from the denormals.
-        t, keep = _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, None, saved, None, only_stage)
+        t, keep = _build_desc(module, x, pw, mode_h, rl_h, mask_h, folded, neg, drop_p, seed, None, saved, None, only_stage, rec)
         need = _lib.lib.hmvit_fusion_backward_workspace_bytes(ctypes.byref(t))
         if need == 0:
             _lib.check(-22, "hmvit_fusion_backward_workspace_bytes")

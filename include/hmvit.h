@@ -273,9 +273,11 @@ typedef struct HmvitFusionTrainDesc {
                                         backward pass; bit 1: neither are the queries LN(x) W_q.  The backward recomputes them with the
                                         forward's own kernels and weight images (the same rows bit for bit).  Each bit takes B L P C
                                         (mlp) floats per stage off hmvit_fusion_train_saved_bytes (cfg2: 19.8 -> 17.1 -> 14.5 GiB; peak
-                                        of a step 32.8 -> 30.1 -> 27.4 GiB) and adds one Linear per stage to the backward (cfg2: + 1.9
-                                        / + 1.2 ms per step).  With any bit set fwd.workspace must hold 2 x max(B L P C, B L P mlp)
-                                        floats                                                                             */
+                                        of a step 32.8 -> 30.1 -> 27.4 GiB) and adds one Linear per stage to the backward (cfg2, whole
+                                        step, cumulative: 92.8 -> 94.4 -> 96.8 ms, i.e. + 1.6 ms with bit 0, + 4.0 ms with both; HISTORY.md
+                                        12.8).  With any bit set fwd.workspace must hold 2 x max(B L P C, B L P mlp) floats.  Values
+                                        other than 0 .. 3 are rejected; the backward checks saved_bytes against the plan of ITS
+                                        descriptor, so the bits must be those of the forward                                   */
 } HmvitFusionTrainDesc;
 
 size_t hmvit_fusion_train_saved_bytes(const HmvitFusionTrainDesc* desc);
@@ -284,7 +286,10 @@ size_t hmvit_fusion_backward_workspace_bytes(const HmvitFusionTrainDesc* desc);
 int hmvit_fusion_train_forward(const HmvitFusionTrainDesc* desc, void* stream);
 /* d_out (B, C, H, W) -> d_x (B, L, C, H, W) (padded agents: 0), grads[2] (window, grid), mlp_head gradients (T, C, C) / (T, C).
  * `desc` must be the descriptor of the matching hmvit_fusion_train_forward call (same saved area, seed, weights).
- * Range (ABI-compatible behaviour change in round 5): d_out may have ANY magnitude.  The products of the pass run on split-f16
+ * Range (ABI-compatible behaviour change in round 5): d_out may have any magnitude in [2^-40, 2^40] times that of the forward's
+ * activations (the per-slab operand scale is a power of two clamped to 2^+-40, and the combined accumulator rescale of the
+ * weight-gradient products stays finite inside that window; the Python binding brings max |d_out| to 2^9 first, exactly, and scales
+ * the results back).  The products of the pass run on split-f16
  * operands, and every kernel scales its own operands by exact powers of two taken from the data (per token row, per 32-token
  * slab, per workgroup against a weights-only bound on |V'|): one pass, no non-finite-detect-and-repeat, nothing read back by the
  * host.  Preconditions are the forward's: the stage's Q, K', V' themselves must be f16-representable (|.| < 65504).
