@@ -16,6 +16,7 @@ whenever the module trains or ``x`` requires a gradient.  No CPU path: CPU tenso
 """
 from __future__ import annotations
 
+import os
 import ctypes
 import warnings
 from typing import Dict, Optional
@@ -112,7 +113,7 @@ class _FusionBase(nn.Module):
     # split mode, local stages: k_attention_patch (de-duplicated source patch, csrc/attn_patch.hpp) instead of the gather kernel when
     # every pair transform is rigid.  Same results to fp32 round-off; 2.6x fewer vector-memory wave loads, ~10 % SLOWER at cfg2
     # (both kernels issue the same VALU work at two waves per SIMD) - off by default, kept tested
-    patch_attention = False
+    patch_attention = os.environ.get("HMVIT_PATCH_ATTENTION", "0") == "1"
     _warned_eval_grad = False
 
     def _init_runtime(self):
