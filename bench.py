@@ -674,6 +674,11 @@ def main(argv=None):
                                      "frac": nbytes / t_s / 1e9 / PEAK_HBM},
                              "traffic": tr, "traffic_over_algorithmic": (tr / nbytes) if tr else None}
             roof["by_phase"] = rbp
+            if dom in rbp:      # whichever roof `roofline` is stated against, the other view of the same kernel rides along
+                if not roof.get("mfma_view"):
+                    roof["mfma_view"] = rbp[dom]["mfma"]
+                if not roof.get("hbm_view"):
+                    roof["hbm_view"] = rbp[dom]["hbm"]
         return roof, phases
 
     if rank == 0 and not args.stub:
