@@ -716,13 +716,15 @@ def main(argv=None):
                                             "note": "every (ego, source, window) tile and every window of every agent computed, masked keys at -inf"}
             net.skip_masked = True
         if side and precision == "split":
-            # the opt-in local-stage kernel of round 6 (k_attention_patch): same results, fewer vector-memory wave loads
-            net.patch_attention = True
-            pdt, _ = timed(net, args.steps, args.warmup)
-            _, pph = roofline_of(net, precision)
-            result["patch_attention"] = {"value": args.steps / pdt, "unit": "scenes/s", "ms_per_step": pdt / args.steps * 1e3, "phases": pph,
-                                         "note": "HeteroFusion.patch_attention = True: the local stages' attention on k_attention_patch"}
-            net.patch_attention = False
+            # the opt-in local-stage kernels of round 6: same results, fewer vector-memory wave loads
+            for which, key in ((1, "patch_attention"), (2, "patch16_attention")):
+                net.patch_attention = which
+                pdt, _ = timed(net, args.steps, args.warmup)
+                _, pph = roofline_of(net, precision)
+                result[key] = {"value": args.steps / pdt, "unit": "scenes/s", "ms_per_step": pdt / args.steps * 1e3, "phases": pph,
+                               "note": f"HeteroFusion.patch_attention = {which}: the local stages' attention on "
+                                       + ("k_attention_patch (8 waves per window)" if which == 1 else "k_attention_patch16 (16 waves per window)")}
+            net.patch_attention = 0
         del net
         torch.cuda.empty_cache()
         if side and precision != "f16":

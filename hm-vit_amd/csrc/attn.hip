@@ -2085,6 +2085,7 @@ static int launch_attn_pcs(const AttnParams& p_in, hipStream_t st) {
 }
 
 #include "attn_patch.hpp"
+#include "attn_patch16.hpp"
 
 template <typename T, int WIN, int HG>
 static int launch_attn_t(const AttnParams& p, hipStream_t st) {
@@ -2441,7 +2442,7 @@ int launch_attention(const AttnParams& p, int precision, hipStream_t st) {
         AttnParams q = p;
         // local stages over rigid transforms: the de-duplicated patch kernel (attn_patch.hpp)
         if (p.partition == HMVIT_PART_WINDOW && p.C == 256 && p.rigid_patch && p.n_src <= PatchShared::NCH + 1 && !HMVIT_ENV("HMVIT_NO_PATCH"))
-            return launch_attn_patch(q, st);
+            return (p.rigid_patch == 2 && p.patch_tab) ? launch_attn_patch16(q, st) : launch_attn_patch(q, st);
         if (p.partition == HMVIT_PART_GRID) q.variant ^= 0x200;   // item order as for k_attention_pc
         // head group per XCD: bit 0 grid stages, bit 1 local stages.  Measured at cfg2 (tools/probe/r03_attn_ab.sh): local stages
         // 1660 -> 1593 us and 4.56 -> 4.13 GB fetched; the grid stages fetch 18 % less (11.3 -> 9.2 GB) but run 6 % SLOWER

@@ -27,7 +27,7 @@ struct Plan {
     int B, L, C, H, W, P, mlp, n_slots, max_cav, E_max;
     size_t es;
     // byte offsets into the workspace
-    size_t off_xs, off_xn, off_q, off_kv, off_o, off_hid, off_ainv, off_ytok, off_xa, off_xb, off_gap, off_sw, off_vis, off_need, off_sched, total;
+    size_t off_xs, off_xn, off_q, off_kv, off_o, off_hid, off_ainv, off_ytok, off_xa, off_xb, off_gap, off_sw, off_vis, off_need, off_sched, off_ptab, total;
 };
 
 int check_desc(const HmvitFusionDesc* d) {
@@ -88,6 +88,10 @@ static void make_plan(const HmvitFusionDesc* d, Plan& pl) {
     pl.off_vis = carve((size_t)pl.n_slots * pl.P / 64 * 4 + 256);   // visible-chunk bits of the attention windows
     pl.off_need = carve(2 * ((size_t)pl.n_slots * pl.P / 64) + 256);      // reachable windows of the stage before the pruned one
     pl.off_sched = carve(attn_schedule_bytes(pl.B, pl.max_cav, pl.H, pl.W));   // world-ordered item list of the local stages
+    // k_attention_patch16's per-item tables (HmvitFusionDesc::rigid_patch == 2, split mode only)
+    pl.off_ptab = 0;
+    if (d->rigid_patch == 2 && d->precision == HMVIT_PREC_SPLIT && d->window == 8 && d->C == 256 && d->H % 8 == 0 && d->W % 8 == 0)
+        pl.off_ptab = carve(patch16_tables_bytes(pl.B, pl.max_cav, pl.H, pl.W));
     pl.off_xa = pl.off_xb = pl.off_gap = pl.off_sw = 0;
     if (d->parallel) {
         // branch outputs of the parallel block + SplitAttn scratch
@@ -577,6 +581,17 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
         sched = ws_s;
     }
 
+    // k_attention_patch16's tables: one set per forward (they depend on the pair transforms and the window, not on the stage)
+    const void* patch_tab = nullptr;
+    if (pl.off_ptab && d->self_identity && pl.max_cav <= 5 && pl.n_slots * L <= 128) {
+        AttnParams ap;
+        memset(&ap, 0, sizeof(ap));
+        ap.ainv = ainv; ap.B = B; ap.L = L; ap.n_ego = pl.max_cav; ap.n_src = pl.max_cav; ap.H = d->H; ap.W = d->W; ap.window = d->window;
+        for (int i = 0; i < pl.n_slots; ++i) ap.cav[i] = (int8_t)(d->cav_mask[i] != 0);
+        HMVIT_TRY(launch_patch16_tables(ap, ws + pl.off_ptab, st));
+        patch_tab = ws + pl.off_ptab;
+    }
+
     bool qkv_done = false;   // this stage's Q / K' / V' were produced by the previous stage's fused tail
     bool head_done = false;  // mlp_head rode on the last stage's tail
     for (int it = 0; it < d->num_iters; ++it) {
@@ -623,6 +638,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                 need = (it == d->num_iters - 1 && s == 0) ? need_last : nullptr;
                 ap.self_identity = d->self_identity;
                 ap.rigid_patch = d->rigid_patch;
+                ap.patch_tab = (n_ego == pl.max_cav) ? patch_tab : nullptr;
                 // split mode: the persistent split kernel needs the table and identity self transforms; otherwise (and for
                 // window 4 / C = 64) the exact-f32 kernel runs on the f32 planes
                 const bool pc_split = split == 1 && d->self_identity && pl.n_slots * L <= 128;

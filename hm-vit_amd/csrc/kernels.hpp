@@ -261,6 +261,7 @@ struct AttnParams {
                                      // (needed by the split-precision persistent kernel, which has no general-self loader)
     int rigid_patch;                 // caller's guarantee that every pair transform is a rotation to 2 % (HmvitFusionDesc::rigid_patch):
                                      // the local stages of the split mode may take k_attention_patch
+    const void* patch_tab;           // rigid_patch == 2: the items' tables (launch_patch16_tables), B n_ego (H/8) (W/8) blocks of 9 KB
     float* lse;               // optional (B, L, P, heads) f32: log-sum-exp of every query row (f32 kernel; kept for the backward pass)
     const int* sched;         // optional world-ordered item list of the persistent kernels (launch_attn_schedule), n_sched items
     int n_sched, sched_sub;   // sched_sub: steps per list segment (pc_fetch_sched)
@@ -285,6 +286,9 @@ int launch_attn_schedule(const AttnParams& p, int* ws, hipStream_t st);
 // marked in `from` (plus those windows themselves).  `to` must be zeroed by the caller.
 int launch_window_need(const AttnParams& p, const unsigned char* from, unsigned char* to, hipStream_t st);
 int launch_debug_tr16(uint16_t* out, hipStream_t st);
+// k_attention_patch16's per-item tables (they depend on the pair transforms only: once per forward); ws: patch16_tables_bytes
+size_t patch16_tables_bytes(int B, int n_ego, int H, int W);
+int launch_patch16_tables(const AttnParams& p, void* ws, hipStream_t st);
 
 // ---- train.hip (backward pass of the fusion, exact-f32 MFMA; SURVEY 8b "autograd must flow") ----
 // dw[n][k] += sum_m dy[m][n] a[m][k]  (weight gradient of y = a w^T), dbias[n] += sum_m dy[m][n]; f32 atomics

@@ -110,10 +110,10 @@ class _FusionBase(nn.Module):
 
     precision = "split"          # the reference's fp32 arithmetic on the f16 matrix pipes (1e-4); "f16" is the opt-in fast mode
     skip_masked = True
-    # split mode, local stages: k_attention_patch (de-duplicated source patch, csrc/attn_patch.hpp) instead of the gather kernel when
-    # every pair transform is rigid.  Same results to fp32 round-off; 2.6x fewer vector-memory wave loads, ~10 % SLOWER at cfg2
-    # (both kernels issue the same VALU work at two waves per SIMD) - off by default, kept tested
-    patch_attention = os.environ.get("HMVIT_PATCH_ATTENTION", "0") == "1"
+    # split mode, local stages: 1 = k_attention_patch, 2 = k_attention_patch16 (de-duplicated source patch, csrc/attn_patch*.hpp) instead of
+    # the gather kernel when every pair transform is rigid.  Same results to fp32 round-off; 2.6x fewer vector-memory wave loads, ~10 %
+    # SLOWER at cfg2 - off by default, kept tested
+    patch_attention = int(os.environ.get("HMVIT_PATCH_ATTENTION", "0") or 0)      # 0 / False: gather kernel, 1 / True: k_attention_patch, 2: k_attention_patch16
     _warned_eval_grad = False
 
     def _init_runtime(self):
@@ -302,7 +302,7 @@ class _FusionBase(nn.Module):
         if prec in (_lib.PREC_SPLIT, _lib.PREC_MIXED):
             mode_h, rl_h, mask_h, pw_flags = self._host_small(mode, record_len, mask, pw if pw_host is None else pw_host)
             d.self_identity = pw_flags & 1
-            d.rigid_patch = ((pw_flags >> 1) & 1) if self.patch_attention else 0
+            d.rigid_patch = int(self.patch_attention) if ((pw_flags >> 1) & 1) else 0
         else:
             mode_h, rl_h, mask_h = self._host_small(mode, record_len, mask)
         if len(mode_h) != B * L or len(mask_h) != B * L or len(rl_h) != B:

@@ -502,36 +502,41 @@ def test_fusion_generic_window_and_dim_head(C, dim_head, window, H, W, arch):
 
 
 # ---- k_attention_patch (csrc/attn_patch.hpp): the opt-in local-stage kernel of the split mode ----
-def _fusion_patch(cfg, sd):
+def _fusion_patch(cfg, sd, which=1):
     net = _fusion(cfg, sd, "split")
-    net.patch_attention = True
+    net.patch_attention = which          # 1: k_attention_patch (8 waves, one per head), 2: k_attention_patch16 (16 waves: head x 16-key tile)
     return net
 
 
+PATCH_KERNELS = [1, 2]
+
+
+@pytest.mark.parametrize("which", PATCH_KERNELS)
 @pytest.mark.parametrize("name", ["g12_fusion_cfg2.npz", "g13_fusion_cfg3.npz", "g18_fusion_cfg4.npz"])
-def test_patch_attention_full_size_goldens(name):
-    """The de-duplicated patch kernel (`module.patch_attention = True`: local stages of the split mode, rigid transforms) against the
+def test_patch_attention_full_size_goldens(name, which):
+    """The de-duplicated patch kernels (`module.patch_attention = 1 / 2`: local stages of the split mode, rigid transforms) against the
     reference's own forward at the headline size, held to the split mode's bounds; masked-tile skipping / reachability pruning stay
     exact on it; and it differs from the gather kernel only at fp32 round-off."""
     g = load_golden(name)
     sd = O.random_state_dict(g["cfg"], g["seed_weights"])
-    net = _fusion_patch(g["cfg"], sd)
+    net = _fusion_patch(g["cfg"], sd, which)
     scene = _cuda(*O.synthetic_scene(**g["scene"]))
     y = net(*scene).cpu()
-    _check_full_size(g, y, TOL["split"], f"{name[:3]}:split+patch", P999["split"])
+    _check_full_size(g, y, TOL["split"], f"{name[:3]}:split+patch{which}", P999["split"])
     net.skip_masked = False
     assert torch.equal(y, net(*scene).cpu())
     net.skip_masked = True
     assert torch.equal(y, net(*scene).cpu())                       # run-to-run
-    net.patch_attention = False
+    net.patch_attention = 0
     y_gather = net(*scene).cpu()
     assert not torch.equal(y, y_gather)                            # (the other kernel really ran)
     assert rel_max_err(y, y_gather) < 2e-5
 
 
+@pytest.mark.parametrize("which", PATCH_KERNELS)
 @pytest.mark.parametrize("modes,n_valid,yaw", [([1, 1, 1, 1, 1], 5, 0.2), ([0, 1, 1, 0, 1], 4, 0.7854), ([1, 0, 0, 0, 0], 1, 0.2),
                                                ([1, 0, 1, 1, 0], 5, 1.5708), ([1, 1, 0, 1, 1], 5, -1.1)])
-def test_patch_attention_vs_oracle(modes, n_valid, yaw):
+def test_patch_attention_vs_oracle(modes, n_valid, yaw, which):
     """Mid-size scenes against the oracle run live: padded agents, a lone ego, yaw steps incl. 45 and 90 degrees (the patch of a
     half window is largest near 45 degrees) and sub-pixel translations; a source at the ego's own pose takes the identity path."""
     cfg = O.make_config(256, 8, 5, voxel=0.4, downsample=4)
@@ -541,20 +546,21 @@ def test_patch_attention_vs_oracle(modes, n_valid, yaw):
     scene[1][0, :, 2] = scene[1][0, :, 0]
     scene[1][0, 2, 2] = torch.eye(4)
     ref = _oracle(tuple(scene), sd, cfg)
-    y = _fusion_patch(cfg, sd)(*_cuda(*scene)).cpu()
+    y = _fusion_patch(cfg, sd, which)(*_cuda(*scene)).cpu()
     assert rel_max_err(y, ref) < TOL["split"]
     assert p999_err(y, ref) < P999["split"]
 
 
-def test_patch_attention_declines_non_rigid_transforms():
+@pytest.mark.parametrize("which", PATCH_KERNELS)
+def test_patch_attention_declines_non_rigid_transforms(which):
     """A sheared pair transform (legal for `forward`, never produced by the datasets) is outside the patch kernel's guarantee (64
     source pixels per half window): hmvit_pack_small reports it and the gather kernel runs - same output as with the switch off."""
     cfg = O.make_config(256, 8, 3, voxel=0.4, downsample=4)
     sd = O.random_state_dict(cfg, seed=9)
     scene = list(O.synthetic_scene(3, 256, 32, 48, [1, 0, 1], seed=4, tx_step=5.0, ty_step=-3.0))
     scene[1][0, 0, 1, 0, 0] *= 1.3                                 # anisotropic scale in one pair
-    net = _fusion_patch(cfg, sd)
+    net = _fusion_patch(cfg, sd, which)
     y = net(*_cuda(*scene)).cpu()
-    net.patch_attention = False
+    net.patch_attention = 0
     assert torch.equal(y, net(*_cuda(*scene)).cpu())
     assert rel_max_err(y, _oracle(tuple(scene), sd, cfg)) < TOL["split"]
