@@ -2250,6 +2250,7 @@ __global__ __launch_bounds__(256) void k_tile_vis(AttnParams p, unsigned* __rest
     const int X = p.H / 8, Y = p.W / 8, n_pos = p.B * p.n_ego * X * Y;
     const int pos = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (p.queue && blockIdx.x == 0 && threadIdx.x < 16) p.queue[threadIdx.x] = 0;   // the pull counters of the attention launch that follows
+    if (p.tail_pull && blockIdx.x == 0 && threadIdx.x >= 16 && threadIdx.x < 64) p.tail_pull[threadIdx.x - 16] = 0;   // and of the stage's tails
     if (pos >= n_pos) return;
     int r = pos;
     const int wy = r % Y; r /= Y;

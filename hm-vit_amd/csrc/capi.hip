@@ -620,6 +620,8 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
 
             // 3. fused warp + partition + attention
             unsigned char* need = nullptr;
+            int* tail_pull = nullptr;              // zeroed pull counters for this stage's tail launches (k_tile_vis), one per launch
+            int n_tail_pull = 0;
             {
                 AttnParams ap;
                 memset(&ap, 0, sizeof(ap));
@@ -661,6 +663,8 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                     if (pc_split && q_fits && q_stage)
                         ap.queue = reinterpret_cast<int*>(vis + (size_t)pl.n_slots * pl.P / 64);
 #endif
+                    if (split && C == 256 && !HMVIT_ENV("HMVIT_X16_STATIC"))
+                        ap.tail_pull = tail_pull = reinterpret_cast<int*>(vis + (size_t)pl.n_slots * pl.P / 64) + 16;
                     HMVIT_TRY(launch_tile_vis(ap, vis, need, st));
                     ap.vis_mask = vis;
                     ap.prune = need != nullptr;
@@ -694,6 +698,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                 fb.p.w_ffn = reinterpret_cast<const half_t*>(wt.img_ffn); fb.p.b_1 = wt.b_1; fb.p.b_2 = wt.b_2;
                 fb.p.P = P; fb.p.W = d->W;
                 set_ffn_scales(fb.p, split ? wt.scales : nullptr, split ? d->head_scales : nullptr);
+                auto next_pull = [&]() -> int* { return (tail_pull && n_tail_pull < 48) ? tail_pull + n_tail_pull++ : nullptr; };
                 fb.variant = FFN_FULL;
                 if (fuse) {
                     const int it2 = s == 1 ? it + 1 : it, s2 = 1 - s;
@@ -718,8 +723,9 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                             j.need = nd ? nd + (size_t)(b * n_ego + i) * (P / 64) : nullptr;
                             fb.p.job[n] = j;
                             qp.job[n] = qkv_job(wn, sn, slot, i, false);
-                            if (++n == kMaxChainJobs) { HMVIT_TRY(launch_out_ffn_qkv(fb.p, qp, n, C, split, st)); n = 0; }
+                            if (++n == kMaxChainJobs) { fb.p.pull = next_pull(); HMVIT_TRY(launch_out_ffn_qkv(fb.p, qp, n, C, split, st)); n = 0; }
                         }
+                    fb.p.pull = next_pull();
                     HMVIT_TRY(launch_out_ffn_qkv(fb.p, qp, n, C, split, st));
                     qkv_done = true;
                 } else if (last && !par && C == 256 && d->head_img_ffn && !HMVIT_ENV("HMVIT_NO_FUSE")) {
@@ -735,8 +741,9 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                         j.out = d->out + (size_t)b * map_elems;
                         j.type = d->mode[slot]; j.pad = 0;
                         fb.p.job[n] = j;
-                        if (++n == kMaxChainJobs) { HMVIT_TRY(launch_out_ffn_head(fb.p, n, C, split, st)); n = 0; }
+                        if (++n == kMaxChainJobs) { fb.p.pull = next_pull(); HMVIT_TRY(launch_out_ffn_head(fb.p, n, C, split, st)); n = 0; }
                     }
+                    fb.p.pull = next_pull();
                     HMVIT_TRY(launch_out_ffn_head(fb.p, n, C, split, st));
                     head_done = true;
                 } else {

@@ -1123,9 +1123,12 @@ constexpr bool X16_DEPHASE = HMVIT_X16_DEPHASE != 0;
 // [step][0 begin, 1 products done, 2 chunk confirmed (B), 3 mid barrier passed, 4 rest of the step + request done, 5 end barrier
 // passed]; read back with hmvit_debug_x16_trace (tools/probe/x16_trace.py).
 __device__ unsigned long long g_x16_trace[2 * 64 * 8];
+#ifndef HMVIT_X16_STAMP_TAIL
+#define HMVIT_X16_STAMP_TAIL 1          // which kernel stamps: 1 = k_out_ffn_qkv16, 2 = k_out_ffn_head16
+#endif
 #define X16_STAMP(step, slot)                                                                             \
     do {                                                                                                  \
-        if (blockIdx.x == 7 && blockIdx.y == 0 && (threadIdx.x & 255) == 0 && (step) < 64)                \
+        if (TAIL == HMVIT_X16_STAMP_TAIL && blockIdx.x == 7 && blockIdx.y == 0 && (threadIdx.x & 255) == 0 && (step) < 64) \
             g_x16_trace[((threadIdx.x >> 8) * 64 + (step)) * 8 + (slot)] = __builtin_readcyclecounter();  \
     } while (0)
 #else
@@ -1438,11 +1441,43 @@ __global__ __launch_bounds__(1024) void k_weight_image16(const float* __restrict
 // before the first MFMA (inputs + the first two chunks arriving with nothing to overlap them); now only the first tile pays.
 // Tiles none of whose tokens a later stage reads (FfnJob::need) are dropped from the walk up front.
 constexpr int X16_MAX_TILES = 32;      // tiles per workgroup (bits of the live mask)
+
+// PULLED TILES (round 6, FfnParams::pull): one workgroup per CU, every workgroup draws (job, tile) tickets from ONE counter of the
+// launch (ticket t = job t / n_tiles, tile t % n_tiles) - the walk's uninterrupted chunk ring without the static partition that lost
+// more to the spread of the CUs' speeds than the walk saved (x16_grid_x).  The draw is a scalar atomic and the reachability lookups
+// are scalar loads (lgkmcnt: the counted vmcnt waits of the ring never see them); wavefront 0 draws the ticket of tile n + 1 in the
+// rest-half of the first step of tile n, where it would otherwise wait ~1 k cycles at the barrier for group B's products, and leaves
+// it in an LDS word every wavefront reads after the out-projection.  Tickets of dead tiles (FfnJob::need) are skipped by the drawer.
+__device__ __forceinline__ int tail16_pull(const FfnParams& p, int n_tiles) {
+    const int total = p.n_jobs * n_tiles;
+    for (;;) {
+        int t = 1;
+        asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t) : "s"(p.pull) : "memory");
+        if (t >= total) return -1;
+        const int job = t / n_tiles, tile = t - job * n_tiles;
+        const unsigned char* need = p.job[job].need;
+        if (!need) return t;
+        unsigned long long last = ~0ull;
+        unsigned word = 0;
+        for (int i = 0; i < 16; ++i) {                   // the tile's 16 runs of 8 tokens: a run lies in one window (W % 8 == 0)
+            const int tok0 = tile * X16_TOKENS + i * 8;
+            if (tok0 >= p.P) break;
+            const int r = tok0 / p.W, c = tok0 - r * p.W;
+            const unsigned long long a = (unsigned long long)(need + (r >> 3) * (p.W >> 3) + (c >> 3)), a4 = a & ~3ull;
+            if (a4 != last) {
+                asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(word) : "s"(a4) : "memory");
+                last = a4;
+            }
+            if ((word >> (8 * (unsigned)(a & 3))) & 0xffu) return t;
+        }
+    }
+}
+
 template <bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW, int TAIL, bool XN, bool A16>
 __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams* qp) {
     constexpr int C = 256, NCH = 8, NH = 8;
     constexpr bool QKV = TAIL == 1, HEAD = TAIL == 2;
-    __shared__ __attribute__((aligned(16))) half_t smem[X16_RING * X16_CHUNK + 14 * C + 2 * X16_WAVES * X16_STG_WAVE];
+    __shared__ __attribute__((aligned(16))) half_t smem[X16_RING * X16_CHUNK + 14 * C + 2 * X16_WAVES * X16_STG_WAVE + 8];
     // layout: [7 vector rows][per-wave store staging][weight ring]: the rows and the staging sit below 64 KB, where the 16-bit
     // offset field of the DS instructions reaches them from one base register (behind the ring every row position needed an
     // address register of its own: 32 of them, spilled, for the LayerNorm parameters alone)
@@ -1450,14 +1485,31 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
     constexpr int X16_VEC = 14 * C, X16_STG = 2 * X16_WAVES * X16_STG_WAVE;      // halves
     half_t* ring = smem + X16_VEC + X16_STG;
     float (*vec)[C] = reinterpret_cast<float (*)[C]>(smem);
-    const FfnJob& J = p.job[blockIdx.y];
     const int P = p.P, n_tiles = (P + X16_TOKENS - 1) / X16_TOKENS;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tk = lane & 15, g = lane >> 4;
     float* stg = reinterpret_cast<float*>(smem + 14 * C) + wave * X16_STG_WAVE;
+    const bool dyn = OUTPROJ && p.pull != nullptr;                        // pulled tiles (tail16_pull)
+    const bool drawer = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;
+    volatile int* nx = reinterpret_cast<volatile int*>(smem + 14 * C + 2 * X16_WAVES * X16_STG_WAVE + X16_RING * X16_CHUNK);   // the next ticket
+    int job = blockIdx.y, tile = 0;                                       // current tile (dyn: from the ticket)
+    int next_job = 0, next_tile = 0;
+    bool pending = false;                                                 // dyn: a tile of another job class follows (new segment)
 
     // ---- the live tiles of this workgroup (thread = (tile k, 8-token run): W is a multiple of 8, so a run lies in one window) ----
-    unsigned live_mask;
-    {
+    unsigned live_mask = 0;
+    if (dyn) {
+        if (drawer) {
+            const int t = tail16_pull(p, n_tiles);
+            if (lane == 0) *nx = t;
+        }
+        __syncthreads();
+        const int t = __builtin_amdgcn_readfirstlane(*nx);
+        __syncthreads();
+        if (t < 0) return;
+        job = t / n_tiles;
+        tile = t - job * n_tiles;
+    } else {
+        const FfnJob& J = p.job[blockIdx.y];
         unsigned* sl = reinterpret_cast<unsigned*>(smem + 14 * C);
         if (threadIdx.x == 0) *sl = 0;
         __syncthreads();
@@ -1473,11 +1525,15 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
         __syncthreads();
         live_mask = __builtin_amdgcn_readfirstlane(*sl);
         __syncthreads();
+        if (live_mask == 0) return;
     }
-    if (live_mask == 0) return;
 
-    const int ty = J.type;
-    const QkvJob* Qj = QKV ? &qp->job[blockIdx.y] : nullptr;
+    // a SEGMENT = consecutive tiles of one job class (FfnJob::cls: same type, matrices and scales - everything the vector rows, the
+    // chunk sequence and the ring depend on); without the pull there is one segment (the workgroup's job)
+#pragma unroll 1
+    for (;;) {
+    const int ty = p.job[job].type, cls = p.job[job].cls;
+    const QkvJob* Qj = QKV ? &qp->job[job] : nullptr;
     for (int i = threadIdx.x; i < C; i += X16_THREADS) {
         vec[0][i] = OUTPROJ ? p.b_o[ty * C + i] : 0.f;
         vec[1][i] = LN ? p.ln_g[ty * C + i] : 1.f;
@@ -1555,6 +1611,10 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
         if (ahead < n_total) stage_chunk16(chunk_ptr(ahead), slot(ahead));
         else if (has_next) stage_chunk16(chunk_ptr(ahead - n_total), slot(ahead));
         X16_STAMP(cc, 4);
+        if (dyn && cc == 0 && drawer) {                  // the ticket of the tile after this one
+            const int t = tail16_pull(p, n_tiles);
+            if (lane == 0) *nx = t;
+        }
         if (!grp_b) ring_wait(flush_now);
         wg_barrier();
         X16_STAMP(cc, 5);
@@ -1575,11 +1635,18 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
     __syncthreads();
     if (grp_b) wg_barrier();
 #pragma unroll 1
-    do {
-        const int tile = blockIdx.x + __builtin_ctz(live_mask) * gridDim.x;
-        live_mask &= live_mask - 1;
-        has_next = live_mask != 0;
-        const int next_tile = has_next ? blockIdx.x + __builtin_ctz(live_mask) * gridDim.x : tile;
+    for (;;) {
+        if (!dyn) {
+            tile = blockIdx.x + __builtin_ctz(live_mask) * gridDim.x;
+            live_mask &= live_mask - 1;
+            has_next = live_mask != 0;
+            next_tile = has_next ? blockIdx.x + __builtin_ctz(live_mask) * gridDim.x : tile;
+            next_job = job;
+        } else {
+            has_next = false;                            // known after the out-projection (read_ticket); not consulted before
+        }
+        const FfnJob& J = p.job[job];
+        const QkvJob* Qt = QKV ? &qp->job[job] : nullptr;      // this tile's planes and scales
         const int tok_w = tile * X16_TOKENS + wave * 16, tok = tok_w + tk;
         const bool valid = tok < P;
         full_wave = tok_w + 16 <= P;
@@ -1687,6 +1754,16 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
                     }
                     step_end(false);
                 }
+            }
+        }
+        if (dyn) {                                       // drawn in step 0, eight barriers ago
+            const int t = __builtin_amdgcn_readfirstlane(*nx);
+            pending = false;
+            if (t >= 0) {
+                next_job = t / n_tiles;
+                next_tile = t - next_job * n_tiles;
+                has_next = p.job[next_job].cls == cls;
+                pending = !has_next;
             }
         }
         if constexpr (LN) ln_to_operands16(xacc, vec[1], vec[2], g, ah, al);
@@ -1798,7 +1875,7 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
             if (n_tail > 0) {
                 ln_to_operands16(xacc, vec[5], vec[6], g, ah, al);
                 store_x();                                   // x'' leaves while the first tiles are computed
-                const float cq0 = Qj->c[0], cq1 = Qj->c[1], cq2 = Qj->c[2], cq3 = Qj->c[3], cq4 = Qj->c[4];
+                const float cq0 = Qt->c[0], cq1 = Qt->c[1], cq2 = Qt->c[2], cq3 = Qt->c[3], cq4 = Qt->c[4];
                 for (int c = 0; c < n_tail; ++c) {
                     const int mat = c / NCH, t = c - mat * NCH;
                     const float cm = mat == 0 ? cq0 : mat == 1 ? cq1 : mat == 2 ? cq2 : mat == 3 ? cq3 : cq4;
@@ -1810,7 +1887,7 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
                         // of a step, i.e. right behind the counted wait of the step before, and landed a step later
                         if (c == 1 && has_next) {
                             const int ntok = min(next_tile * X16_TOKENS + wave * 16 + tk, P - 1);
-                            const float* op = reinterpret_cast<const float*>(J.o) + (size_t)ntok * C + 4 * g;
+                            const float* op = reinterpret_cast<const float*>(p.job[next_job].o) + (size_t)ntok * C + 4 * g;
 #pragma unroll
                             for (int t2 = 0; t2 < 16; ++t2) {
                                 const float4 f = *reinterpret_cast<const float4*>(op + 16 * t2);
@@ -1823,8 +1900,8 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
                     float4v acc[2] = {(float4v)(0.f), (float4v)(0.f)};
                     mma_proj16(acc, slot(cc), ah, al, lane);
                     products_end(flushes(c - 1));
-                    if constexpr (A16) store_proj16_h(stg, reinterpret_cast<half_t*>(Qj->y[mat]), t, acc, cm, tk, g, lane, tok_w, P);
-                    else store_proj16(stg, reinterpret_cast<float*>(Qj->y[mat]), t, acc, cm, tk, g, lane, tok_w, P);
+                    if constexpr (A16) store_proj16_h(stg, reinterpret_cast<half_t*>(Qt->y[mat]), t, acc, cm, tk, g, lane, tok_w, P);
+                    else store_proj16(stg, reinterpret_cast<float*>(Qt->y[mat]), t, acc, cm, tk, g, lane, tok_w, P);
                     step_end(flushes(c));
                 }
             } else {
@@ -1832,8 +1909,18 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
             }
         }
         gs3 = (gs3 + n_total) % X16_RING;
-    } while (live_mask);
+        if (dyn) {
+            if (!has_next) break;
+            job = next_job;
+            tile = next_tile;
+        } else if (!live_mask) break;
+    }
     if (X16_DEPHASE && !grp_b) wg_barrier();             // group A's share of group B's extra first barrier
+    if (!(dyn && pending)) break;
+    job = next_job;                                      // next segment: rows, chunk sequence and ring start over
+    tile = next_tile;
+    __syncthreads();
+    }
 }
 
 template <bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW, bool A16>
@@ -1925,11 +2012,45 @@ static int x16_grid_x(int P, int n_jobs) {
     return gx < n_tiles ? gx : n_tiles;
 }
 
+// pulled tiles: job classes (a workgroup keeps its vector rows, chunk sequence and ring across tiles of one class) and the job count
+constexpr int kX16Persistent = 256;    // one workgroup per CU (140 KB of LDS each)
+static void x16_job_classes(FfnParams& p, const QkvParams* q, int n_jobs) {
+    p.n_jobs = n_jobs;
+    for (int j = 0; j < n_jobs; ++j) {
+        int c = j;
+        for (int k = 0; k < j && c == j; ++k) {
+            bool same = p.job[k].type == p.job[j].type && p.job[k].x_nchw == p.job[j].x_nchw;
+            if (same && q) {
+                const QkvJob &a = q->job[k], &b = q->job[j];
+                same = a.n_mat == b.n_mat;
+                for (int m = 0; same && m < a.n_mat; ++m) same = a.w[m] == b.w[m] && a.c[m] == b.c[m];
+            }
+            if (same) c = p.job[k].cls;
+        }
+        p.job[j].cls = c;
+    }
+}
+
 int launch_out_ffn_qkv(const FfnParams& p, const QkvParams& q, int n_jobs, int C, int split, hipStream_t st) {
     if (n_jobs == 0) return HMVIT_OK;
     HMVIT_CHECK_ARG(C == 256, "out_ffn_qkv: C=%d unsupported (256)", C);
     dim3 grid(cdiv(p.P, CHAIN_TOKENS), n_jobs), block(CHAIN_THREADS);
     // FfnJob::x_nchw (all jobs of a launch alike): the residual is read from (C, P) maps
+    if (split && p.pull && !HMVIT_ENV("HMVIT_X16_STATIC")) {   // pulled tiles: one workgroup per CU (tail16_pull)
+        FfnParams pp = p;
+        x16_job_classes(pp, &q, n_jobs);
+        const int n_wg = std::min(kX16Persistent, n_jobs * cdiv(p.P, X16_TOKENS));
+        const dim3 grid16(n_wg, 1), block16(X16_THREADS);
+        if (split == 2) {
+            if (p.job[0].x_nchw) hipLaunchKernelGGL((k_out_ffn_qkv16<true, true>), grid16, block16, 0, st, pp, q);
+            else hipLaunchKernelGGL((k_out_ffn_qkv16<false, true>), grid16, block16, 0, st, pp, q);
+        } else {
+            if (p.job[0].x_nchw) hipLaunchKernelGGL((k_out_ffn_qkv16<true, false>), grid16, block16, 0, st, pp, q);
+            else hipLaunchKernelGGL((k_out_ffn_qkv16<false, false>), grid16, block16, 0, st, pp, q);
+        }
+        HMVIT_CHECK_LAUNCH();
+        return HMVIT_OK;
+    }
     if (split) {
         const dim3 grid16(x16_grid_x(p.P, n_jobs), n_jobs), block16(X16_THREADS);
         if (split == 2) {
@@ -1951,6 +2072,15 @@ int launch_out_ffn_head(const FfnParams& p, int n_jobs, int C, int split, hipStr
     if (n_jobs == 0) return HMVIT_OK;
     HMVIT_CHECK_ARG(C == 256 && p.w_head && p.hb_1 && p.hb_2, "out_ffn_head: C=%d (256) / head weights missing", C);
     dim3 grid(cdiv(p.P, CHAIN_TOKENS), n_jobs), block(CHAIN_THREADS);
+    if (split && p.pull && !HMVIT_ENV("HMVIT_X16_STATIC")) {   // pulled tiles: one workgroup per CU (tail16_pull)
+        FfnParams pp = p;
+        x16_job_classes(pp, nullptr, n_jobs);
+        const dim3 grid16(std::min(kX16Persistent, n_jobs * cdiv(p.P, X16_TOKENS)), 1);
+        if (split == 2) hipLaunchKernelGGL(k_out_ffn_head16<true>, grid16, dim3(X16_THREADS), 0, st, pp);
+        else hipLaunchKernelGGL(k_out_ffn_head16<false>, grid16, dim3(X16_THREADS), 0, st, pp);
+        HMVIT_CHECK_LAUNCH();
+        return HMVIT_OK;
+    }
     if (split == 2) hipLaunchKernelGGL(k_out_ffn_head16<true>, dim3(x16_grid_x(p.P, n_jobs), n_jobs), dim3(X16_THREADS), 0, st, p);
     else if (split) hipLaunchKernelGGL(k_out_ffn_head16<false>, dim3(x16_grid_x(p.P, n_jobs), n_jobs), dim3(X16_THREADS), 0, st, p);
     else hipLaunchKernelGGL((k_out_ffn_head<256, false>), grid, block, 0, st, p);

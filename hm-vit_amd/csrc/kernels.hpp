@@ -122,6 +122,7 @@ struct FfnJob {
     float* out;              // (P, C) token-major (may alias x) or (C, P) for FFN_HEAD_NCHW
     int type;
     int pad;
+    int cls;                 // pulled tiles: job class, set by the launcher (x16_job_classes)
     int x_nchw;              // k_out_ffn_qkv only: x is a (C, P) map (the module input) instead of the token-major stream
     const unsigned char* need;   // optional (H/8, W/8): windows of this agent that a later stage can reach (k_window_need);
                                  // workgroups whose 128 tokens lie in unreachable windows return at once
@@ -145,6 +146,10 @@ struct FfnParams {
     float c_o[HMVIT_NUM_TYPES], c_1[HMVIT_NUM_TYPES], s_g[HMVIT_NUM_TYPES], k_2[HMVIT_NUM_TYPES];
     HmvitHeadScales head;    // mlp_head (k_out_ffn_head, FFN_HEAD_NCHW): operand scaled per token when dyn_head
     int dyn_head;
+    // split modes, C = 256, optional: ONE zeroed int per launch - the x16 tails then run one workgroup per CU that pulls (job, tile)
+    // tickets from it (chain.hip tail16_pull) instead of one workgroup per tile; n_jobs is set by the launcher
+    int* pull;
+    int n_jobs;
 };
 // FfnParams scale fields <- a stage's scales (null: all 1)
 inline void set_ffn_scales(FfnParams& p, const HmvitStageScales* sc, const HmvitHeadScales* hs) {
@@ -265,6 +270,7 @@ struct AttnParams {
     float* lse;               // optional (B, L, P, heads) f32: log-sum-exp of every query row (f32 kernel; kept for the backward pass)
     const int* sched;         // optional world-ordered item list of the persistent kernels (launch_attn_schedule), n_sched items
     int n_sched, sched_sub;   // sched_sub: steps per list segment (pc_fetch_sched)
+    int* tail_pull;           // optional, 48 ints zeroed by k_tile_vis: the pull counters of the tail launches that follow (FfnParams::pull)
     int* queue;               // optional, 16 zeroed ints: per-(XCD, head group) pull counters of k_attention_pcs2's dynamic item
                               // assignment (the workgroups of an XCD pull the XCD's item sequence instead of walking fixed shares)
     float k_logit;            // f32-plane kernels: logits formed from the planes * k_logit = natural units (HmvitStageScales;

@@ -511,6 +511,27 @@ def _fusion_patch(cfg, sd, which=1):
 PATCH_KERNELS = [1, 2]
 
 
+@pytest.mark.parametrize("precision", ["split", "mixed"])
+def test_pulled_tail_tiles_are_exact(precision):
+    """Split / mixed modes, C = 256: with the visibility table in use the stage tails run one workgroup per CU that PULLS (job, tile)
+    tickets (chain.hip tail16_pull: job classes, dead tiles of the reachability tables skipped by the drawer, the chunk ring carried
+    across tiles); `skip_masked = 0` launches them one workgroup per tile.  Two samples, mixed agent types (class switches), a token
+    count that is not a multiple of the 128-token tile, strongly shifted poses (dead tiles): bit-identical, run to run as well."""
+    cfg = O.make_config(256, 8, 4, voxel=0.4, downsample=4)
+    sd = O.random_state_dict(cfg, seed=35)
+    x, pw, mode, rl, mask = O.synthetic_scene(4, 256, 40, 56, [1, 0, 0, 1], seed=17, B=2, yaw_step=0.45, tx_step=30.0, ty_step=-20.0)
+    x2, pw2, mode2, rl2, mask2 = O.synthetic_scene(4, 256, 40, 56, [0, 1, 1, 0], n_valid=3, seed=18, yaw_step=-0.3)
+    x[1], pw[1], mode[1], rl[1], mask[1] = x2[0], pw2[0], mode2[0], rl2[0], mask2[0]
+    scene = _cuda(x, pw, mode, rl, mask)
+    net = _fusion(cfg, sd, precision)
+    a = net(*scene)
+    assert torch.isfinite(a).all() and torch.equal(a, net(*scene))
+    net.skip_masked = 0
+    assert torch.equal(a, net(*scene))
+    ref = O.hetero_fusion(*[t.cpu() for t in scene], sd, cfg, dtype=torch.float64, device="cuda").cpu()
+    assert rel_max_err(a.cpu(), ref) < TOL[precision]
+
+
 @pytest.mark.parametrize("which", PATCH_KERNELS)
 @pytest.mark.parametrize("name", ["g12_fusion_cfg2.npz", "g13_fusion_cfg3.npz", "g18_fusion_cfg4.npz"])
 def test_patch_attention_full_size_goldens(name, which):
