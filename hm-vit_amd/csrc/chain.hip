@@ -926,6 +926,9 @@ __device__ __forceinline__ float quad_sum(float v) { return xor32_sum(xor16_sum(
 // measured equal).  What remains is the issue of the 32 ds_read_b128 of a chunk between the products.)
 // HMVIT_X16_REFILL_LAG: after the products of fragment f the ring slot of fragment f - LAG is refilled (0: the slot just
 // consumed).  Measured 0 / 1 / 2: tails 5.25 / 5.21 / 5.16 ms - the refill does not wait on the MFMA that read the slot.
+#ifndef HMVIT_X16_DEFER
+#define HMVIT_X16_DEFER 0               // group B's barrier behind a step that is followed by non-ring work moves behind that work
+#endif
 #ifndef HMVIT_X16_REFILL_LAG
 #define HMVIT_X16_REFILL_LAG 0
 #endif
@@ -1605,8 +1608,11 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
         }
         X16_STAMP(cc, 3);
     };
-    // end of step cc; flush_now: this rest-half stored a tile
-    auto step_end = [&](bool flush_now) {
+    bool b_owes = grp_b;                                 // group B owes a barrier: its extra first one, later a deferred one
+    // end of step cc; flush_now: this rest-half stored a tile.  defer_b (round 6): the step is followed by work outside the ring
+    // (a LayerNorm + operand conversion, the next tile's rows): group B does that work BEFORE this barrier (b_barrier() below) and
+    // group A after it, so the two groups' ~5 k cycles of it run side by side instead of one after the other
+    auto step_end = [&](bool flush_now, bool defer_b = false) {
         const int ahead = cc + 2 + (grp_b ? 1 : 0);
         if (ahead < n_total) stage_chunk16(chunk_ptr(ahead), slot(ahead));
         else if (has_next) stage_chunk16(chunk_ptr(ahead - n_total), slot(ahead));
@@ -1616,9 +1622,14 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
             if (lane == 0) *nx = t;
         }
         if (!grp_b) ring_wait(flush_now);
-        wg_barrier();
+        if (HMVIT_X16_DEFER && defer_b && grp_b) b_owes = true;
+        else wg_barrier();
         X16_STAMP(cc, 5);
         ++cc;
+    };
+    auto b_barrier = [&]() {                             // group B's deferred barrier (and its extra first one)
+        if (b_owes) wg_barrier();
+        b_owes = false;
     };
     stage_chunk16(chunk_ptr(0), slot(0));
     stage_chunk16(chunk_ptr(1), slot(1));
@@ -1633,7 +1644,7 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
 
     dma_wait();
     __syncthreads();
-    if (grp_b) wg_barrier();
+    // (group B's extra first barrier: after the first tile's rows, where the deferred barrier of a tile's last step falls later on)
 #pragma unroll 1
     for (;;) {
         if (!dyn) {
@@ -1718,6 +1729,7 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
             rows_to_operands16(xacc, ah, al, s_tok);
         }
         extra = XN ? 64 : 16;
+        b_barrier();
 
         // ---- phase 1: x' = x + b_o + W_o . O, two 16-channel tiles per chunk ----
         if constexpr (OUTPROJ) {
@@ -1752,7 +1764,7 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
                                 for (int v = 0; v < OU; ++v) { xacc[2 * (t0 + v)] += upd[v][0]; xacc[2 * (t0 + v) + 1] += upd[v][1]; }
                             }
                     }
-                    step_end(false);
+                    step_end(false, c == N_OUT - 1);
                 }
             }
         }
@@ -1767,6 +1779,7 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
             }
         }
         if constexpr (LN) ln_to_operands16(xacc, vec[1], vec[2], g, ah, al);
+        if constexpr (OUTPROJ) b_barrier();      // (behind the b_2 loop below hipcc spills 59 registers)
 
         // the row is carried as x k_2 while W_2's (scaled) products accumulate into it.  Stage chain: b_2 arrives as b_2 k_2;
         // mlp_head (no residual, per-token k_2): b_2 at its true scale
@@ -1780,6 +1793,7 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
                 xacc[t][0] = b2.x * k_2; xacc[t][1] = b2.y * k_2; xacc[t][2] = b2.z * k_2; xacc[t][3] = b2.w * k_2;
             }
         }
+
 
         // ---- phase 2: per hidden tile hc: h = GELU(W_1[hc] . xn + b_1[hc]);  x'' += W_2[:, hc] . h ----
         // DYN (mlp_head on a raw row): per-token factors, b_1 (row `b1row` of vec) at its true scale; otherwise it arrives as b_1 / c_1
@@ -1816,7 +1830,7 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
                 step_begin();
                 mma_slice16(xacc, slot(cc), hh, hl, lane);
                 products_end(false);
-                step_end(false);
+                step_end(false, hc == NH - 1);           // followed by a conversion / the tile's end
             }
         };
         ffn_pass(std::integral_constant<bool, !OUTPROJ && !LN>{}, vec[3]);
@@ -1856,6 +1870,7 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
                 const float4 b2 = *reinterpret_cast<const float4*>(&vec[6][16 * t + 4 * g]);
                 xacc[t][0] = b2.x * k_2; xacc[t][1] = b2.y * k_2; xacc[t][2] = b2.z * k_2; xacc[t][3] = b2.w * k_2;
             }
+            b_barrier();
             ffn_pass(std::integral_constant<bool, true>{}, vec[5]);
             {
                 const float k_inv = pow2_inv(k_2);
@@ -1875,6 +1890,7 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
             if (n_tail > 0) {
                 ln_to_operands16(xacc, vec[5], vec[6], g, ah, al);
                 store_x();                                   // x'' leaves while the first tiles are computed
+                b_barrier();
                 const float cq0 = Qt->c[0], cq1 = Qt->c[1], cq2 = Qt->c[2], cq3 = Qt->c[3], cq4 = Qt->c[4];
                 for (int c = 0; c < n_tail; ++c) {
                     const int mat = c / NCH, t = c - mat * NCH;
@@ -1902,7 +1918,7 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
                     products_end(flushes(c - 1));
                     if constexpr (A16) store_proj16_h(stg, reinterpret_cast<half_t*>(Qt->y[mat]), t, acc, cm, tk, g, lane, tok_w, P);
                     else store_proj16(stg, reinterpret_cast<float*>(Qt->y[mat]), t, acc, cm, tk, g, lane, tok_w, P);
-                    step_end(flushes(c));
+                    step_end(flushes(c), c == n_tail - 1);
                 }
             } else {
                 store_x();
@@ -1915,6 +1931,7 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
             tile = next_tile;
         } else if (!live_mask) break;
     }
+    b_barrier();                                         // the deferred barrier of the last tile's last step
     if (X16_DEPHASE && !grp_b) wg_barrier();             // group A's share of group B's extra first barrier
     if (!(dyn && pending)) break;
     job = next_job;                                      // next segment: rows, chunk sequence and ring start over
