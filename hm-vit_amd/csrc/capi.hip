@@ -430,8 +430,12 @@ struct QkvBatcher {
     int n, C;
     int split;
     hipStream_t st;
+    int* pull_base = nullptr;    // zeroed ints, 8 apart (the padding word of consecutive affine records); pull_left of them
+    int pull_left = 0;
     int flush() {
         if (n == 0) return HMVIT_OK;
+        p.pull = nullptr;
+        if (pull_left > 0) { p.pull = pull_base; pull_base += 8; --pull_left; }
         int rc = launch_ln_qkv(p, n, C, split, st);
         n = 0;
         return rc;
@@ -611,6 +615,9 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                 memset(&qb_.p, 0, sizeof(qb_.p));
                 qb_.n = 0; qb_.C = C; qb_.st = st; qb_.split = split;
                 qb_.p.gamma = wt.ln_gamma; qb_.p.beta = wt.ln_beta; qb_.p.P = P; qb_.p.in_nchw = first ? 1 : 0;
+                // first stage: pulled tiles; the counters are the padding words of the affine records, zeroed by k_pair_affines
+                // a moment ago (one per launch)
+                if (first) { qb_.pull_base = reinterpret_cast<int*>(ainv) + 7; qb_.pull_left = pl.n_slots * L; }
                 for (int b = 0; b < B; ++b)
                     for (int l = 0; l < pl.max_cav; ++l) HMVIT_TRY(qb_.add(qkv_job(wt, si, b * L + l, l, first)));
                 HMVIT_TRY(qb_.flush());

@@ -23,6 +23,7 @@
 // in global memory in exactly fragment order, so staging is a linear copy and every ds_read_b128 is
 // lane-linear (conflict-free).  Loads of chunk c+1 are issued before the MFMAs of chunk c and
 // written to LDS after them (one barrier per chunk).
+#include <cstring>
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -1479,7 +1480,9 @@ __device__ __forceinline__ int tail16_pull(const FfnParams& p, int n_tiles) {
 template <bool OUTPROJ, bool LN, bool RESID, bool OUT_NCHW, int TAIL, bool XN, bool A16>
 __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams* qp) {
     constexpr int C = 256, NCH = 8, NH = 8;
-    constexpr bool QKV = TAIL == 1, HEAD = TAIL == 2;
+    constexpr bool QKV = TAIL == 1 || TAIL == 3, HEAD = TAIL == 2;
+    constexpr bool FFN = TAIL != 3;                 // TAIL 3 (round 6): LayerNorm + Q / K' / V' only - k_ln_qkv16 as pulled tiles
+    static_assert(FFN || (!OUTPROJ && !LN && !RESID && !OUT_NCHW), "TAIL 3 is the projection phase alone");
     __shared__ __attribute__((aligned(16))) half_t smem[X16_RING * X16_CHUNK + 14 * C + 2 * X16_WAVES * X16_STG_WAVE + 8];
     // layout: [7 vector rows][per-wave store staging][weight ring]: the rows and the staging sit below 64 KB, where the 16-bit
     // offset field of the DS instructions reaches them from one base register (behind the ring every row position needed an
@@ -1491,7 +1494,7 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
     const int P = p.P, n_tiles = (P + X16_TOKENS - 1) / X16_TOKENS;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tk = lane & 15, g = lane >> 4;
     float* stg = reinterpret_cast<float*>(smem + 14 * C) + wave * X16_STG_WAVE;
-    const bool dyn = OUTPROJ && p.pull != nullptr;                        // pulled tiles (tail16_pull)
+    const bool dyn = (OUTPROJ || !FFN) && p.pull != nullptr;                        // pulled tiles (tail16_pull)
     const bool drawer = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;
     volatile int* nx = reinterpret_cast<volatile int*>(smem + 14 * C + 2 * X16_WAVES * X16_STG_WAVE + X16_RING * X16_CHUNK);   // the next ticket
     int job = blockIdx.y, tile = 0;                                       // current tile (dyn: from the ticket)
@@ -1541,16 +1544,16 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
         vec[0][i] = OUTPROJ ? p.b_o[ty * C + i] : 0.f;
         vec[1][i] = LN ? p.ln_g[ty * C + i] : 1.f;
         vec[2][i] = LN ? p.ln_b[ty * C + i] : 0.f;
-        vec[3][i] = p.b_1[ty * C + i];
-        vec[4][i] = p.b_2[ty * C + i];
+        vec[3][i] = FFN ? p.b_1[ty * C + i] : 0.f;
+        vec[4][i] = FFN ? p.b_2[ty * C + i] : 0.f;
         if constexpr (QKV) { vec[5][i] = qp->gamma[ty * C + i]; vec[6][i] = qp->beta[ty * C + i]; }
         if constexpr (HEAD) { vec[5][i] = p.hb_1[ty * C + i]; vec[6][i] = p.hb_2[ty * C + i]; }
     }
     // a tile as ONE chunk sequence: [out-projection 8] [FFN 16: W_1 tile, W_2 slice alternating] [tail: mlp_head 16 |
     // next stage's Q / K' / V' 8 per matrix]
-    constexpr int N_OUT = OUTPROJ ? NCH : 0, N_FFN = 2 * NH;
+    constexpr int N_OUT = OUTPROJ ? NCH : 0, N_FFN = FFN ? 2 * NH : 0;
     const half_t* wo = OUTPROJ ? p.w_o + (size_t)ty * NCH * X16_CHUNK : nullptr;
-    const half_t* wf = p.w_ffn + (size_t)ty * N_FFN * X16_CHUNK;
+    const half_t* wf = FFN ? p.w_ffn + (size_t)ty * N_FFN * X16_CHUNK : nullptr;
     const half_t* wh = HEAD ? p.w_head + (size_t)ty * N_FFN * X16_CHUNK : nullptr;
     const int n_tail = QKV ? Qj->n_mat * NCH : (HEAD ? N_FFN : 0);
     const int n_total = N_OUT + N_FFN + n_tail;
@@ -1638,6 +1641,7 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
     float4v xacc[16];
     half8 ah[8], al[8];
     bool have_o = false;                                 // xacc holds this tile's attention rows (requested during the tile before)
+    bool have_x = false;                                 // TAIL 3: xacc holds this tile's input rows (requested during the tile before)
     // range normalisation (HmvitStageScales): uniform powers of two for the stage's own chain; the stand-alone mlp_head launch
     // (!OUTPROJ && !LN) multiplies the un-normalised row itself and takes per-token factors (head_token_scales)
     const float c_1s = p.c_1[ty], s_gs = p.s_g[ty], k_2s = p.k_2[ty], c_o = p.c_o[ty];
@@ -1702,7 +1706,11 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
             rows_to_operands16(xacc, ah, al, 1.f);
             have_o = false;
         }
-        // ---- the residual row ----
+        // ---- the residual row (TAIL 3: the input row, already requested during the tile before when have_x) ----
+        if (!FFN && have_x) {
+            have_x = false;
+            extra = 0;
+        } else {
         if constexpr (XN) {
             const unsigned long long a = (unsigned long long)J.x;
             int4v rs;
@@ -1723,12 +1731,13 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
                 xacc[t][0] = f.x; xacc[t][1] = f.y; xacc[t][2] = f.z; xacc[t][3] = f.w;
             }
         }
-        if constexpr (!OUTPROJ && !LN) {   // mlp_head: x itself is the operand
+        extra = XN ? 64 : 16;
+        }
+        if constexpr (!OUTPROJ && !LN && FFN) {   // mlp_head: x itself is the operand
             float s_tok;
             head_token_scales(s_tok);
             rows_to_operands16(xacc, ah, al, s_tok);
         }
-        extra = XN ? 64 : 16;
         b_barrier();
 
         // ---- phase 1: x' = x + b_o + W_o . O, two 16-channel tiles per chunk ----
@@ -1768,7 +1777,7 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
                 }
             }
         }
-        if (dyn) {                                       // drawn in step 0, eight barriers ago
+        auto read_ticket = [&]() {
             const int t = __builtin_amdgcn_readfirstlane(*nx);
             pending = false;
             if (t >= 0) {
@@ -1777,12 +1786,14 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
                 has_next = p.job[next_job].cls == cls;
                 pending = !has_next;
             }
-        }
+        };
+        if (OUTPROJ && dyn) read_ticket();               // drawn in step 0, eight barriers ago
         if constexpr (LN) ln_to_operands16(xacc, vec[1], vec[2], g, ah, al);
         if constexpr (OUTPROJ) b_barrier();      // (behind the b_2 loop below hipcc spills 59 registers)
 
         // the row is carried as x k_2 while W_2's (scaled) products accumulate into it.  Stage chain: b_2 arrives as b_2 k_2;
         // mlp_head (no residual, per-token k_2): b_2 at its true scale
+        if constexpr (FFN) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const float4 b2 = *reinterpret_cast<const float4*>(&vec[4][16 * t + 4 * g]);
@@ -1792,6 +1803,7 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
             } else {
                 xacc[t][0] = b2.x * k_2; xacc[t][1] = b2.y * k_2; xacc[t][2] = b2.z * k_2; xacc[t][3] = b2.w * k_2;
             }
+        }
         }
 
 
@@ -1833,8 +1845,8 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
                 step_end(false, hc == NH - 1);           // followed by a conversion / the tile's end
             }
         };
-        ffn_pass(std::integral_constant<bool, !OUTPROJ && !LN>{}, vec[3]);
-        {
+        if constexpr (FFN) {
+            ffn_pass(std::integral_constant<bool, !OUTPROJ && !LN>{}, vec[3]);
             const float k_inv = pow2_inv(k_2);
 #pragma unroll
             for (int t = 0; t < 16; ++t) xacc[t] *= k_inv;
@@ -1913,6 +1925,39 @@ __device__ __forceinline__ void tail16_body(const FfnParams& p, const QkvParams*
                             extra = 16;
                         }
                     }
+                    if constexpr (!FFN) {
+                        // TAIL 3: the ticket drawn in step 0 (one barrier ago), then the next tile's input rows into xacc (idle since
+                        // the LayerNorm and store_x)
+                        if (c == 1) {
+                            if (dyn) read_ticket();
+                            if (has_next) {
+                                const int ntok = min(next_tile * X16_TOKENS + wave * 16 + tk, P - 1);
+                                const float* nxp = p.job[next_job].x;
+                                if constexpr (XN) {
+                                    const unsigned long long a = (unsigned long long)nxp;
+                                    int4v rs;
+                                    rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+                                    rs.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+                                    rs.z = C * P * 4;
+                                    rs.w = 0x00020000;
+                                    const int voff = (4 * g * P + ntok) * 4;
+#pragma unroll
+                                    for (int t2 = 0; t2 < 16; ++t2)
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r) xacc[t2][r] = llvm_raw_buffer_load_f32(rs, voff, (16 * t2 + r) * P * 4, 0);
+                                } else {
+                                    const float* xp2 = nxp + (size_t)ntok * C + 4 * g;
+#pragma unroll
+                                    for (int t2 = 0; t2 < 16; ++t2) {
+                                        const float4 f = *reinterpret_cast<const float4*>(xp2 + 16 * t2);
+                                        xacc[t2][0] = f.x; xacc[t2][1] = f.y; xacc[t2][2] = f.z; xacc[t2][3] = f.w;
+                                    }
+                                }
+                                have_x = true;
+                                extra = XN ? 64 : 16;
+                            }
+                        }
+                    }
                     float4v acc[2] = {(float4v)(0.f), (float4v)(0.f)};
                     mma_proj16(acc, slot(cc), ah, al, lane);
                     products_end(flushes(c - 1));
@@ -1948,6 +1993,12 @@ template <bool XN, bool A16>
 __global__ __launch_bounds__(X16_THREADS, 2) void k_out_ffn_qkv16(FfnParams p, QkvParams q) {
     tail16_body<true, true, true, false, 1, XN, A16>(p, &q);
 }
+// k_ln_qkv16 as pulled tiles: the projection phase of tail16_body alone (TAIL 3); FfnParams carries the jobs' input rows (x, XN =
+// (C, P) maps), the token-major copy (out; pad = 1: none) and the pull counter
+template <bool XN, bool A16>
+__global__ __launch_bounds__(X16_THREADS, 2) void k_ln_qkv16p(FfnParams p, QkvParams q) {
+    tail16_body<false, false, false, false, 3, XN, A16>(p, &q);
+}
 template <bool A16>
 __global__ __launch_bounds__(X16_THREADS, 2) void k_out_ffn_head16(FfnParams p) {
     tail16_body<true, true, true, false, 2, false, A16>(p, nullptr);
@@ -1972,6 +2023,25 @@ __global__ __launch_bounds__(CHAIN_THREADS, SP ? 1 : 2) void k_out_ffn_head(FfnP
 // ------------------------------------------------------------------------------------------
 // launchers (split = the "split" precision mode: hi / lo weight images, f32 Q / K' / V' / O planes)
 // ------------------------------------------------------------------------------------------
+// pulled tiles: job classes (a workgroup keeps its vector rows, chunk sequence and ring across tiles of one class) and the job count
+constexpr int kX16Persistent = 256;    // one workgroup per CU (140 KB of LDS each)
+static void x16_job_classes(FfnParams& p, const QkvParams* q, int n_jobs) {
+    p.n_jobs = n_jobs;
+    for (int j = 0; j < n_jobs; ++j) {
+        int c = j;
+        for (int k = 0; k < j && c == j; ++k) {
+            bool same = p.job[k].type == p.job[j].type && p.job[k].x_nchw == p.job[j].x_nchw;
+            if (same && q) {
+                const QkvJob &a = q->job[k], &b = q->job[j];
+                same = a.n_mat == b.n_mat;
+                for (int m = 0; same && m < a.n_mat; ++m) same = a.w[m] == b.w[m] && a.c[m] == b.c[m];
+            }
+            if (same) c = p.job[k].cls;
+        }
+        p.job[j].cls = c;
+    }
+}
+
 template <bool SP>
 static int launch_ln_qkv_t(const QkvParams& p, int n_jobs, int C, hipStream_t st) {
     dim3 grid(cdiv(p.P, CHAIN_TOKENS), n_jobs), block(CHAIN_THREADS);
@@ -1987,6 +2057,27 @@ static int launch_ln_qkv_t(const QkvParams& p, int n_jobs, int C, hipStream_t st
 int launch_ln_qkv(const QkvParams& p, int n_jobs, int C, int split, hipStream_t st) {
     if (n_jobs == 0) return HMVIT_OK;
     HMVIT_CHECK_ARG(split != 2 || C == 256, "mixed precision planes need C = 256 (got %d)", C);
+    if (split && C == 256 && p.pull && !HMVIT_ENV("HMVIT_X16_STATIC")) {   // pulled tiles (tail16_pull), one workgroup per CU
+        FfnParams f;
+        std::memset(&f, 0, sizeof(f));
+        f.P = p.P; f.pull = p.pull;
+        set_ffn_scales(f, nullptr, nullptr);
+        for (int j = 0; j < n_jobs; ++j) {
+            f.job[j].x = p.job[j].x; f.job[j].out = p.job[j].xs_out; f.job[j].pad = p.job[j].xs_out ? 0 : 1;
+            f.job[j].type = p.job[j].type; f.job[j].x_nchw = p.in_nchw;
+        }
+        x16_job_classes(f, &p, n_jobs);
+        const dim3 grid(std::min(kX16Persistent, n_jobs * cdiv(p.P, X16_TOKENS)), 1), block(X16_THREADS);
+        if (p.in_nchw) {
+            if (split == 2) hipLaunchKernelGGL((k_ln_qkv16p<true, true>), grid, block, 0, st, f, p);
+            else hipLaunchKernelGGL((k_ln_qkv16p<true, false>), grid, block, 0, st, f, p);
+        } else {
+            if (split == 2) hipLaunchKernelGGL((k_ln_qkv16p<false, true>), grid, block, 0, st, f, p);
+            else hipLaunchKernelGGL((k_ln_qkv16p<false, false>), grid, block, 0, st, f, p);
+        }
+        HMVIT_CHECK_LAUNCH();
+        return HMVIT_OK;
+    }
     if (split && C == 256) {      // 16 tokens per wavefront, images in the x16 layout (weights.py weight_image16)
         const dim3 grid(cdiv(p.P, X16_TOKENS), n_jobs), block(X16_THREADS);
         if (split == 2) hipLaunchKernelGGL(k_ln_qkv16<true>, grid, block, 0, st, p);
@@ -2027,25 +2118,6 @@ static int x16_grid_x(int P, int n_jobs) {
     if (gx < 1) gx = 1;
     gx = gx > cdiv(n_tiles, X16_MAX_TILES) ? gx : cdiv(n_tiles, X16_MAX_TILES);
     return gx < n_tiles ? gx : n_tiles;
-}
-
-// pulled tiles: job classes (a workgroup keeps its vector rows, chunk sequence and ring across tiles of one class) and the job count
-constexpr int kX16Persistent = 256;    // one workgroup per CU (140 KB of LDS each)
-static void x16_job_classes(FfnParams& p, const QkvParams* q, int n_jobs) {
-    p.n_jobs = n_jobs;
-    for (int j = 0; j < n_jobs; ++j) {
-        int c = j;
-        for (int k = 0; k < j && c == j; ++k) {
-            bool same = p.job[k].type == p.job[j].type && p.job[k].x_nchw == p.job[j].x_nchw;
-            if (same && q) {
-                const QkvJob &a = q->job[k], &b = q->job[j];
-                same = a.n_mat == b.n_mat;
-                for (int m = 0; same && m < a.n_mat; ++m) same = a.w[m] == b.w[m] && a.c[m] == b.c[m];
-            }
-            if (same) c = p.job[k].cls;
-        }
-        p.job[j].cls = c;
-    }
 }
 
 int launch_out_ffn_qkv(const FfnParams& p, const QkvParams& q, int n_jobs, int C, int split, hipStream_t st) {

@@ -112,6 +112,7 @@ struct QkvParams {
     const float* beta;
     int P;
     int in_nchw;
+    int* pull;               // split modes, C = 256, optional: one zeroed int - k_ln_qkv16 then runs as pulled tiles (FfnParams::pull)
 };
 // split: 0 = f16 operands, 1 = split (hi + lo) operands with f32 planes, 2 = split operands with f16 Q / K' / V' / O planes ("mixed")
 int launch_ln_qkv(const QkvParams& p, int n_jobs, int C, int split, hipStream_t st);

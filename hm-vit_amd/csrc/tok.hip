@@ -132,7 +132,7 @@ __global__ void k_pair_affines(const float* __restrict__ t, float* __restrict__ 
     const bool ident = (i00 == 1.f) && (i01 == 0.f) && (i02 == 0.f) && (i10 == 0.f) && (i11 == 1.f) &&
                        (i12 == 0.f);
     o[6] = ident ? 1.f : 0.f;
-    o[7] = 0.f;
+    o[7] = 0.f;     // (fused forward: doubles as the zeroed pull counter of the first stage's k_ln_qkv16 launches - capi.hip QkvBatcher)
 }
 
 int launch_pair_affines(const float* t, float* ainv, int n, int H, int W, float discrete_ratio,
