@@ -211,7 +211,10 @@ __global__ __launch_bounds__(256) void k_gemm_tn_split(GemmTnJobs jobs) {
     const bool do_bias = J.dbias != nullptr && tk == 0;
     float4 bsum[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
 
-    // item = tid + 256 i: token pair (item >> 5), column group item & 31 (columns 4 cg .. 4 cg + 3)
+    // item = tid + 256 i: token pair (item >> 5), column group item & 31 (columns 4 cg .. 4 cg + 3).  (Round 6, measured and not kept: token
+    // pair fastest over the lanes - item & 15, item >> 4 - makes the 32 lanes of a ds_write_b32 group hit 32 different banks instead of 8
+    // banks four times (the 65 % bank-conflict share of profiles/r06_train_pmc.txt), bit-identical results, and the kernel got SLOWER, 757 ->
+    // 817 us per launch: a load then reads 16 rows x 64 bytes instead of 2 rows x 512, and the staging stores were not what it waits for.)
     float4 fd[2][2], fa[2][2];
     auto fetch = [&](int m0) {
 #pragma unroll

@@ -188,11 +188,15 @@ typedef struct HmvitFusionDesc {
     int32_t self_identity;        /* 1: the caller guarantees pairwise_t[b, i, i] = I for every agent (what the reference's
                                      datasets produce, mixed/intermediate_fusion_dataset.py:163-202); lets HMVIT_PREC_SPLIT use
                                      its persistent attention kernel.  0: unknown (always correct, slower in split mode) */
-    int32_t rigid_patch;          /* 1: the caller guarantees that the upper-left 2 x 2 block M of every pairwise_t[b, i, j] is a rotation
-                                     to 2 % (|M^T M - I| <= 0.02 elementwise; the reference's poses are rigid: x / y / yaw and small
-                                     roll / pitch).  Then the 32 keys of a half window never touch more than 64 source pixels and the
-                                     local stages of HMVIT_PREC_SPLIT run the de-duplicated patch kernel (k_attention_patch).
-                                     0: unknown (always correct: the gather kernel).  hmvit_pack_small reports both guarantees. */
+    int32_t rigid_patch;          /* 1 / 2: the caller guarantees that the upper-left 2 x 2 block M of every pairwise_t[b, i, j] is a
+                                     rotation to 2 % (|M^T M - I| <= 0.02 elementwise; the reference's poses are rigid: x / y / yaw and
+                                     small roll / pitch).  Then the 32 keys of a half window never touch more than 64 source pixels (a
+                                     16-key block: 40) and the local stages of HMVIT_PREC_SPLIT run a de-duplicated patch kernel:
+                                     1 = k_attention_patch (8 wavefronts per window), 2 = k_attention_patch16 (16; its per-item tables
+                                     come from a pre-pass once per forward).  Same results as the gather kernel to fp32 round-off; both
+                                     measured ~10 % slower than it at cfg2, hence opt-in.
+                                     0: unknown / not wanted (always correct: the gather kernel).  hmvit_pack_small reports both
+                                     guarantees. */
 } HmvitFusionDesc;
 
 int hmvit_abi_version(void);
