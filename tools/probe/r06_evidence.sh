@@ -33,5 +33,6 @@ HMVIT_PATCH_ATTENTION=1 timeout 600 bash tools/probe/r06_attn_prof.sh patch > $P
 HMVIT_LIB=tools/probe/lib_probe.so python tools/probe/x16_trace.py split > $P/r06_x16_trace.txt 2>&1
 HMVIT_PATCH_ATTENTION=2 HMVIT_LIB=tools/probe/lib_probe.so python tests/tools/patch16_trace.py > $P/r06_patch16_trace.txt 2>&1
 (echo "# tools/probe/r06_tailpull.sh: x16 tails pulled (static=0) against one workgroup per tile (static=1), probe library, interleaved on one box"; bash tools/probe/r06_tailpull.sh "pulled_tail or (full_size and split)" 2>&1 | grep -E "passed|failed|static=") > $P/r06_tailpull_ab.txt
+(echo "# tools/probe/r06_soak_pull.py 300: pulled tiles, every forward bit-compared with the first and with one workgroup per tile"; python tools/probe/r06_soak_pull.py 300 2>&1 | grep -E "forwards") > $P/r06_soak_pull.txt
 (echo "# tools/probe/r06_clocks.sh split: rocm-smi once a second while bench.py --precision split --steps 5000 loops"; bash tools/probe/r06_clocks.sh split 2>&1 | sed 's/=\{5,\}//g; s/GPU\[0\]\t*: //g; s/Power Consumption//' | grep -E "sclk|scenes") > $P/r06_clocks.txt
 cut -c1-600 $P/r06_bench.json; cat $P/r06_model.txt $P/r06_train.txt $P/r06_attention_per_stage.txt
