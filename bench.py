@@ -100,6 +100,7 @@ def phase_work(c, num_iters, es):
         kind, w_full = full[k]
         out[k] = (kind, (w_full * (n_stages - 1) + last[k][1]) / n_stages)   # mean per launch
     out["head"] = ("mfma", 2 * 2 * P * C * C)
+    out["_full"], out["_last"] = full, last            # per-stage figures (the fused launches are not one phase of one stage each)
     out["layout_in"] = ("hbm", L * P * C * 8)
     out["layout_out"] = ("hbm", P * C * 8)
     return out
@@ -558,6 +559,7 @@ def main(argv=None):
         runs = [net.profile_phases(*scene) for _ in range(5)]
         es = ES[prec]
         work = phase_work(c, args.num_iters, es)
+        full_st, last_st = work.pop("_full"), work.pop("_last")
         fused = prec in ("f16", "split", "mixed")
         rename = {"qkv_gemm": "ln_qkv", "ffn2": "stage_tail"} if fused else {}
         phases = {}
@@ -569,10 +571,18 @@ def main(argv=None):
         if fused:
             # one fused kernel per stage does out-proj + LayerNorm + FFN (+ the next stage's LayerNorm + Q / K' / V'
             # projections): "stage_tail"; the first stage's LayerNorm + projections run as "ln_qkv"
+            # "head" = the LAST stage's tail with mlp_head appended (one launch, ego rows): its own phase since round 6
             n_st = 2 * args.num_iters
-            work["stage_tail"] = ("mfma", work["out_proj"][1] + work["ffn1"][1] + work["ffn2"][1] +
-                                  work["qkv_gemm"][1] * (n_st - 1) / n_st)
-            work["ln_qkv"] = work["qkv_gemm"]
+            tail_of = lambda st_: st_["out_proj"][1] + st_["ffn1"][1] + st_["ffn2"][1]
+            fused_head = phases.get("head", {}).get("ms_total", 0.0) > 0.05        # (f32 mode / old libraries: mlp_head alone, or nothing)
+            if fused_head and n_st > 1:
+                # n_st - 1 fused tails of full stages, each with the next stage's projections (the last of them: the pruned stage's)
+                work["stage_tail"] = ("mfma", ((n_st - 1) * tail_of(full_st) + (n_st - 2) * full_st["qkv_gemm"][1] + last_st["qkv_gemm"][1]) / (n_st - 1))
+                work["head"] = ("mfma", tail_of(last_st) + work["head"][1])
+            else:
+                work["stage_tail"] = ("mfma", work["out_proj"][1] + work["ffn1"][1] + work["ffn2"][1] +
+                                      work["qkv_gemm"][1] * (n_st - 1) / n_st)
+            work["ln_qkv"] = ("mfma", full_st["qkv_gemm"][1])
         dom = max(phases, key=lambda k: phases[k]["ms_total"])
         kind, per_launch = work[dom]
         avg_s = phases[dom]["ms_total"] / phases[dom]["launches"] * 1e-3
@@ -653,9 +663,12 @@ def main(argv=None):
             for st in range(n_st - 1):
                 n_q = 1 if st == n_st - 2 else L_
                 tail_bytes += L_ * plane * (es + 4 + 4) + (n_q + 2 * L_ * E_) * plane * es
-            tail_bytes += plane * (es + 4 + 4)
-            head_flops = work["head"][1]
-            by["stage_tail"] = (work["stage_tail"][1] + head_flops / n_st, tail_bytes / n_st)
+            head_bytes = plane * (es + 4 + 4)
+            if fused_head and n_st > 1:
+                by["stage_tail"] = (work["stage_tail"][1], tail_bytes / (n_st - 1))
+                by["head"] = (work["head"][1], head_bytes)
+            else:
+                by["stage_tail"] = (work["stage_tail"][1] + work["head"][1] / n_st, (tail_bytes + head_bytes) / n_st)
             tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
             t_ok = tj.get("kernel_source_hash") == kernel_source_hash() and args.config == "cfg2"
             rbp = {}
@@ -663,8 +676,8 @@ def main(argv=None):
                 if name not in phases:
                     continue
                 t_s = phases[name]["ms_total"] / phases[name]["launches"] * 1e-3
-                tr = tj.get(prec, {}).get(name) if t_ok else None
-                if name == "stage_tail" and t_ok and tr is not None and tj.get(prec, {}).get("stage_tail_head") is not None:
+                tr = tj.get(prec, {}).get("stage_tail_head" if name == "head" else name) if t_ok else None
+                if name == "stage_tail" and "head" not in by and t_ok and tr is not None and tj.get(prec, {}).get("stage_tail_head") is not None:
                     # the file keeps the three fused tails and the tail + head launch apart: mean over the launches of the phase
                     tr = (tr * (n_st - 1) + tj[prec]["stage_tail_head"]) / n_st
                 rbp[name] = {"launches": phases[name]["launches"], "avg_launch_ms": t_s * 1e3,

@@ -784,7 +784,8 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
                     HMVIT_TRY(fb.flush());
                 }
             }
-            HMVIT_MARK(HMVIT_PHASE_FFN2);
+            // the last stage's tail with mlp_head appended (k_out_ffn_head) is the HEAD phase: one launch, ego rows only
+            HMVIT_MARK(head_done ? HMVIT_PHASE_HEAD : HMVIT_PHASE_FFN2);
         }
         if (d->parallel) {
             HMVIT_TRY(merge_branches(d, pl, d->apply_head && it == d->num_iters - 1, st));
@@ -816,7 +817,7 @@ static int fusion_forward_f16(const HmvitFusionDesc* d, const Plan& pl, hipStrea
         }
         HMVIT_TRY(fb.flush());
     }
-    HMVIT_MARK(HMVIT_PHASE_HEAD);
+    HMVIT_MARK_IF(HMVIT_PHASE_HEAD, !head_done);
     return HMVIT_OK;
 }
 
