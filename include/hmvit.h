@@ -220,7 +220,8 @@ int hmvit_fusion_forward(const HmvitFusionDesc* desc, void* stream);
 #define HMVIT_PHASE_LN_FFN 5      /* HeteroLayerNorm of the FFN                             */
 #define HMVIT_PHASE_FFN1 6        /* Linear + GELU                                          */
 #define HMVIT_PHASE_FFN2 7        /* Linear + residual                                      */
-#define HMVIT_PHASE_HEAD 8        /* mlp_head (two GEMMs)                                   */
+#define HMVIT_PHASE_HEAD 8        /* mlp_head (two GEMMs); fused modes at C = 256: the LAST stage's
+                                     tail launch with mlp_head appended (k_out_ffn_head)      */
 #define HMVIT_PHASE_LAYOUT_OUT 9  /* token-major -> NCHW                                    */
 #define HMVIT_NUM_PHASES 10
 int hmvit_fusion_profile(const HmvitFusionDesc* desc, void* stream, float* phase_ms,
